@@ -1,0 +1,128 @@
+/*
+ * ribodetector_amd.h - C ABI of the MI355X-native RiboDetector inference path (librd_hip.so).
+ *
+ * The reference (hzi-bifo/RiboDetector v0.3.1) is pure Python and has no FFI of its own; the seam it offers
+ * is a Python duck type resolved from config.json. Each entry point below names the reference
+ * interface it replaces (paths relative to /root/reference/ribodetector). INTEGRATION.md shows the ctypes
+ * binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer marked [dev] is device (HBM) memory owned by the caller,
+ *     [host] is host memory. Nothing is allocated behind the caller's back except inside rd_model_create.
+ *   - every launch takes an explicit hipStream_t (passed as void*; 0 = the null stream) and is asynchronous;
+ *     the caller synchronises.
+ *   - return value: 0 = ok, <0 = error (RD_E_*); rd_last_error() returns a thread-local message.
+ *     No C++ exception crosses this boundary.
+ *   - reads are handed over as raw ASCII: one byte arena + per-read start offset + per-read length
+ *     (exactly what a FASTQ/FASTA chunk in memory looks like). Only the first `max_len` bases of a read are
+ *     used (reference detect.py:682,714,717 `read[1][:max_len]`).
+ */
+#ifndef RIBODETECTOR_AMD_H
+#define RIBODETECTOR_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RD_OK 0
+#define RD_E_INVALID (-1)   /* bad argument                                   */
+#define RD_E_HIP (-2)       /* a HIP runtime call failed                      */
+#define RD_E_UNSUPPORTED (-3) /* architecture / arg combination not covered   */
+#define RD_E_WORKSPACE (-4) /* workspace too small                            */
+
+/* --ensure modes of reference detect.py:616-663 */
+#define RD_ENSURE_NONE 0
+#define RD_ENSURE_RRNA 1
+#define RD_ENSURE_NORRNA 2
+#define RD_ENSURE_BOTH 3
+
+/* LSTM kernel variants (rd_set_variant): all compute the same function */
+#define RD_VARIANT_AUTO 0
+#define RD_VARIANT_MFMA_F32 1   /* persistent-weight fp32 MFMA recurrence (exact fp32)     */
+#define RD_VARIANT_SIMPLE 2     /* plain fp32 FMA kernel, correctness cross-check         */
+#define RD_VARIANT_MFMA_F16X3 3 /* split-precision f16 MFMA (hi*hi + hi*lo + lo*hi)       */
+
+typedef struct rd_model rd_model; /* opaque: device-resident, pre-packed weights */
+
+/* Host pointers to the 10 tensors of the reference state_dict (reference model/model.py:16-24; names as in
+ * torch: rnn.weight_ih_l0 [4H,I], rnn.weight_hh_l0 [4H,H], rnn.bias_ih_l0 [4H], rnn.bias_hh_l0 [4H], the same
+ * four with suffix _reverse, out.weight [C,2H], out.bias [C]); row-major fp32, torch gate order i,f,g,o. */
+typedef struct rd_weights {
+    const float *w_ih, *w_hh, *b_ih, *b_hh;
+    const float *w_ih_r, *w_hh_r, *b_ih_r, *b_hh_r;
+    const float *w_out, *b_out;
+    int32_t input_size;   /* must be 4   */
+    int32_t hidden_size;  /* must be 128 */
+    int32_t num_classes;  /* must be 2   */
+} rd_weights;
+
+/* Replaces: SeqModel(**arch.args); load_state_dict(...); .to('cuda'); .eval()
+ * (reference detect.py:93,115-119, model/model.py:10-29). Uploads the weights to `device` and pre-packs them
+ * (per-lane MFMA operand order for W_hh, fused input table  W_ih[:,base]+b_ih+b_hh, reverse-direction table).
+ * Synchronous. */
+int rd_model_create(const rd_weights *w, int device, rd_model **out);
+void rd_model_destroy(rd_model *m);
+
+/* Select the recurrence kernel (RD_VARIANT_*); default AUTO = MFMA_F32. */
+int rd_set_variant(rd_model *m, int variant);
+
+/* Bytes of [dev] scratch rd_classify needs for n reads with truncation length max_len. */
+size_t rd_classify_workspace_bytes(int64_t n, int32_t max_len);
+
+/* Replaces: collate (one-hot + pack_sequence, reference detect.py:666-689) + model(x) (model/model.py:32-37
+ * forward1: BiLSTM over min(len,max_len) steps, last-timestep gather, Linear) + torch.argmax (detect.py:288,481).
+ *   arena   [dev] ASCII bytes;  seq_off [dev] int64[n] start of read i in arena;  seq_len [dev] int32[n]
+ *   logits  [dev] float[n*2], row i <-> read i (input order);  labels [dev] uint8[n] or NULL (1 = rRNA)
+ *   workspace [dev] >= rd_classify_workspace_bytes(n, max_len), 256-byte aligned */
+int rd_classify(const rd_model *m, const uint8_t *arena, const int64_t *seq_off, const int32_t *seq_len, int64_t n,
+                int32_t max_len, float *logits, uint8_t *labels, void *workspace, size_t workspace_bytes, void *stream);
+
+/* Replaces: Predictor.separate_paired_reads label logic (reference detect.py:616-663).
+ *   logits1/logits2 [dev] float[n*2];  pair_labels [dev] int8[n] in {0,1,-1}
+ *   counts [dev] uint64[3] or NULL: (non-rRNA, rRNA, unclassified) ADDED to the existing values
+ *   (the running counters of detect.py:331-333,388-389,400). */
+int rd_pair_fuse(const float *logits1, const float *logits2, int64_t n, int32_t ensure_mode, int8_t *pair_labels,
+                 uint64_t *counts, void *stream);
+
+/* Replaces: Predictor.separate_reads counters for single-end (reference detect.py:600-614,485-486).
+ *   labels [dev] uint8[n]; counts [dev] uint64[3], ADDED to. */
+int rd_count_labels(const uint8_t *labels, int64_t n, uint64_t *counts, void *stream);
+
+/* Replaces: SeqEncoder.encode_read / BASE_DICT (reference data_loader/seq_encoder.py:11-18,126-127) for a batch.
+ * codes [dev] uint8[n*stride]: 0 A, 1 C, 2 G, 3 T/U, 4 anything else; positions >= min(len,max_len) hold 4.
+ * stride >= max_len. */
+int rd_encode_codes(const uint8_t *arena, const int64_t *seq_off, const int32_t *seq_len, int64_t n, int32_t max_len,
+                    int32_t stride, uint8_t *codes, void *stream);
+
+/* Replaces: encode_variable_len_read + np.array(..., float32) (reference seq_encoder.py:130-145,
+ * detect_cpu.py:699-700): onehot [dev] float[n*max_len*4], zero rows after the read. */
+int rd_encode_onehot_padded(const uint8_t *arena, const int64_t *seq_off, const int32_t *seq_len, int64_t n,
+                            int32_t max_len, float *onehot, void *stream);
+
+/* Replaces: torch.FloatTensor(encode_read(...)) + pack_sequence(enforce_sorted=False) (reference
+ * detect.py:681-685). Two calls:
+ *   rd_pack_plan: fills sorted_idx [dev] int64[n] (lengths descending, ties by input index), unsorted_idx [dev]
+ *     int64[n], batch_sizes [dev] int64[max_len] (entries past the longest read are 0) and total_steps [dev]
+ *     int64[1] = sum_i min(len_i,max_len).  workspace as for rd_classify.
+ *   rd_pack_onehot: writes data [dev] float[total_steps*4], time-major over the sorted reads. */
+int rd_pack_plan(const int32_t *seq_len, int64_t n, int32_t max_len, int64_t *sorted_idx, int64_t *unsorted_idx,
+                 int64_t *batch_sizes, int64_t *total_steps, void *workspace, size_t workspace_bytes, void *stream);
+int rd_pack_onehot(const uint8_t *arena, const int64_t *seq_off, const int32_t *seq_len, int64_t n, int32_t max_len,
+                   const int64_t *sorted_idx, const int64_t *batch_sizes, float *data, void *stream);
+
+/* Timing of the dominant kernel, for bench.py's roofline: rd_classify records hipEvents around the recurrence
+ * kernel on the launch stream when enabled. rd_profile_read synchronises those events and returns the number of
+ * recorded launches and their total duration. */
+int rd_profile_enable(rd_model *m, int enable);
+int rd_profile_read(rd_model *m, int64_t *launches, double *total_ms);
+
+const char *rd_last_error(void);
+const char *rd_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RIBODETECTOR_AMD_H */

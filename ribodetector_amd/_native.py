@@ -1,0 +1,80 @@
+"""ctypes binding of the C ABI in include/ribodetector_amd.h (librd_hip.so, built by __graft_entry__.build()).
+
+There is NO CPU fallback: if the shared library is missing or a call fails, a RuntimeError is raised.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "librd_hip.so")
+
+ENSURE_MODES = {"none": 0, "rrna": 1, "norrna": 2, "both": 3}
+VARIANTS = {"auto": 0, "mfma_f32": 1, "simple": 2, "mfma_f16x3": 3}
+
+# every symbol include/ribodetector_amd.h declares (tests/test_abi.py checks the .so exports all of them)
+SYMBOLS = [
+    "rd_model_create", "rd_model_destroy", "rd_set_variant", "rd_classify_workspace_bytes", "rd_classify",
+    "rd_pair_fuse", "rd_count_labels", "rd_encode_codes", "rd_encode_onehot_padded", "rd_pack_plan",
+    "rd_pack_onehot", "rd_profile_enable", "rd_profile_read", "rd_last_error", "rd_version",
+]
+
+
+class RdWeights(C.Structure):
+    _fields_ = [(n, C.POINTER(C.c_float)) for n in
+                ("w_ih", "w_hh", "b_ih", "b_hh", "w_ih_r", "w_hh_r", "b_ih_r", "b_hh_r", "w_out", "b_out")] + \
+               [("input_size", C.c_int32), ("hidden_size", C.c_int32), ("num_classes", C.c_int32)]
+
+
+_lib = None
+
+
+def lib():
+    """Load librd_hip.so (once). Raises RuntimeError if the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "ribodetector_amd: HIP extension %s is missing - run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(there is no CPU fallback)" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i64, i32, sz = C.c_void_p, C.c_int64, C.c_int32, C.c_size_t
+    L.rd_model_create.argtypes = [C.POINTER(RdWeights), C.c_int, C.POINTER(vp)]
+    L.rd_model_create.restype = C.c_int
+    L.rd_model_destroy.argtypes = [vp]
+    L.rd_model_destroy.restype = None
+    L.rd_set_variant.argtypes = [vp, C.c_int]
+    L.rd_classify_workspace_bytes.argtypes = [i64, i32]
+    L.rd_classify_workspace_bytes.restype = sz
+    L.rd_classify.argtypes = [vp, vp, vp, vp, i64, i32, vp, vp, vp, sz, vp]
+    L.rd_pair_fuse.argtypes = [vp, vp, i64, i32, vp, vp, vp]
+    L.rd_count_labels.argtypes = [vp, i64, vp, vp]
+    L.rd_encode_codes.argtypes = [vp, vp, vp, i64, i32, i32, vp, vp]
+    L.rd_encode_onehot_padded.argtypes = [vp, vp, vp, i64, i32, vp, vp]
+    L.rd_pack_plan.argtypes = [vp, i64, i32, vp, vp, vp, vp, vp, sz, vp]
+    L.rd_pack_onehot.argtypes = [vp, vp, vp, i64, i32, vp, vp, vp, vp]
+    L.rd_profile_enable.argtypes = [vp, C.c_int]
+    L.rd_profile_read.argtypes = [vp, C.POINTER(i64), C.POINTER(C.c_double)]
+    L.rd_last_error.restype = C.c_char_p
+    L.rd_version.restype = C.c_char_p
+    for name in SYMBOLS:
+        f = getattr(L, name)
+        if f.restype is C.c_int and name not in ("rd_last_error", "rd_version"):
+            pass
+    _lib = L
+    return L
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed (%d): %s" % (what, rc, lib().rd_last_error().decode()))
+
+
+def stream_ptr(device=None):
+    import torch
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def ptr(t):
+    """device/host pointer of a torch tensor (None -> NULL)"""
+    return C.c_void_p(0 if t is None else t.data_ptr())

@@ -1,0 +1,892 @@
+// rd_kernels.hip - CDNA4 (gfx950) kernels + C ABI of the RiboDetector BiLSTM inference path.
+//
+// Reference path being replaced (paths relative to /root/reference/ribodetector):
+//   data_loader/seq_encoder.py:11-18,126-127   one-hot nucleotide encoder
+//   detect.py:666-726                          collate: truncate to max_len, one-hot, pack_sequence
+//   model/model.py:32-37,114-119               forward1: BiLSTM, last-timestep gather, Linear(256->2)
+//   detect.py:288,481                          argmax
+//   detect.py:616-663                          paired-end label fusion
+//
+// Structural facts used (verified by tests against the reference's own outputs):
+//   * forward1 gathers timestep len-1. There the reverse LSTM has made exactly ONE step from the zero state,
+//     so its contribution to the logits is a 5-entry table keyed by the last base (rev_lut).
+//   * the input is one-hot/zero, so W_ih x + b_ih + b_hh is a 5-row table (in_lut) - a gather, not a GEMM.
+//   => the only dense work is the forward recurrence h[B,128] . W_hh^T[128,512] per timestep.
+//
+// Kernel inventory
+//   rd_prep_kernel            weight pre-packing (once per model)
+//   rd_len_hist/scan/scatter  length bucketing = pack_sequence's sort (descending length)
+//   rd_lstm_mfma_f32_kernel   persistent-weight fp32-MFMA recurrence + fused encoder/FC/argmax epilogue
+//   rd_lstm_simple_kernel     plain-FMA cross-check of the same function
+//   rd_encode_* / rd_pack_*   standalone encoder kernels (reference tensor layouts), HBM-bound
+//   rd_pair_fuse_kernel, rd_count_kernel
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/ribodetector_amd.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int HID = 128;     // hidden size
+constexpr int G4 = 512;      // 4 gates x hidden
+constexpr int NT = 4;        // 16-read tiles per workgroup (ring)
+constexpr int BT = NT * 16;  // reads per workgroup
+constexpr int HSTR = 132;    // LDS row stride (floats) of an h tile: 128 + 4 pad -> conflict-free b128 reads
+constexpr int TC = 128;      // timesteps per staged code chunk
+constexpr int LUTSTR = 528;  // LDS row stride of the input table
+
+thread_local char g_err[512] = "";
+
+#define RD_FAIL(code, ...)                              \
+    do {                                                \
+        snprintf(g_err, sizeof(g_err), __VA_ARGS__);    \
+        return (code);                                  \
+    } while (0)
+#define RD_HIP(call)                                                                             \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess) RD_FAIL(RD_E_HIP, "%s failed: %s", #call, hipGetErrorString(e_));  \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// encoder: seq_encoder.py:11-18  A C G T U(=T) -> 0 1 2 3 ; anything else (lowercase included) -> 4
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int rd_code(unsigned ch) {
+    return ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : (ch == 'T' || ch == 'U') ? 3 : 4;
+}
+
+// ------------------------------------------------------------------------------------------------
+// activations. v_exp_f32 evaluates 2^x to ~1 ulp; the argument x*log2(e) is formed with an FMA-compensated
+// product so the result stays within ~2 ulp of expf over the whole range (SURVEY §7 "transcendental accuracy").
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float rd_exp(float x) {
+    const float L2E_HI = 1.44269502162933349609375f;    // fl(log2 e)
+    const float L2E_LO = 1.925963033500011e-8f;         // log2 e - L2E_HI
+    float t = x * L2E_HI;
+    float e = __builtin_fmaf(x, L2E_HI, -t);             // rounding error of the product
+    e = __builtin_fmaf(x, L2E_LO, e);
+    float r = __builtin_amdgcn_exp2f(t);
+    return __builtin_fmaf(r, e * 0.693147182464599609375f, r);   // 2^(t+e) ~= 2^t (1 + e ln2)
+}
+__device__ __forceinline__ float rd_sigmoid(float x) {
+    x = fmaxf(x, -80.0f);                                // keep exp(-x) finite: rcp(inf) would still be 0, but avoid inf*0 downstream
+    return __builtin_amdgcn_rcpf(1.0f + rd_exp(-x));
+}
+__device__ __forceinline__ float rd_tanh(float x) {     // tanh x = 2 sigmoid(2x) - 1
+    return __builtin_fmaf(2.0f, rd_sigmoid(2.0f * x), -1.0f);
+}
+
+// ------------------------------------------------------------------------------------------------
+// model blob (device)
+// ------------------------------------------------------------------------------------------------
+struct DevModel {
+    float *raw;       // uploaded tensors, concatenated
+    float *wpack32;   // [4 waves][8 col tiles][32 k-steps][64 lanes]  fp32 MFMA B-operand order
+    float *wt_hh;     // [128][512]  W_hh^T  (simple kernel)
+    float *in_lut;    // [5][512]    W_ih[:,code] + (b_ih + b_hh); code 4 = bias only
+    float *rev_lut;   // [5][2]      W_out[:,128:] . h_rev(one step from zero on `code`)
+    float *w_out;     // [2][256]
+    float *b_out;     // [2]
+    uint32_t *wpack16; // f16x3 variant: [4 waves][...] packed halves (see rd_lstm_f16.hip section)
+};
+
+}  // namespace
+
+struct rd_model {
+    int device;
+    int variant;
+    DevModel d;
+    // profiling of the recurrence kernel (bench.py roofline)
+    int prof_enabled;
+    int prof_count;
+    hipEvent_t prof_ev[2 * 512];
+    double prof_ms_accum;
+    int64_t prof_launches_accum;
+};
+
+namespace {
+
+// raw layout offsets (floats)
+constexpr int OFF_WIH = 0, OFF_WHH = OFF_WIH + 512 * 4, OFF_BIH = OFF_WHH + 512 * 128, OFF_BHH = OFF_BIH + 512;
+constexpr int OFF_WIHR = OFF_BHH + 512, OFF_WHHR = OFF_WIHR + 512 * 4, OFF_BIHR = OFF_WHHR + 512 * 128;
+constexpr int OFF_BHHR = OFF_BIHR + 512, OFF_WOUT = OFF_BHHR + 512, OFF_BOUT = OFF_WOUT + 512, RAW_FLOATS = OFF_BOUT + 2;
+
+// gate column handled by (wave w, column tile c = gate*2 + sub, lane&15)
+__device__ __host__ __forceinline__ int gate_col(int w, int c, int l15) { return (c >> 1) * HID + 32 * w + 16 * (c & 1) + l15; }
+
+__global__ void rd_prep_kernel(DevModel d) {
+    const float *raw = d.raw;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nth = gridDim.x * blockDim.x;
+    // fp32 MFMA B operand: lane l (col = l&15, q = l>>4), k-step s = 4m + j  <->  hidden index 16m + 4q + j
+    for (int i = tid; i < 4 * 8 * 32 * 64; i += nth) {
+        int lane = i & 63, s = (i >> 6) & 31, c = (i >> 11) & 7, w = i >> 14;
+        int m = s >> 2, j = s & 3, q = lane >> 4;
+        d.wpack32[i] = raw[OFF_WHH + gate_col(w, c, lane & 15) * HID + 16 * m + 4 * q + j];
+    }
+    for (int i = tid; i < HID * G4; i += nth) {
+        int k = i / G4, col = i % G4;
+        d.wt_hh[i] = raw[OFF_WHH + col * HID + k];
+    }
+    for (int i = tid; i < 5 * G4; i += nth) {
+        int code = i / G4, col = i % G4;
+        float b = raw[OFF_BIH + col] + raw[OFF_BHH + col];
+        d.in_lut[i] = code < 4 ? b + raw[OFF_WIH + col * 4 + code] : b;
+    }
+    for (int i = tid; i < 512; i += nth) d.w_out[i] = raw[OFF_WOUT + i];
+    if (tid < 2) d.b_out[tid] = raw[OFF_BOUT + tid];
+    // reverse direction: one cell step from (h,c) = 0 on base `code` (W_hh_r . 0 vanishes), then the FC's reverse half.
+    if (tid < 10) {
+        int code = tid >> 1, k = tid & 1;
+        float s = 0.0f;
+        for (int u = 0; u < HID; ++u) {
+            float g[4];
+            for (int gi = 0; gi < 4; ++gi) {
+                int col = gi * HID + u;
+                float b = raw[OFF_BIHR + col] + raw[OFF_BHHR + col];
+                g[gi] = code < 4 ? b + raw[OFF_WIHR + col * 4 + code] : b;
+            }
+            float ig = 1.0f / (1.0f + expf(-g[0])), gg = tanhf(g[2]), og = 1.0f / (1.0f + expf(-g[3]));
+            float c = ig * gg;                    // f * 0 + i * g~
+            float h = og * tanhf(c);
+            s += raw[OFF_WOUT + k * 256 + HID + u] * h;
+        }
+        d.rev_lut[code * 2 + k] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// length bucketing: order[] = read indices sorted by T = min(len,max_len) descending (pack_sequence's sort,
+// detect.py:685). Ties are ordered by input index (stable) so that the order is deterministic.
+// Three kernels: per-block histograms -> exclusive scan over (length desc, block asc) -> stable scatter.
+// ------------------------------------------------------------------------------------------------
+constexpr int SORT_BLOCK = 256;
+constexpr int SORT_ITEMS = 2048;   // reads per block
+
+__device__ __forceinline__ int rd_T(const int32_t *len, int64_t i, int max_len) {
+    int t = len[i];
+    t = t < 0 ? 0 : t;
+    return t < max_len ? t : max_len;
+}
+
+// hist[(T)*(nblk) + blk] = number of reads of truncated length T in block blk
+__global__ void rd_len_hist_kernel(const int32_t *__restrict__ len, int64_t n, int max_len, int nblk,
+                                   uint32_t *__restrict__ hist) {
+    extern __shared__ uint32_t sh[];   // max_len+1
+    for (int i = threadIdx.x; i <= max_len; i += blockDim.x) sh[i] = 0;
+    __syncthreads();
+    int64_t base = (int64_t)blockIdx.x * SORT_ITEMS;
+    for (int k = threadIdx.x; k < SORT_ITEMS; k += blockDim.x) {
+        int64_t i = base + k;
+        if (i < n) atomicAdd(&sh[rd_T(len, i, max_len)], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i <= max_len; i += blockDim.x) hist[(size_t)i * nblk + blockIdx.x] = sh[i];
+}
+
+// single block: exclusive scan of hist in the order (T descending, blk ascending); also per-length totals:
+// len_start[T] = first sorted position of length T; batch_sizes[t] = #reads with T > t; total_steps.
+__global__ void rd_len_scan_kernel(uint32_t *__restrict__ hist, int max_len, int nblk, int64_t *__restrict__ len_start,
+                                   int64_t *__restrict__ batch_sizes, int64_t *__restrict__ total_steps) {
+    __shared__ unsigned long long carry;
+    __shared__ unsigned long long wsum[SORT_BLOCK / 64];
+    const int tid = threadIdx.x;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    const int64_t total = (int64_t)(max_len + 1) * nblk;
+    unsigned long long steps = 0;
+    for (int64_t base = 0; base < total; base += SORT_BLOCK) {
+        int64_t e = base + tid;               // element in scan order
+        unsigned v = 0;
+        int T = 0;
+        if (e < total) {
+            T = max_len - (int)(e / nblk);
+            v = hist[(size_t)T * nblk + (e % nblk)];
+        }
+        // inclusive scan within the block
+        unsigned long long x = v;
+        for (int o = 1; o < 64; o <<= 1) {
+            unsigned long long y = __shfl_up(x, o);
+            if ((tid & 63) >= o) x += y;
+        }
+        if ((tid & 63) == 63) wsum[tid >> 6] = x;
+        __syncthreads();
+        unsigned long long pre = carry;
+        for (int w = 0; w < (tid >> 6); ++w) pre += wsum[w];
+        unsigned long long excl = pre + x - v;
+        if (e < total) {
+            hist[(size_t)T * nblk + (e % nblk)] = (uint32_t)excl;   // n < 2^31
+            if ((e % nblk) == 0 && len_start) len_start[T] = (int64_t)excl;
+        }
+        __syncthreads();
+        if (tid == SORT_BLOCK - 1) carry = pre + x;
+        __syncthreads();
+    }
+    (void)steps;
+    if (batch_sizes || total_steps) {
+        // batch_sizes[t] = #reads with T >= t+1 = len_start[t] (start of the first length <= t) ... computed from len_start:
+        // reads with T > t occupy sorted positions [0, len_start[t]) because lengths are descending.
+        __syncthreads();
+        unsigned long long acc = 0;
+        for (int t = tid; t < max_len; t += SORT_BLOCK) {
+            int64_t bs = len_start[t];
+            if (batch_sizes) batch_sizes[t] = bs;
+            acc += (unsigned long long)bs;
+        }
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+        if ((tid & 63) == 0) wsum[tid >> 6] = acc;
+        __syncthreads();
+        if (tid == 0 && total_steps) {
+            unsigned long long s = 0;
+            for (int w = 0; w < SORT_BLOCK / 64; ++w) s += wsum[w];
+            *total_steps = (int64_t)s;
+        }
+    }
+}
+
+// stable scatter: one wave-serial pass per block keeps input order inside a length bucket.
+__global__ void rd_len_scatter_kernel(const int32_t *__restrict__ len, int64_t n, int max_len, int nblk,
+                                      const uint32_t *__restrict__ hist, int32_t *__restrict__ order,
+                                      int64_t *__restrict__ sorted_idx, int64_t *__restrict__ unsorted_idx) {
+    extern __shared__ uint32_t cur[];   // max_len+1 running cursors of this block
+    for (int i = threadIdx.x; i <= max_len; i += blockDim.x) cur[i] = hist[(size_t)i * nblk + blockIdx.x];
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * SORT_ITEMS;
+    // process 64 reads at a time with wave 0 only (stability needs an order; the work is a few bytes per read)
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        for (int k0 = 0; k0 < SORT_ITEMS; k0 += 64) {
+            int64_t i = base + k0 + lane;
+            bool valid = i < n;
+            int T = valid ? rd_T(len, i, max_len) : -1;
+            // rank among earlier lanes with the same T
+            unsigned rank = 0, cnt = 0;
+            for (int o = 0; o < 64; ++o) {
+                int To = __shfl(T, o);
+                if (To == T) { cnt++; if (o < lane) rank++; }
+            }
+            uint32_t pos = 0;
+            if (valid) pos = cur[T] + rank;
+            __builtin_amdgcn_wave_barrier();
+            if (valid && rank == cnt - 1) cur[T] = pos + 1;   // last lane of each group advances the cursor
+            __builtin_amdgcn_wave_barrier();
+            if (valid) {
+                if (order) order[pos] = (int32_t)i;
+                if (sorted_idx) sorted_idx[pos] = i;
+                if (unsorted_idx) unsorted_idx[i] = pos;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// shared pieces of the recurrence kernels
+// ------------------------------------------------------------------------------------------------
+struct ReadBatch {
+    const uint8_t *arena;
+    const int64_t *off;
+    const int32_t *len;
+    const int32_t *order;   // sorted position -> read index (nullptr = identity)
+    int64_t n;
+    int max_len;
+};
+
+// FC + argmax epilogue for one workgroup's reads. hl(row,u) = captured last forward hidden state.
+// logits = b_out + W_out[:, :128] . h_fwd + rev_lut[last base]   (model.py:36; reverse half folded, see header)
+template <typename HL>
+__device__ __forceinline__ void rd_fc_epilogue(int nrows, HL hl, const int *Trow, const long long *offrow, const int *origrow,
+                                               const float *s_wout, const DevModel &d, const ReadBatch &rb, float *logits,
+                                               uint8_t *labels) {
+    const int tid = threadIdx.x;
+    if (tid < 2 * nrows) {
+        const int row = tid >> 1, k = tid & 1;
+        float s = d.b_out[k];
+        for (int u = 0; u < HID; ++u) s = __builtin_fmaf(s_wout[k * HID + u], hl(row, u), s);
+        const int T = Trow[row];
+        if (T > 0) s += d.rev_lut[rd_code(rb.arena[offrow[row] + T - 1]) * 2 + k];
+        const float other = __shfl_xor(s, 1);
+        const int orig = origrow[row];
+        if (orig >= 0) {
+            logits[(size_t)orig * 2 + k] = s;
+            if (labels && k == 0) labels[orig] = other > s ? 1 : 0;   // torch.argmax: first max wins ties -> 0
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// rd_lstm_mfma_f32_kernel - persistent-weight fp32-MFMA forward recurrence.
+//
+// Workgroup = 256 threads = 4 waves (one per SIMD, 512 VGPR/AGPR each), 64 reads = ring of NT=4 tiles x 16 reads.
+// Wave w owns hidden units [32w, 32w+32) of all four gates: 8 column tiles of 16 (gate g, sub s), W_hh slice held in
+// 256 registers per lane for the whole kernel (64 KiB per wave, 256 KiB per CU = all of W_hh).
+// One "phase" = one tile x one timestep = 256 v_mfma_f32_16x16x4_f32 per wave (A = h tile from LDS, B = weights):
+//     G[16 reads, 128 cols] += h[16,128] . W^T           (k index permuted identically on both operands)
+// The C/D layout (col = lane&15, row = 4*(lane>>4)+reg) puts i,f,g,o of one (read, unit) cell in ONE lane, so the gate
+// math needs no cross-lane traffic. Phase p runs the MFMAs of (t, tile) while the VALU does the gate math of phase p-1
+// and the LDS prefetches the A fragments of phase p+1; one barrier per phase. h and c live in LDS between phases.
+// ------------------------------------------------------------------------------------------------
+struct __attribute__((aligned(16))) LstmSmem {
+    float Hs[NT][16][HSTR];        // current h of every tile (A operand source)
+    float Hl[NT][16][HSTR];        // h captured at t == T-1 (last_items, model.py:114-119)
+    f32x4 cA[NT][256];             // cell state, sub-tile 0 (4 reads per lane)
+    f32x4 cB[NT][256];             // cell state, sub-tile 1
+    float lut[5][LUTSTR];          // in_lut staged
+    float wout[2][HID];            // forward half of W_out
+    float dummy[256];              // sink of predicated-off Hl stores (keeps the phase body branch-free)
+    uint8_t codes[2][TC][BT];      // double-buffered code chunks, [t][row]
+    int T[BT];
+    long long off[BT];
+    int orig[BT];
+    int tmax;
+};
+
+__device__ __forceinline__ void rd_stage_codes(LstmSmem &S, const ReadBatch &rb, int chunk) {
+    const int t0 = chunk * TC;
+    uint8_t(*dst)[BT] = S.codes[chunk & 1];
+    for (int idx = threadIdx.x; idx < BT * TC; idx += 256) {
+        const int row = idx / TC, tt = idx % TC, t = t0 + tt;
+        int code = 4;
+        if (t < S.T[row]) code = rd_code(rb.arena[S.off[row] + t]);
+        dst[tt][row] = (uint8_t)code;
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void rd_lstm_mfma_f32_kernel(DevModel d, ReadBatch rb, float *__restrict__ logits,
+                                                                  uint8_t *__restrict__ labels) {
+    __shared__ LstmSmem S;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane >> 4, l15 = lane & 15;
+
+    // ---- per-read metadata, zero state ---------------------------------------------------------
+    if (tid < BT) {
+        const int64_t g = (int64_t)blockIdx.x * BT + tid;
+        int T = 0, orig = -1;
+        long long off = 0;
+        if (g < rb.n) {
+            orig = rb.order ? rb.order[g] : (int)g;
+            T = rd_T(rb.len, orig, rb.max_len);
+            off = rb.off[orig];
+        }
+        S.T[tid] = T; S.off[tid] = off; S.orig[tid] = orig;
+    }
+    if (tid == 0) S.tmax = 0;
+    for (int i = tid; i < NT * 16 * HSTR; i += 256) { (&S.Hs[0][0][0])[i] = 0.0f; (&S.Hl[0][0][0])[i] = 0.0f; }
+    for (int i = tid; i < NT * 256; i += 256) { (&S.cA[0][0])[i] = f32x4{0, 0, 0, 0}; (&S.cB[0][0])[i] = f32x4{0, 0, 0, 0}; }
+    for (int i = tid; i < 5 * G4; i += 256) S.lut[i / G4][i % G4] = d.in_lut[i];
+    S.wout[tid >> 7][tid & 127] = d.w_out[(tid >> 7) * 256 + (tid & 127)];
+    __syncthreads();
+    if (tid < BT) atomicMax(&S.tmax, S.T[tid]);
+    rd_stage_codes(S, rb, 0);
+
+    // ---- resident weights: 8 column tiles x 32 k-steps, one f32 per lane each ------------------
+    float Wr[8][32];
+    {
+        const float *wp = d.wpack32 + (size_t)wave * (8 * 32 * 64) + lane;
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+#pragma unroll
+            for (int s = 0; s < 32; ++s) Wr[c][s] = wp[(c * 32 + s) * 64];
+    }
+    __syncthreads();
+    const int tmax = S.tmax;
+    const int nphase = tmax * NT;
+
+    f32x4 accP[8];   // gate pre-activations (recurrent part) of the previous phase
+#pragma unroll
+    for (int c = 0; c < 8; ++c) accP[c] = f32x4{0, 0, 0, 0};
+    f32x4 hA[8];     // A fragments of the current phase: h[read l15][16m + 4q .. +3]
+#pragma unroll
+    for (int m = 0; m < 8; ++m) hA[m] = f32x4{0, 0, 0, 0};
+
+    int tile = 0, t = 0;          // current phase
+    int ptile = NT - 1, pt = -1;  // previous phase (dummy before the first: accP = 0 -> h = c = 0, a no-op update)
+
+    // p == nphase is a drain iteration: its MFMAs run on a dummy tile, its gate math finishes the last real phase.
+    for (int p = 0; p <= nphase; ++p) {
+        // stage the next code chunk one full chunk ahead (visible long before its first use, barriers in between)
+        // (tile 1, not 0: the gate math of phase (t, 0) still reads the chunk that this overwrites)
+        if (tile == 1 && (t % TC) == 0) {
+            const int chunk = t / TC + 1;
+            if (chunk * TC < tmax + 1) rd_stage_codes(S, rb, chunk);
+        }
+        const int ntile = tile + 1 == NT ? 0 : tile + 1;
+        const int nt = tile + 1 == NT ? t + 1 : t;
+
+        // ---- LDS prefetch: A fragments of the next phase (written >= 2 barriers ago) -----------
+        f32x4 hN[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) hN[m] = *reinterpret_cast<const f32x4 *>(&S.Hs[ntile][l15][16 * m + 4 * q]);
+
+        // ---- MFMA: 256 x v_mfma_f32_16x16x4_f32, 8 independent accumulators ---------------------
+        f32x4 acc[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[c] = f32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float a = hA[m][j];
+#pragma unroll
+                for (int c = 0; c < 8; ++c)
+                    acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Wr[c][m * 4 + j], acc[c], 0, 0, 0);
+            }
+        }
+
+        // ---- gate math of the previous phase (VALU, overlaps the MFMAs above) -------------------
+        {
+            const int ptc = pt < 0 ? 0 : pt;
+            const uint32_t cw = *reinterpret_cast<const uint32_t *>(&S.codes[(ptc / TC) & 1][ptc % TC][ptile * 16 + 4 * q]);
+            const int4 Tr = *reinterpret_cast<const int4 *>(&S.T[ptile * 16 + 4 * q]);
+            const int Tq[4] = {Tr.x, Tr.y, Tr.z, Tr.w};
+            f32x4 cs[2] = {S.cA[ptile][tid], S.cB[ptile][tid]};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int code = pt < 0 ? 4 : (int)((cw >> (8 * r)) & 0xff);
+                const float *lrow = &S.lut[code][32 * wave + l15];
+                const bool last = (pt == Tq[r] - 1);
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const float gi = accP[0 + s][r] + lrow[0 * HID + 16 * s];
+                    const float gf = accP[2 + s][r] + lrow[1 * HID + 16 * s];
+                    const float gg = accP[4 + s][r] + lrow[2 * HID + 16 * s];
+                    const float go = accP[6 + s][r] + lrow[3 * HID + 16 * s];
+                    float cn = __builtin_fmaf(rd_sigmoid(gf), cs[s][r], rd_sigmoid(gi) * rd_tanh(gg));
+                    float h = rd_sigmoid(go) * rd_tanh(cn);
+                    cn = pt < 0 ? 0.0f : cn;     // the dummy phase before t = 0 must leave the zero state untouched
+                    h = pt < 0 ? 0.0f : h;
+                    cs[s][r] = cn;
+                    const int row = 4 * q + r, u = 32 * wave + 16 * s + l15;
+                    S.Hs[ptile][row][u] = h;
+                    float *dst = last ? &S.Hl[ptile][row][u] : &S.dummy[tid];
+                    *dst = h;
+                }
+            }
+            S.cA[ptile][tid] = cs[0];
+            S.cB[ptile][tid] = cs[1];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 8; ++c) accP[c] = acc[c];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) hA[m] = hN[m];
+        ptile = tile; pt = t; tile = ntile; t = nt;
+    }
+
+    // ---- epilogue: FC + reverse table + argmax ----------------------------------------------------
+    rd_fc_epilogue(
+        BT, [&](int row, int u) { return S.Hl[row >> 4][row & 15][u]; }, S.T, S.off, S.orig, &S.wout[0][0], d, rb, logits, labels);
+}
+
+// ------------------------------------------------------------------------------------------------
+// rd_lstm_simple_kernel - plain fp32 FMA statement of the same function (cross-check / bring-up).
+// 512 threads = one per gate column, 8 reads per workgroup, W_hh^T streamed from L2 every step.
+// ------------------------------------------------------------------------------------------------
+constexpr int SB = 8;
+__global__ __launch_bounds__(512) void rd_lstm_simple_kernel(DevModel d, ReadBatch rb, float *__restrict__ logits,
+                                                             uint8_t *__restrict__ labels) {
+    __shared__ float h[SB][HID], c[SB][HID], hl[SB][HID], g[SB][G4], s_wout[2 * HID];
+    __shared__ int T[SB], orig[SB], tmax_s;
+    __shared__ long long off[SB];
+    const int tid = threadIdx.x;
+    if (tid < SB) {
+        const int64_t gi = (int64_t)blockIdx.x * SB + tid;
+        int Ti = 0, o = -1;
+        long long of = 0;
+        if (gi < rb.n) { o = rb.order ? rb.order[gi] : (int)gi; Ti = rd_T(rb.len, o, rb.max_len); of = rb.off[o]; }
+        T[tid] = Ti; orig[tid] = o; off[tid] = of;
+    }
+    if (tid == 0) tmax_s = 0;
+    for (int i = tid; i < SB * HID; i += 512) { (&h[0][0])[i] = 0; (&c[0][0])[i] = 0; (&hl[0][0])[i] = 0; }
+    if (tid < 256) s_wout[tid] = d.w_out[(tid >> 7) * 256 + (tid & 127)];
+    __syncthreads();
+    if (tid < SB) atomicMax(&tmax_s, T[tid]);
+    __syncthreads();
+    const int tmax = tmax_s;
+    for (int t = 0; t < tmax; ++t) {
+        float a[SB];
+#pragma unroll
+        for (int r = 0; r < SB; ++r) {
+            int code = 4;
+            if (t < T[r]) code = rd_code(rb.arena[off[r] + t]);
+            a[r] = d.in_lut[code * G4 + tid];
+        }
+        for (int k = 0; k < HID; ++k) {
+            const float w = d.wt_hh[k * G4 + tid];
+#pragma unroll
+            for (int r = 0; r < SB; ++r) a[r] = __builtin_fmaf(h[r][k], w, a[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < SB; ++r) g[r][tid] = a[r];
+        __syncthreads();
+        for (int cell = tid; cell < SB * HID; cell += 512) {
+            const int r = cell / HID, u = cell % HID;
+            const float ig = rd_sigmoid(g[r][u]), fg = rd_sigmoid(g[r][HID + u]), gg = rd_tanh(g[r][2 * HID + u]);
+            const float og = rd_sigmoid(g[r][3 * HID + u]);
+            const float cn = __builtin_fmaf(fg, c[r][u], ig * gg);
+            const float hn = og * rd_tanh(cn);
+            c[r][u] = cn; h[r][u] = hn;
+            if (t == T[r] - 1) hl[r][u] = hn;
+        }
+        __syncthreads();
+    }
+    rd_fc_epilogue(
+        SB, [&](int row, int u) { return hl[row][u]; }, T, off, orig, s_wout, d, rb, logits, labels);
+}
+
+// ------------------------------------------------------------------------------------------------
+// standalone encoders (reference tensor layouts). HBM-bound streaming kernels.
+// ------------------------------------------------------------------------------------------------
+// codes[n][stride] u8: one workgroup row-block per read group; consecutive lanes walk consecutive bases.
+__global__ void rd_encode_codes_kernel(const uint8_t *__restrict__ arena, const int64_t *__restrict__ off,
+                                       const int32_t *__restrict__ len, int64_t n, int max_len, int stride,
+                                       uint8_t *__restrict__ codes) {
+    // one wave per read, grid-stride over reads; 64 consecutive bytes per wave instruction
+    const int lane = threadIdx.x & 63;
+    const int64_t wave_id = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t i = wave_id; i < n; i += nwaves) {
+        const int T = rd_T(len, i, max_len);
+        const uint8_t *src = arena + off[i];
+        uint8_t *dst = codes + (size_t)i * stride;
+        for (int j = lane; j < stride; j += 64) dst[j] = (uint8_t)(j < T ? rd_code(src[j]) : 4);
+    }
+}
+
+// onehot[n][max_len][4] fp32 (encode_variable_len_read): one lane per (read, base) -> one float4 store (16 B/lane)
+__global__ void rd_encode_onehot_padded_kernel(const uint8_t *__restrict__ arena, const int64_t *__restrict__ off,
+                                               const int32_t *__restrict__ len, int64_t n, int max_len,
+                                               f32x4 *__restrict__ out) {
+    const int64_t total = n * (int64_t)max_len;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = e / max_len;
+        const int j = (int)(e % max_len);
+        int code = 4;
+        if (j < rd_T(len, i, max_len)) code = rd_code(arena[off[i] + j]);
+        out[e] = f32x4{code == 0 ? 1.f : 0.f, code == 1 ? 1.f : 0.f, code == 2 ? 1.f : 0.f, code == 3 ? 1.f : 0.f};
+    }
+}
+
+// PackedSequence.data [sum T][4]: row(t, j) = cum[t] + j with cum[t] = sum_{t'<t} batch_sizes[t'].
+// One workgroup per timestep slab: lanes walk the sorted reads (coalesced 16-B stores).
+__global__ void rd_pack_onehot_kernel(const uint8_t *__restrict__ arena, const int64_t *__restrict__ off,
+                                      const int32_t *__restrict__ len, int max_len, const int64_t *__restrict__ sorted_idx,
+                                      const int64_t *__restrict__ batch_sizes, f32x4 *__restrict__ data) {
+    const int t = blockIdx.y;
+    const int64_t bs = batch_sizes[t];
+    __shared__ int64_t s_base;
+    if (threadIdx.x == 0) {
+        int64_t b = 0;
+        for (int tt = 0; tt < t; ++tt) b += batch_sizes[tt];
+        s_base = b;
+    }
+    __syncthreads();
+    const int64_t base = s_base;
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < bs; j += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = sorted_idx[j];
+        const int code = rd_code(arena[off[i] + t]);
+        data[base + j] = f32x4{code == 0 ? 1.f : 0.f, code == 1 ? 1.f : 0.f, code == 2 ? 1.f : 0.f, code == 3 ? 1.f : 0.f};
+    }
+    (void)len; (void)max_len;
+}
+
+// ------------------------------------------------------------------------------------------------
+// label logic
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void rd_block_count3(unsigned c0, unsigned c1, unsigned c2, uint64_t *counts) {
+    for (int o = 32; o > 0; o >>= 1) { c0 += __shfl_down(c0, o); c1 += __shfl_down(c1, o); c2 += __shfl_down(c2, o); }
+    __shared__ unsigned sh[3];
+    if (threadIdx.x < 3) sh[threadIdx.x] = 0;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&sh[0], c0); atomicAdd(&sh[1], c1); atomicAdd(&sh[2], c2); }
+    __syncthreads();
+    if (threadIdx.x < 3 && sh[threadIdx.x]) atomicAdd((unsigned long long *)&counts[threadIdx.x], (unsigned long long)sh[threadIdx.x]);
+}
+
+// detect.py:616-663
+__global__ void rd_pair_fuse_kernel(const float2 *__restrict__ l1, const float2 *__restrict__ l2, int64_t n, int mode,
+                                    int8_t *__restrict__ out, uint64_t *__restrict__ counts) {
+    unsigned c0 = 0, c1 = 0, c2 = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float2 a = l1[i], b = l2[i];
+        const int la = a.y > a.x, lb = b.y > b.x;
+        int f;
+        if (mode == RD_ENSURE_RRNA) f = (la & lb);
+        else if (mode == RD_ENSURE_NORRNA) f = (la | lb);
+        else if (mode == RD_ENSURE_BOTH) f = (la == lb) ? la : -1;
+        else f = __fadd_rn(a.y, b.y) > __fadd_rn(a.x, b.x) ? 1 : 0;   // argmax(r1_outs + r2_outs), :657
+        out[i] = (int8_t)f;
+        c0 += f == 0; c1 += f == 1; c2 += f < 0;
+    }
+    if (counts) rd_block_count3(c0, c1, c2, counts);
+}
+
+__global__ void rd_count_kernel(const uint8_t *__restrict__ labels, int64_t n, uint64_t *__restrict__ counts) {
+    unsigned c0 = 0, c1 = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int f = labels[i];
+        c0 += f == 0; c1 += f == 1;
+    }
+    rd_block_count3(c0, c1, 0, counts);
+}
+
+// ------------------------------------------------------------------------------------------------
+// host helpers
+// ------------------------------------------------------------------------------------------------
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+struct SortPlan {
+    int nblk;
+    size_t hist_bytes, order_bytes, lenstart_bytes, total;
+};
+inline SortPlan sort_plan(int64_t n, int max_len) {
+    SortPlan p;
+    p.nblk = (int)((n + SORT_ITEMS - 1) / SORT_ITEMS);
+    if (p.nblk < 1) p.nblk = 1;
+    p.hist_bytes = align_up((size_t)(max_len + 1) * p.nblk * sizeof(uint32_t), 256);
+    p.order_bytes = align_up((size_t)(n > 0 ? n : 1) * sizeof(int32_t), 256);
+    p.lenstart_bytes = align_up((size_t)(max_len + 1) * sizeof(int64_t) * 2, 256);   // len_start + cum scratch
+    p.total = p.hist_bytes + p.order_bytes + p.lenstart_bytes;
+    return p;
+}
+
+constexpr int MAX_LEN_LIMIT = 16000;   // LDS histogram of max_len+1 uint32 must fit in 64 KB
+
+int run_sort(const int32_t *seq_len, int64_t n, int max_len, void *workspace, size_t wbytes, int32_t *&order,
+             int64_t *sorted_idx, int64_t *unsorted_idx, int64_t *batch_sizes, int64_t *total_steps, int64_t *&len_start,
+             hipStream_t st) {
+    SortPlan p = sort_plan(n, max_len);
+    if (wbytes < p.total) RD_FAIL(RD_E_WORKSPACE, "workspace too small: %zu < %zu", wbytes, p.total);
+    char *w = (char *)workspace;
+    uint32_t *hist = (uint32_t *)w;
+    order = (int32_t *)(w + p.hist_bytes);
+    len_start = (int64_t *)(w + p.hist_bytes + p.order_bytes);
+    const size_t sh = (size_t)(max_len + 1) * sizeof(uint32_t);
+    hipLaunchKernelGGL(rd_len_hist_kernel, dim3(p.nblk), dim3(SORT_BLOCK), sh, st, seq_len, n, max_len, p.nblk, hist);
+    hipLaunchKernelGGL(rd_len_scan_kernel, dim3(1), dim3(SORT_BLOCK), 0, st, hist, max_len, p.nblk, len_start, batch_sizes,
+                       total_steps);
+    hipLaunchKernelGGL(rd_len_scatter_kernel, dim3(p.nblk), dim3(SORT_BLOCK), sh, st, seq_len, n, max_len, p.nblk, hist, order,
+                       sorted_idx, unsorted_idx);
+    RD_HIP(hipGetLastError());
+    return RD_OK;
+}
+
+}  // namespace
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" {
+
+const char *rd_last_error(void) { return g_err; }
+const char *rd_version(void) { return "ribodetector_amd 0.1.0 (gfx950)"; }
+
+int rd_model_create(const rd_weights *w, int device, rd_model **out) {
+    if (!w || !out) RD_FAIL(RD_E_INVALID, "rd_model_create: null argument");
+    if (w->input_size != 4 || w->hidden_size != HID || w->num_classes != 2)
+        RD_FAIL(RD_E_UNSUPPORTED, "rd_model_create: kernels cover input_size=4, hidden_size=128, num_classes=2 (got %d,%d,%d)",
+                w->input_size, w->hidden_size, w->num_classes);
+    const float *src[10] = {w->w_ih, w->w_hh, w->b_ih, w->b_hh, w->w_ih_r, w->w_hh_r, w->b_ih_r, w->b_hh_r, w->w_out, w->b_out};
+    const int offs[11] = {OFF_WIH, OFF_WHH, OFF_BIH, OFF_BHH, OFF_WIHR, OFF_WHHR, OFF_BIHR, OFF_BHHR, OFF_WOUT, OFF_BOUT, RAW_FLOATS};
+    for (int i = 0; i < 10; ++i)
+        if (!src[i]) RD_FAIL(RD_E_INVALID, "rd_model_create: weight pointer %d is null", i);
+    RD_HIP(hipSetDevice(device));
+    rd_model *m = new rd_model();
+    memset(m, 0, sizeof(*m));
+    m->device = device;
+    m->variant = RD_VARIANT_MFMA_F32;
+    float *host = new float[RAW_FLOATS];
+    for (int i = 0; i < 10; ++i) memcpy(host + offs[i], src[i], sizeof(float) * (size_t)(offs[i + 1] - offs[i]));
+    hipError_t e = hipSuccess;
+    auto A = [&](void **p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes); };
+    A((void **)&m->d.raw, sizeof(float) * RAW_FLOATS);
+    A((void **)&m->d.wpack32, sizeof(float) * 4 * 8 * 32 * 64);
+    A((void **)&m->d.wt_hh, sizeof(float) * HID * G4);
+    A((void **)&m->d.in_lut, sizeof(float) * 5 * G4);
+    A((void **)&m->d.rev_lut, sizeof(float) * 10);
+    A((void **)&m->d.w_out, sizeof(float) * 512);
+    A((void **)&m->d.b_out, sizeof(float) * 2);
+    if (e == hipSuccess) e = hipMemcpy(m->d.raw, host, sizeof(float) * RAW_FLOATS, hipMemcpyHostToDevice);
+    delete[] host;
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(rd_prep_kernel, dim3(64), dim3(256), 0, 0, m->d);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) {
+        snprintf(g_err, sizeof(g_err), "rd_model_create: %s", hipGetErrorString(e));
+        rd_model_destroy(m);
+        return RD_E_HIP;
+    }
+    *out = m;
+    return RD_OK;
+}
+
+void rd_model_destroy(rd_model *m) {
+    if (!m) return;
+    hipSetDevice(m->device);
+    hipFree(m->d.raw); hipFree(m->d.wpack32); hipFree(m->d.wt_hh); hipFree(m->d.in_lut);
+    hipFree(m->d.rev_lut); hipFree(m->d.w_out); hipFree(m->d.b_out);
+    if (m->d.wpack16) hipFree(m->d.wpack16);
+    for (int i = 0; i < 2 * 512; ++i)
+        if (m->prof_ev[i]) hipEventDestroy(m->prof_ev[i]);
+    delete m;
+}
+
+int rd_set_variant(rd_model *m, int variant) {
+    if (!m) RD_FAIL(RD_E_INVALID, "rd_set_variant: null model");
+    if (variant == RD_VARIANT_AUTO) variant = RD_VARIANT_MFMA_F32;
+    if (variant != RD_VARIANT_MFMA_F32 && variant != RD_VARIANT_SIMPLE)
+        RD_FAIL(RD_E_UNSUPPORTED, "rd_set_variant: variant %d not available in this build", variant);
+    m->variant = variant;
+    return RD_OK;
+}
+
+size_t rd_classify_workspace_bytes(int64_t n, int32_t max_len) {
+    if (n < 0 || max_len < 1) return 0;
+    return sort_plan(n, max_len).total;
+}
+
+int rd_profile_enable(rd_model *m, int enable) {
+    if (!m) RD_FAIL(RD_E_INVALID, "rd_profile_enable: null model");
+    m->prof_enabled = enable;
+    m->prof_count = 0;
+    m->prof_ms_accum = 0;
+    m->prof_launches_accum = 0;
+    return RD_OK;
+}
+
+static int rd_profile_drain(rd_model *m) {
+    for (int i = 0; i < m->prof_count; ++i) {
+        float ms = 0;
+        RD_HIP(hipEventSynchronize(m->prof_ev[2 * i + 1]));
+        RD_HIP(hipEventElapsedTime(&ms, m->prof_ev[2 * i], m->prof_ev[2 * i + 1]));
+        m->prof_ms_accum += ms;
+        m->prof_launches_accum += 1;
+    }
+    m->prof_count = 0;
+    return RD_OK;
+}
+
+int rd_profile_read(rd_model *m, int64_t *launches, double *total_ms) {
+    if (!m) RD_FAIL(RD_E_INVALID, "rd_profile_read: null model");
+    int rc = rd_profile_drain(m);
+    if (rc) return rc;
+    if (launches) *launches = m->prof_launches_accum;
+    if (total_ms) *total_ms = m->prof_ms_accum;
+    return RD_OK;
+}
+
+int rd_classify(const rd_model *cm, const uint8_t *arena, const int64_t *seq_off, const int32_t *seq_len, int64_t n,
+                int32_t max_len, float *logits, uint8_t *labels, void *workspace, size_t workspace_bytes, void *stream) {
+    rd_model *m = const_cast<rd_model *>(cm);
+    if (!m || !logits) RD_FAIL(RD_E_INVALID, "rd_classify: null model or logits");
+    if (n < 0 || n > 0x7fffffffLL) RD_FAIL(RD_E_INVALID, "rd_classify: n=%lld out of range", (long long)n);
+    if (max_len < 1 || max_len > MAX_LEN_LIMIT) RD_FAIL(RD_E_INVALID, "rd_classify: max_len=%d out of range [1,%d]", max_len, MAX_LEN_LIMIT);
+    if (n == 0) return RD_OK;
+    if (!arena || !seq_off || !seq_len || !workspace) RD_FAIL(RD_E_INVALID, "rd_classify: null input pointer");
+    hipStream_t st = (hipStream_t)stream;
+    int32_t *order = nullptr;
+    int64_t *len_start = nullptr;
+    int rc = run_sort(seq_len, n, max_len, workspace, workspace_bytes, order, nullptr, nullptr, nullptr, nullptr, len_start, st);
+    if (rc) return rc;
+    ReadBatch rb{arena, seq_off, seq_len, order, n, max_len};
+    hipEvent_t *ev = nullptr;
+    if (m->prof_enabled) {
+        if (m->prof_count == 512) { rc = rd_profile_drain(m); if (rc) return rc; }
+        ev = &m->prof_ev[2 * m->prof_count];
+        for (int i = 0; i < 2; ++i)
+            if (!ev[i]) RD_HIP(hipEventCreate(&ev[i]));
+        RD_HIP(hipEventRecord(ev[0], st));
+    }
+    if (m->variant == RD_VARIANT_SIMPLE) {
+        const int64_t nwg = (n + SB - 1) / SB;
+        hipLaunchKernelGGL(rd_lstm_simple_kernel, dim3((unsigned)nwg), dim3(512), 0, st, m->d, rb, logits, labels);
+    } else {
+        const int64_t nwg = (n + BT - 1) / BT;
+        hipLaunchKernelGGL(rd_lstm_mfma_f32_kernel, dim3((unsigned)nwg), dim3(256), 0, st, m->d, rb, logits, labels);
+    }
+    RD_HIP(hipGetLastError());
+    if (ev) { RD_HIP(hipEventRecord(ev[1], st)); m->prof_count++; }
+    return RD_OK;
+}
+
+int rd_pair_fuse(const float *logits1, const float *logits2, int64_t n, int32_t ensure_mode, int8_t *pair_labels,
+                 uint64_t *counts, void *stream) {
+    if (n < 0 || ensure_mode < 0 || ensure_mode > 3) RD_FAIL(RD_E_INVALID, "rd_pair_fuse: bad n or ensure_mode");
+    if (n == 0) return RD_OK;
+    if (!logits1 || !logits2 || !pair_labels) RD_FAIL(RD_E_INVALID, "rd_pair_fuse: null pointer");
+    int64_t nb = (n + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(rd_pair_fuse_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const float2 *)logits1,
+                       (const float2 *)logits2, n, ensure_mode, pair_labels, counts);
+    RD_HIP(hipGetLastError());
+    return RD_OK;
+}
+
+int rd_count_labels(const uint8_t *labels, int64_t n, uint64_t *counts, void *stream) {
+    if (n < 0) RD_FAIL(RD_E_INVALID, "rd_count_labels: bad n");
+    if (n == 0) return RD_OK;
+    if (!labels || !counts) RD_FAIL(RD_E_INVALID, "rd_count_labels: null pointer");
+    int64_t nb = (n + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(rd_count_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, labels, n, counts);
+    RD_HIP(hipGetLastError());
+    return RD_OK;
+}
+
+int rd_encode_codes(const uint8_t *arena, const int64_t *seq_off, const int32_t *seq_len, int64_t n, int32_t max_len,
+                    int32_t stride, uint8_t *codes, void *stream) {
+    if (n < 0 || max_len < 1 || stride < max_len) RD_FAIL(RD_E_INVALID, "rd_encode_codes: bad n/max_len/stride");
+    if (n == 0) return RD_OK;
+    if (!arena || !seq_off || !seq_len || !codes) RD_FAIL(RD_E_INVALID, "rd_encode_codes: null pointer");
+    int64_t nb = (n + 3) / 4;   // 4 waves (reads) per block per pass
+    if (nb > 256 * 32) nb = 256 * 32;
+    hipLaunchKernelGGL(rd_encode_codes_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, arena, seq_off, seq_len, n,
+                       max_len, stride, codes);
+    RD_HIP(hipGetLastError());
+    return RD_OK;
+}
+
+int rd_encode_onehot_padded(const uint8_t *arena, const int64_t *seq_off, const int32_t *seq_len, int64_t n,
+                            int32_t max_len, float *onehot, void *stream) {
+    if (n < 0 || max_len < 1) RD_FAIL(RD_E_INVALID, "rd_encode_onehot_padded: bad n/max_len");
+    if (n == 0) return RD_OK;
+    if (!arena || !seq_off || !seq_len || !onehot) RD_FAIL(RD_E_INVALID, "rd_encode_onehot_padded: null pointer");
+    int64_t nb = (n * max_len + 255) / 256;
+    if (nb > 256 * 32) nb = 256 * 32;
+    hipLaunchKernelGGL(rd_encode_onehot_padded_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, arena, seq_off,
+                       seq_len, n, max_len, (f32x4 *)onehot);
+    RD_HIP(hipGetLastError());
+    return RD_OK;
+}
+
+int rd_pack_plan(const int32_t *seq_len, int64_t n, int32_t max_len, int64_t *sorted_idx, int64_t *unsorted_idx,
+                 int64_t *batch_sizes, int64_t *total_steps, void *workspace, size_t workspace_bytes, void *stream) {
+    if (n < 1 || max_len < 1 || max_len > MAX_LEN_LIMIT) RD_FAIL(RD_E_INVALID, "rd_pack_plan: bad n/max_len");
+    if (!seq_len || !sorted_idx || !unsorted_idx || !batch_sizes || !total_steps || !workspace)
+        RD_FAIL(RD_E_INVALID, "rd_pack_plan: null pointer");
+    int32_t *order = nullptr;
+    int64_t *len_start = nullptr;
+    return run_sort(seq_len, n, max_len, workspace, workspace_bytes, order, sorted_idx, unsorted_idx, batch_sizes, total_steps,
+                    len_start, (hipStream_t)stream);
+}
+
+int rd_pack_onehot(const uint8_t *arena, const int64_t *seq_off, const int32_t *seq_len, int64_t n, int32_t max_len,
+                   const int64_t *sorted_idx, const int64_t *batch_sizes, float *data, void *stream) {
+    if (n < 1 || max_len < 1) RD_FAIL(RD_E_INVALID, "rd_pack_onehot: bad n/max_len");
+    if (!arena || !seq_off || !seq_len || !sorted_idx || !batch_sizes || !data) RD_FAIL(RD_E_INVALID, "rd_pack_onehot: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    int64_t nbx = (n + 255) / 256;
+    if (nbx > 1024) nbx = 1024;
+    hipLaunchKernelGGL(rd_pack_onehot_kernel, dim3((unsigned)nbx, (unsigned)max_len), dim3(256), 0, st, arena, seq_off, seq_len,
+                       max_len, sorted_idx, batch_sizes, (f32x4 *)data);
+    RD_HIP(hipGetLastError());
+    return RD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,217 @@
+"""SeqModel - drop-in for the reference's `ribodetector.model.model.SeqModel` (model/model.py:10-37) on MI355X.
+
+Same constructor arguments (`config.json: arch.args`), same `load_state_dict` tensor names/shapes, same call:
+`model.to('cuda'); model.eval(); logits = model(packed_sequence)` -> fp32 Tensor[B,2] in input order.
+The arithmetic runs in hand-written HIP kernels behind the C ABI (include/ribodetector_amd.h); there is no
+torch.nn.LSTM inside and no CPU fallback.
+
+Two entries:
+  * `forward(x: PackedSequence)`  - API parity with the reference (the one-hot tensor is turned back into bases);
+  * `classify_bytes(arena, offsets, lens, max_len)` - the native fast entry: raw ASCII reads resident in HBM,
+    encoder + recurrence + FC + argmax fused on the device.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+from torch.nn.utils.rnn import PackedSequence
+
+from .. import _native as N
+
+STATE_KEYS = ["rnn.weight_ih_l0", "rnn.weight_hh_l0", "rnn.bias_ih_l0", "rnn.bias_hh_l0",
+              "rnn.weight_ih_l0_reverse", "rnn.weight_hh_l0_reverse", "rnn.bias_ih_l0_reverse",
+              "rnn.bias_hh_l0_reverse", "out.weight", "out.bias"]
+
+
+class SeqModel:
+    def __init__(self, input_size, hidden_size, num_layers, num_classes, batch_first=True, bidirectional=True,
+                 pack_seq=True):
+        # the kernels cover exactly the shipped architecture (reference config.json:4-15); anything else is an error,
+        # never a silent fallback.
+        if num_layers != 1:
+            raise NotImplementedError("SeqModel: num_layers=%r is not covered by the HIP kernels (only 1)" % (num_layers,))
+        if not bidirectional:
+            raise NotImplementedError("SeqModel: bidirectional=False is not covered by the HIP kernels")
+        if not pack_seq:
+            raise NotImplementedError("SeqModel: pack_seq=False (reference forward2, padded input) is not covered; "
+                                      "config.json ships pack_seq=true")
+        if input_size != 4 or hidden_size != 128 or num_classes != 2:
+            raise NotImplementedError("SeqModel: kernels are built for input_size=4, hidden_size=128, num_classes=2")
+        self.input_size, self.hidden_size, self.num_layers, self.num_classes = input_size, hidden_size, num_layers, num_classes
+        self.batch_first, self.bidirectional, self.pack_seq = batch_first, bidirectional, pack_seq
+        H4, H = 4 * hidden_size, hidden_size
+        self._shapes = dict(zip(STATE_KEYS, [(H4, input_size), (H4, H), (H4,), (H4,), (H4, input_size), (H4, H), (H4,), (H4,),
+                                             (num_classes, 2 * H), (num_classes,)]))
+        self._state = None
+        self._handle = None
+        self.device = None
+        self._variant = "auto"
+        self._ws = None
+        self.training = True
+
+    # ---- weights ---------------------------------------------------------------------------------
+    def load_state_dict(self, state_dict, strict=True):
+        sd = {}
+        missing = [k for k in STATE_KEYS if k not in state_dict]
+        unexpected = [k for k in state_dict if k not in STATE_KEYS]
+        if missing or (strict and unexpected):
+            raise RuntimeError("Error(s) in loading state_dict for SeqModel: Missing key(s): %s. Unexpected key(s): %s."
+                               % (missing, unexpected))
+        for k in STATE_KEYS:
+            v = state_dict[k]
+            a = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            if a.shape != self._shapes[k]:
+                raise RuntimeError("size mismatch for %s: got %s, expected %s" % (k, a.shape, self._shapes[k]))
+            sd[k] = a
+        self._state = sd
+        if self._handle is not None:
+            self._create()
+        return self
+
+    def state_dict(self):
+        if self._state is None:
+            raise RuntimeError("SeqModel: no weights loaded")
+        return {k: torch.from_numpy(v.copy()) for k, v in self._state.items()}
+
+    def _destroy(self):
+        if self._handle is not None:
+            N.lib().rd_model_destroy(self._handle)
+            self._handle = None
+
+    def _create(self):
+        self._destroy()
+        if self._state is None:
+            raise RuntimeError("SeqModel.to(): call load_state_dict() first")
+        w = N.RdWeights(*[self._state[k].ctypes.data_as(C.POINTER(C.c_float)) for k in STATE_KEYS],
+                        self.input_size, self.hidden_size, self.num_classes)
+        h = C.c_void_p()
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        N.check(N.lib().rd_model_create(C.byref(w), idx, C.byref(h)), "rd_model_create")
+        self._handle = h
+        self.set_variant(self._variant)
+
+    def to(self, device, non_blocking=False):
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("SeqModel runs on the GPU only (HIP kernels); got device %r. "
+                               "The reference's CPU product is `ribodetector_cpu`." % (device,))
+        if not torch.cuda.is_available():
+            raise RuntimeError("No visible ROCm/HIP device")
+        self.device = device
+        self._create()
+        return self
+
+    def cuda(self, device=None):
+        return self.to("cuda" if device is None else "cuda:%d" % device)
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def set_variant(self, name):
+        self._variant = name
+        if self._handle is not None:
+            N.check(N.lib().rd_set_variant(self._handle, N.VARIANTS[name]), "rd_set_variant")
+        return self
+
+    def __del__(self):
+        try:
+            self._destroy()
+        except Exception:
+            pass
+
+    # ---- native fast entry --------------------------------------------------------------------------
+    def _workspace(self, n, max_len):
+        need = int(N.lib().rd_classify_workspace_bytes(n, max_len))
+        if self._ws is None or self._ws.numel() < need or self._ws.device != self.device:
+            self._ws = torch.empty(max(need, 1 << 16), dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def classify_bytes(self, arena, offsets, lens, max_len, want_labels=True, logits=None, labels=None):
+        """arena uint8[*] (ASCII), offsets int64[n] (start of read i), lens int32[n]; all on self.device.
+        Returns (logits fp32[n,2], labels uint8[n] | None), row i <-> read i. Asynchronous on the current stream."""
+        if self._handle is None:
+            raise RuntimeError("SeqModel: call .to('cuda') before inference")
+        n = int(lens.numel())
+        for t, dt, nm in ((arena, torch.uint8, "arena"), (offsets, torch.int64, "offsets"), (lens, torch.int32, "lens")):
+            if t.dtype != dt or not t.is_cuda or not t.is_contiguous():
+                raise TypeError("classify_bytes: %s must be a contiguous %s CUDA tensor" % (nm, dt))
+        if offsets.numel() < n:
+            raise ValueError("classify_bytes: offsets shorter than lens")
+        if logits is None:
+            logits = torch.empty((n, 2), dtype=torch.float32, device=self.device)
+        if want_labels and labels is None:
+            labels = torch.empty((n,), dtype=torch.uint8, device=self.device)
+        ws = self._workspace(n, max_len)
+        N.check(N.lib().rd_classify(self._handle, N.ptr(arena), N.ptr(offsets), N.ptr(lens), n, int(max_len), N.ptr(logits),
+                                    N.ptr(labels if want_labels else None), N.ptr(ws), ws.numel(), N.stream_ptr(self.device)),
+                "rd_classify")
+        return logits, (labels if want_labels else None)
+
+    # ---- reference-compatible call --------------------------------------------------------------------
+    def forward(self, x):
+        """x: PackedSequence of one-hot fp32 rows [sum T, 4] (what the reference collate builds, detect.py:681-685).
+        Returns logits fp32[B,2] in the original (unsorted) batch order, like forward1 + last_items(unsort=True)."""
+        if not isinstance(x, PackedSequence):
+            raise TypeError("SeqModel.forward expects a PackedSequence (config pack_seq=true); got %s" % type(x).__name__)
+        if self._handle is None:
+            raise RuntimeError("SeqModel: call .to('cuda') before inference")
+        dev = self.device
+        data = x.data.to(dev, non_blocking=True)
+        if data.dim() != 2 or data.shape[1] != 4:
+            raise ValueError("SeqModel.forward: PackedSequence.data must be [sum T, 4]")
+        bs = x.batch_sizes.to(torch.int64).cpu()
+        tmax, n, total = int(bs.numel()), int(bs[0]), int(data.shape[0])
+        # rows must be one-hot or all-zero: that is the only input the reference encoder can produce
+        rs, mx = data.sum(1), data.max(1)
+        ok = ((rs == 1) & (mx.values == 1)) | ((rs == 0) & (data.abs().sum(1) == 0))
+        if not bool(ok.all()):
+            raise ValueError("SeqModel.forward: input rows must be one-hot (A,C,G,T) or all-zero")
+        code = torch.where(rs == 1, mx.indices, torch.full_like(mx.indices, 4))
+        ascii_ = torch.tensor(list(b"ACGTN"), dtype=torch.uint8, device=dev)[code]
+        bs_d = bs.to(dev)
+        t_of_row = torch.repeat_interleave(torch.arange(tmax, device=dev), bs_d, output_size=total)
+        cum = torch.cumsum(bs_d, 0) - bs_d
+        j_of_row = torch.arange(total, device=dev) - cum[t_of_row]
+        sorted_idx = x.sorted_indices.to(dev) if x.sorted_indices is not None else torch.arange(n, device=dev)
+        orig = sorted_idx[j_of_row]
+        arena = torch.full((n, tmax), ord("N"), dtype=torch.uint8, device=dev)
+        arena[orig, t_of_row] = ascii_
+        len_sorted = (bs_d[None, :] > torch.arange(n, device=dev)[:, None]).sum(1)
+        lens = torch.empty(n, dtype=torch.int32, device=dev)
+        lens[sorted_idx] = len_sorted.to(torch.int32)
+        offsets = torch.arange(n, dtype=torch.int64, device=dev) * tmax
+        logits, _ = self.classify_bytes(arena.reshape(-1), offsets, lens, tmax, want_labels=False)
+        return logits
+
+    __call__ = forward
+
+    # ---- profiling hooks for bench.py ---------------------------------------------------------------
+    def profile_enable(self, on=True):
+        N.check(N.lib().rd_profile_enable(self._handle, 1 if on else 0), "rd_profile_enable")
+
+    def profile_read(self):
+        n, ms = C.c_int64(0), C.c_double(0)
+        N.check(N.lib().rd_profile_read(self._handle, C.byref(n), C.byref(ms)), "rd_profile_read")
+        return int(n.value), float(ms.value)
+
+    def __str__(self):
+        return "SeqModel(BiLSTM 4->128 x2, Linear 256->2) [HIP/gfx950]\nTrainable parameters: 137730"
+
+
+def pair_fuse(logits1, logits2, ensure, counts=None):
+    """Pair label logic of reference detect.py:616-663 on the device. Returns int8[n] in {0,1,-1};
+    `counts` (uint64... stored as int64[3] tensor) is added to when given."""
+    n = int(logits1.shape[0])
+    out = torch.empty((n,), dtype=torch.int8, device=logits1.device)
+    N.check(N.lib().rd_pair_fuse(N.ptr(logits1), N.ptr(logits2), n, N.ENSURE_MODES[ensure], N.ptr(out), N.ptr(counts),
+                                 N.stream_ptr(logits1.device)), "rd_pair_fuse")
+    return out
+
+
+def count_labels(labels, counts):
+    """counts int64[3] device tensor (non-rRNA, rRNA, unclassified), added to (reference detect.py:485-486)."""
+    N.check(N.lib().rd_count_labels(N.ptr(labels), int(labels.numel()), N.ptr(counts), N.stream_ptr(labels.device)),
+            "rd_count_labels")
+    return counts

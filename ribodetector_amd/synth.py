@@ -1,0 +1,96 @@
+"""Seeded synthetic read generator (SURVEY.md §8d "Synthetic inputs").
+
+Base distribution: 90 % i.i.d. uniform ACGT reads, 10 % windows of an embedded
+rRNA-like template (E. coli 16S 5' fragment, the known-answer string of
+SURVEY.md §8c) with 5 % substitutions; 0.1 % of all bases are turned into 'N'.
+
+Two back ends with the same distribution:
+  * numpy  (`reads_numpy`)  - small fixtures, FASTQ files, the CPU-baseline sample
+  * torch  (`reads_torch`)  - 10^7..10^8 reads generated directly in HBM for bench.py
+
+The numpy stream is what the golden fixtures are generated from, so it must not
+change without regenerating tests/golden (tests/golden/make_golden.py).
+"""
+import numpy as np
+
+RRNA_16S = (
+    "AAATTGAAGAGTTTGATCATGGCTCAGATTGAACGCTGGCGGCAGGCCTAACACATGCAAGTCGAACGGTAACAGGAAGAAGCTTGCTTC"
+    "TTTGCTGACGAGTGGCGGACGGGTGAGTAATGTCTGGGAAACTGCCTGATGGAGGGGGATAACTACTGGAAACGGTAGC"
+)
+assert len(RRNA_16S) == 169
+
+_ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+_TEMPLATE = np.frombuffer(RRNA_16S.encode(), dtype=np.uint8)
+
+
+def reads_numpy(n, length, seed, rrna_frac=0.10, sub_rate=0.05, n_rate=0.001):
+    """Return (arena uint8[sum(len)], offsets int64[n+1], lens int32[n]).
+
+    `length` is an int (fixed length) or a (lo, hi) tuple (uniform integer
+    lengths, inclusive)."""
+    rng = np.random.default_rng(seed)
+    if isinstance(length, (tuple, list)):
+        lens = rng.integers(length[0], length[1] + 1, size=n, dtype=np.int64)
+    else:
+        lens = np.full(n, int(length), dtype=np.int64)
+    offsets = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(lens, out=offsets[1:])
+    total = int(offsets[-1])
+    arena = _ACGT[rng.integers(0, 4, size=total, dtype=np.int64)]
+    is_rrna = rng.random(n) < rrna_frac
+    tl = len(_TEMPLATE)
+    starts = rng.integers(0, tl, size=n, dtype=np.int64)
+    # position of every base inside its read
+    read_of = np.repeat(np.arange(n, dtype=np.int64), lens)
+    pos = np.arange(total, dtype=np.int64) - offsets[:-1][read_of]
+    sel = is_rrna[read_of]
+    tpl = _TEMPLATE[(starts[read_of] + pos) % tl]
+    keep = rng.random(total) >= sub_rate           # 5 % substitutions stay random
+    arena = np.where(sel & keep, tpl, arena)
+    arena = np.where(rng.random(total) < n_rate, np.uint8(ord("N")), arena).astype(np.uint8)
+    return arena, offsets, lens.astype(np.int32)
+
+
+def as_strings(arena, offsets):
+    b = arena.tobytes()
+    return [b[offsets[i]:offsets[i + 1]].decode() for i in range(len(offsets) - 1)]
+
+
+def write_fastq(path, arena, offsets, mate=None, prefix="syn"):
+    """4-line FASTQ, header @syn.<idx>[/mate], quality 'I' * len."""
+    import gzip
+    op = gzip.open if str(path).endswith("gz") else open
+    b = arena.tobytes()
+    with op(path, "wt") as fh:
+        for i in range(len(offsets) - 1):
+            s = b[offsets[i]:offsets[i + 1]].decode()
+            tag = "@%s.%d" % (prefix, i) + ("/%d" % mate if mate else "")
+            fh.write("%s\n%s\n+\n%s\n" % (tag, s, "I" * len(s)))
+
+
+def reads_torch(n, length, seed, device, rrna_frac=0.10, sub_rate=0.05, n_rate=0.001):
+    """Fixed-length reads generated on `device`: (arena uint8[n*length], offsets int64[n+1], lens int32[n]).
+
+    Same distribution as reads_numpy (not the same stream)."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(int(seed))
+    L = int(length)
+    acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
+    tpl = torch.tensor(list(RRNA_16S.encode()), dtype=torch.uint8, device=device)
+    arena = torch.empty(n * L, dtype=torch.uint8, device=device)
+    step = 1 << 20                                   # reads per generation block (bounds temp memory)
+    for s in range(0, n, step):
+        m = min(step, n - s)
+        base = acgt[torch.randint(0, 4, (m, L), generator=g, device=device)]
+        is_r = torch.rand(m, 1, generator=g, device=device) < rrna_frac
+        st = torch.randint(0, tpl.numel(), (m, 1), generator=g, device=device)
+        win = tpl[(st + torch.arange(L, device=device)[None, :]) % tpl.numel()]
+        keep = torch.rand(m, L, generator=g, device=device) >= sub_rate
+        base = torch.where(is_r & keep, win, base)
+        isn = torch.rand(m, L, generator=g, device=device) < n_rate
+        base = torch.where(isn, torch.full_like(base, ord("N")), base)
+        arena[s * L:(s + m) * L] = base.reshape(-1)
+    offsets = torch.arange(n + 1, dtype=torch.int64, device=device) * L
+    lens = torch.full((n,), L, dtype=torch.int32, device=device)
+    return arena, offsets, lens

@@ -1,0 +1,48 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run through gpurun)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import oracle as O
+    O.build()
+    return O.load_default()
+
+
+@pytest.fixture(scope="session")
+def golden():
+    import json
+    import numpy as np
+
+    class G:
+        def npz(self, name):
+            return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+        def json(self, name):
+            with open(os.path.join(GOLDEN, name + ".json")) as fh:
+                return json.load(fh)
+    return G()
+
+
+@pytest.fixture(scope="session")
+def gpu_model():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from ribodetector_amd.model import model as module_arch
+    from ribodetector_amd.parse_config import ConfigParser
+    cfg = ConfigParser.from_json(os.path.join(ROOT, "ribodetector_amd", "config.json"))
+    m = cfg.init_obj("arch", module_arch)
+    m.load_state_dict(cfg.load_state_dict("mcc"))
+    return m.to("cuda:0").eval()
