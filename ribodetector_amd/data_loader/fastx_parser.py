@@ -1,0 +1,216 @@
+"""FASTQ / FASTA ingest - mirror of the reference's `data_loader/fastx_parser.py:15-55` (record semantics) and of the
+chunked readers `seq_encoder.py:21-39,75-92`, re-designed so that a chunk is ONE byte arena plus offset arrays
+(what the C ABI consumes) instead of a Python list of 4-tuples of str.
+
+Record semantics kept from the reference:
+  * FASTQ: 4-line state machine, every line `rstrip()`-ed, header / '+' line / quality preserved verbatim,
+    bases NOT upper-cased (fastx_parser.py:18-37);
+  * FASTA: multi-line sequences joined and upper-cased, blank lines skipped (fastx_parser.py:39-55);
+  * gzip chosen by file extension, format by the extension before it (seq_encoder.py:21-39).
+"""
+import gzip
+import io
+from collections import namedtuple
+from mimetypes import guess_type
+from pathlib import Path
+
+import numpy as np
+
+FA_EXTS = [".fasta", ".fa", ".fna", ".fas"]
+FQ_EXTS = [".fq", ".fastq"]
+
+
+def get_seq_format(seq_file):
+    """'fa' | 'fq' (+ 'gz') from the file name (reference seq_encoder.py:21-39)."""
+    encoding = guess_type(str(seq_file))[1]
+    if encoding is None:
+        encoding = ""
+    elif encoding == "gzip":
+        encoding = "gz"
+    else:
+        raise ValueError('Unknown file encoding: "{}"'.format(encoding))
+    name = Path(seq_file).stem if encoding == "gz" else Path(seq_file).name
+    ext = Path(name).suffix
+    if ext not in FA_EXTS + FQ_EXTS:
+        raise ValueError('Unknown extension {}. Only fastq and fasta sequence formats are supported.\n'
+                         'And the file must end with one of ".fasta", ".fa", ".fna", ".fas", ".fq", ".fastq"\n'
+                         'and followed by ".gz" or ".gzip" if they are gzipped.'.format(ext))
+    return ("fa" if ext in FA_EXTS else "fq") + encoding
+
+
+def seq_parser(seq_fh, seq_type):
+    """Record generator with the reference's semantics: FASTQ -> (header, seq, plus, qual), FASTA -> (header, seq)."""
+    if seq_type == "fastq":
+        state, rec = 0, []
+        for line in seq_fh:
+            line = line.rstrip()
+            if state == 0:
+                if line[:1] != "@":
+                    # the reference would mis-frame silently here; malformed input is an error in this build
+                    raise ValueError("FASTQ record does not start with '@': %r" % line[:50])
+                rec = [line]
+                state = 1
+            else:
+                rec.append(line)
+                state += 1
+                if state == 4:
+                    yield tuple(rec)
+                    state = 0
+    else:
+        header, parts = "", []
+        for line in seq_fh:
+            line = line.strip()
+            if line == "":
+                continue
+            if line[0] == ">":
+                if header != "":
+                    yield header, "".join(parts)
+                header, parts = line, []
+            else:
+                parts.append(line.upper())
+        if parts:
+            yield header, "".join(parts)
+
+
+# A chunk of records as arrays.  buf: uint8 arena holding the record text; rec_start int64[n+1]: byte range of record i
+# (verbatim text incl. its final newline, valid when `verbatim`); seq_off int64[n] / seq_len int32[n]: the bases.
+Chunk = namedtuple("Chunk", "buf rec_start seq_off seq_len verbatim records")
+
+_WS = np.zeros(256, dtype=bool)
+_WS[[9, 10, 11, 12, 13, 32]] = True
+
+
+def _open_binary(path):
+    fmt = get_seq_format(path)
+    return (gzip.open(path, "rb") if fmt.endswith("gz") else open(path, "rb")), fmt
+
+
+def _fastq_chunks(fh, chunk_reads, block_bytes=64 << 20):
+    """Vectorised FASTQ framing: newline scan with numpy, no per-read Python."""
+    carry = b""
+    eof = False
+    while not eof or carry:
+        want_lines = 4 * chunk_reads
+        data = carry
+        nl = None
+        while True:
+            arr = np.frombuffer(data, dtype=np.uint8)
+            nl = np.flatnonzero(arr == 10)
+            if len(nl) >= want_lines or eof:
+                break
+            more = fh.read(block_bytes)
+            if not more:
+                eof = True
+                if data and data[-1:] != b"\n":
+                    data += b"\n"            # last line without newline: the reference's rstrip makes no difference
+                continue
+            data += more
+        if len(nl) == 0:
+            if data.strip():
+                raise ValueError("truncated FASTQ record at end of file")
+            return
+        nlines = min(len(nl) - len(nl) % 4, want_lines) if not eof else len(nl)
+        if eof and nlines > want_lines:
+            nlines = want_lines
+        if nlines % 4:
+            raise ValueError("FASTQ: number of lines is not a multiple of 4 (truncated record)")
+        if nlines == 0:
+            carry = data
+            if eof:
+                return
+            continue
+        end_byte = int(nl[nlines - 1]) + 1
+        arr = np.frombuffer(data, dtype=np.uint8)[:end_byte]
+        carry = data[end_byte:]
+        line_end = nl[:nlines]                                   # position of '\n'
+        line_start = np.empty(nlines, dtype=np.int64)
+        line_start[0] = 0
+        line_start[1:] = line_end[:-1] + 1
+        if not (arr[line_start[0::4]] == ord("@")).all():
+            raise ValueError("FASTQ record does not start with '@'")
+        # rstrip(): trailing whitespace of every line
+        stripped_end = line_end.copy()
+        verbatim = True
+        while True:
+            has = stripped_end > line_start
+            prev = arr[np.maximum(stripped_end - 1, 0)]
+            m = has & _WS[prev]
+            if not m.any():
+                break
+            verbatim = False
+            stripped_end[m] -= 1
+        seq_off = line_start[1::4].copy()
+        seq_len = (stripped_end[1::4] - seq_off).astype(np.int32)
+        rec_start = np.empty(nlines // 4 + 1, dtype=np.int64)
+        rec_start[:-1] = line_start[0::4]
+        rec_start[-1] = end_byte
+        records = None
+        if not verbatim:                                         # rare: keep the stripped lines for the writer
+            b = arr.tobytes()
+            records = ["\n".join(b[line_start[4 * i + k]:stripped_end[4 * i + k]].decode("latin-1") for k in range(4))
+                       for i in range(nlines // 4)]
+        yield Chunk(arr, rec_start, seq_off, seq_len, verbatim, records)
+
+
+def _fasta_chunks(fh, chunk_reads):
+    text = io.TextIOWrapper(fh, encoding="latin-1")
+    it = seq_parser(text, "fasta")
+    while True:
+        recs = []
+        for r in it:
+            recs.append(r)
+            if len(recs) == chunk_reads:
+                break
+        if not recs:
+            return
+        out = [h + "\n" + s for h, s in recs]
+        blob = ("\n".join(out) + "\n").encode("latin-1")
+        arr = np.frombuffer(blob, dtype=np.uint8)
+        lens_rec = np.array([len(o) + 1 for o in out], dtype=np.int64)
+        rec_start = np.zeros(len(out) + 1, dtype=np.int64)
+        np.cumsum(lens_rec, out=rec_start[1:])
+        hl = np.array([len(h) + 1 for h, _ in recs], dtype=np.int64)
+        seq_len = np.array([len(s) for _, s in recs], dtype=np.int32)
+        yield Chunk(arr, rec_start, rec_start[:-1] + hl, seq_len, True, None)
+
+
+def get_seq_chunks(seq_file, chunk_size=1048576):
+    """Chunks of at most `chunk_size` records (reference seq_encoder.py:75-87), as `Chunk` arrays."""
+    fh, fmt = _open_binary(seq_file)
+    with fh:
+        if fmt.startswith("fq"):
+            yield from _fastq_chunks(fh, chunk_size)
+        else:
+            yield from _fasta_chunks(fh, chunk_size)
+
+
+def get_pairedread_chunks(r1_seq_file, r2_seq_file, chunk_size=1048576):
+    """zip of the two mates' chunk streams (reference seq_encoder.py:90-92)."""
+    for c1, c2 in zip(get_seq_chunks(r1_seq_file, chunk_size), get_seq_chunks(r2_seq_file, chunk_size)):
+        if len(c1.seq_len) != len(c2.seq_len):
+            raise ValueError("paired-end files have different numbers of records")
+        yield c1, c2
+
+
+def select_records(chunk, mask):
+    """Bytes of the records where mask is True, in input order, each terminated by '\\n'
+    (reference: fh.write('\\n'.join(selected) + '\\n'), detect.py:489-492)."""
+    mask = np.asarray(mask, dtype=bool)
+    if not mask.any():
+        return b""
+    if not chunk.verbatim:
+        return ("\n".join(r for r, m in zip(chunk.records, mask) if m) + "\n").encode("latin-1")
+    if mask.all():
+        return chunk.buf[chunk.rec_start[0]:chunk.rec_start[-1]].tobytes()
+    delta = np.zeros(len(chunk.buf) + 1, dtype=np.int8)
+    np.add.at(delta, chunk.rec_start[:-1][mask], 1)
+    np.add.at(delta, chunk.rec_start[1:][mask], -1)
+    keep = np.cumsum(delta[:-1], dtype=np.int8).astype(bool)
+    return chunk.buf[keep].tobytes()
+
+
+def open_for_write(read_file):
+    """gzip level 5 when the name ends with 'gz', else plain (reference detect.py:729-741)."""
+    if read_file.endswith("gz"):
+        return gzip.open(read_file, mode="wb", compresslevel=5)
+    return open(read_file, "wb")

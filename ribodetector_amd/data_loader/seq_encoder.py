@@ -36,13 +36,13 @@ def batch_from_strings(seqs, device="cuda"):
 
 
 def batch_from_numpy(arena, offsets, lens, device="cuda"):
-    arena = np.ascontiguousarray(arena, dtype=np.uint8)
+    arena = np.array(arena, dtype=np.uint8)      # private writable copy
     if arena.size == 0:
         arena = np.zeros(1, dtype=np.uint8)
     n = len(lens)
     return ReadBatch(torch.from_numpy(arena).to(device),
-                     torch.from_numpy(np.ascontiguousarray(offsets[:n], dtype=np.int64)).to(device),
-                     torch.from_numpy(np.ascontiguousarray(lens, dtype=np.int32)).to(device))
+                     torch.from_numpy(np.array(offsets[:n], dtype=np.int64)).to(device),
+                     torch.from_numpy(np.array(lens, dtype=np.int32)).to(device))
 
 
 def encode_codes(batch, max_len, stride=None):

@@ -1,0 +1,80 @@
+"""Multi-GPU sharding of the read stream.
+
+Reads are independent, so a chunk of n reads (or pairs - R1[i] and R2[i] stay on the same rank) is split into W
+contiguous sub-ranges; rank r classifies [r*n/W, (r+1)*n/W). The only exchange is (1) a gather of the 1-byte labels to
+rank 0, which concatenated in rank order ARE the labels in input order, and (2) an all-reduce(SUM) of the three
+counters (non-rRNA, rRNA, unclassified - reference detect.py:331-333,388-389,400). Backend "nccl" (= RCCL over xGMI on
+ROCm) for device tensors, "gloo" for the CPU tests. The reference has no working multi-GPU path to mirror (its
+DataParallel wrap fails to load the checkpoint).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun). Returns (rank, world, local_rank)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_range(n, rank, world):
+    """contiguous sub-range of rank `rank`: [r*n//W, (r+1)*n//W)"""
+    return (rank * n) // world, ((rank + 1) * n) // world
+
+
+def shard_sizes(n, world):
+    return [shard_range(n, r, world)[1] - shard_range(n, r, world)[0] for r in range(world)]
+
+
+def gather_labels(local_labels, n_total, dst=0, group=None, async_op=False, out=None):
+    """Gather the per-rank label vectors (int8/uint8, 1 B per read or pair) to rank `dst`, in input order.
+
+    Every rank passes its shard's labels (length shard_range(n_total, rank, world)). Returns the [n_total] tensor on
+    `dst` (None elsewhere); with async_op=True returns (tensor_or_None, finish) where finish() waits and trims."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return (local_labels, (lambda: local_labels)) if async_op else local_labels
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    sizes = shard_sizes(n_total, world)
+    assert local_labels.numel() == sizes[rank], (local_labels.numel(), sizes[rank])
+    mx = max(sizes)
+    send = local_labels
+    if send.numel() != mx:                       # shards differ by at most one element: pad to the common size
+        send = torch.zeros(mx, dtype=local_labels.dtype, device=local_labels.device)
+        send[: local_labels.numel()] = local_labels
+    recv = None
+    if rank == dst:
+        buf = out if out is not None and out.numel() == mx * world else torch.empty(mx * world, dtype=send.dtype, device=send.device)
+        recv = list(buf.view(world, mx).unbind(0))
+    work = dist.gather(send, recv, dst=dst, group=group, async_op=True)
+
+    def finish():
+        work.wait()
+        if rank != dst:
+            return None
+        if all(s == mx for s in sizes):
+            return buf
+        return torch.cat([recv[r][: sizes[r]] for r in range(world)])
+    if async_op:
+        return (None if rank != dst else buf), finish
+    return finish()
+
+
+def reduce_counts(counts, group=None):
+    """all-reduce(SUM) of the int64[3] counters; every rank gets the totals."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
+    return counts

@@ -1,0 +1,200 @@
+"""Parity of the HIP path (through the C ABI) with the reference's golden outputs and with the CPU oracle.
+
+Tolerances: logits 1e-4 absolute (BASELINE.json north_star: "per-read logits within 1e-4 fp32"); labels identical,
+except that a label may differ only where the oracle's own margin |logit1-logit0| < 2e-4 (SURVEY §7 "label identity");
+integer / byte outputs (codes, one-hot, indices, pair labels from given logits, counts) are bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+VARIANTS = ["mfma_f32", "simple"]
+
+
+def _run(model, arena, offsets, lens, max_len):
+    from ribodetector_amd.data_loader import seq_encoder as E
+    b = E.batch_from_numpy(arena, offsets, lens, model.device)
+    lg, lab = model.classify_bytes(b.arena, b.offsets, b.lens, max_len)
+    torch.cuda.synchronize()
+    return lg.cpu().numpy(), lab.cpu().numpy()
+
+
+def _check(lg, lab, ref_logits, what):
+    err = np.abs(lg - ref_logits).max()
+    assert err < TOL, "%s: max logit error %.3g" % (what, err)
+    ref_lab = (ref_logits[:, 1] > ref_logits[:, 0]).astype(np.uint8)
+    bad = np.flatnonzero(lab != ref_lab)
+    margin = np.abs(ref_logits[:, 1] - ref_logits[:, 0])
+    assert (margin[bad] < 2e-4).all(), "%s: label mismatch at margins %s" % (what, margin[bad])
+    assert ((lg[:, 1] > lg[:, 0]).astype(np.uint8) == lab).all(), what   # labels consistent with own logits
+    return err
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_kat(gpu_model, golden, variant):
+    gpu_model.set_variant(variant)
+    kat = golden.json("kat")
+    reads = [c["read"].encode() for c in kat["cases"].values()]
+    ref = np.array([c["logits"] for c in kat["cases"].values()], dtype=np.float32)
+    lens = np.array([len(r) for r in reads], dtype=np.int32)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    lg, lab = _run(gpu_model, np.frombuffer(b"".join(reads), dtype=np.uint8), off, lens, kat["max_len"])
+    _check(lg, lab, ref, "kat/" + variant)
+    assert [int(x) for x in lab] == [c["label"] for c in kat["cases"].values()]
+    gpu_model.set_variant("auto")
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_golden_se_edge_varlen(gpu_model, golden, variant):
+    gpu_model.set_variant(variant)
+    d = golden.npz("se100")
+    lg, lab = _run(gpu_model, d["arena"], d["offsets"], d["lens"], 100)
+    e1 = _check(lg, lab, d["logits"], "se100/" + variant)
+    assert (lab == d["labels"]).all()
+    d = golden.npz("edge")
+    lg, lab = _run(gpu_model, d["arena"], d["offsets"], d["lens"], 100)
+    e2 = _check(lg, lab, d["logits"], "edge/" + variant)
+    assert (lab == d["labels"]).all()
+    d = golden.npz("varlen")
+    e3 = 0
+    for L in (300, 170):
+        lg, lab = _run(gpu_model, d["arena"], d["offsets"], d["lens"], L)
+        e3 = max(e3, _check(lg, lab, d["logits_l%d" % L], "varlen%d/%s" % (L, variant)))
+    print("max logit error vs reference golden [%s]: se100 %.3g edge %.3g varlen %.3g" % (variant, e1, e2, e3))
+    gpu_model.set_variant("auto")
+
+
+def test_vs_oracle_ragged_and_empty(gpu_model, oracle):
+    """seeded inputs against the oracle: ragged lengths incl. 0 and 1, reads longer than max_len, tile-boundary counts"""
+    from ribodetector_amd import synth
+    for n, length, L, seed in ((1, 100, 100, 1), (63, (1, 130), 100, 2), (64, 100, 100, 3), (65, (0, 40), 50, 4),
+                               (257, (90, 110), 100, 5), (1000, (0, 260), 128, 6), (300, (120, 140), 129, 7)):
+        arena, off, lens = synth.reads_numpy(n, length, seed)
+        ref = oracle.forward_packed(arena, off, lens, L)
+        lg, lab = _run(gpu_model, arena, off, lens, L)
+        _check(lg, lab, ref, "oracle n=%d" % n)
+
+
+def test_long_reads_chunked_codes(gpu_model, oracle):
+    """max_len beyond one staged code chunk (TC=128) exercises the double-buffered code staging"""
+    from ribodetector_amd import synth
+    arena, off, lens = synth.reads_numpy(96, (380, 700), seed=9)
+    ref = oracle.forward_packed(arena, off, lens, 600)
+    lg, lab = _run(gpu_model, arena, off, lens, 600)
+    _check(lg, lab, ref, "long")
+
+
+def test_reference_call_packed_sequence(gpu_model, golden):
+    """model(PackedSequence) - the reference's own call signature (detect.py:185-188) incl. un-permutation"""
+    from torch.nn.utils.rnn import pack_sequence
+    d = golden.npz("varlen")
+    idx = np.arange(0, 512)
+    lut = np.zeros((256, 4), dtype=np.float32)
+    for k, ch in enumerate(b"ACGT"):
+        lut[ch, k] = 1
+    lut[ord("U"), 3] = 1
+    seqs = [torch.from_numpy(lut[d["arena"][d["offsets"][i]:d["offsets"][i + 1]][:170]]) for i in idx]
+    x = pack_sequence(seqs, enforce_sorted=False)
+    out = gpu_model(x.to("cuda"))
+    assert out.shape == (512, 2) and out.dtype == torch.float32
+    assert np.abs(out.cpu().numpy() - d["logits_l170"][idx]).max() < TOL
+    with pytest.raises(ValueError):
+        bad = x.data.clone()
+        bad[3, 1] = 0.5
+        gpu_model(torch.nn.utils.rnn.PackedSequence(bad, x.batch_sizes, x.sorted_indices, x.unsorted_indices))
+
+
+def test_encoders_bit_exact(gpu_model, golden, oracle):
+    from ribodetector_amd.data_loader import seq_encoder as E
+    d = golden.npz("collate")
+    b = E.batch_from_numpy(d["arena"], d["offsets"], d["lens"], "cuda")
+    L = int(d["max_len"])
+    assert (E.encode_padded(b, L).cpu().numpy() == d["padded"]).all()
+    p = E.pack_reads(b, L)
+    assert (p.data.cpu().numpy() == d["data"]).all()
+    assert (p.batch_sizes.numpy() == d["batch_sizes"]).all()
+    T = np.minimum(d["lens"], L)
+    si, ui = p.sorted_indices.cpu().numpy(), p.unsorted_indices.cpu().numpy()
+    assert (T[si] == np.sort(T)[::-1]).all() and (si[ui] == np.arange(len(T))).all()
+    # larger ragged batch against the oracle
+    e = golden.npz("edge")
+    b = E.batch_from_numpy(e["arena"], e["offsets"], e["lens"], "cuda")
+    codes = E.encode_codes(b, 100, stride=112).cpu().numpy()
+    for i in range(len(e["lens"])):
+        s = bytes(e["arena"][e["offsets"][i]:e["offsets"][i + 1]])[:100]
+        want = np.full(112, 4, dtype=np.uint8)
+        want[:len(s)] = oracle.encode_codes(s)
+        assert (codes[i] == want).all(), i
+    data, bs, osi, oui = oracle.pack_sequence(e["arena"], e["offsets"], e["lens"], 100)
+    p = E.pack_reads(b, 100)
+    assert (p.batch_sizes.numpy() == bs).all()
+    assert (p.sorted_indices.cpu().numpy() == osi).all() and (p.unsorted_indices.cpu().numpy() == oui).all()
+    assert (p.data.cpu().numpy() == data).all()
+    assert (E.encode_read("ACGTUNacgt").cpu().numpy() == oracle.encode_onehot(b"ACGTUNacgt")).all()
+
+
+def test_pair_fusion_and_counts(gpu_model, golden, oracle):
+    from ribodetector_amd.model import model as M
+    d = golden.npz("pe")
+    l1, l2 = torch.from_numpy(d["r1_logits"]).cuda(), torch.from_numpy(d["r2_logits"]).cuda()
+    for mode in ("none", "rrna", "norrna", "both"):
+        counts = torch.zeros(3, dtype=torch.int64, device="cuda")
+        lab = M.pair_fuse(l1, l2, mode, counts)
+        lab2 = M.pair_fuse(l1, l2, mode, counts)     # counters accumulate like detect.py:388-389
+        torch.cuda.synchronize()
+        assert (lab.cpu().numpy() == d["labels_" + mode]).all() and (lab2 == lab).all()
+        want = oracle.count_labels(d["labels_" + mode])
+        assert counts.cpu().tolist() == [2 * w for w in want]
+    # end to end on the pair fixture: HIP logits -> HIP fuse
+    g1, _ = _run(gpu_model, d["r1_arena"], d["r1_offsets"], d["r1_lens"], 100)
+    g2, _ = _run(gpu_model, d["r2_arena"], d["r2_offsets"], d["r2_lens"], 100)
+    assert np.abs(g1 - d["r1_logits"]).max() < TOL and np.abs(g2 - d["r2_logits"]).max() < TOL
+    for mode in ("none", "rrna", "norrna", "both"):
+        lab = M.pair_fuse(torch.from_numpy(g1).cuda(), torch.from_numpy(g2).cuda(), mode).cpu().numpy()
+        assert (lab == oracle.pair_fuse(g1, g2, mode)).all()
+        assert (lab != d["labels_" + mode]).mean() < 0.005
+    lab8 = torch.from_numpy((g1[:, 1] > g1[:, 0]).astype(np.uint8)).cuda()
+    counts = torch.zeros(3, dtype=torch.int64, device="cuda")
+    M.count_labels(lab8, counts)
+    assert counts.cpu().tolist() == [int((lab8 == 0).sum()), int((lab8 == 1).sum()), 0]
+
+
+def test_properties_order_and_batching(gpu_model):
+    """size-independent properties: permutation equivariance, batch-split invariance, determinism (bit-exact:
+    every read is computed independently of its tile mates)"""
+    from ribodetector_amd import synth
+    n = 5000
+    arena, off, lens = synth.reads_numpy(n, (40, 200), seed=12)
+    lg, lab = _run(gpu_model, arena, off, lens, 150)
+    lg2, lab2 = _run(gpu_model, arena, off, lens, 150)
+    assert (lg == lg2).all() and (lab == lab2).all()
+    perm = np.random.default_rng(0).permutation(n)
+    lgp, labp = _run(gpu_model, arena, off[:-1][perm], lens[perm], 150)
+    assert (lgp == lg[perm]).all() and (labp == lab[perm]).all()
+    parts = [_run(gpu_model, arena, off[:-1][s:e], lens[s:e], 150)[0] for s, e in ((0, 1), (1, 777), (777, n))]
+    assert (np.concatenate(parts) == lg).all()
+
+
+def test_full_size_batch_properties(gpu_model, oracle):
+    """BASELINE config A batch (32,768 reads x 100 bp, reference batch size at -m 32) + a 1M-read chunk:
+    label counts consistent, spot-checked against the oracle, checksum stable across runs."""
+    from ribodetector_amd import synth
+    from ribodetector_amd.model import model as M
+    arena, off, lens = synth.reads_torch(1 << 20, 100, seed=1, device="cuda")
+    lg, lab = gpu_model.classify_bytes(arena, off[:-1].contiguous(), lens, 100)
+    lg_b, lab_b = gpu_model.classify_bytes(arena, off[:-1].contiguous(), lens, 100)
+    torch.cuda.synchronize()
+    assert torch.equal(lg, lg_b) and torch.equal(lab, lab_b)
+    counts = torch.zeros(3, dtype=torch.int64, device="cuda")
+    M.count_labels(lab, counts)
+    c = counts.cpu().tolist()
+    assert c[0] + c[1] == 1 << 20 and c[2] == 0 and 0.03 < c[1] / (1 << 20) < 0.3
+    assert torch.equal(((lg[:, 1] > lg[:, 0]).to(torch.uint8)), lab)
+    idx = torch.arange(0, 1 << 20, 4099, device="cuda")[:256]
+    sub_arena = arena.view(-1, 100)[idx].cpu().numpy().reshape(-1)
+    ref = oracle.forward_packed(sub_arena, np.arange(257, dtype=np.int64) * 100, np.full(256, 100, dtype=np.int32), 100)
+    _check(lg[idx].cpu().numpy(), lab[idx].cpu().numpy(), ref, "1M spot check")
+    # the reference batch (32,768) as one call gives the same rows
+    lg32, _ = gpu_model.classify_bytes(arena, off[:32768].contiguous(), lens[:32768].contiguous(), 100)
+    assert torch.equal(lg32, lg[:32768])

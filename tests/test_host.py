@@ -1,0 +1,73 @@
+"""Host-side mirror of the reference interface (no GPU): config surface, SeqModel argument handling, synthetic data."""
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def _cfg():
+    from ribodetector_amd.parse_config import ConfigParser
+    return ConfigParser.from_json(os.path.join(ROOT, "ribodetector_amd", "config.json"))
+
+
+def test_config_surface():
+    cfg = _cfg()
+    assert cfg["n_gpu"] == 1 and cfg["arch"]["type"] == "SeqModel"
+    assert dict(cfg["arch"]["args"]) == dict(input_size=4, hidden_size=128, num_layers=1, num_classes=2, batch_first=True,
+                                             bidirectional=True, pack_seq=True)
+    assert set(cfg["state_file"]) == {"mcc", "recall"}
+    sd = cfg.load_state_dict("recall")
+    assert sorted(sd) == sorted(["rnn.weight_ih_l0", "rnn.weight_hh_l0", "rnn.bias_ih_l0", "rnn.bias_hh_l0",
+                                 "rnn.weight_ih_l0_reverse", "rnn.weight_hh_l0_reverse", "rnn.bias_ih_l0_reverse",
+                                 "rnn.bias_hh_l0_reverse", "out.weight", "out.bias"])
+    assert sum(v.size for v in sd.values()) == 137730
+
+
+def test_weights_digest():
+    import hashlib
+    import json
+    dg = json.load(open(os.path.join(ROOT, "ribodetector_amd", "data", "weights_digest.json")))
+    assert dg["source_sha256"] == "54d58c03967f2425b0bebde7a6b1a81d12ef55ca539e388480c9aea5aa401b78"
+    sd = _cfg().load_state_dict("mcc")
+    for k, v in dg["tensors"].items():
+        assert list(sd[k].shape) == v["shape"]
+        assert hashlib.sha256(np.ascontiguousarray(sd[k]).tobytes()).hexdigest() == v["sha256"], k
+
+
+def test_init_obj_and_arg_validation():
+    from ribodetector_amd.model import model as module_arch
+    cfg = _cfg()
+    m = cfg.init_obj("arch", module_arch)
+    assert m.hidden_size == 128 and m.pack_seq
+    with pytest.raises(AssertionError):
+        cfg.init_obj("arch", module_arch, hidden_size=64)          # overriding config kwargs is not allowed
+    for bad in (dict(num_layers=2), dict(bidirectional=False), dict(pack_seq=False), dict(hidden_size=64)):
+        args = dict(cfg["arch"]["args"])
+        args.update(bad)
+        with pytest.raises(NotImplementedError):
+            module_arch.SeqModel(**args)
+    sd = cfg.load_state_dict("mcc")
+    m.load_state_dict(sd)
+    assert set(m.state_dict()) == set(sd)
+    broken = dict(sd)
+    broken.pop("out.bias")
+    with pytest.raises(RuntimeError, match="Missing key"):
+        m.load_state_dict(broken)
+    pref = {"module." + k: v for k, v in sd.items()}            # the reference's DataParallel failure mode
+    with pytest.raises(RuntimeError, match="Missing key"):
+        m.load_state_dict(pref)
+    with pytest.raises(RuntimeError, match="GPU only"):
+        m.to("cpu")
+
+
+def test_synth_deterministic():
+    from ribodetector_amd import synth
+    a1, o1, l1 = synth.reads_numpy(500, (40, 300), seed=3)
+    a2, o2, l2 = synth.reads_numpy(500, (40, 300), seed=3)
+    assert (a1 == a2).all() and (o1 == o2).all() and (l1 == l2).all()
+    assert l1.min() >= 40 and l1.max() <= 300 and o1[-1] == len(a1)
+    assert set(np.unique(a1)) <= set(b"ACGTN")
+    a3, _, _ = synth.reads_numpy(500, 100, seed=4)
+    assert abs((a3 == ord("N")).mean() - 0.001) < 0.002
