@@ -1,0 +1,284 @@
+#!/usr/bin/env python3
+"""`ribodetector` command line on MI355X - same flags, config.json lookup, log lines, output files and label rules as
+the reference's GPU product (reference detect.py:34-809), with the per-batch host work (one-hot + pack_sequence in
+DataLoader workers, detect.py:666-726) replaced by raw bytes -> HBM -> fused HIP kernels.
+
+Flow per chunk (reference run_with_chunks, detect.py:326-523):
+    FASTQ/FASTA chunk as one byte arena + offsets (data_loader/fastx_parser.py)
+    -> pinned host buffer -> H2D on a copy stream (double buffered: chunk k+1 is parsed/copied while chunk k computes)
+    -> rd_classify (R1 [, R2]) -> rd_pair_fuse / argmax -> labels D2H (1 B/read)
+    -> records written by label in input order.
+Under torchrun (WORLD_SIZE > 1) every rank classifies a contiguous shard of each chunk and rank 0 gathers the labels
+over RCCL and writes (ribodetector_amd/dist.py).
+"""
+import argparse
+import math
+import os
+import threading
+import queue
+from argparse import RawTextHelpFormatter
+
+import numpy as np
+import torch
+
+from . import __version__
+from . import dist as rdist
+from .data_loader import fastx_parser as fx
+from .model import model as module_arch
+from .parse_config import ConfigParser
+
+cd = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_CHUNK_READS = 1 << 20      # records per chunk when --chunk_size is not given (reference: whole file in RAM)
+
+
+class colors:
+    HEADER = '\033[95m'
+    OKBLUE = '\033[94m'
+    OKCYAN = '\033[96m'
+    OKGREEN = '\033[92m'
+    OKYELLOW = '\033[33m'
+    WARNING = '\033[93m'
+    FAIL = '\033[91m'
+    ENDC = '\033[0m'
+    BOLD = '\033[1m'
+
+
+class Predictor:
+    """Main class of predictor for rRNA, non-rRNA sequences (interface of reference detect.py:34-43)."""
+
+    def __init__(self, config, args):
+        self.config = config
+        self.args = args
+        self.logger = config.get_logger('predict', 1, self.args.log)
+        self.chunk_size = self.args.chunk_size
+        self.rank, self.world, self.local_rank = 0, 1, 0
+
+    # ---- model -------------------------------------------------------------------------------------
+    def get_state_dict(self):
+        """'recall' weights iff --ensure norrna, else 'mcc' (reference detect.py:45-82)."""
+        self.len = self.args.len
+        if self.len < 40:
+            self.logger.info('The accuracy will drop with reads shorter than 40.')
+        model_file_ext = 'recall' if self.args.ensure == 'norrna' else 'mcc'
+        self.state_key = model_file_ext
+        self.state_file = self.config.state_file(model_file_ext)
+        self.logger.info('Using high {} model'.format(model_file_ext.upper()))
+        self.logger.info('Log file: {}'.format(self.args.log))
+
+    def load_model(self):
+        """Load the model onto the GPU (reference detect.py:84-119). Raises RuntimeError without a visible device."""
+        if self.args.deviceid is not None:
+            os.environ["HIP_VISIBLE_DEVICES"] = self.args.deviceid
+            os.environ["CUDA_VISIBLE_DEVICES"] = self.args.deviceid
+        self.rank, self.world, self.local_rank = rdist.init_from_env()
+        self.get_state_dict()
+        model = self.config.init_obj('arch', module_arch)
+        if not torch.cuda.is_available():
+            self.logger.error('{}No visible GPU devices!{} This build runs the HIP kernels only; the CPU product of the '
+                              'reference is ribodetector_cpu'.format(colors.FAIL, colors.ENDC))
+            raise RuntimeError("Set HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES or use CPU inference.")
+        self.device = torch.device('cuda', self.local_rank if self.world > 1 else torch.cuda.current_device())
+        self.has_cuda = True
+        model.load_state_dict(self.config.load_state_dict(self.state_key))
+        self.logger.info('Model using {} for read length {}{}{}{} loaded'.format(
+            self.device, colors.BOLD, colors.OKCYAN, self.len, colors.ENDC))
+        self.model = model.to(self.device)
+        self.model.eval()
+
+    # ---- classification of one chunk ------------------------------------------------------------------
+    def _to_device(self, chunk, lo, hi, stream):
+        """pinned staging + async H2D of records [lo, hi) of a chunk: only the bytes spanning those reads travel."""
+        b0 = int(chunk.rec_start[lo])
+        b1 = int(chunk.rec_start[hi])
+        with torch.cuda.stream(stream):
+            host = torch.from_numpy(chunk.buf[b0:b1]) if chunk.buf.flags.writeable else torch.from_numpy(chunk.buf[b0:b1].copy())
+            arena = host.pin_memory().to(self.device, non_blocking=True) if b1 > b0 else torch.zeros(1, dtype=torch.uint8, device=self.device)
+            off = torch.from_numpy(chunk.seq_off[lo:hi] - b0).pin_memory().to(self.device, non_blocking=True)
+            ln = torch.from_numpy(np.ascontiguousarray(chunk.seq_len[lo:hi])).pin_memory().to(self.device, non_blocking=True)
+        return arena, off, ln
+
+    def classify_chunk(self, chunks):
+        """chunks: (c1,) or (c1, c2). Returns the int8 labels of the whole chunk on rank 0 (numpy), None elsewhere."""
+        n = len(chunks[0].seq_len)
+        lo, hi = rdist.shard_range(n, self.rank, self.world)
+        cs = self._copy_stream
+        dev_in = [self._to_device(c, lo, hi, cs) for c in chunks]
+        torch.cuda.current_stream(self.device).wait_stream(cs)
+        outs = [self.model.classify_bytes(a, o, l, self.len, want_labels=not self.is_paired) for a, o, l in dev_in]
+        if self.is_paired:
+            labels = module_arch.pair_fuse(outs[0][0], outs[1][0], self.args.ensure)
+        else:
+            labels = outs[0][1].view(torch.int8)
+        if self.world > 1:
+            labels = rdist.gather_labels(labels, n, dst=0)
+            if self.rank != 0:
+                return None
+        return labels.cpu().numpy()
+
+    # ---- drivers ----------------------------------------------------------------------------------------
+    def _chunk_stream(self, chunk_reads):
+        if self.is_paired:
+            yield from fx.get_pairedread_chunks(*self.input, chunk_size=chunk_reads)
+        else:
+            for c in fx.get_seq_chunks(*self.input, chunk_size=chunk_reads):
+                yield (c,)
+
+    def _prefetching(self, it, depth=2):
+        """parse chunk k+1 on a host thread while chunk k is on the GPU"""
+        q = queue.Queue(maxsize=depth)
+        END = object()
+
+        def work():
+            try:
+                for x in it:
+                    q.put(x)
+                q.put(END)
+            except BaseException as e:  # surface parser errors on the main thread
+                q.put(e)
+        th = threading.Thread(target=work, daemon=True)
+        th.start()
+        while True:
+            x = q.get()
+            if x is END:
+                return
+            if isinstance(x, BaseException):
+                raise x
+            yield x
+
+    def run_with_chunks(self, chunk_reads=None):
+        """Classify the input in chunks and write the outputs (reference detect.py:326-523)."""
+        if chunk_reads is None:
+            chunk_reads = self.batch_size * self.chunk_size
+        writer = self.rank == 0
+        ends = (0, 1) if self.is_paired else (0,)
+        fhs = {}
+        if writer:
+            if self.rrna is not None:
+                self.logger.info('Writing output rRNA sequences into file: {}{}{}'.format(
+                    colors.OKBLUE, ", ".join(self.rrna), colors.ENDC))
+                fhs[1] = [fx.open_for_write(self.rrna[e]) for e in ends]
+            self.logger.info('Writing output non-rRNA sequences into file: {}{}{}'.format(
+                colors.OKBLUE, ", ".join(self.output), colors.ENDC))
+            fhs[0] = [fx.open_for_write(self.output[e]) for e in ends]
+            if self.is_paired and self.args.ensure == 'both':
+                unclf = [self.output[e] + '.unclassified.gz' for e in ends]
+                fhs[-1] = [fx.open_for_write(u) for u in unclf]
+                self.logger.info('Writing unclassified sequences into file: {}{}{}'.format(
+                    colors.OKYELLOW, ", ".join(unclf), colors.ENDC))
+        num_read = num_nonrrna = num_rrna = num_unknown = 0
+        self._copy_stream = torch.cuda.Stream(self.device)
+        for chunks in self._prefetching(self._chunk_stream(chunk_reads)):
+            labels = self.classify_chunk(chunks)
+            num_read += len(chunks[0].seq_len)
+            if writer:
+                num_nonrrna += int((labels == 0).sum())
+                num_rrna += int((labels == 1).sum())
+                num_unknown += int((labels == -1).sum())
+                for lab, handles in fhs.items():
+                    mask = labels == lab
+                    if mask.any():
+                        for e, fh in zip(ends, handles):
+                            fh.write(fx.select_records(chunks[e], mask))
+                self.logger.info('{}{}{} sequences finished!'.format(colors.OKGREEN, num_read, colors.ENDC))
+        if writer:
+            self.logger.info('Processed {}{}{}{} sequences in total'.format(colors.BOLD, colors.OKCYAN, num_read, colors.ENDC))
+            self.logger.info('Detected {}{}{}{} non-rRNA sequences'.format(colors.BOLD, colors.OKCYAN, num_nonrrna, colors.ENDC))
+            self.logger.info('Detected {}{}{}{} rRNA sequences'.format(colors.BOLD, colors.OKCYAN, num_rrna, colors.ENDC))
+            if self.is_paired and self.args.ensure == 'both':
+                self.logger.info('Discarded {}{}{}{} unclassified sequences'.format(
+                    colors.BOLD, colors.OKCYAN, num_unknown, colors.ENDC))
+            for handles in fhs.values():
+                for fh in handles:
+                    fh.close()
+        self.num_read, self.num_nonrrna, self.num_rrna, self.num_unknown = num_read, num_nonrrna, num_rrna, num_unknown
+
+    def run(self):
+        """Whole-file mode of the reference (detect.py:121-324): same outputs; streamed here in 1 Mi-record chunks
+        instead of holding the parsed file in host RAM."""
+        self.run_with_chunks(chunk_reads=DEFAULT_CHUNK_READS)
+
+    def detect(self):
+        """Argument checks, batch-size rule, dispatch (reference detect.py:525-584)."""
+        self.input = self.args.input
+        self.output = self.args.output
+        self.rrna = self.args.rrna
+        self.pack_seq = self.config['arch']['args']['pack_seq']
+        num_inputs = len(self.input)
+        num_rrna_outputs = None if self.rrna is None else len(self.rrna)
+        if num_inputs != len(self.output) or num_inputs > 2 or num_inputs < 1:
+            self.logger.error('{}The number of input and output sequence files is invalid!{}'.format(colors.FAIL, colors.ENDC))
+            raise RuntimeError(
+                "Input or output should have no more than two files and they should have the same number of files.")
+        if num_rrna_outputs is not None and num_rrna_outputs != num_inputs:
+            self.logger.error('{}The number of output rRNA sequence files is invalid!{}'.format(colors.FAIL, colors.ENDC))
+            raise RuntimeError(
+                "Ouput rRNA should have no more than two files and they should the same number with input files.")
+        self.is_paired = (num_inputs == 2)
+        # reference batch-size heuristic (detect.py:558-568); kept because --chunk_size is expressed in these batches
+        denom = (2 * self.len * 6.4) if self.is_paired else (self.len * 6.4)
+        self.batch_size = 2 ** math.floor(math.log2(((self.args.memory - 2) * 1024 * 1024) / denom))
+        self.logger.info('Choose batch size: {}{}{}{} based on the given GPU RAM size {}GB and max read length {}'.format(
+            colors.BOLD, colors.OKCYAN, self.batch_size, colors.ENDC, self.args.memory, self.len))
+        if self.chunk_size is None:
+            self.run()
+        else:
+            self.run_with_chunks()
+
+    # ---- label helpers with the reference's signatures (host lists; used by tests / API users) -----------------
+    @staticmethod
+    def separate_reads(reads, labels):
+        """{label: [reads]} (reference detect.py:600-614)"""
+        out = {}
+        for read, label in zip(reads, labels):
+            out.setdefault(int(label), []).append(read)
+        return out
+
+    def separate_paired_reads(self, r1_reads, r1_outs, r2_reads, r2_outs):
+        """Pair fusion on the device (rd_pair_fuse) then the reference's dict-of-lists result (detect.py:616-663)."""
+        lab = module_arch.pair_fuse(r1_outs.contiguous(), r2_outs.contiguous(), self.args.ensure).cpu().tolist()
+        return Predictor.separate_reads(r1_reads, lab), Predictor.separate_reads(r2_reads, lab)
+
+
+def build_parser():
+    args = argparse.ArgumentParser(description='rRNA sequence detector', formatter_class=RawTextHelpFormatter)
+    args.add_argument('-c', '--config', default=None, type=str, help='Path of config file')
+    args.add_argument('-d', '--deviceid', default=None, type=str,
+                      help='Indices of GPUs to enable. Quotated comma-separated device ID numbers. (default: all)')
+    args.add_argument('-l', '--len', type=int, required=True,
+                      help='Sequencing read length. Note: the accuracy reduces for reads shorter than 40.')
+    args.add_argument('-i', '--input', default=None, type=str, nargs='*', required=True,
+                      help='Path of input sequence files (fasta and fastq), the second file will be considered as second end if two files given.')
+    args.add_argument('-o', '--output', default=None, type=str, nargs='*', required=True,
+                      help='Path of the output sequence files after rRNAs removal (same number of files as input). \n(Note: 2 times slower to write gz files)')
+    args.add_argument('-r', '--rrna', default=None, type=str, nargs='*',
+                      help='Path of the output sequence file of detected rRNAs (same number of files as input)')
+    args.add_argument('-e', '--ensure', default="none", type=str, choices=['rrna', 'norrna', 'both', 'none'],
+                      help='''Ensure which classificaion has high confidence for paired end reads.
+norrna: output only high confident non-rRNAs, the rest are clasified as rRNAs;
+rrna: vice versa, only high confident rRNAs are classified as rRNA and the rest output as non-rRNAs;
+both: both non-rRNA and rRNA prediction with high confidence;
+none: give label based on the mean probability of read pair.
+      (Only applicable for paired end reads, discard the read pair when their predicitons are discordant)''')
+    args.add_argument('-t', '--threads', default=10, type=int, help='Number of threads to use. (default: 10)')
+    args.add_argument('-m', '--memory', default=32, type=int, help='Amount (GB) of GPU RAM. (default: 12)')
+    args.add_argument('--chunk_size', default=None, type=int,
+                      help='Use this parameter when having low memory. Parsing the file in chunks.\n{}.\n{}.'.format(
+                          'Not needed when free RAM >=5 * your_file_size (uncompressed, sum of paired ends)',
+                          'When chunk_size=256, memory=16 it will load 256 * 16 * 1024 reads each chunk (use ~20 GB for 100bp paired end)'))
+    args.add_argument('--log', default=None, type=str, help='Log file name')
+    args.add_argument('-v', '--version', action='version', version='%(prog)s {version}'.format(version=__version__))
+    return args
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    config_file = os.path.join(cd, 'config.json') if args.config is None else args.config
+    config = ConfigParser.from_json(config_file)
+    seq_pred = Predictor(config, args)
+    seq_pred.load_model()
+    seq_pred.detect()
+    return seq_pred
+
+
+if __name__ == '__main__':
+    main()

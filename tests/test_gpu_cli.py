@@ -1,0 +1,79 @@
+"""End-to-end `ribodetector` CLI on the GPU (BASELINE configs[0] plumbing case and the paired-end modes):
+output files must hold exactly the records the reference's label rules select, in input order."""
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _read(path):
+    op = gzip.open if path.endswith("gz") else open
+    with op(path, "rt") as fh:
+        return fh.read()
+
+
+def _fastq_text(arena, off, mate, idx):
+    b = arena.tobytes()
+    out = []
+    for i in idx:
+        s = b[off[i]:off[i + 1]].decode()
+        out.append("@syn.%d/%d\n%s\n+\n%s\n" % (i, mate, s, "I" * len(s)))
+    return "".join(out)
+
+
+def test_cli_single_end_10k(tmp_path, oracle):
+    from ribodetector_amd import detect, synth
+    arena, off, lens = synth.reads_numpy(10000, 100, seed=0)          # cfg0: 10k SE 100 bp, seed 0
+    inp = str(tmp_path / "in.fq")
+    synth.write_fastq(inp, arena, off, mate=1)
+    out, rr = str(tmp_path / "nonrrna.fq"), str(tmp_path / "rrna.fq.gz")
+    p = detect.main(["-l", "100", "-i", inp, "-o", out, "-r", rr, "--chunk_size", "1", "-m", "3", "-t", "2"])
+    ref = oracle.forward_packed(arena, off, lens, 100)
+    lab = oracle.argmax(ref)
+    margin = np.abs(ref[:, 1] - ref[:, 0])
+    assert margin.min() > 2e-4                                          # no borderline read in this fixture
+    assert p.num_read == 10000 and p.num_rrna == int(lab.sum()) and p.num_nonrrna == int((lab == 0).sum())
+    assert _read(out) == _fastq_text(arena, off, 1, np.flatnonzero(lab == 0))
+    assert _read(rr) == _fastq_text(arena, off, 1, np.flatnonzero(lab == 1))
+    # whole-file mode gives the same files
+    out2 = str(tmp_path / "nonrrna2.fq")
+    detect.main(["-l", "100", "-i", inp, "-o", out2])
+    assert _read(out2) == _read(out)
+
+
+@pytest.mark.parametrize("ensure", ["none", "rrna", "norrna", "both"])
+def test_cli_paired(tmp_path, oracle, ensure):
+    from ribodetector_amd import detect, synth
+    n = 3000
+    a1, o1, l1 = synth.reads_numpy(n, (60, 120), seed=41, rrna_frac=0.3)
+    a2, o2, l2 = synth.reads_numpy(n, (60, 120), seed=42, rrna_frac=0.3)
+    i1, i2 = str(tmp_path / "r_1.fq.gz"), str(tmp_path / "r_2.fq.gz")
+    synth.write_fastq(i1, a1, o1, 1)
+    synth.write_fastq(i2, a2, o2, 2)
+    outs = [str(tmp_path / "n1.fq"), str(tmp_path / "n2.fq")]
+    rrs = [str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq")]
+    p = detect.main(["-l", "100", "-i", i1, i2, "-o", *outs, "-r", *rrs, "-e", ensure, "--chunk_size", "1", "-m", "3"])
+    g1, g2 = oracle.forward_packed(a1, o1, l1, 100), oracle.forward_packed(a2, o2, l2, 100)
+    lab = oracle.pair_fuse(g1, g2, ensure)
+    # reads whose decision is numerically borderline may legitimately differ; exclude them from the exact comparison
+    m1, m2 = np.abs(g1[:, 1] - g1[:, 0]), np.abs(g2[:, 1] - g2[:, 0])
+    ms = np.abs((g1[:, 1] + g2[:, 1]) - (g1[:, 0] + g2[:, 0]))
+    assert min(m1.min(), m2.min(), ms.min()) > 2e-4
+    assert p.num_nonrrna == int((lab == 0).sum()) and p.num_rrna == int((lab == 1).sum())
+    assert _read(outs[0]) == _fastq_text(a1, o1, 1, np.flatnonzero(lab == 0))
+    assert _read(outs[1]) == _fastq_text(a2, o2, 2, np.flatnonzero(lab == 0))
+    assert _read(rrs[1]) == _fastq_text(a2, o2, 2, np.flatnonzero(lab == 1))
+    if ensure == "both":
+        assert p.num_unknown == int((lab == -1).sum()) > 0
+        assert _read(outs[0] + ".unclassified.gz") == _fastq_text(a1, o1, 1, np.flatnonzero(lab == -1))
+
+
+def test_cli_argument_errors(tmp_path):
+    from ribodetector_amd import detect
+    with pytest.raises(RuntimeError):
+        detect.main(["-l", "100", "-i", "a.fq", "b.fq", "-o", "x.fq"])
+    with pytest.raises(RuntimeError):
+        detect.main(["-l", "100", "-i", "a.fq", "-o", "x.fq", "-r", "r1.fq", "r2.fq"])
