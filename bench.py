@@ -143,7 +143,7 @@ def main():
         reads_per_launch = P
         avg_ms = kms / max(launches, 1)
         achieved = reads_per_launch * FLOPS_PER_READ / (avg_ms * 1e-3) / 1e12 if launches else None
-        peak = PEAKS[variant]
+        peak = PEAKS["mfma_f32" if variant.startswith("mfma_f32_") else variant]
         out = {
             "metric": "reads/sec classified, 100 bp paired-end",
             "value": 2.0 * total_pairs / dt,
@@ -164,7 +164,7 @@ def main():
                        "label_counts": {"non_rrna": c[0], "rrna": c[1], "unclassified": c[2]}},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": (achieved / peak) if achieved else None, "traffic": None,
-                         "kernel": "rd_lstm_%s_kernel" % variant, "launches": launches, "avg_launch_ms": avg_ms,
+                         "kernel": "rd_lstm_%s_kernel" % ("mfma_f32" if variant.startswith("mfma_f32") else variant), "launches": launches, "avg_launch_ms": avg_ms,
                          "algorithmic_flops_per_launch": reads_per_launch * FLOPS_PER_READ,
                          "algorithmic_bytes_per_launch": reads_per_launch * BYTES_PER_READ},
         }

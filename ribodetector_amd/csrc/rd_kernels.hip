@@ -37,7 +37,6 @@ constexpr int NT = 4;        // 16-read tiles per workgroup (ring)
 constexpr int BT = NT * 16;  // reads per workgroup
 constexpr int HSTR = 132;    // LDS row stride (floats) of an h tile: 128 + 4 pad -> conflict-free b128 reads
 constexpr int TC = 128;      // timesteps per staged code chunk
-constexpr int LUTSTR = 528;  // LDS row stride of the input table
 
 thread_local char g_err[512] = "";
 
@@ -131,6 +130,19 @@ __global__ void rd_prep_kernel(DevModel d) {
     for (int i = tid; i < HID * G4; i += nth) {
         int k = i / G4, col = i % G4;
         d.wt_hh[i] = raw[OFF_WHH + col * HID + k];
+    }
+    // f16x3 A operand: [wave][W1|W2][tile a][k-step s][lane][8 halves]; lane (i = lane&15, q): row i of tile a is
+    // gate i&3 of unit 32w + 8(i>>2) + a; element e is hidden index 32s + 8q + e.  W1 = fp16(16 w), W2 = fp16(2^11 (16 w - W1)).
+    for (int i = tid; i < 4 * 8 * 4 * 64 * 8; i += nth) {
+        int e = i & 7, lane = (i >> 3) & 63, s = (i >> 9) & 3, a = (i >> 11) & 7, w = i >> 14;
+        int row = lane & 15, q = lane >> 4;
+        int col = (row & 3) * HID + 32 * w + 8 * (row >> 2) + a;
+        float x = 16.0f * raw[OFF_WHH + col * HID + 32 * s + 8 * q + e];
+        _Float16 hi = (_Float16)x;
+        _Float16 lo = (_Float16)((x - (float)hi) * 2048.0f);
+        _Float16 *base = reinterpret_cast<_Float16 *>(d.wpack16);
+        base[((((size_t)(w * 2 + 0) * 8 + a) * 4 + s) * 64 + lane) * 8 + e] = hi;
+        base[((((size_t)(w * 2 + 1) * 8 + a) * 4 + s) * 64 + lane) * 8 + e] = lo;
     }
     for (int i = tid; i < 5 * G4; i += nth) {
         int code = i / G4, col = i % G4;
@@ -334,7 +346,7 @@ struct __attribute__((aligned(16))) LstmSmem {
     float Hl[NT][16][HSTR];        // h captured at t == T-1 (last_items, model.py:114-119)
     f32x4 cA[NT][256];             // cell state, sub-tile 0 (4 reads per lane)
     f32x4 cB[NT][256];             // cell state, sub-tile 1
-    float lut[5][LUTSTR];          // in_lut staged
+    f32x4 lut[5][4][16][2];        // in_lut staged per lane: [code][wave][lane&15][half] -> 8 floats = column tiles c=0..7
     float wout[2][HID];            // forward half of W_out
     float dummy[256];              // sink of predicated-off Hl stores (keeps the phase body branch-free)
     uint8_t codes[2][TC][BT];      // double-buffered code chunks, [t][row]
@@ -355,6 +367,24 @@ __device__ __forceinline__ void rd_stage_codes(LstmSmem &S, const ReadBatch &rb,
     }
 }
 
+// Cheap activations for the recurrence: sigmoid(x) = rcp(1 + 2^(-x log2 e)). The rounding of the product x*log2(e)
+// perturbs the exponent by <= |x| 2^-24, i.e. sigmoid by <= s(1-s) |x| ln2 2^-24 < 1.5e-8 |x| e^-|x|... < 1e-7 absolute:
+// the same order as one fp32 ulp of the result, so the compensated form (rd_exp) is only kept for the A/B variant.
+template <int ACT>
+__device__ __forceinline__ float act_sigmoid(float x) {
+    if (ACT == 0) return rd_sigmoid(x);
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896341f));
+}
+template <int ACT>
+__device__ __forceinline__ float act_tanh(float x) {
+    if (ACT == 0) return rd_tanh(x);
+    // tanh x = 1 - 2 / (1 + 2^(2x log2 e))
+    return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * 2.88539008177792681f)), 1.0f);
+}
+
+// ACT: 0 = compensated exp, 1 = plain v_exp_f32 forms.  SCHED: 0 = compiler's own order, 1 = LDS reads of the gate math
+// pinned to the top of the phase + explicit MFMA/VALU interleave (sched_group_barrier).
+template <int ACT, int SCHED, int DIAG = 0>   // DIAG (bench diagnosis only, wrong results): 1 = no gate math, 2 = no MFMA
 __global__ __launch_bounds__(256, 1) void rd_lstm_mfma_f32_kernel(DevModel d, ReadBatch rb, float *__restrict__ logits,
                                                                   uint8_t *__restrict__ labels) {
     __shared__ LstmSmem S;
@@ -377,7 +407,10 @@ __global__ __launch_bounds__(256, 1) void rd_lstm_mfma_f32_kernel(DevModel d, Re
     if (tid == 0) S.tmax = 0;
     for (int i = tid; i < NT * 16 * HSTR; i += 256) { (&S.Hs[0][0][0])[i] = 0.0f; (&S.Hl[0][0][0])[i] = 0.0f; }
     for (int i = tid; i < NT * 256; i += 256) { (&S.cA[0][0])[i] = f32x4{0, 0, 0, 0}; (&S.cB[0][0])[i] = f32x4{0, 0, 0, 0}; }
-    for (int i = tid; i < 5 * G4; i += 256) S.lut[i / G4][i % G4] = d.in_lut[i];
+    for (int i = tid; i < 5 * G4; i += 256) {      // i = ((code*4 + w)*16 + l15)*8 + c
+        const int c = i & 7, l = (i >> 3) & 15, w = (i >> 7) & 3, code = i >> 9;
+        (reinterpret_cast<float *>(&S.lut[0][0][0][0]))[i] = d.in_lut[code * G4 + gate_col(w, c, l)];
+    }
     S.wout[tid >> 7][tid & 127] = d.w_out[(tid >> 7) * 256 + (tid & 127)];
     __syncthreads();
     if (tid < BT) atomicMax(&S.tmax, S.T[tid]);
@@ -390,7 +423,14 @@ __global__ __launch_bounds__(256, 1) void rd_lstm_mfma_f32_kernel(DevModel d, Re
 #pragma unroll
         for (int c = 0; c < 8; ++c)
 #pragma unroll
-            for (int s = 0; s < 32; ++s) Wr[c][s] = wp[(c * 32 + s) * 64];
+            for (int s = 0; s < 32; ++s) {
+                // Register plan (512 per lane): column tiles 1..7 of the weights are pinned in 224 AGPRs (the MFMAs read
+                // them there directly as srcB), the 8 accumulators take the other 32 AGPRs, and tile 0's 32 weights stay
+                // in architectural VGPRs next to the h fragments and the gate math.
+                const float x = wp[(c * 32 + s) * 64];
+                if (c == 0) Wr[c][s] = x;
+                else asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(Wr[c][s]) : "v"(x));
+            }
     }
     __syncthreads();
     const int tmax = S.tmax;
@@ -404,7 +444,8 @@ __global__ __launch_bounds__(256, 1) void rd_lstm_mfma_f32_kernel(DevModel d, Re
     for (int m = 0; m < 8; ++m) hA[m] = f32x4{0, 0, 0, 0};
 
     int tile = 0, t = 0;          // current phase
-    int ptile = NT - 1, pt = -1;  // previous phase (dummy before the first: accP = 0 -> h = c = 0, a no-op update)
+    int ptile = NT - 1, pt = -1;  // previous phase (dummy before the first: its state update is masked to zero)
+    uint32_t cwP = 0x04040404u;   // codes of the previous phase's 4 reads of this lane (loaded one phase ahead)
 
     // p == nphase is a drain iteration: its MFMAs run on a dummy tile, its gate math finishes the last real phase.
     for (int p = 0; p <= nphase; ++p) {
@@ -417,48 +458,73 @@ __global__ __launch_bounds__(256, 1) void rd_lstm_mfma_f32_kernel(DevModel d, Re
         const int ntile = tile + 1 == NT ? 0 : tile + 1;
         const int nt = tile + 1 == NT ? t + 1 : t;
 
-        // ---- LDS prefetch: A fragments of the next phase (written >= 2 barriers ago) -----------
+        // ---- LDS reads, all issued at the top of the phase ------------------------------------------
+        // A fragments of the next phase (written >= 2 barriers ago)
         f32x4 hN[8];
 #pragma unroll
         for (int m = 0; m < 8; ++m) hN[m] = *reinterpret_cast<const f32x4 *>(&S.Hs[ntile][l15][16 * m + 4 * q]);
+        if (DIAG >= 3) {
+#pragma unroll
+            for (int m = 0; m < 8; ++m) hN[m] = hA[m] + accP[m] * 1e-30f;
+        }
+        // operands of the previous phase's gate math
+        const int tcur = t < tmax ? t : 0;
+        const uint32_t cwN = *reinterpret_cast<const uint32_t *>(&S.codes[(tcur / TC) & 1][tcur % TC][tile * 16 + 4 * q]);
+        const int4 Tr = *reinterpret_cast<const int4 *>(&S.T[ptile * 16 + 4 * q]);
+        f32x4 cs[2] = {S.cA[ptile][tid], S.cB[ptile][tid]};
+        f32x4 lv[4][2];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int code = (int)((cwP >> (8 * r)) & 0xff);
+            lv[r][0] = S.lut[code][wave][l15][0];
+            lv[r][1] = S.lut[code][wave][l15][1];
+        }
+        if (SCHED) __builtin_amdgcn_sched_barrier(0);
 
         // ---- MFMA: 256 x v_mfma_f32_16x16x4_f32, 8 independent accumulators ---------------------
         f32x4 acc[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) acc[c] = f32x4{0, 0, 0, 0};
+        if (DIAG != 2) {
 #pragma unroll
-        for (int m = 0; m < 8; ++m) {
+            for (int m = 0; m < 8; ++m) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float a = hA[m][j];
+                for (int j = 0; j < 4; ++j) {
+                    const float a = hA[m][j];
 #pragma unroll
-                for (int c = 0; c < 8; ++c)
-                    acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Wr[c][m * 4 + j], acc[c], 0, 0, 0);
+                    for (int c = 0; c < 8; ++c)
+                        acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Wr[c][m * 4 + j], acc[c], 0, 0, 0);
+                }
             }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) acc[c] = f32x4{hA[c][0] + Wr[c][0], hA[c][1] + Wr[c][9], hA[c][2] + Wr[c][17], hA[c][3] + Wr[c][31]};
         }
 
         // ---- gate math of the previous phase (VALU, overlaps the MFMAs above) -------------------
-        {
-            const int ptc = pt < 0 ? 0 : pt;
-            const uint32_t cw = *reinterpret_cast<const uint32_t *>(&S.codes[(ptc / TC) & 1][ptc % TC][ptile * 16 + 4 * q]);
-            const int4 Tr = *reinterpret_cast<const int4 *>(&S.T[ptile * 16 + 4 * q]);
+        if (DIAG >= 3) {
+        } else if (DIAG == 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+                    S.Hs[ptile][4 * q + r][32 * wave + 16 * s + l15] = accP[s][r] + accP[2 + s][r] + accP[4 + s][r] + accP[6 + s][r] + lv[r][s][0] + cs[s][r];
+        } else {
             const int Tq[4] = {Tr.x, Tr.y, Tr.z, Tr.w};
-            f32x4 cs[2] = {S.cA[ptile][tid], S.cB[ptile][tid]};
+            const float live = pt < 0 ? 0.0f : 1.0f;   // the dummy phase before t = 0 must leave the zero state untouched
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int code = pt < 0 ? 4 : (int)((cw >> (8 * r)) & 0xff);
-                const float *lrow = &S.lut[code][32 * wave + l15];
                 const bool last = (pt == Tq[r] - 1);
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    const float gi = accP[0 + s][r] + lrow[0 * HID + 16 * s];
-                    const float gf = accP[2 + s][r] + lrow[1 * HID + 16 * s];
-                    const float gg = accP[4 + s][r] + lrow[2 * HID + 16 * s];
-                    const float go = accP[6 + s][r] + lrow[3 * HID + 16 * s];
-                    float cn = __builtin_fmaf(rd_sigmoid(gf), cs[s][r], rd_sigmoid(gi) * rd_tanh(gg));
-                    float h = rd_sigmoid(go) * rd_tanh(cn);
-                    cn = pt < 0 ? 0.0f : cn;     // the dummy phase before t = 0 must leave the zero state untouched
-                    h = pt < 0 ? 0.0f : h;
+                    // column tile c = gate*2 + s ; lv[r][c>>2][c&3]
+                    const float gi = accP[0 + s][r] + lv[r][0][0 + s];
+                    const float gf = accP[2 + s][r] + lv[r][0][2 + s];
+                    const float gg = accP[4 + s][r] + lv[r][1][0 + s];
+                    const float go = accP[6 + s][r] + lv[r][1][2 + s];
+                    float cn = __builtin_fmaf(act_sigmoid<ACT>(gf), cs[s][r], act_sigmoid<ACT>(gi) * act_tanh<ACT>(gg));
+                    cn *= live;
+                    const float h = act_sigmoid<ACT>(go) * act_tanh<ACT>(cn) * live;
                     cs[s][r] = cn;
                     const int row = 4 * q + r, u = 32 * wave + 16 * s + l15;
                     S.Hs[ptile][row][u] = h;
@@ -469,14 +535,30 @@ __global__ __launch_bounds__(256, 1) void rd_lstm_mfma_f32_kernel(DevModel d, Re
             S.cA[ptile][tid] = cs[0];
             S.cB[ptile][tid] = cs[1];
         }
-        __syncthreads();
+        if (SCHED) {
+            // one MFMA, then up to three VALU/transcendental ops in its shadow (single wave per SIMD issues in order)
+#pragma unroll
+            for (int i = 0; i < 256; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x402, 3, 0);
+            }
+        }
+        if (DIAG != 3) __syncthreads();
 #pragma unroll
         for (int c = 0; c < 8; ++c) accP[c] = acc[c];
 #pragma unroll
         for (int m = 0; m < 8; ++m) hA[m] = hN[m];
+        cwP = cwN;
         ptile = tile; pt = t; tile = ntile; t = nt;
     }
 
+    if (DIAG >= 3) {   // keep the diagnostic MFMA chain live
+        float sink = 0;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) sink += accP[c][0] + accP[c][1] + accP[c][2] + accP[c][3] + hA[c][0];
+        S.Hl[0][l15][tid & 127] = sink;
+        __syncthreads();
+    }
     // ---- epilogue: FC + reverse table + argmax ----------------------------------------------------
     rd_fc_epilogue(
         BT, [&](int row, int u) { return S.Hl[row >> 4][row & 15][u]; }, S.T, S.off, S.orig, &S.wout[0][0], d, rb, logits, labels);
@@ -536,6 +618,202 @@ __global__ __launch_bounds__(512) void rd_lstm_simple_kernel(DevModel d, ReadBat
     }
     rd_fc_epilogue(
         SB, [&](int row, int u) { return hl[row][u]; }, T, off, orig, s_wout, d, rb, logits, labels);
+}
+
+// ------------------------------------------------------------------------------------------------
+// rd_lstm_mfma_f16x3_kernel - split-precision recurrence on the f16 matrix pipe.
+//
+// Measured on MI355X (tools/ubench/mfma_fill.hip): v_mfma_f32_16x16x4_f32 issues every 36 cycles and does NOT overlap
+// with VALU work of the same wave (one filler VALU op costs +12 cycles: the f32 MFMA runs at the f32 vector rate on the
+// same datapath), so the fp32 kernel above pays MFMA time + gate-math time. v_mfma_f32_16x16x32_f16 issues every 17
+// cycles with two VALU ops per MFMA hidden for free. This kernel therefore evaluates the fp32 product as three f16
+// products accumulated in fp32:
+//     h = h_hi + h_lo,  w = w_hi + w_lo   (hi = fp16 rounding, lo = fp16 rounding of the exact residual)
+//     h.w ~= h_hi w_hi + h_hi w_lo + h_lo w_hi          (dropped: h_lo w_lo <= 2^-22 |h w|)
+// Operands are pre-scaled by powers of two so that no residual lands in the fp16 subnormal range:
+//     A (weights, registers):  W1 = 16 w_hi            W2 = 2^11 (16 w - W1)
+//     B (hidden state, LDS):   H1s = 2^11 h_hi'  (h_hi' = fp16(2^11 h)/2^11)   H1 = h_hi'   H2 = 2^11 h - H1s
+//     acc = LUT*2^15 + W1.H1s + W2.H1 + W1.H2  = 2^15 * (W_ih x + b + W_hh h)      (every term carries 2^15)
+// and the 2^-15 is folded into the activation's exp2 argument. Products of fp16 pairs are exact in fp32; the only
+// extra error over the fp32 kernel is the 2^-22-relative representation error of each operand (same order as fp32's
+// own 2^-24 rounding of the 128-term sum). tests/test_gpu_parity.py holds this path to the same 1e-4 logit bound.
+//
+// Orientation: A = weights (rows = 16 gate rows of a column tile), B = h^T (cols = 16 reads). A tile's 16 rows are
+// {4 units x (i,f,g,o)}: row 4*qr + gate <-> unit 32*wave + 8*qr + a for tile a = 0..7, so the D layout
+// (col = lane&15, row = 4*(lane>>4) + reg) hands lane (read l15, q) the four gates of unit 32w + 8q + a in ONE
+// accumulator, and over a = 0..7 eight CONTIGUOUS units: h leaves as one 16-byte LDS store per operand array.
+// ------------------------------------------------------------------------------------------------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+constexpr int H16STR = 136;   // f16 per LDS row: 128 + 8 pad = 272 B -> conflict-free ds_read_b128 over 16 rows
+constexpr int TC16 = 64;      // timesteps per staged code chunk
+constexpr float W_SCALE = 16.0f, H_SCALE = 2048.0f, G_SCALE = 32768.0f;   // 2^4, 2^11, 2^15
+
+struct __attribute__((aligned(16))) Lstm16Smem {
+    _Float16 H1s[NT][16][H16STR];
+    _Float16 H1[NT][16][H16STR];
+    _Float16 H2[NT][16][H16STR];
+    float Hl[NT][16][HSTR];        // h captured at t == T-1
+    f32x4 cA[NT][256];             // cell state of units a = 0..3
+    f32x4 cB[NT][256];             // cell state of units a = 4..7
+    f32x4 lut[5][4][4][8];         // [code][wave][q][a] -> (i,f,g,o) pre-activation offsets * 2^15
+    float wout[2][HID];
+    uint8_t codes[2][TC16][BT];
+    int T[BT];
+    long long off[BT];
+    int orig[BT];
+    int tmax;
+};
+
+__device__ __forceinline__ void rd_stage_codes16(Lstm16Smem &S, const ReadBatch &rb, int chunk) {
+    const int t0 = chunk * TC16;
+    uint8_t(*dst)[BT] = S.codes[chunk & 1];
+    for (int idx = threadIdx.x; idx < BT * TC16; idx += 256) {
+        const int row = idx / TC16, tt = idx % TC16, t = t0 + tt;
+        int code = 4;
+        if (t < S.T[row]) code = rd_code(rb.arena[S.off[row] + t]);
+        dst[tt][row] = (uint8_t)code;
+    }
+}
+
+__device__ __forceinline__ float sig_scaled(float G) {    // sigmoid(G / 2^15)
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(G * (-1.44269504088896341f / G_SCALE)));
+}
+__device__ __forceinline__ float tanh_scaled(float G) {   // tanh(G / 2^15)
+    return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(G * (2.88539008177792681f / G_SCALE))), 1.0f);
+}
+
+__global__ __launch_bounds__(256, 1) void rd_lstm_mfma_f16x3_kernel(DevModel d, ReadBatch rb, float *__restrict__ logits,
+                                                                    uint8_t *__restrict__ labels) {
+    __shared__ Lstm16Smem S;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane >> 4, l15 = lane & 15;
+
+    if (tid < BT) {
+        const int64_t g = (int64_t)blockIdx.x * BT + tid;
+        int T = 0, orig = -1;
+        long long off = 0;
+        if (g < rb.n) {
+            orig = rb.order ? rb.order[g] : (int)g;
+            T = rd_T(rb.len, orig, rb.max_len);
+            off = rb.off[orig];
+        }
+        S.T[tid] = T; S.off[tid] = off; S.orig[tid] = orig;
+    }
+    if (tid == 0) S.tmax = 0;
+    for (int i = tid; i < 3 * NT * 16 * H16STR / 2; i += 256) (reinterpret_cast<uint32_t *>(&S.H1s[0][0][0]))[i] = 0u;
+    for (int i = tid; i < NT * 16 * HSTR; i += 256) (&S.Hl[0][0][0])[i] = 0.0f;
+    for (int i = tid; i < NT * 256; i += 256) { (&S.cA[0][0])[i] = f32x4{0, 0, 0, 0}; (&S.cB[0][0])[i] = f32x4{0, 0, 0, 0}; }
+    for (int i = tid; i < 5 * G4; i += 256) {      // i = (((code*4 + w)*4 + qq)*8 + a)*4 + gate
+        const int gate = i & 3, a = (i >> 2) & 7, qq = (i >> 5) & 3, w = (i >> 7) & 3, code = i >> 9;
+        (reinterpret_cast<float *>(&S.lut[0][0][0][0]))[i] = G_SCALE * d.in_lut[code * G4 + gate * HID + 32 * w + 8 * qq + a];
+    }
+    S.wout[tid >> 7][tid & 127] = d.w_out[(tid >> 7) * 256 + (tid & 127)];
+    __syncthreads();
+    if (tid < BT) atomicMax(&S.tmax, S.T[tid]);
+    rd_stage_codes16(S, rb, 0);
+
+    // ---- resident weights: 8 tiles x 4 k-steps x (W1, W2), one f16x8 (4 registers) per lane each = 256 registers ----
+    f16x8 W1[8][4], W2[8][4];
+    {
+        const uint4 *wp = reinterpret_cast<const uint4 *>(d.wpack16) + (size_t)wave * (2 * 8 * 4 * 64) + lane;
+#pragma unroll
+        for (int a = 0; a < 8; ++a)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const uint4 x1 = wp[((0 * 8 + a) * 4 + s) * 64], x2 = wp[((1 * 8 + a) * 4 + s) * 64];
+                W1[a][s] = __builtin_bit_cast(f16x8, x1);
+                W2[a][s] = __builtin_bit_cast(f16x8, x2);
+            }
+    }
+    __syncthreads();
+    const int tmax = S.tmax;
+    const int nphase = tmax * NT;
+
+    f32x4 accP[8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) accP[a] = f32x4{0, 0, 0, 0};
+    int tile = 0, t = 0, ptile = NT - 1, pt = -1;
+    int codeC = S.codes[0][0][l15];        // code of this lane's read in the current phase (drives the accumulator init)
+    const int boff = l15 * H16STR + 8 * q; // f16 offset of this lane's B fragment inside a tile, k-step 0
+
+    for (int p = 0; p <= nphase; ++p) {
+        if (tile == 1 && (t % TC16) == 0) {
+            const int chunk = t / TC16 + 1;
+            if (chunk * TC16 < tmax + 1) rd_stage_codes16(S, rb, chunk);
+        }
+        const int ntile = tile + 1 == NT ? 0 : tile + 1;
+        const int nt = tile + 1 == NT ? t + 1 : t;
+
+        // ---- LDS reads of this phase: B fragments (h^T of the tile), accumulator init, state of the previous phase --
+        f16x8 b1s[4], b1[4], b2[4];
+        const _Float16 *h1s = &S.H1s[tile][0][0] + boff, *h1 = &S.H1[tile][0][0] + boff, *h2 = &S.H2[tile][0][0] + boff;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            b1s[s] = *reinterpret_cast<const f16x8 *>(h1s + 32 * s);
+            b1[s] = *reinterpret_cast<const f16x8 *>(h1 + 32 * s);
+            b2[s] = *reinterpret_cast<const f16x8 *>(h2 + 32 * s);
+        }
+        f32x4 acc[8];
+#pragma unroll
+        for (int a = 0; a < 8; ++a) acc[a] = S.lut[codeC][wave][q][a];
+        const int tn = nt < tmax ? nt : 0;
+        const int codeN = S.codes[(tn / TC16) & 1][tn % TC16][ntile * 16 + l15];
+        const int Tp = S.T[ptile * 16 + l15];
+        f32x4 cs[2] = {S.cA[ptile][tid], S.cB[ptile][tid]};
+
+        // ---- 96 x v_mfma_f32_16x16x32_f16: same accumulator every 8th instruction --------------------------------
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int a = 0; a < 8; ++a) acc[a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W1[a][s], b1s[s], acc[a], 0, 0, 0);
+#pragma unroll
+            for (int a = 0; a < 8; ++a) acc[a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W2[a][s], b1[s], acc[a], 0, 0, 0);
+#pragma unroll
+            for (int a = 0; a < 8; ++a) acc[a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W1[a][s], b2[s], acc[a], 0, 0, 0);
+        }
+
+        // ---- gate math of the previous phase: lane (read l15) x units 32w + 8q + a -------------------------------
+        const float live = pt < 0 ? 0.0f : 1.0f;
+        float hv[8];
+        f16x8 o1s, o1, o2;
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+            const f32x4 G = accP[a];
+            const float cold = cs[a >> 2][a & 3];
+            float cn = __builtin_fmaf(sig_scaled(G[1]), cold, sig_scaled(G[0]) * tanh_scaled(G[2]));
+            cn *= live;
+            const float h = sig_scaled(G[3]) * tanh_scaled(cn * G_SCALE) * live;
+            cs[a >> 2][a & 3] = cn;
+            hv[a] = h;
+            const float hs = h * H_SCALE;
+            const _Float16 p16 = (_Float16)hs;                  // 2^11 h_hi'
+            o1s[a] = p16;
+            o1[a] = p16 * (_Float16)(1.0f / H_SCALE);           // exact power-of-two scaling
+            o2[a] = (_Float16)(hs - (float)p16);                // exact residual, rounded once
+        }
+        {
+            const int wo = l15 * H16STR + 32 * wave + 8 * q;
+            *reinterpret_cast<f16x8 *>(&S.H1s[ptile][0][0] + wo) = o1s;
+            *reinterpret_cast<f16x8 *>(&S.H1[ptile][0][0] + wo) = o1;
+            *reinterpret_cast<f16x8 *>(&S.H2[ptile][0][0] + wo) = o2;
+            S.cA[ptile][tid] = cs[0];
+            S.cB[ptile][tid] = cs[1];
+            if (pt == Tp - 1) {
+                float *hl = &S.Hl[ptile][l15][32 * wave + 8 * q];
+                *reinterpret_cast<f32x4 *>(hl) = f32x4{hv[0], hv[1], hv[2], hv[3]};
+                *reinterpret_cast<f32x4 *>(hl + 4) = f32x4{hv[4], hv[5], hv[6], hv[7]};
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < 8; ++a) accP[a] = acc[a];
+        codeC = codeN;
+        ptile = tile; pt = t; tile = ntile; t = nt;
+    }
+
+    rd_fc_epilogue(
+        BT, [&](int row, int u) { return S.Hl[row >> 4][row & 15][u]; }, S.T, S.off, S.orig, &S.wout[0][0], d, rb, logits, labels);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -706,6 +984,7 @@ int rd_model_create(const rd_weights *w, int device, rd_model **out) {
     A((void **)&m->d.raw, sizeof(float) * RAW_FLOATS);
     A((void **)&m->d.wpack32, sizeof(float) * 4 * 8 * 32 * 64);
     A((void **)&m->d.wt_hh, sizeof(float) * HID * G4);
+    A((void **)&m->d.wpack16, sizeof(uint16_t) * 4 * 2 * 8 * 4 * 64 * 8);
     A((void **)&m->d.in_lut, sizeof(float) * 5 * G4);
     A((void **)&m->d.rev_lut, sizeof(float) * 10);
     A((void **)&m->d.w_out, sizeof(float) * 512);
@@ -740,7 +1019,7 @@ void rd_model_destroy(rd_model *m) {
 int rd_set_variant(rd_model *m, int variant) {
     if (!m) RD_FAIL(RD_E_INVALID, "rd_set_variant: null model");
     if (variant == RD_VARIANT_AUTO) variant = RD_VARIANT_MFMA_F32;
-    if (variant != RD_VARIANT_MFMA_F32 && variant != RD_VARIANT_SIMPLE)
+    if (variant != RD_VARIANT_MFMA_F32 && variant != RD_VARIANT_SIMPLE && variant != RD_VARIANT_MFMA_F16X3 && !(variant >= 10 && variant <= 23))
         RD_FAIL(RD_E_UNSUPPORTED, "rd_set_variant: variant %d not available in this build", variant);
     m->variant = variant;
     return RD_OK;
@@ -808,7 +1087,18 @@ int rd_classify(const rd_model *cm, const uint8_t *arena, const int64_t *seq_off
         hipLaunchKernelGGL(rd_lstm_simple_kernel, dim3((unsigned)nwg), dim3(512), 0, st, m->d, rb, logits, labels);
     } else {
         const int64_t nwg = (n + BT - 1) / BT;
-        hipLaunchKernelGGL(rd_lstm_mfma_f32_kernel, dim3((unsigned)nwg), dim3(256), 0, st, m->d, rb, logits, labels);
+        switch (m->variant) {
+        case 10: hipLaunchKernelGGL((rd_lstm_mfma_f32_kernel<0, 0>), dim3((unsigned)nwg), dim3(256), 0, st, m->d, rb, logits, labels); break;
+        case 11: hipLaunchKernelGGL((rd_lstm_mfma_f32_kernel<1, 0>), dim3((unsigned)nwg), dim3(256), 0, st, m->d, rb, logits, labels); break;
+        case 12: hipLaunchKernelGGL((rd_lstm_mfma_f32_kernel<0, 1>), dim3((unsigned)nwg), dim3(256), 0, st, m->d, rb, logits, labels); break;
+        case 13: hipLaunchKernelGGL((rd_lstm_mfma_f32_kernel<1, 1>), dim3((unsigned)nwg), dim3(256), 0, st, m->d, rb, logits, labels); break;
+        case 20: hipLaunchKernelGGL((rd_lstm_mfma_f32_kernel<1, 0, 1>), dim3((unsigned)nwg), dim3(256), 0, st, m->d, rb, logits, labels); break;
+        case 21: hipLaunchKernelGGL((rd_lstm_mfma_f32_kernel<1, 0, 2>), dim3((unsigned)nwg), dim3(256), 0, st, m->d, rb, logits, labels); break;
+        case 22: hipLaunchKernelGGL((rd_lstm_mfma_f32_kernel<1, 0, 3>), dim3((unsigned)nwg), dim3(256), 0, st, m->d, rb, logits, labels); break;
+        case 23: hipLaunchKernelGGL((rd_lstm_mfma_f32_kernel<1, 0, 4>), dim3((unsigned)nwg), dim3(256), 0, st, m->d, rb, logits, labels); break;
+        case RD_VARIANT_MFMA_F16X3: hipLaunchKernelGGL(rd_lstm_mfma_f16x3_kernel, dim3((unsigned)nwg), dim3(256), 0, st, m->d, rb, logits, labels); break;
+        default: hipLaunchKernelGGL((rd_lstm_mfma_f32_kernel<1, 0>), dim3((unsigned)nwg), dim3(256), 0, st, m->d, rb, logits, labels); break;
+        }
     }
     RD_HIP(hipGetLastError());
     if (ev) { RD_HIP(hipEventRecord(ev[1], st)); m->prof_count++; }

@@ -46,3 +46,16 @@ def gpu_model():
     m = cfg.init_obj("arch", module_arch)
     m.load_state_dict(cfg.load_state_dict("mcc"))
     return m.to("cuda:0").eval()
+
+
+@pytest.fixture(scope="session")
+def report():
+    """numbers worth keeping from a GPU test session (max logit errors ...): written to gpurun_out/parity_report.json"""
+    import json
+    data = {}
+    yield data
+    if data:
+        out = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_report.json"), "w") as fh:
+            json.dump(data, fh, indent=1, sort_keys=True)

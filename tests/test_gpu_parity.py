@@ -9,7 +9,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
-VARIANTS = ["mfma_f32", "simple"]
+VARIANTS = ["mfma_f32", "simple", "mfma_f32_a0s0", "mfma_f16x3"]
 
 
 def _run(model, arena, offsets, lens, max_len):
@@ -46,7 +46,7 @@ def test_kat(gpu_model, golden, variant):
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
-def test_golden_se_edge_varlen(gpu_model, golden, variant):
+def test_golden_se_edge_varlen(gpu_model, golden, variant, report):
     gpu_model.set_variant(variant)
     d = golden.npz("se100")
     lg, lab = _run(gpu_model, d["arena"], d["offsets"], d["lens"], 100)
@@ -62,6 +62,7 @@ def test_golden_se_edge_varlen(gpu_model, golden, variant):
         lg, lab = _run(gpu_model, d["arena"], d["offsets"], d["lens"], L)
         e3 = max(e3, _check(lg, lab, d["logits_l%d" % L], "varlen%d/%s" % (L, variant)))
     print("max logit error vs reference golden [%s]: se100 %.3g edge %.3g varlen %.3g" % (variant, e1, e2, e3))
+    report["golden_max_logit_err/" + variant] = {"se100": float(e1), "edge": float(e2), "varlen": float(e3)}
     gpu_model.set_variant("auto")
 
 
