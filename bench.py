@@ -27,14 +27,28 @@ READ_LEN = 100
 FLOPS_PER_READ = READ_LEN * 131072 + 1024        # forward recurrence h.W_hh^T + FC
 BYTES_PER_READ = READ_LEN + 4 + 8 + 8 + 1        # ASCII + len + offset + logits + label
 PEAKS = {"mfma_f32": 157.3, "simple": 157.3, "mfma_f16x3": 2500.0}   # dense TFLOP/s, MI355X_MICROARCH.md
+MFMA_FLOPS_PER_ALGO_FLOP = {"mfma_f32": 1, "simple": 1, "mfma_f16x3": 3}   # f16x3 issues three f16 products per fp32 product
+
+
+def usable_cores():
+    """host cores this process may actually use: min(affinity, cgroup cpu quota). The GPU boxes expose 256 logical CPUs
+    but cap the container at 16 CPUs' worth of time (cpu.max = 1600000 100000)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
 
 
 def cpu_baseline(arena_np, n_reads, target_s=15.0):
-    """Time the oracle's batched ribodetector_cpu restatement on all host cores; bounded to ~target_s seconds."""
+    """Time the oracle's batched ribodetector_cpu restatement on all usable host cores; bounded to ~target_s seconds."""
     import numpy as np
     from oracle import oracle as O
     ora = O.load_default()
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     off = np.arange(n_reads + 1, dtype=np.int64) * READ_LEN
     lens = np.full(n_reads, READ_LEN, dtype=np.int32)
     probe = min(n_reads, 1024 * min(cores, 8))
@@ -48,7 +62,8 @@ def cpu_baseline(arena_np, n_reads, target_s=15.0):
     return {"value": n / dt, "unit": "reads/s", "cores": cores, "kind": "port",
             "sample": "first %d reads of the rank-0 R1 stream (100 bp), oracle rdo_forward_padded_batched = ribodetector_cpu "
                       "algorithm (padded BiLSTM over all 100 steps x 2 directions, batch 1024, one batch per thread, "
-                      "%d OpenMP threads), %.1f s; onnxruntime is not installed, so this C port stands in for it" % (n, cores, dt)}
+                      "%d OpenMP threads = usable cores of this container; os.cpu_count() = %d), %.1f s; onnxruntime is not installed, so this C port "
+                      "stands in for it" % (n, cores, os.cpu_count() or 0, dt)}
 
 
 def main():
@@ -60,6 +75,7 @@ def main():
     ap.add_argument("--variant", default="auto")
     ap.add_argument("--ensure", default="rrna")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alt", action="store_true", help="skip the short extra measurement of the exact-fp32 MFMA kernel")
     args = ap.parse_args()
 
     import torch
@@ -82,7 +98,7 @@ def main():
     model.load_state_dict(cfg.load_state_dict("mcc"))
     model.to(dev).eval()
     model.set_variant(args.variant)
-    variant = "mfma_f32" if args.variant == "auto" else args.variant
+    variant = "mfma_f16x3" if args.variant == "auto" else args.variant
 
     P = args.pairs_per_step
     nslices = max(1, min(args.steps, 10))                 # distinct batches resident in HBM (2 x 100 MiB each), reused cyclically
@@ -143,7 +159,8 @@ def main():
         reads_per_launch = P
         avg_ms = kms / max(launches, 1)
         achieved = reads_per_launch * FLOPS_PER_READ / (avg_ms * 1e-3) / 1e12 if launches else None
-        peak = PEAKS["mfma_f32" if variant.startswith("mfma_f32_") else variant]
+        base = "mfma_f16x3" if variant.startswith("mfma_f16x3") else ("mfma_f32" if variant.startswith("mfma_f32") else variant)
+        peak = PEAKS[base]
         out = {
             "metric": "reads/sec classified, 100 bp paired-end",
             "value": 2.0 * total_pairs / dt,
@@ -155,7 +172,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" if variant != "mfma_f16x3" else "f16x3-split (f32 accumulate)",
+            "dtype": "f32" if not variant.startswith("mfma_f16x3") else "f16x3-split (f32 accumulate)",
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[2]: paired-end 100 bp, --ensure %s, %d pairs/step/GPU x %d steps "
                                    "(%.1f M pairs total), inputs resident in HBM" % (args.ensure, P, args.steps, total_pairs / 1e6),
@@ -164,10 +181,29 @@ def main():
                        "label_counts": {"non_rrna": c[0], "rrna": c[1], "unclassified": c[2]}},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": (achieved / peak) if achieved else None, "traffic": None,
-                         "kernel": "rd_lstm_%s_kernel" % ("mfma_f32" if variant.startswith("mfma_f32") else variant), "launches": launches, "avg_launch_ms": avg_ms,
+                         "kernel": "rd_lstm_%s_kernel" % base, "launches": launches, "avg_launch_ms": avg_ms,
                          "algorithmic_flops_per_launch": reads_per_launch * FLOPS_PER_READ,
-                         "algorithmic_bytes_per_launch": reads_per_launch * BYTES_PER_READ},
+                         "algorithmic_bytes_per_launch": reads_per_launch * BYTES_PER_READ,
+                         "mfma_flops_executed_per_algorithmic_flop": MFMA_FLOPS_PER_ALGO_FLOP[base],
+                         "mfma_pipe_frac": (achieved * MFMA_FLOPS_PER_ALGO_FLOP[base] / peak) if achieved else None},
         }
+        if world == 1 and not args.no_alt and base != "mfma_f32":
+            # the same step on the exact-fp32 MFMA kernel (v_mfma_f32_16x16x4_f32), for the fp32-MFMA roofline of SURVEY §8d
+            model.set_variant("mfma_f32")
+            model.profile_enable(True)
+            sync()
+            t1 = time.perf_counter()
+            for i in range(2):
+                step(i)
+            sync()
+            d1 = time.perf_counter() - t1
+            l2, k2 = model.profile_read()
+            model.profile_enable(False)
+            model.set_variant(args.variant)
+            a2 = P * FLOPS_PER_READ / (k2 / max(l2, 1) * 1e-3) / 1e12
+            out["alt_fp32_kernel"] = {"kernel": "rd_lstm_mfma_f32_kernel", "value": 2.0 * P * 2 / d1, "unit": "reads/s", "steps": 2,
+                                      "roofline": {"bound": "mfma", "achieved": a2, "peak": PEAKS["mfma_f32"], "unit": "TFLOP/s",
+                                                   "frac": a2 / PEAKS["mfma_f32"], "avg_launch_ms": k2 / max(l2, 1)}}
         if not args.no_cpu_baseline and world == 1:
             try:
                 nb = min(P, 400000)

@@ -655,7 +655,7 @@ struct __attribute__((aligned(16))) Lstm16Smem {
     float Hl[NT][16][HSTR];        // h captured at t == T-1
     f32x4 cA[NT][256];             // cell state of units a = 0..3
     f32x4 cB[NT][256];             // cell state of units a = 4..7
-    f32x4 lut[5][4][4][8];         // [code][wave][q][a] -> (i,f,g,o) pre-activation offsets * 2^15
+    f32x4 lut[5][4][4][8];         // [code][wave][q][a] -> exp2 arguments' constant terms of (i,f,g,o), see KI/KG
     float wout[2][HID];
     uint8_t codes[2][TC16][BT];
     int T[BT];
@@ -675,13 +675,10 @@ __device__ __forceinline__ void rd_stage_codes16(Lstm16Smem &S, const ReadBatch 
     }
 }
 
-__device__ __forceinline__ float sig_scaled(float G) {    // sigmoid(G / 2^15)
-    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(G * (-1.44269504088896341f / G_SCALE)));
-}
-__device__ __forceinline__ float tanh_scaled(float G) {   // tanh(G / 2^15)
-    return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(G * (2.88539008177792681f / G_SCALE))), 1.0f);
-}
+// sigmoid(x) = 1 / (1 + 2^(KS x)),  tanh(x) = 1 - 2 / (1 + 2^(KT x))
+constexpr float KS = -1.44269504088896341f, KT = 2.88539008177792681f;
 
+template <int FILL>   // VALU ops scheduled behind each MFMA
 __global__ __launch_bounds__(256, 1) void rd_lstm_mfma_f16x3_kernel(DevModel d, ReadBatch rb, float *__restrict__ logits,
                                                                     uint8_t *__restrict__ labels) {
     __shared__ Lstm16Smem S;
@@ -704,16 +701,20 @@ __global__ __launch_bounds__(256, 1) void rd_lstm_mfma_f16x3_kernel(DevModel d, 
     for (int i = tid; i < 3 * NT * 16 * H16STR / 2; i += 256) (reinterpret_cast<uint32_t *>(&S.H1s[0][0][0]))[i] = 0u;
     for (int i = tid; i < NT * 16 * HSTR; i += 256) (&S.Hl[0][0][0])[i] = 0.0f;
     for (int i = tid; i < NT * 256; i += 256) { (&S.cA[0][0])[i] = f32x4{0, 0, 0, 0}; (&S.cB[0][0])[i] = f32x4{0, 0, 0, 0}; }
+    // The input/bias term of each gate enters as the constant term of the activation's exp2 argument:
+    //   2^(KS (G/2^15 + lut)) = 2^(fma(G, KS/2^15, KS lut))  - no add, no accumulator init.
     for (int i = tid; i < 5 * G4; i += 256) {      // i = (((code*4 + w)*4 + qq)*8 + a)*4 + gate
         const int gate = i & 3, a = (i >> 2) & 7, qq = (i >> 5) & 3, w = (i >> 7) & 3, code = i >> 9;
-        (reinterpret_cast<float *>(&S.lut[0][0][0][0]))[i] = G_SCALE * d.in_lut[code * G4 + gate * HID + 32 * w + 8 * qq + a];
+        (reinterpret_cast<float *>(&S.lut[0][0][0][0]))[i] = (gate == 2 ? KT : KS) * d.in_lut[code * G4 + gate * HID + 32 * w + 8 * qq + a];
     }
     S.wout[tid >> 7][tid & 127] = d.w_out[(tid >> 7) * 256 + (tid & 127)];
     __syncthreads();
     if (tid < BT) atomicMax(&S.tmax, S.T[tid]);
     rd_stage_codes16(S, rb, 0);
 
-    // ---- resident weights: 8 tiles x 4 k-steps x (W1, W2), one f16x8 (4 registers) per lane each = 256 registers ----
+    // ---- resident weights: 8 tiles x 4 k-steps x (W1, W2), one f16x8 (4 registers) per lane each = 256 registers.
+    // Register plan: tiles 1..7 pinned in 224 AGPRs (read there directly as srcA), the 8 accumulators in the other 32
+    // AGPRs, tile 0 (32 registers) in architectural VGPRs with the B fragments and the gate math.
     f16x8 W1[8][4], W2[8][4];
     {
         const uint4 *wp = reinterpret_cast<const uint4 *>(d.wpack16) + (size_t)wave * (2 * 8 * 4 * 64) + lane;
@@ -721,9 +722,19 @@ __global__ __launch_bounds__(256, 1) void rd_lstm_mfma_f16x3_kernel(DevModel d, 
         for (int a = 0; a < 8; ++a)
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const uint4 x1 = wp[((0 * 8 + a) * 4 + s) * 64], x2 = wp[((1 * 8 + a) * 4 + s) * 64];
-                W1[a][s] = __builtin_bit_cast(f16x8, x1);
-                W2[a][s] = __builtin_bit_cast(f16x8, x2);
+#pragma unroll
+                for (int hl = 0; hl < 2; ++hl) {
+                    const uint4 x = wp[((hl * 8 + a) * 4 + s) * 64];
+                    uint4 y = x;
+                    if (a != 0) {
+                        asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(y.x) : "v"(x.x));
+                        asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(y.y) : "v"(x.y));
+                        asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(y.z) : "v"(x.z));
+                        asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(y.w) : "v"(x.w));
+                    }
+                    if (hl == 0) W1[a][s] = __builtin_bit_cast(f16x8, y);
+                    else W2[a][s] = __builtin_bit_cast(f16x8, y);
+                }
             }
     }
     __syncthreads();
@@ -734,8 +745,12 @@ __global__ __launch_bounds__(256, 1) void rd_lstm_mfma_f16x3_kernel(DevModel d, 
 #pragma unroll
     for (int a = 0; a < 8; ++a) accP[a] = f32x4{0, 0, 0, 0};
     int tile = 0, t = 0, ptile = NT - 1, pt = -1;
-    int codeC = S.codes[0][0][l15];        // code of this lane's read in the current phase (drives the accumulator init)
+    int codeP = 4;                         // code of this lane's read in the previous phase (constant terms of its gates)
     const int boff = l15 * H16STR + 8 * q; // f16 offset of this lane's B fragment inside a tile, k-step 0
+    // k-step 0 of the B fragments is fetched one phase ahead; k-steps 1..3 stream in behind the MFMAs of the step before
+    f16x8 b1s0 = *reinterpret_cast<const f16x8 *>(&S.H1s[0][0][0] + boff);
+    f16x8 b10 = *reinterpret_cast<const f16x8 *>(&S.H1[0][0][0] + boff);
+    f16x8 b20 = *reinterpret_cast<const f16x8 *>(&S.H2[0][0][0] + boff);
 
     for (int p = 0; p <= nphase; ++p) {
         if (tile == 1 && (t % TC16) == 0) {
@@ -744,34 +759,43 @@ __global__ __launch_bounds__(256, 1) void rd_lstm_mfma_f16x3_kernel(DevModel d, 
         }
         const int ntile = tile + 1 == NT ? 0 : tile + 1;
         const int nt = tile + 1 == NT ? t + 1 : t;
-
-        // ---- LDS reads of this phase: B fragments (h^T of the tile), accumulator init, state of the previous phase --
-        f16x8 b1s[4], b1[4], b2[4];
         const _Float16 *h1s = &S.H1s[tile][0][0] + boff, *h1 = &S.H1[tile][0][0] + boff, *h2 = &S.H2[tile][0][0] + boff;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            b1s[s] = *reinterpret_cast<const f16x8 *>(h1s + 32 * s);
-            b1[s] = *reinterpret_cast<const f16x8 *>(h1 + 32 * s);
-            b2[s] = *reinterpret_cast<const f16x8 *>(h2 + 32 * s);
-        }
-        f32x4 acc[8];
-#pragma unroll
-        for (int a = 0; a < 8; ++a) acc[a] = S.lut[codeC][wave][q][a];
-        const int tn = nt < tmax ? nt : 0;
-        const int codeN = S.codes[(tn / TC16) & 1][tn % TC16][ntile * 16 + l15];
+
+        // ---- operands of the previous phase's gate math (not latency critical) ------------------------------------
+        const int tc = t < tmax ? t : 0;
+        const int codeN = S.codes[(tc / TC16) & 1][tc % TC16][tile * 16 + l15];
         const int Tp = S.T[ptile * 16 + l15];
         f32x4 cs[2] = {S.cA[ptile][tid], S.cB[ptile][tid]};
+        f32x4 kc[8];
+#pragma unroll
+        for (int a = 0; a < 8; ++a) kc[a] = S.lut[codeP][wave][q][a];
 
         // ---- 96 x v_mfma_f32_16x16x32_f16: same accumulator every 8th instruction --------------------------------
+        f32x4 acc[8];
+#pragma unroll
+        for (int a = 0; a < 8; ++a) acc[a] = f32x4{0, 0, 0, 0};
+        f16x8 bs = b1s0, bh = b10, bl = b20;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
+            f16x8 ns = bs, nh = bh, nl = bl;
+            if (s < 3) {
+                ns = *reinterpret_cast<const f16x8 *>(h1s + 32 * (s + 1));
+                nh = *reinterpret_cast<const f16x8 *>(h1 + 32 * (s + 1));
+                nl = *reinterpret_cast<const f16x8 *>(h2 + 32 * (s + 1));
+            } else {                                  // next phase's k-step 0 (its tile was written >= 2 barriers ago)
+                ns = *reinterpret_cast<const f16x8 *>(&S.H1s[ntile][0][0] + boff);
+                nh = *reinterpret_cast<const f16x8 *>(&S.H1[ntile][0][0] + boff);
+                nl = *reinterpret_cast<const f16x8 *>(&S.H2[ntile][0][0] + boff);
+            }
 #pragma unroll
-            for (int a = 0; a < 8; ++a) acc[a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W1[a][s], b1s[s], acc[a], 0, 0, 0);
+            for (int a = 0; a < 8; ++a) acc[a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W1[a][s], bs, acc[a], 0, 0, 0);
 #pragma unroll
-            for (int a = 0; a < 8; ++a) acc[a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W2[a][s], b1[s], acc[a], 0, 0, 0);
+            for (int a = 0; a < 8; ++a) acc[a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W2[a][s], bh, acc[a], 0, 0, 0);
 #pragma unroll
-            for (int a = 0; a < 8; ++a) acc[a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W1[a][s], b2[s], acc[a], 0, 0, 0);
+            for (int a = 0; a < 8; ++a) acc[a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W1[a][s], bl, acc[a], 0, 0, 0);
+            bs = ns; bh = nh; bl = nl;
         }
+        b1s0 = bs; b10 = bh; b20 = bl;
 
         // ---- gate math of the previous phase: lane (read l15) x units 32w + 8q + a -------------------------------
         const float live = pt < 0 ? 0.0f : 1.0f;
@@ -781,9 +805,15 @@ __global__ __launch_bounds__(256, 1) void rd_lstm_mfma_f16x3_kernel(DevModel d, 
         for (int a = 0; a < 8; ++a) {
             const f32x4 G = accP[a];
             const float cold = cs[a >> 2][a & 3];
-            float cn = __builtin_fmaf(sig_scaled(G[1]), cold, sig_scaled(G[0]) * tanh_scaled(G[2]));
+            const float ig = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(__builtin_fmaf(G[0], KS / G_SCALE, kc[a][0])));
+            const float fg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(__builtin_fmaf(G[1], KS / G_SCALE, kc[a][1])));
+            const float gr = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(__builtin_fmaf(G[2], KT / G_SCALE, kc[a][2])));
+            const float og = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(__builtin_fmaf(G[3], KS / G_SCALE, kc[a][3])));
+            const float gg = __builtin_fmaf(-2.0f, gr, 1.0f);
+            float cn = __builtin_fmaf(fg, cold, ig * gg);
             cn *= live;
-            const float h = sig_scaled(G[3]) * tanh_scaled(cn * G_SCALE) * live;
+            const float tc2 = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(cn * KT)), 1.0f);
+            const float h = og * tc2 * live;
             cs[a >> 2][a & 3] = cn;
             hv[a] = h;
             const float hs = h * H_SCALE;
@@ -799,16 +829,22 @@ __global__ __launch_bounds__(256, 1) void rd_lstm_mfma_f16x3_kernel(DevModel d, 
             *reinterpret_cast<f16x8 *>(&S.H2[ptile][0][0] + wo) = o2;
             S.cA[ptile][tid] = cs[0];
             S.cB[ptile][tid] = cs[1];
-            if (pt == Tp - 1) {
-                float *hl = &S.Hl[ptile][l15][32 * wave + 8 * q];
-                *reinterpret_cast<f32x4 *>(hl) = f32x4{hv[0], hv[1], hv[2], hv[3]};
-                *reinterpret_cast<f32x4 *>(hl + 4) = f32x4{hv[4], hv[5], hv[6], hv[7]};
-            }
+        }
+        // the f16 MFMA hides two VALU/transcendental ops per instruction (tools/ubench/mfma_fill.hip): pin that interleave
+#pragma unroll
+        for (int i = 0; i < 96; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x402, FILL, 0);
+        }
+        if (pt == Tp - 1) {
+            float *hl = &S.Hl[ptile][l15][32 * wave + 8 * q];
+            *reinterpret_cast<f32x4 *>(hl) = f32x4{hv[0], hv[1], hv[2], hv[3]};
+            *reinterpret_cast<f32x4 *>(hl + 4) = f32x4{hv[4], hv[5], hv[6], hv[7]};
         }
         __syncthreads();
 #pragma unroll
         for (int a = 0; a < 8; ++a) accP[a] = acc[a];
-        codeC = codeN;
+        codeP = codeN;
         ptile = tile; pt = t; tile = ntile; t = nt;
     }
 
@@ -976,7 +1012,7 @@ int rd_model_create(const rd_weights *w, int device, rd_model **out) {
     rd_model *m = new rd_model();
     memset(m, 0, sizeof(*m));
     m->device = device;
-    m->variant = RD_VARIANT_MFMA_F32;
+    m->variant = RD_VARIANT_MFMA_F16X3;
     float *host = new float[RAW_FLOATS];
     for (int i = 0; i < 10; ++i) memcpy(host + offs[i], src[i], sizeof(float) * (size_t)(offs[i + 1] - offs[i]));
     hipError_t e = hipSuccess;
@@ -1018,8 +1054,8 @@ void rd_model_destroy(rd_model *m) {
 
 int rd_set_variant(rd_model *m, int variant) {
     if (!m) RD_FAIL(RD_E_INVALID, "rd_set_variant: null model");
-    if (variant == RD_VARIANT_AUTO) variant = RD_VARIANT_MFMA_F32;
-    if (variant != RD_VARIANT_MFMA_F32 && variant != RD_VARIANT_SIMPLE && variant != RD_VARIANT_MFMA_F16X3 && !(variant >= 10 && variant <= 23))
+    if (variant == RD_VARIANT_AUTO) variant = RD_VARIANT_MFMA_F16X3;
+    if (variant != RD_VARIANT_MFMA_F32 && variant != RD_VARIANT_SIMPLE && variant != RD_VARIANT_MFMA_F16X3 && !(variant >= 10 && variant <= 32))
         RD_FAIL(RD_E_UNSUPPORTED, "rd_set_variant: variant %d not available in this build", variant);
     m->variant = variant;
     return RD_OK;
@@ -1096,7 +1132,11 @@ int rd_classify(const rd_model *cm, const uint8_t *arena, const int64_t *seq_off
         case 21: hipLaunchKernelGGL((rd_lstm_mfma_f32_kernel<1, 0, 2>), dim3((unsigned)nwg), dim3(256), 0, st, m->d, rb, logits, labels); break;
         case 22: hipLaunchKernelGGL((rd_lstm_mfma_f32_kernel<1, 0, 3>), dim3((unsigned)nwg), dim3(256), 0, st, m->d, rb, logits, labels); break;
         case 23: hipLaunchKernelGGL((rd_lstm_mfma_f32_kernel<1, 0, 4>), dim3((unsigned)nwg), dim3(256), 0, st, m->d, rb, logits, labels); break;
-        case RD_VARIANT_MFMA_F16X3: hipLaunchKernelGGL(rd_lstm_mfma_f16x3_kernel, dim3((unsigned)nwg), dim3(256), 0, st, m->d, rb, logits, labels); break;
+        case RD_VARIANT_MFMA_F16X3: hipLaunchKernelGGL(rd_lstm_mfma_f16x3_kernel<2>, dim3((unsigned)nwg), dim3(256), 0, st, m->d, rb, logits, labels); break;
+        case 30: hipLaunchKernelGGL(rd_lstm_mfma_f16x3_kernel<0>, dim3((unsigned)nwg), dim3(256), 0, st, m->d, rb, logits, labels); break;
+        case 31: hipLaunchKernelGGL(rd_lstm_mfma_f16x3_kernel<3>, dim3((unsigned)nwg), dim3(256), 0, st, m->d, rb, logits, labels); break;
+        case 32: hipLaunchKernelGGL(rd_lstm_mfma_f16x3_kernel<4>, dim3((unsigned)nwg), dim3(256), 0, st, m->d, rb, logits, labels); break;
+        case RD_VARIANT_MFMA_F32:
         default: hipLaunchKernelGGL((rd_lstm_mfma_f32_kernel<1, 0>), dim3((unsigned)nwg), dim3(256), 0, st, m->d, rb, logits, labels); break;
         }
     }
