@@ -161,6 +161,12 @@ def main():
         achieved = reads_per_launch * FLOPS_PER_READ / (avg_ms * 1e-3) / 1e12 if launches else None
         base = "mfma_f16x3" if variant.startswith("mfma_f16x3") else ("mfma_f32" if variant.startswith("mfma_f32") else variant)
         peak = PEAKS[base]
+        traffic = None
+        try:   # HBM bytes per launch from the PMC passes of tools/profile_round.sh (bench.py cannot collect PMC itself)
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["rd_lstm_%s_kernel" % base]
+            traffic = tj["hbm_bytes_per_launch"] * (P * READ_LEN) / (tj["reads_per_launch"] * tj["read_len"])
+        except Exception:
+            pass
         out = {
             "metric": "reads/sec classified, 100 bp paired-end",
             "value": 2.0 * total_pairs / dt,
@@ -180,7 +186,7 @@ def main():
                        "kernel_variant": variant, "parallelism": "reads sharded x%d, RCCL label gather" % world,
                        "label_counts": {"non_rrna": c[0], "rrna": c[1], "unclassified": c[2]}},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": (achieved / peak) if achieved else None, "traffic": None,
+                         "frac": (achieved / peak) if achieved else None, "traffic": traffic,
                          "kernel": "rd_lstm_%s_kernel" % base, "launches": launches, "avg_launch_ms": avg_ms,
                          "algorithmic_flops_per_launch": reads_per_launch * FLOPS_PER_READ,
                          "algorithmic_bytes_per_launch": reads_per_launch * BYTES_PER_READ,

@@ -1,0 +1,85 @@
+"""Multi-GPU sharding logic on CPU: world_size-2 gloo processes (the RCCL path differs only in the backend string).
+Invariant: the gathered label vector with W ranks == the W=1 label vector, bit for bit, and the
+all-reduced counters equal the global counts."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n, ensure, tmp):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from oracle import oracle as O
+    from ribodetector_amd import dist as rdist
+    from ribodetector_amd import synth
+    r, w, _ = rdist.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    ora = O.load_default()
+    a1, o1, l1 = synth.reads_numpy(n, (50, 110), seed=5)
+    a2, o2, l2 = synth.reads_numpy(n, (50, 110), seed=6)
+    lo, hi = rdist.shard_range(n, rank, world)
+    # per-rank classifier = the CPU oracle on this rank's contiguous shard of the pairs
+    g1 = ora.forward_packed(a1, o1[lo:hi + 1], l1[lo:hi], 100)
+    g2 = ora.forward_packed(a2, o2[lo:hi + 1], l2[lo:hi], 100)
+    lab = torch.from_numpy(ora.pair_fuse(g1, g2, ensure))
+    counts = torch.tensor(ora.count_labels(lab.numpy()), dtype=torch.int64)
+    full = rdist.gather_labels(lab, n, dst=0)
+    _, fin = rdist.gather_labels(lab, n, dst=0, async_op=True)
+    full2 = fin()
+    rdist.reduce_counts(counts)
+    if rank == 0:
+        assert torch.equal(full, full2)
+        np.save(os.path.join(tmp, "labels.npy"), full.numpy())
+    np.save(os.path.join(tmp, "counts%d.npy" % rank), counts.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,ensure", [(101, "both"), (64, "rrna")])
+def test_two_rank_gather_matches_single(tmp_path, oracle, n, ensure):
+    from ribodetector_amd import synth
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, n, ensure, str(tmp_path)), nprocs=2, join=True)
+    a1, o1, l1 = synth.reads_numpy(n, (50, 110), seed=5)
+    a2, o2, l2 = synth.reads_numpy(n, (50, 110), seed=6)
+    want = oracle.pair_fuse(oracle.forward_packed(a1, o1, l1, 100), oracle.forward_packed(a2, o2, l2, 100), ensure)
+    got = np.load(str(tmp_path / "labels.npy"))
+    assert got.dtype == np.int8 and (got == want).all()
+    c = oracle.count_labels(want)
+    for r in range(2):
+        assert np.load(str(tmp_path / ("counts%d.npy" % r))).tolist() == c
+
+
+def test_shard_ranges_cover_and_order():
+    from ribodetector_amd import dist as rdist
+    for n in (0, 1, 7, 64, 1000003):
+        for w in (1, 2, 3, 8):
+            rs = [rdist.shard_range(n, r, w) for r in range(w)]
+            assert rs[0][0] == 0 and rs[-1][1] == n
+            assert all(rs[i][1] == rs[i + 1][0] for i in range(w - 1))
+            sz = rdist.shard_sizes(n, w)
+            assert sum(sz) == n and max(sz) - min(sz) <= 1
+
+
+def test_single_process_passthrough():
+    from ribodetector_amd import dist as rdist
+    x = torch.arange(5, dtype=torch.int8)
+    assert rdist.gather_labels(x, 5) is x
+    c = torch.tensor([1, 2, 3])
+    assert rdist.reduce_counts(c) is c
