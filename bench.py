@@ -26,8 +26,8 @@ sys.path.insert(0, ROOT)
 READ_LEN = 100
 FLOPS_PER_READ = READ_LEN * 131072 + 1024        # forward recurrence h.W_hh^T + FC
 BYTES_PER_READ = READ_LEN + 4 + 8 + 8 + 1        # ASCII + len + offset + logits + label
-PEAKS = {"mfma_f32": 157.3, "simple": 157.3, "mfma_f16x3": 2500.0}   # dense TFLOP/s, MI355X_MICROARCH.md
-MFMA_FLOPS_PER_ALGO_FLOP = {"mfma_f32": 1, "simple": 1, "mfma_f16x3": 3}   # f16x3 issues three f16 products per fp32 product
+PEAKS = {"mfma_f32": 157.3, "simple": 157.3, "mfma_f16x3": 2500.0, "mfma_f16x3_t32": 2500.0}   # dense TFLOP/s, MI355X_MICROARCH.md
+MFMA_FLOPS_PER_ALGO_FLOP = {"mfma_f32": 1, "simple": 1, "mfma_f16x3": 3, "mfma_f16x3_t32": 3}   # f16x3 issues three f16 products per fp32 product
 
 
 def usable_cores():
@@ -74,6 +74,10 @@ def main():
     ap.add_argument("--pairs-per-step", type=int, default=1 << 20)
     ap.add_argument("--variant", default="auto")
     ap.add_argument("--ensure", default="rrna")
+    ap.add_argument("--workload", default="pe100", choices=["pe100", "se100", "pe150", "var300"],
+                    help="pe100 = BASELINE configs[2] (the metric's configuration, default); se100 = configs[1]; pe150 = the per-GPU "
+                         "shard of configs[3]; var300 = the per-GPU shard of configs[4] (40-300 bp, -l 300)")
+    ap.add_argument("--pcie", action="store_true", help="also time the step with the read bytes starting in pinned host memory")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the short extra measurement of the exact-fp32 MFMA kernel")
     args = ap.parse_args()
@@ -98,24 +102,40 @@ def main():
     model.load_state_dict(cfg.load_state_dict("mcc"))
     model.to(dev).eval()
     model.set_variant(args.variant)
-    variant = "mfma_f16x3" if args.variant == "auto" else args.variant
+    variant = "mfma_f16x3_t32" if args.variant == "auto" else args.variant
 
     P = args.pairs_per_step
-    nslices = max(1, min(args.steps, 10))                 # distinct batches resident in HBM (2 x 100 MiB each), reused cyclically
-    r1 = [synth.reads_torch(P, READ_LEN, seed=2000 + 100 * rank + i, device=dev) for i in range(nslices)]
-    r2 = [synth.reads_torch(P, READ_LEN, seed=7000 + 100 * rank + i, device=dev) for i in range(nslices)]
+    WL = {"pe100": (True, 100, 100), "se100": (False, 100, 100), "pe150": (True, 150, 150), "var300": (False, 300, 300)}[args.workload]
+    paired, RL, MAXLEN = WL
+    nslices = max(1, min(args.steps, 10))                 # distinct batches resident in HBM, reused cyclically
+    r1 = [synth.reads_torch(P, RL, seed=2000 + 100 * rank + i, device=dev) for i in range(nslices)]
+    r2 = [synth.reads_torch(P, RL, seed=7000 + 100 * rank + i, device=dev) for i in range(nslices)] if paired else None
     offs = r1[0][1][:-1].contiguous()
     lens = r1[0][2]
+    if args.workload == "var300":                          # lengths ~ U{40..300}; rows keep their 300-byte stride in the arena
+        g = torch.Generator(device=dev)
+        g.manual_seed(4 + rank)
+        lens = torch.randint(40, 301, (P,), generator=g, device=dev, dtype=torch.int32)
+    flops_per_launch = float((torch.clamp(lens, max=MAXLEN).to(torch.float64) * 131072 + 1024).sum().item())
+    bytes_per_launch = float(lens.to(torch.float64).sum().item()) + P * (4 + 8 + 8 + 1)
     lg1 = torch.empty((P, 2), dtype=torch.float32, device=dev)
     lg2 = torch.empty((P, 2), dtype=torch.float32, device=dev)
     counts = torch.zeros(3, dtype=torch.int64, device=dev)
     gathered = torch.empty(P * world, dtype=torch.int8, device=dev) if (world > 1 and rank == 0) else None
 
-    def step(i):
-        a1, a2 = r1[i % nslices][0], r2[i % nslices][0]
-        model.classify_bytes(a1, offs, lens, READ_LEN, want_labels=False, logits=lg1)
-        model.classify_bytes(a2, offs, lens, READ_LEN, want_labels=False, logits=lg2)
-        lab = module_arch.pair_fuse(lg1, lg2, args.ensure, counts)
+    lab8 = torch.empty((P,), dtype=torch.uint8, device=dev)
+
+    def step(i, a1=None, a2=None):
+        a1 = r1[i % nslices][0] if a1 is None else a1
+        if paired:
+            a2 = r2[i % nslices][0] if a2 is None else a2
+            model.classify_bytes(a1, offs, lens, MAXLEN, want_labels=False, logits=lg1)
+            model.classify_bytes(a2, offs, lens, MAXLEN, want_labels=False, logits=lg2)
+            lab = module_arch.pair_fuse(lg1, lg2, args.ensure, counts)
+        else:
+            model.classify_bytes(a1, offs, lens, MAXLEN, want_labels=True, logits=lg1, labels=lab8)
+            module_arch.count_labels(lab8, counts)
+            lab = lab8.view(torch.int8)
         if world > 1:
             _, fin = rdist.gather_labels(lab, P * world, dst=0, async_op=True, out=gathered)
             return fin
@@ -158,18 +178,19 @@ def main():
     if rank == 0:
         reads_per_launch = P
         avg_ms = kms / max(launches, 1)
-        achieved = reads_per_launch * FLOPS_PER_READ / (avg_ms * 1e-3) / 1e12 if launches else None
-        base = "mfma_f16x3" if variant.startswith("mfma_f16x3") else ("mfma_f32" if variant.startswith("mfma_f32") else variant)
+        achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if launches else None
+        base = ("mfma_f16x3_t32" if variant.startswith("mfma_f16x3_t32") else "mfma_f16x3" if variant.startswith("mfma_f16x3")
+                else "mfma_f32" if variant.startswith("mfma_f32") else variant)
         peak = PEAKS[base]
         traffic = None
         try:   # HBM bytes per launch from the PMC passes of tools/profile_round.sh (bench.py cannot collect PMC itself)
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["rd_lstm_%s_kernel" % base]
-            traffic = tj["hbm_bytes_per_launch"] * (P * READ_LEN) / (tj["reads_per_launch"] * tj["read_len"])
+            traffic = tj["hbm_bytes_per_launch"] * bytes_per_launch / (tj["reads_per_launch"] * (tj["read_len"] + 21))
         except Exception:
             pass
         out = {
-            "metric": "reads/sec classified, 100 bp paired-end",
-            "value": 2.0 * total_pairs / dt,
+            "metric": "reads/sec classified, 100 bp paired-end" if args.workload == "pe100" else "reads/sec classified, " + args.workload,
+            "value": (2.0 if paired else 1.0) * total_pairs / dt,
             "unit": "reads/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -180,16 +201,21 @@ def main():
             "vs_baseline": None,
             "dtype": "f32" if not variant.startswith("mfma_f16x3") else "f16x3-split (f32 accumulate)",
             "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: paired-end 100 bp, --ensure %s, %d pairs/step/GPU x %d steps "
-                                   "(%.1f M pairs total), inputs resident in HBM" % (args.ensure, P, args.steps, total_pairs / 1e6),
-                       "pairs_per_s": total_pairs / dt, "pairs_per_step_per_gpu": P, "read_len": READ_LEN, "ensure": args.ensure,
+            "config": {"workload": {"pe100": "BASELINE configs[2]: paired-end 100 bp, --ensure %s" % args.ensure,
+                                    "se100": "BASELINE configs[1]: single-end 100 bp",
+                                    "pe150": "BASELINE configs[3] per-GPU shard: paired-end 150 bp, -l 150, --ensure %s" % args.ensure,
+                                    "var300": "BASELINE configs[4] per-GPU shard: single-end 40-300 bp, -l 300, length-bucketed"}[args.workload]
+                                   + ", %d %s/step/GPU x %d steps (%.1f M total), inputs resident in HBM"
+                                   % (P, "pairs" if paired else "reads", args.steps, total_pairs / 1e6),
+                       "pairs_per_s": (total_pairs / dt) if paired else None, "per_step_per_gpu": P, "read_len": RL if args.workload != "var300" else "40-300",
+                       "ensure": args.ensure if paired else None,
                        "kernel_variant": variant, "parallelism": "reads sharded x%d, RCCL label gather" % world,
                        "label_counts": {"non_rrna": c[0], "rrna": c[1], "unclassified": c[2]}},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": (achieved / peak) if achieved else None, "traffic": traffic,
                          "kernel": "rd_lstm_%s_kernel" % base, "launches": launches, "avg_launch_ms": avg_ms,
-                         "algorithmic_flops_per_launch": reads_per_launch * FLOPS_PER_READ,
-                         "algorithmic_bytes_per_launch": reads_per_launch * BYTES_PER_READ,
+                         "algorithmic_flops_per_launch": flops_per_launch,
+                         "algorithmic_bytes_per_launch": bytes_per_launch,
                          "mfma_flops_executed_per_algorithmic_flop": MFMA_FLOPS_PER_ALGO_FLOP[base],
                          "mfma_pipe_frac": (achieved * MFMA_FLOPS_PER_ALGO_FLOP[base] / peak) if achieved else None},
         }
@@ -206,11 +232,38 @@ def main():
             l2, k2 = model.profile_read()
             model.profile_enable(False)
             model.set_variant(args.variant)
-            a2 = P * FLOPS_PER_READ / (k2 / max(l2, 1) * 1e-3) / 1e12
-            out["alt_fp32_kernel"] = {"kernel": "rd_lstm_mfma_f32_kernel", "value": 2.0 * P * 2 / d1, "unit": "reads/s", "steps": 2,
+            a2 = flops_per_launch / (k2 / max(l2, 1) * 1e-3) / 1e12
+            out["alt_fp32_kernel"] = {"kernel": "rd_lstm_mfma_f32_kernel", "value": (2.0 if paired else 1.0) * P * 2 / d1, "unit": "reads/s", "steps": 2,
                                       "roofline": {"bound": "mfma", "achieved": a2, "peak": PEAKS["mfma_f32"], "unit": "TFLOP/s",
                                                    "frac": a2 / PEAKS["mfma_f32"], "avg_launch_ms": k2 / max(l2, 1)}}
-        if not args.no_cpu_baseline and world == 1:
+        if args.pcie and world == 1:
+            # same step, but every batch's bytes start in pinned host memory: H2D on a copy stream, double buffered
+            hosts = [[t[0].cpu().pin_memory() for t in (r1[:2] if not paired else r1[:2] + r2[:2])]]
+            h = hosts[0]
+            cs = torch.cuda.Stream(dev)
+            bufs = [[torch.empty_like(r1[0][0]) for _ in range(2 if paired else 1)] for _ in range(2)]
+            evs = [torch.cuda.Event() for _ in range(2)]
+            def h2d(i):
+                with torch.cuda.stream(cs):
+                    bufs[i & 1][0].copy_(h[i & 1], non_blocking=True)
+                    if paired:
+                        bufs[i & 1][1].copy_(h[2 + (i & 1)], non_blocking=True)
+                    evs[i & 1].record(cs)
+            counts.zero_()
+            sync()
+            t2 = time.perf_counter()
+            h2d(0)
+            for i in range(args.steps):
+                if i + 1 < args.steps:
+                    h2d(i + 1)
+                torch.cuda.current_stream(dev).wait_event(evs[i & 1])
+                step(i, bufs[i & 1][0], bufs[i & 1][1] if paired else None)
+                cs.wait_stream(torch.cuda.current_stream(dev))    # buffer (i&1) is reused by h2d(i+2)
+            lab_host = torch.empty((P,), dtype=torch.int8).pin_memory()
+            sync()
+            d2 = time.perf_counter() - t2
+            out["config"]["pcie_inclusive_reads_per_s"] = (2.0 if paired else 1.0) * P * args.steps / d2
+        if not args.no_cpu_baseline and world == 1 and args.workload in ("pe100", "se100"):
             try:
                 nb = min(P, 400000)
                 out["cpu_baseline"] = cpu_baseline(r1[0][0][: nb * READ_LEN].cpu().numpy(), nb)

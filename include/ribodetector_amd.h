@@ -40,10 +40,11 @@ extern "C" {
 #define RD_ENSURE_BOTH 3
 
 /* LSTM kernel variants (rd_set_variant): all compute the same function within the 1e-4 logit bound */
-#define RD_VARIANT_AUTO 0       /* = MFMA_F16X3                                                                */
+#define RD_VARIANT_AUTO 0       /* = MFMA_F16X3_T32                                                            */
 #define RD_VARIANT_MFMA_F32 1   /* persistent-weight fp32 MFMA recurrence (v_mfma_f32_16x16x4_f32)              */
 #define RD_VARIANT_SIMPLE 2     /* plain fp32 FMA kernel, correctness cross-check                              */
 #define RD_VARIANT_MFMA_F16X3 3 /* fp32 product as 3 fp16 MFMA products (hi*hi + hi*lo + lo*hi), fp32 accumulate */
+#define RD_VARIANT_MFMA_F16X3_T32 4 /* the same on v_mfma_f32_32x32x16_f16, 32-read tiles, hand-interleaved gate math */
 /* ids >= 10 are A/B and diagnostic builds used by bench.py --variant; not part of the stable ABI */
 
 typedef struct rd_model rd_model; /* opaque: device-resident, pre-packed weights */
@@ -67,7 +68,7 @@ typedef struct rd_weights {
 int rd_model_create(const rd_weights *w, int device, rd_model **out);
 void rd_model_destroy(rd_model *m);
 
-/* Select the recurrence kernel (RD_VARIANT_*); default AUTO = MFMA_F16X3. */
+/* Select the recurrence kernel (RD_VARIANT_*); default AUTO = MFMA_F16X3_T32. */
 int rd_set_variant(rd_model *m, int variant);
 
 /* Bytes of [dev] scratch rd_classify needs for n reads with truncation length max_len. */

@@ -9,11 +9,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "librd_hip.so")
 
 ENSURE_MODES = {"none": 0, "rrna": 1, "norrna": 2, "both": 3}
-VARIANTS = {"auto": 0, "mfma_f32": 1, "simple": 2, "mfma_f16x3": 3,
+VARIANTS = {"auto": 0, "mfma_f32": 1, "simple": 2, "mfma_f16x3": 3, "mfma_f16x3_t32": 4,
             # A/B builds of the fp32 kernel (activation form x schedule), see rd_kernels.hip
             "mfma_f32_a0s0": 10, "mfma_f32_a1s0": 11, "mfma_f32_a0s1": 12, "mfma_f32_a1s1": 13,
             "mfma_f32_diag_noew": 20, "mfma_f32_diag_nomfma": 21, "mfma_f32_diag_mfmaonly": 22,
-            "mfma_f32_diag_mfmabar": 23, "mfma_f16x3_fill0": 30, "mfma_f16x3_fill3": 31, "mfma_f16x3_fill4": 32}
+            "mfma_f32_diag_mfmabar": 23, "mfma_f16x3_fill0": 30, "mfma_f16x3_fill3": 31, "mfma_f16x3_fill4": 32,
+            "mfma_f16x3_t32_fill0": 40}
 
 # every symbol include/ribodetector_amd.h declares (tests/test_abi.py checks the .so exports all of them)
 SYMBOLS = [

@@ -90,7 +90,8 @@ struct DevModel {
     float *rev_lut;   // [5][2]      W_out[:,128:] . h_rev(one step from zero on `code`)
     float *w_out;     // [2][256]
     float *b_out;     // [2]
-    uint32_t *wpack16; // f16x3 variant: [4 waves][...] packed halves (see rd_lstm_f16.hip section)
+    uint32_t *wpack16;  // f16x3 16x16x32 A operand (hi/lo halves), see rd_prep_kernel
+    uint32_t *wpack16b; // f16x3 32x32x16 A operand
 };
 
 }  // namespace
@@ -148,6 +149,20 @@ __global__ void rd_prep_kernel(DevModel d) {
         int code = i / G4, col = i % G4;
         float b = raw[OFF_BIH + col] + raw[OFF_BHH + col];
         d.in_lut[i] = code < 4 ? b + raw[OFF_WIH + col * 4 + code] : b;
+    }
+    // f16x3 / 32x32x16 A operand: [wave][W1|W2][row-tile a][k-step s][lane][8 halves]; lane (i = lane&31, kh = lane>>5):
+    // row i = 8b + 4hf + g is gate g of unit 32w + 16hf + 4a + b; element e is hidden index 16s + 8kh + e.
+    for (int i = tid; i < 4 * 4 * 8 * 64 * 8; i += nth) {
+        int e = i & 7, lane = (i >> 3) & 63, s = (i >> 9) & 7, a = (i >> 12) & 3, w = i >> 14;
+        int row = lane & 31, kh = lane >> 5;
+        int g = row & 3, hf = (row >> 2) & 1, b = row >> 3;
+        int col = g * HID + 32 * w + 16 * hf + 4 * a + b;
+        float x = 16.0f * raw[OFF_WHH + col * HID + 16 * s + 8 * kh + e];
+        _Float16 hi = (_Float16)x;
+        _Float16 lo = (_Float16)((x - (float)hi) * 2048.0f);
+        _Float16 *base = reinterpret_cast<_Float16 *>(d.wpack16b);
+        base[((((size_t)(w * 2 + 0) * 4 + a) * 8 + s) * 64 + lane) * 8 + e] = hi;
+        base[((((size_t)(w * 2 + 1) * 4 + a) * 8 + s) * 64 + lane) * 8 + e] = lo;
     }
     for (int i = tid; i < 512; i += nth) d.w_out[i] = raw[OFF_WOUT + i];
     if (tid < 2) d.b_out[tid] = raw[OFF_BOUT + tid];
@@ -853,6 +868,288 @@ __global__ __launch_bounds__(256, 1) void rd_lstm_mfma_f16x3_kernel(DevModel d, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// rd_lstm_mfma_f16x3_t32_kernel - the same split-precision recurrence on v_mfma_f32_32x32x16_f16 with 32-read tiles.
+//
+// Why: one wave per SIMD issues one instruction per ~4.6 cycles, and the 16x16x32 kernel above spends 2,215 of its
+// 3,900 cycles per phase issuing ~450 instructions (PMC, profiles/r01_summary.txt). The 32x32x16 MFMA does twice the
+// work per instruction (37 cycles) and hides six VALU ops instead of two (tools/ubench/mfma_fill.hip), so the whole
+// gate math fits in MFMA shadows.
+//   * workgroup = 4 waves, 64 reads = 2 tiles x 32 reads; the two tiles alternate (phase A: tile 0, phase B: tile 1),
+//     so tile indices, LDS addresses and the accumulator set of each half are compile-time constants;
+//   * accumulators ping-pong between two VGPR sets (X: tile 0, Y: tile 1): the gate math reads the other set in place
+//     - no copies, no v_accvgpr_read; ALL 256 AGPRs hold weights (read directly as MFMA srcA);
+//   * A = weights: row-tile a (0..3) of 32 rows = 8 units x (i,f,g,o); row 8b + 4hf + g  <->  gate g of unit
+//     32w + 16hf + 4a + b.  With the 32x32 C/D layout (col = lane&31, row = (reg&3) + 8(reg>>2) + 4(lane>>5)) lane
+//     (read j, half) holds in acc[a][4b + g] the four gates of unit 32w + 16half + 4a + b: 16 contiguous units/lane;
+//   * the dummy gate pass before t = 0 uses an all-zero table row (code 5): sigmoid -> 1/2, tanh -> 0 => c = h = 0.
+// ------------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+struct __attribute__((aligned(16))) Lstm16bSmem {
+    _Float16 H1s[2][32][H16STR];
+    _Float16 H1[2][32][H16STR];
+    _Float16 H2[2][32][H16STR];
+    float Hl[64][HSTR];            // h captured at t == T-1
+    f32x4 cS[2][4][256];           // cell state [tile][row-tile a][tid] -> units b = 0..3
+    f32x4 lut[4][2][4][4][6];      // [wave][half][a][b][code] -> exp2-argument constants of (i,f,g,o); code 5 = zeros
+    f32x4 dummy[256];              // sink of predicated-off Hl stores
+    float wout[2][HID];
+    uint8_t codes[2][TC16][64];
+    int T[64];
+    long long off[64];
+    int orig[64];
+    int tmax;
+};
+
+__device__ __forceinline__ void rd_stage_codes16b(Lstm16bSmem &S, const ReadBatch &rb, int chunk) {
+    const int t0 = chunk * TC16;
+    uint8_t(*dst)[64] = S.codes[chunk & 1];
+    for (int idx = threadIdx.x; idx < 64 * TC16; idx += 256) {
+        const int row = idx / TC16, tt = idx % TC16, t = t0 + tt;
+        int code = 4;
+        if (t < S.T[row]) code = rd_code(rb.arena[S.off[row] + t]);
+        dst[tt][row] = (uint8_t)code;
+    }
+}
+
+// One phase: MFMAs of (tile TL, current step) into accC; gate math of (tile TL^1, step tEW) from accP.
+//
+// The compiler's scheduler neither interleaves the two streams on its own nor honours a 96-group sched_group_barrier
+// pipeline in a region this large, so the interleave is written out: the gate math is cut into 212 "units" of 1-5
+// instructions (13 stages per cell, two cells in flight and never in the same stage, at most two transcendentals per
+// unit, table rows fetched one cell ahead) and the units are dealt out behind the 96 MFMAs, ~2.2 units (about 5 VALU
+// ops) per MFMA - what a 32x32x16 MFMA mostly hides (tools/ubench/mfma_fill.hip: 38.7 cycles bare, 48 with 2 exp + 3 fma).
+// A sched_barrier after every slot pins the order.
+constexpr int EW_NU = 212;
+constexpr unsigned char EW_CELL[EW_NU] = {0,0,0,0,0,0,0,1,0,1,0,1,0,1,0,1,0,1,0,1,1,2,1,2,1,2,1,2,1,2,1,2,2,3,2,3,2,3,2,3,2,3,2,3,2,3,3,4,3,4,3,4,3,4,3,4,3,4,3,4,5,4,5,4,5,4,5,4,5,4,5,4,5,5,6,5,6,5,6,5,6,5,6,5,6,6,7,6,7,6,7,6,7,6,7,6,7,6,7,7,8,7,8,7,8,7,8,7,8,7,8,7,8,9,8,9,8,9,8,9,8,9,8,9,8,9,9,10,9,10,9,10,9,10,9,10,9,10,10,11,10,11,10,11,10,11,10,11,10,11,10,11,11,12,11,12,11,12,11,12,11,12,11,12,11,12,13,12,13,12,13,12,13,12,13,12,13,12,13,13,14,13,14,13,14,13,14,13,14,13,14,14,15,14,15,14,15,14,15,14,15,14,15,14,15,15,15,15,15,15,15,15};
+constexpr unsigned char EW_STAGE[EW_NU] = {0,1,2,3,4,5,6,0,7,1,8,2,9,3,10,4,11,5,12,6,7,0,8,1,9,2,10,3,11,4,12,5,6,0,7,1,8,2,9,3,10,4,11,5,12,6,7,0,8,1,9,2,10,3,11,4,12,5,13,6,0,7,1,8,2,9,3,10,4,11,5,12,6,7,0,8,1,9,2,10,3,11,4,12,5,6,0,7,1,8,2,9,3,10,4,11,5,12,6,7,0,8,1,9,2,10,3,11,4,12,5,13,6,0,7,1,8,2,9,3,10,4,11,5,12,6,7,0,8,1,9,2,10,3,11,4,12,5,6,0,7,1,8,2,9,3,10,4,11,5,12,6,7,0,8,1,9,2,10,3,11,4,12,5,13,6,0,7,1,8,2,9,3,10,4,11,5,12,6,7,0,8,1,9,2,10,3,11,4,12,5,6,0,7,1,8,2,9,3,10,4,11,5,12,6,7,8,9,10,11,12,13};
+// (schedule above: 16 cells x 13 stages, cell c starts at step floor(6.5 c) so that two cells are in flight and never in
+//  the same stage; stage 13 = stores of a finished row-tile; generated offline, units are dealt out in this order)
+struct EwRegs {
+    f32x4 kc[2];        // table rows of the cells in flight, by cell parity
+    float v[2][4];      // gate pipeline values, by cell parity
+    float y[2], og[2], hs[2];
+    _Float16 p16[2];
+    f32x4 cs[2], hv[2]; // per row-tile, by row-tile parity
+    f16x4 o1s[2], o1[2], o2[2];
+};
+
+struct PhaseCtx {       // per-lane constants of a phase
+    int codeEW, wave, half, j, tid;
+    bool last;
+};
+
+template <int TP, int U>
+__device__ __forceinline__ void rd_ew_unit(Lstm16bSmem &S, EwRegs &R, const f32x16 (&accP)[4], const PhaseCtx &c) {
+    constexpr int cell = EW_CELL[U], stage = EW_STAGE[U];
+    constexpr int a = cell >> 2, b = cell & 3, k = cell & 1, ap = a & 1;
+    if constexpr (stage == 0) {   // table row of the NEXT cell (this cell's row was fetched one cell ago); cell state per row-tile
+        constexpr int nc = cell + 1;
+        if constexpr (nc < 16) R.kc[k ^ 1] = S.lut[c.wave][c.half][nc >> 2][nc & 3][c.codeEW];
+        if constexpr (b == 0) R.cs[ap] = S.cS[TP][a][c.tid];
+    } else if constexpr (stage == 1) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) R.v[k][g] = __builtin_fmaf(accP[a][4 * b + g], (g == 2 ? KT : KS) / G_SCALE, R.kc[k][g]);
+    } else if constexpr (stage == 2) {
+        R.v[k][0] = __builtin_amdgcn_exp2f(R.v[k][0]); R.v[k][1] = __builtin_amdgcn_exp2f(R.v[k][1]);
+    } else if constexpr (stage == 3) {
+        R.v[k][2] = __builtin_amdgcn_exp2f(R.v[k][2]); R.v[k][3] = __builtin_amdgcn_exp2f(R.v[k][3]);
+    } else if constexpr (stage == 4) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) R.v[k][g] = 1.0f + R.v[k][g];
+    } else if constexpr (stage == 5) {
+        R.v[k][0] = __builtin_amdgcn_rcpf(R.v[k][0]); R.v[k][1] = __builtin_amdgcn_rcpf(R.v[k][1]);
+    } else if constexpr (stage == 6) {
+        R.v[k][2] = __builtin_amdgcn_rcpf(R.v[k][2]); R.v[k][3] = __builtin_amdgcn_rcpf(R.v[k][3]);
+    } else if constexpr (stage == 7) {
+        const float gg = __builtin_fmaf(-2.0f, R.v[k][2], 1.0f);
+        const float cn = __builtin_fmaf(R.v[k][1], R.cs[ap][b], R.v[k][0] * gg);
+        R.cs[ap][b] = cn;
+        R.y[k] = cn * KT;
+        R.og[k] = R.v[k][3];
+    } else if constexpr (stage == 8) {
+        R.y[k] = __builtin_amdgcn_exp2f(R.y[k]);
+    } else if constexpr (stage == 9) {
+        R.y[k] = 1.0f + R.y[k];
+    } else if constexpr (stage == 10) {
+        R.y[k] = __builtin_amdgcn_rcpf(R.y[k]);
+    } else if constexpr (stage == 11) {
+        const float h = R.og[k] * __builtin_fmaf(-2.0f, R.y[k], 1.0f);
+        R.hv[ap][b] = h;
+        R.hs[k] = h * H_SCALE;
+        R.p16[k] = (_Float16)R.hs[k];                                // 2^11 h_hi'
+    } else if constexpr (stage == 12) {
+        R.o1s[ap][b] = R.p16[k];
+        R.o1[ap][b] = R.p16[k] * (_Float16)(1.0f / H_SCALE);         // exact power-of-two scaling
+        R.o2[ap][b] = (_Float16)(R.hs[k] - (float)R.p16[k]);         // exact residual, rounded once
+    } else {   // 13: the row-tile's 4 cells are complete
+        const int wo = c.j * H16STR + 32 * c.wave + 16 * c.half + 4 * a;
+        *reinterpret_cast<f16x4 *>(&S.H1s[TP][0][0] + wo) = R.o1s[ap];
+        *reinterpret_cast<f16x4 *>(&S.H1[TP][0][0] + wo) = R.o1[ap];
+        *reinterpret_cast<f16x4 *>(&S.H2[TP][0][0] + wo) = R.o2[ap];
+        S.cS[TP][a][c.tid] = R.cs[ap];
+        f32x4 *dst = c.last ? reinterpret_cast<f32x4 *>(&S.Hl[TP * 32 + c.j][32 * c.wave + 16 * c.half + 4 * a]) : &S.dummy[c.tid];
+        *dst = R.hv[ap];
+    }
+}
+
+template <int TP, int U0, int U1>
+__device__ __forceinline__ void rd_ew_units(Lstm16bSmem &S, EwRegs &R, const f32x16 (&accP)[4], const PhaseCtx &c) {
+    if constexpr (U0 < U1) {
+        rd_ew_unit<TP, U0>(S, R, accP, c);
+        rd_ew_units<TP, U0 + 1, U1>(S, R, accP, c);
+    }
+}
+
+// slot M = MFMA number M (k-step s = M/12, product (M%12)/4, row-tile M%4) followed by its share of gate-math units
+template <int TL, int FILL, int M>
+__device__ __forceinline__ void rd_slots(Lstm16bSmem &S, const f16x8 (&W1)[4][8], const f16x8 (&W2)[4][8], f32x16 (&accC)[4],
+                                         const f32x16 (&accP)[4], f16x8 (&Bf)[2][3], EwRegs &R, const PhaseCtx &c,
+                                         const _Float16 *h1s, const _Float16 *h1, const _Float16 *h2) {
+    if constexpr (M < 96) {
+        constexpr int s = M / 12, pr = (M % 12) / 4, a = M % 4;
+        if constexpr (M % 12 == 0 && s < 7) {       // B fragments of the next k-step stream in behind this one's MFMAs
+            Bf[(s + 1) & 1][0] = *reinterpret_cast<const f16x8 *>(h1s + 16 * (s + 1));
+            Bf[(s + 1) & 1][1] = *reinterpret_cast<const f16x8 *>(h1 + 16 * (s + 1));
+            Bf[(s + 1) & 1][2] = *reinterpret_cast<const f16x8 *>(h2 + 16 * (s + 1));
+        }
+        const f16x8 A = pr == 1 ? W2[a][s] : W1[a][s];
+        if constexpr (M < 4) {
+            f32x16 z;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) z[r] = 0.0f;
+            accC[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, Bf[s & 1][pr], z, 0, 0, 0);
+        } else {
+            accC[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, Bf[s & 1][pr], accC[a], 0, 0, 0);
+        }
+        if constexpr (FILL > 0) {
+            rd_ew_units<TL ^ 1, (M * EW_NU) / 96, ((M + 1) * EW_NU) / 96>(S, R, accP, c);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        rd_slots<TL, FILL, M + 1>(S, W1, W2, accC, accP, Bf, R, c, h1s, h1, h2);
+    }
+}
+
+// One phase: MFMAs of (tile TL, current step) into accC; gate math of (tile TL^1, step tEW) from accP.
+//
+// The compiler's scheduler neither interleaves the two streams on its own nor honours a 96-group sched_group_barrier
+// pipeline in a region this large, so the interleave is written out: the gate math is cut into 212 "units" of 1-5
+// instructions (13 stages per cell, two cells in flight and never in the same stage, at most two transcendentals per
+// unit, table rows fetched one cell ahead) and the units are dealt out behind the 96 MFMAs, ~2.2 units (about 5 VALU
+// ops) per MFMA - what a 32x32x16 MFMA mostly hides (tools/ubench/mfma_fill.hip: 38.7 cycles bare, 48 with 2 exp + 3 fma).
+// A sched_barrier after every slot pins the order.
+template <int TL, int FILL>
+__device__ __forceinline__ void rd_phase_t32(Lstm16bSmem &S, const f16x8 (&W1)[4][8], const f16x8 (&W2)[4][8], f32x16 (&accC)[4],
+                                             f32x16 (&accP)[4], int tEW, int codeEW, int wave, int half, int j, int tid) {
+    constexpr int TP = TL ^ 1;
+    const int boff = j * H16STR + 8 * half;     // this lane's B fragment: row j, k = 16s + 8half + e
+    const _Float16 *h1s = &S.H1s[TL][0][0] + boff, *h1 = &S.H1[TL][0][0] + boff, *h2 = &S.H2[TL][0][0] + boff;
+    f16x8 Bf[2][3];
+    Bf[0][0] = *reinterpret_cast<const f16x8 *>(h1s);
+    Bf[0][1] = *reinterpret_cast<const f16x8 *>(h1);
+    Bf[0][2] = *reinterpret_cast<const f16x8 *>(h2);
+    PhaseCtx c;
+    c.codeEW = codeEW; c.wave = wave; c.half = half; c.j = j; c.tid = tid;
+    c.last = (tEW == S.T[TP * 32 + j] - 1);
+    EwRegs R;
+    R.kc[0] = S.lut[wave][half][0][0][codeEW];
+    if (FILL > 0) __builtin_amdgcn_sched_barrier(0);
+    rd_slots<TL, FILL, 0>(S, W1, W2, accC, accP, Bf, R, c, h1s, h1, h2);
+    if constexpr (FILL == 0) rd_ew_units<TP, 0, EW_NU>(S, R, accP, c);
+    __syncthreads();
+}
+
+template <int FILL>
+__global__ __launch_bounds__(256, 1) void rd_lstm_mfma_f16x3_t32_kernel(DevModel d, ReadBatch rb, float *__restrict__ logits,
+                                                                        uint8_t *__restrict__ labels) {
+    __shared__ Lstm16bSmem S;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, j = lane & 31;
+
+    if (tid < 64) {
+        const int64_t g = (int64_t)blockIdx.x * 64 + tid;
+        int T = 0, orig = -1;
+        long long off = 0;
+        if (g < rb.n) {
+            orig = rb.order ? rb.order[g] : (int)g;
+            T = rd_T(rb.len, orig, rb.max_len);
+            off = rb.off[orig];
+        }
+        S.T[tid] = T; S.off[tid] = off; S.orig[tid] = orig;
+    }
+    if (tid == 0) S.tmax = 0;
+    for (int i = tid; i < 3 * 2 * 32 * H16STR / 2; i += 256) (reinterpret_cast<uint32_t *>(&S.H1s[0][0][0]))[i] = 0u;
+    for (int i = tid; i < 64 * HSTR; i += 256) (&S.Hl[0][0])[i] = 0.0f;
+    for (int i = tid; i < 2 * 4 * 256; i += 256) (&S.cS[0][0][0])[i] = f32x4{0, 0, 0, 0};
+    for (int i = tid; i < 4 * 2 * 4 * 4 * 6 * 4; i += 256) {   // i = ((((w*2 + hf)*4 + a)*4 + b)*6 + code)*4 + gate
+        const int gate = i & 3, rest = i >> 2, code = rest % 6, cell = rest / 6;
+        const int b = cell & 3, a = (cell >> 2) & 3, hf = (cell >> 4) & 1, w = cell >> 5;
+        float v = 0.0f;
+        if (code < 5) v = (gate == 2 ? KT : KS) * d.in_lut[code * G4 + gate * HID + 32 * w + 16 * hf + 4 * a + b];
+        (reinterpret_cast<float *>(&S.lut[0][0][0][0][0]))[i] = v;
+    }
+    S.wout[tid >> 7][tid & 127] = d.w_out[(tid >> 7) * 256 + (tid & 127)];
+    __syncthreads();
+    if (tid < 64) atomicMax(&S.tmax, S.T[tid]);
+    rd_stage_codes16b(S, rb, 0);
+
+    // ---- resident weights: 4 row-tiles x 8 k-steps x (W1, W2) x 4 registers = 256 registers, all pinned in AGPRs ----
+    f16x8 W1[4][8], W2[4][8];
+    {
+        const uint4 *wp = reinterpret_cast<const uint4 *>(d.wpack16b) + (size_t)wave * (2 * 4 * 8 * 64) + lane;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+#pragma unroll
+                for (int hl = 0; hl < 2; ++hl) {
+                    const uint4 x = wp[((hl * 4 + a) * 8 + s) * 64];
+                    uint4 y;
+                    asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(y.x) : "v"(x.x));
+                    asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(y.y) : "v"(x.y));
+                    asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(y.z) : "v"(x.z));
+                    asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(y.w) : "v"(x.w));
+                    if (hl == 0) W1[a][s] = __builtin_bit_cast(f16x8, y);
+                    else W2[a][s] = __builtin_bit_cast(f16x8, y);
+                }
+            }
+    }
+    __syncthreads();
+    const int tmax = S.tmax;
+
+    f32x16 X[4], Y[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { X[a][r] = 0.0f; Y[a][r] = 0.0f; }
+    int codeY = 5;   // code of (tile 1, step t-1): zero row before the first step
+
+    for (int t = 0; t <= tmax; ++t) {
+        const int tc = t < tmax ? t : 0;
+        const uint8_t *crow = &S.codes[(tc / TC16) & 1][tc % TC16][0];
+        const int codeX = crow[j];            // (tile 0, step t): consumed by phase B's gate math
+        const int codeYn = crow[32 + j];      // (tile 1, step t): consumed by the next iteration's phase A
+        // phase A: MFMAs of (tile 0, t) -> X ; gate math of (tile 1, t-1) <- Y
+        rd_phase_t32<0, FILL>(S, W1, W2, X, Y, t - 1, codeY, wave, half, j, tid);
+        if (t < tmax) {
+            // next code chunk: its buffer was last read by the gate math of phase A above (step t-1)
+            if ((t % TC16) == 0) {
+                const int chunk = t / TC16 + 1;
+                if (chunk * TC16 < tmax + 1) rd_stage_codes16b(S, rb, chunk);
+            }
+            // phase B: MFMAs of (tile 1, t) -> Y ; gate math of (tile 0, t) <- X
+            rd_phase_t32<1, FILL>(S, W1, W2, Y, X, t, codeX, wave, half, j, tid);
+        }
+        codeY = codeYn;
+    }
+
+    rd_fc_epilogue(
+        64, [&](int row, int u) { return S.Hl[row][u]; }, S.T, S.off, S.orig, &S.wout[0][0], d, rb, logits, labels);
+}
+
+// ------------------------------------------------------------------------------------------------
 // standalone encoders (reference tensor layouts). HBM-bound streaming kernels.
 // ------------------------------------------------------------------------------------------------
 // codes[n][stride] u8: one workgroup row-block per read group; consecutive lanes walk consecutive bases.
@@ -1012,7 +1309,7 @@ int rd_model_create(const rd_weights *w, int device, rd_model **out) {
     rd_model *m = new rd_model();
     memset(m, 0, sizeof(*m));
     m->device = device;
-    m->variant = RD_VARIANT_MFMA_F16X3;
+    m->variant = RD_VARIANT_MFMA_F16X3_T32;
     float *host = new float[RAW_FLOATS];
     for (int i = 0; i < 10; ++i) memcpy(host + offs[i], src[i], sizeof(float) * (size_t)(offs[i + 1] - offs[i]));
     hipError_t e = hipSuccess;
@@ -1021,6 +1318,7 @@ int rd_model_create(const rd_weights *w, int device, rd_model **out) {
     A((void **)&m->d.wpack32, sizeof(float) * 4 * 8 * 32 * 64);
     A((void **)&m->d.wt_hh, sizeof(float) * HID * G4);
     A((void **)&m->d.wpack16, sizeof(uint16_t) * 4 * 2 * 8 * 4 * 64 * 8);
+    A((void **)&m->d.wpack16b, sizeof(uint16_t) * 4 * 2 * 4 * 8 * 64 * 8);
     A((void **)&m->d.in_lut, sizeof(float) * 5 * G4);
     A((void **)&m->d.rev_lut, sizeof(float) * 10);
     A((void **)&m->d.w_out, sizeof(float) * 512);
@@ -1047,6 +1345,7 @@ void rd_model_destroy(rd_model *m) {
     hipFree(m->d.raw); hipFree(m->d.wpack32); hipFree(m->d.wt_hh); hipFree(m->d.in_lut);
     hipFree(m->d.rev_lut); hipFree(m->d.w_out); hipFree(m->d.b_out);
     if (m->d.wpack16) hipFree(m->d.wpack16);
+    if (m->d.wpack16b) hipFree(m->d.wpack16b);
     for (int i = 0; i < 2 * 512; ++i)
         if (m->prof_ev[i]) hipEventDestroy(m->prof_ev[i]);
     delete m;
@@ -1054,8 +1353,8 @@ void rd_model_destroy(rd_model *m) {
 
 int rd_set_variant(rd_model *m, int variant) {
     if (!m) RD_FAIL(RD_E_INVALID, "rd_set_variant: null model");
-    if (variant == RD_VARIANT_AUTO) variant = RD_VARIANT_MFMA_F16X3;
-    if (variant != RD_VARIANT_MFMA_F32 && variant != RD_VARIANT_SIMPLE && variant != RD_VARIANT_MFMA_F16X3 && !(variant >= 10 && variant <= 32))
+    if (variant == RD_VARIANT_AUTO) variant = RD_VARIANT_MFMA_F16X3_T32;
+    if (variant != RD_VARIANT_MFMA_F32 && variant != RD_VARIANT_SIMPLE && variant != RD_VARIANT_MFMA_F16X3 && variant != RD_VARIANT_MFMA_F16X3_T32 && !(variant >= 10 && variant <= 42))
         RD_FAIL(RD_E_UNSUPPORTED, "rd_set_variant: variant %d not available in this build", variant);
     m->variant = variant;
     return RD_OK;
@@ -1133,6 +1432,8 @@ int rd_classify(const rd_model *cm, const uint8_t *arena, const int64_t *seq_off
         case 22: hipLaunchKernelGGL((rd_lstm_mfma_f32_kernel<1, 0, 3>), dim3((unsigned)nwg), dim3(256), 0, st, m->d, rb, logits, labels); break;
         case 23: hipLaunchKernelGGL((rd_lstm_mfma_f32_kernel<1, 0, 4>), dim3((unsigned)nwg), dim3(256), 0, st, m->d, rb, logits, labels); break;
         case RD_VARIANT_MFMA_F16X3: hipLaunchKernelGGL(rd_lstm_mfma_f16x3_kernel<2>, dim3((unsigned)nwg), dim3(256), 0, st, m->d, rb, logits, labels); break;
+        case RD_VARIANT_MFMA_F16X3_T32: hipLaunchKernelGGL(rd_lstm_mfma_f16x3_t32_kernel<6>, dim3((unsigned)nwg), dim3(256), 0, st, m->d, rb, logits, labels); break;
+        case 40: hipLaunchKernelGGL(rd_lstm_mfma_f16x3_t32_kernel<0>, dim3((unsigned)nwg), dim3(256), 0, st, m->d, rb, logits, labels); break;
         case 30: hipLaunchKernelGGL(rd_lstm_mfma_f16x3_kernel<0>, dim3((unsigned)nwg), dim3(256), 0, st, m->d, rb, logits, labels); break;
         case 31: hipLaunchKernelGGL(rd_lstm_mfma_f16x3_kernel<3>, dim3((unsigned)nwg), dim3(256), 0, st, m->d, rb, logits, labels); break;
         case 32: hipLaunchKernelGGL(rd_lstm_mfma_f16x3_kernel<4>, dim3((unsigned)nwg), dim3(256), 0, st, m->d, rb, logits, labels); break;

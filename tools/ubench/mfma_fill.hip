@@ -58,6 +58,17 @@ __global__ __launch_bounds__(256, 1) void kern32(float *out, int iters) {
                 for (int k = 0; k < K; ++k) {
                     if (FILL == 0) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[(c + k) & 7]) : "v"(b), "v"(a));
                     else if (FILL == 1) asm volatile("v_exp_f32 %0, %0" : "+v"(v[(c + k) & 7]));
+                    else if (FILL == 3) {   // mixed: first two fillers transcendental, the rest fma
+                        if (k < 2) asm volatile("v_exp_f32 %0, %0" : "+v"(v[(c + k) & 7]));
+                        else asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[(c + k) & 7]) : "v"(b), "v"(a));
+                    } else if (FILL == 4) {   // mixed: one exp, one rcp, rest fma
+                        if (k == 0) asm volatile("v_exp_f32 %0, %0" : "+v"(v[(c + k) & 7]));
+                        else if (k == 1) asm volatile("v_rcp_f32 %0, %0" : "+v"(v[(c + k) & 7]));
+                        else asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[(c + k) & 7]) : "v"(b), "v"(a));
+                    } else if (FILL == 5) {   // one trans + rest fma
+                        if (k == 0) asm volatile("v_exp_f32 %0, %0" : "+v"(v[(c + k) & 7]));
+                        else asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[(c + k) & 7]) : "v"(b), "v"(a));
+                    }
                     else asm volatile("ds_read_b128 %0, %1" : "=v"(l[(c + k) & 7]) : "v"(addr));
                 }
             }
@@ -113,6 +124,9 @@ int main() {
     run32<0, 0>(d, "f16 32x32x16 +fma"); run32<2, 0>(d, "f16 32x32x16 +fma"); run32<4, 0>(d, "f16 32x32x16 +fma"); run32<5, 0>(d, "f16 32x32x16 +fma");
     run32<6, 0>(d, "f16 32x32x16 +fma"); run32<8, 0>(d, "f16 32x32x16 +fma");
     run32<1, 1>(d, "f16 32x32x16 +exp"); run32<2, 1>(d, "f16 32x32x16 +exp"); run32<4, 1>(d, "f16 32x32x16 +exp");
+    run32<4, 3>(d, "f16 32x32x16 +2exp+fma"); run32<5, 3>(d, "f16 32x32x16 +2exp+fma"); run32<6, 3>(d, "f16 32x32x16 +2exp+fma"); run32<7, 3>(d, "f16 32x32x16 +2exp+fma");
+    run32<5, 4>(d, "f16 32x32x16 +exp+rcp+fma"); run32<6, 4>(d, "f16 32x32x16 +exp+rcp+fma");
+    run32<4, 5>(d, "f16 32x32x16 +1exp+fma"); run32<5, 5>(d, "f16 32x32x16 +1exp+fma"); run32<6, 5>(d, "f16 32x32x16 +1exp+fma");
     run32<1, 2>(d, "f16 32x32x16 +ds_read_b128"); run32<2, 2>(d, "f16 32x32x16 +ds_read_b128");
     return 0;
 }
