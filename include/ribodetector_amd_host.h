@@ -1,0 +1,57 @@
+/*
+ * ribodetector_amd_host.h - C ABI of the host-side ingest / output library (librd_host.so, plain C++ + zlib, no GPU).
+ *
+ * the reference's FASTQ/FASTA reader and label-partitioned writer are Python loops over
+ * per-record tuples (0.5 M reads/s parse, 0.2-0.34 M reads/s write); the kernels classify ~27 M reads/s. This
+ * library produces exactly the arrays rd_classify consumes - one byte arena + offsets - and writes the selected records
+ * back in input order.
+ *
+ * Reference interfaces replaced (paths relative to /root/reference/ribodetector):
+ *   rd_reader_*   data_loader/seq_encoder.py:21-39,75-92 (get_seq_format, get_seq_chunks) over
+ *                 data_loader/fastx_parser.py:15-55 (seq_parser): FASTQ = 4-line records, every line rstrip()-ed, bases NOT
+ *                 upper-cased; FASTA = multi-line sequences joined and upper-cased, blank lines skipped; gzip by extension.
+ *   rd_writer_*   detect.py:729-741 (open_for_write: gzip level 5 iff the name ends with "gz") and
+ *                 detect.py:485-492 (fh.write('\n'.join(selected_records) + '\n')).
+ *
+ * All buffers are caller-owned (e.g. pinned torch tensors); return 0 = ok (rd_reader_next: also 1 = end of file),
+ * <0 = error + rd_host_last_error().
+ */
+#ifndef RIBODETECTOR_AMD_HOST_H
+#define RIBODETECTOR_AMD_HOST_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rd_reader rd_reader;
+typedef struct rd_writer rd_writer;
+
+/* format: 0 = FASTQ, 1 = FASTA, -1 = decide from the file name like get_seq_format (.fq/.fastq/.fa/.fasta/.fna/.fas [+ .gz]) */
+int rd_reader_open(const char *path, int format, rd_reader **out);
+void rd_reader_close(rd_reader *r);
+
+/* Parse up to max_records records into caller buffers.
+ *   buf[0 .. *nbytes)      normalised record text: for record i, buf[rec_start[i] .. rec_start[i+1]) is exactly
+ *                          '\n'.join(record_lines) + '\n' as the reference would write it
+ *   rec_start int64[max_records+1], seq_off int64[max_records] (start of the bases in buf), seq_len int32[max_records]
+ * Stops early when the next record would not fit into buf_cap (it is delivered by the next call).
+ * *n = number of records delivered. Returns 1 when the end of the file was reached (no record follows those delivered),
+ * 0 when more may follow (*n == 0 then means: the next record does not fit into the remaining buffer), <0 on error. */
+int rd_reader_next(rd_reader *r, int64_t max_records, uint8_t *buf, int64_t buf_cap, int64_t *rec_start, int64_t *seq_off,
+                   int32_t *seq_len, int64_t *n, int64_t *nbytes);
+
+int rd_writer_open(const char *path, rd_writer **out);
+/* append, in input order, every record i of the chunk with labels[i] == want */
+int rd_writer_write_selected(rd_writer *w, const uint8_t *buf, const int64_t *rec_start, int64_t n, const int8_t *labels,
+                             int32_t want);
+int rd_writer_close(rd_writer *w);
+
+const char *rd_host_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -83,3 +83,36 @@ def stream_ptr(device=None):
 def ptr(t):
     """device/host pointer of a torch tensor (None -> NULL)"""
     return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+# ---- host ingest library (librd_host.so: C++ + zlib, no GPU) -------------------------------------------------------
+HOST_LIB_PATH = os.path.join(_HERE, "csrc", "librd_host.so")
+HOST_SYMBOLS = ["rd_reader_open", "rd_reader_close", "rd_reader_next", "rd_writer_open", "rd_writer_write_selected",
+                "rd_writer_close", "rd_host_last_error"]
+_host = None
+
+
+def host_lib():
+    """Load librd_host.so (once); raises RuntimeError if it has not been built."""
+    global _host
+    if _host is not None:
+        return _host
+    if not os.path.exists(HOST_LIB_PATH):
+        raise RuntimeError("ribodetector_amd: host library %s is missing - run __graft_entry__.build()" % HOST_LIB_PATH)
+    L = C.CDLL(HOST_LIB_PATH)
+    vp, i64 = C.c_void_p, C.c_int64
+    L.rd_reader_open.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
+    L.rd_reader_close.argtypes = [vp]
+    L.rd_reader_close.restype = None
+    L.rd_reader_next.argtypes = [vp, i64, vp, i64, vp, vp, vp, C.POINTER(i64), C.POINTER(i64)]
+    L.rd_writer_open.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.rd_writer_write_selected.argtypes = [vp, vp, vp, i64, vp, C.c_int32]
+    L.rd_writer_close.argtypes = [vp]
+    L.rd_host_last_error.restype = C.c_char_p
+    _host = L
+    return L
+
+
+def host_check(rc, what):
+    if rc != 0:
+        raise ValueError("%s: %s" % (what, host_lib().rd_host_last_error().decode()))

@@ -1,0 +1,281 @@
+// rd_host.cpp - host-side FASTQ/FASTA ingest and label-partitioned output (librd_host.so). See
+// include/ribodetector_amd_host.h for the reference interfaces this replaces.
+#include <ctype.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <zlib.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/ribodetector_amd_host.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+#define RDH_FAIL(...)                                  \
+    do {                                               \
+        snprintf(g_err, sizeof(g_err), __VA_ARGS__);   \
+        return -1;                                     \
+    } while (0)
+
+bool ends_with(const std::string &s, const char *suf) {
+    size_t n = strlen(suf);
+    return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
+}
+
+// Python str.rstrip()/strip() whitespace for the byte values that can occur in these files
+inline bool is_ws(unsigned char c) { return c == ' ' || (c >= 9 && c <= 13) || c == 0x1c || c == 0x1d || c == 0x1e || c == 0x1f || c == 0x85 || c == 0xa0; }
+
+}  // namespace
+
+struct rd_reader {
+    gzFile fh;
+    int fasta;
+    std::vector<uint8_t> in;     // raw input window
+    size_t pos, end;             // unconsumed bytes are in[pos, end)
+    bool eof;
+    std::string pending_header;  // FASTA: header of the record being assembled ('' until the first '>' line, like the reference)
+    std::string pending_seq;
+    size_t scan_next;            // window offset just past the lines returned by scan_lines
+
+    // Offsets [lb[k], le[k]) of the next `want` lines (terminators excluded) without consuming them; the offsets are
+    // relative to in.data() and stay valid until the next fill(). Returns how many lines exist (fewer only at end of file;
+    // the last line of a file may lack its '\n').
+    int scan_lines(int want, size_t *lb, size_t *le) {
+        for (;;) {
+            size_t p = pos;
+            int k = 0;
+            while (k < want) {
+                const uint8_t *nl = (const uint8_t *)memchr(in.data() + p, '\n', end - p);
+                if (!nl) break;
+                lb[k] = p;
+                le[k] = (size_t)(nl - in.data());
+                p = le[k] + 1;
+                ++k;
+            }
+            if (k == want) { scan_next = p; return k; }
+            if (eof) {   // nothing more will arrive: a last line without terminator still counts
+                if (p < end) { lb[k] = p; le[k] = end; p = end; ++k; }
+                scan_next = p;
+                return k;
+            }
+            fill();      // may compact the window: rescan from pos either way
+        }
+    }
+
+    bool fill() {   // make room and read more; false when nothing more arrives
+        if (eof) return false;
+        if (pos > 0) {
+            memmove(in.data(), in.data() + pos, end - pos);
+            end -= pos;
+            pos = 0;
+        }
+        if (end == in.size()) in.resize(in.size() * 2);
+        int got = gzread(fh, in.data() + end, (unsigned)std::min<size_t>(in.size() - end, 1u << 30));
+        if (got <= 0) {
+            eof = true;
+            return false;
+        }
+        end += (size_t)got;
+        return true;
+    }
+};
+
+struct rd_writer {
+    gzFile gz;
+    FILE *fp;
+};
+
+extern "C" {
+
+const char *rd_host_last_error(void) { return g_err; }
+
+int rd_reader_open(const char *path, int format, rd_reader **out) {
+    if (!path || !out) RDH_FAIL("rd_reader_open: null argument");
+    std::string p(path), stem = p;
+    if (ends_with(p, ".gz")) stem = p.substr(0, p.size() - 3);
+    else if (ends_with(p, ".gzip")) stem = p.substr(0, p.size() - 5);
+    if (format < 0) {
+        if (ends_with(stem, ".fq") || ends_with(stem, ".fastq")) format = 0;
+        else if (ends_with(stem, ".fasta") || ends_with(stem, ".fa") || ends_with(stem, ".fna") || ends_with(stem, ".fas")) format = 1;
+        else RDH_FAIL("Unknown extension of %s. Only fastq and fasta sequence formats are supported.", path);
+    }
+    gzFile fh = gzopen(path, "rb");   // transparently reads plain files too
+    if (!fh) RDH_FAIL("cannot open %s", path);
+    gzbuffer(fh, 1 << 20);
+    rd_reader *r = new rd_reader();
+    r->fh = fh;
+    r->fasta = format;
+    r->in.resize(8 << 20);
+    r->pos = r->end = 0;
+    r->eof = false;
+    r->scan_next = 0;
+    *out = r;
+    return 0;
+}
+
+void rd_reader_close(rd_reader *r) {
+    if (!r) return;
+    gzclose(r->fh);
+    delete r;
+}
+
+int rd_reader_next(rd_reader *r, int64_t max_records, uint8_t *buf, int64_t buf_cap, int64_t *rec_start, int64_t *seq_off,
+                   int32_t *seq_len, int64_t *n_out, int64_t *nbytes_out) {
+    if (!r || !buf || !rec_start || !seq_off || !seq_len || !n_out || !nbytes_out) RDH_FAIL("rd_reader_next: null argument");
+    int64_t n = 0, w = 0;
+    bool at_eof = false;
+    if (!r->fasta) {
+        // FASTQ: 4 lines per record, each rstrip()-ed (fastx_parser.py:18-37)
+        while (n < max_records) {
+            size_t lb[4], le[4];
+            const int got = r->scan_lines(4, lb, le);
+            if (got == 0) { at_eof = true; break; }   // clean end of file
+            if (got < 4) {
+                bool blank = true;   // tolerate trailing blank lines only
+                for (int k = 0; k < got; ++k)
+                    for (size_t x = lb[k]; x < le[k]; ++x) blank = blank && is_ws(r->in[x]);
+                if (blank) { r->pos = r->scan_next; at_eof = true; break; }
+                RDH_FAIL("truncated FASTQ record at end of file (number of lines is not a multiple of 4)");
+            }
+            const uint8_t *base = r->in.data();
+            for (int k = 0; k < 4; ++k)
+                while (le[k] > lb[k] && is_ws(base[le[k] - 1])) --le[k];
+            if (le[0] == lb[0] || base[lb[0]] != '@') RDH_FAIL("FASTQ record does not start with '@'");
+            int64_t need = 4;
+            for (int k = 0; k < 4; ++k) need += (int64_t)(le[k] - lb[k]);
+            if (need > buf_cap) RDH_FAIL("rd_reader_next: one record (%lld bytes) exceeds the buffer", (long long)need);
+            if (w + need > buf_cap) break;   // does not fit: the record stays in the window for the next call
+            rec_start[n] = w;
+            for (int k = 0; k < 4; ++k) {
+                const size_t len = le[k] - lb[k];
+                if (k == 1) { seq_off[n] = w; seq_len[n] = (int32_t)len; }
+                memcpy(buf + w, base + lb[k], len);
+                w += (int64_t)len;
+                buf[w++] = '\n';
+            }
+            r->pos = r->scan_next;
+            ++n;
+        }
+    } else {
+        // FASTA: strip() every line, skip blanks, '>' starts a record, sequence lines joined + upper-cased
+        // (fastx_parser.py:39-55; like the reference, a record is yielded at the next header if header != '', and at end of
+        // file if seq != '')
+        auto emit = [&](void) -> int {   // 1 = emitted, 0 = does not fit, -1 = error
+            int64_t need = (int64_t)r->pending_header.size() + 1 + (int64_t)r->pending_seq.size() + 1;
+            if (need > buf_cap) {
+                snprintf(g_err, sizeof(g_err), "rd_reader_next: one record (%lld bytes) exceeds the buffer", (long long)need);
+                return -1;
+            }
+            if (w + need > buf_cap || n >= max_records) return 0;
+            rec_start[n] = w;
+            memcpy(buf + w, r->pending_header.data(), r->pending_header.size());
+            w += (int64_t)r->pending_header.size();
+            buf[w++] = '\n';
+            seq_off[n] = w;
+            seq_len[n] = (int32_t)r->pending_seq.size();
+            memcpy(buf + w, r->pending_seq.data(), r->pending_seq.size());
+            w += (int64_t)r->pending_seq.size();
+            buf[w++] = '\n';
+            ++n;
+            return 1;
+        };
+        while (n < max_records) {
+            size_t lb, le;
+            if (r->scan_lines(1, &lb, &le) == 0) {   // end of input
+                if (!r->pending_seq.empty()) {
+                    int rc = emit();
+                    if (rc < 0) return -1;
+                    if (rc == 0) break;
+                    r->pending_seq.clear();
+                    r->pending_header.clear();
+                }
+                at_eof = true;
+                break;
+            }
+            const uint8_t *base = r->in.data();
+            while (le > lb && is_ws(base[le - 1])) --le;
+            while (lb < le && is_ws(base[lb])) ++lb;
+            if (lb == le) { r->pos = r->scan_next; continue; }
+            if (base[lb] == '>') {
+                if (!r->pending_header.empty()) {
+                    int rc = emit();
+                    if (rc < 0) return -1;
+                    if (rc == 0) break;            // header line stays unconsumed for the next call
+                    r->pending_seq.clear();
+                }
+                r->pending_header.assign((const char *)base + lb, le - lb);
+            } else {
+                const size_t o = r->pending_seq.size();
+                r->pending_seq.append((const char *)base + lb, le - lb);
+                for (size_t i = o; i < r->pending_seq.size(); ++i) r->pending_seq[i] = (char)toupper((unsigned char)r->pending_seq[i]);
+            }
+            r->pos = r->scan_next;
+        }
+    }
+    rec_start[n] = w;
+    *n_out = n;
+    *nbytes_out = w;
+    return at_eof ? 1 : 0;
+}
+
+int rd_writer_open(const char *path, rd_writer **out) {
+    if (!path || !out) RDH_FAIL("rd_writer_open: null argument");
+    rd_writer *w = new rd_writer();
+    w->gz = nullptr;
+    w->fp = nullptr;
+    std::string p(path);
+    if (ends_with(p, "gz")) {
+        w->gz = gzopen(path, "wb5");   // compresslevel=5, detect.py:739
+        if (w->gz) gzbuffer(w->gz, 1 << 20);
+    } else {
+        w->fp = fopen(path, "wb");
+        if (w->fp) setvbuf(w->fp, nullptr, _IOFBF, 4 << 20);
+    }
+    if (!w->gz && !w->fp) {
+        delete w;
+        RDH_FAIL("cannot open %s for writing", path);
+    }
+    *out = w;
+    return 0;
+}
+
+int rd_writer_write_selected(rd_writer *w, const uint8_t *buf, const int64_t *rec_start, int64_t n, const int8_t *labels,
+                             int32_t want) {
+    if (!w || !buf || !rec_start || !labels) RDH_FAIL("rd_writer_write_selected: null argument");
+    int64_t i = 0;
+    while (i < n) {
+        if (labels[i] != want) { ++i; continue; }
+        int64_t j = i + 1;
+        while (j < n && labels[j] == want) ++j;   // one write per run of consecutive selected records
+        const uint8_t *p = buf + rec_start[i];
+        int64_t len = rec_start[j] - rec_start[i];
+        while (len > 0) {
+            unsigned chunk = (unsigned)std::min<int64_t>(len, 1 << 30);
+            if (w->gz) {
+                if (gzwrite(w->gz, p, chunk) != (int)chunk) RDH_FAIL("gzwrite failed");
+            } else if (fwrite(p, 1, chunk, w->fp) != chunk) {
+                RDH_FAIL("fwrite failed");
+            }
+            p += chunk;
+            len -= chunk;
+        }
+        i = j;
+    }
+    return 0;
+}
+
+int rd_writer_close(rd_writer *w) {
+    if (!w) return 0;
+    int rc = 0;
+    if (w->gz) rc = gzclose(w->gz) == Z_OK ? 0 : -1;
+    if (w->fp) rc = fclose(w->fp) == 0 ? 0 : -1;
+    delete w;
+    if (rc) RDH_FAIL("close failed");
+    return 0;
+}
+
+}  // extern "C"

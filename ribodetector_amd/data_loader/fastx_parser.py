@@ -8,6 +8,7 @@ Record semantics kept from the reference:
   * FASTA: multi-line sequences joined and upper-cased, blank lines skipped (fastx_parser.py:39-55);
   * gzip chosen by file extension, format by the extension before it (seq_encoder.py:21-39).
 """
+import ctypes as C
 import gzip
 import io
 from collections import namedtuple
@@ -15,6 +16,8 @@ from mimetypes import guess_type
 from pathlib import Path
 
 import numpy as np
+
+from .. import _native as N
 
 FA_EXTS = [".fasta", ".fa", ".fna", ".fas"]
 FQ_EXTS = [".fq", ".fastq"]
@@ -74,7 +77,8 @@ def seq_parser(seq_fh, seq_type):
 
 # A chunk of records as arrays.  buf: uint8 arena holding the record text; rec_start int64[n+1]: byte range of record i
 # (verbatim text incl. its final newline, valid when `verbatim`); seq_off int64[n] / seq_len int32[n]: the bases.
-Chunk = namedtuple("Chunk", "buf rec_start seq_off seq_len verbatim records")
+# tensors: (buf, seq_off, seq_len) as (pinned) torch tensors when the chunk came from the native reader, else None.
+Chunk = namedtuple("Chunk", "buf rec_start seq_off seq_len verbatim records tensors", defaults=(None,))
 
 _WS = np.zeros(256, dtype=bool)
 _WS[[9, 10, 11, 12, 13, 32]] = True
@@ -174,14 +178,90 @@ def _fasta_chunks(fh, chunk_reads):
         yield Chunk(arr, rec_start, rec_start[:-1] + hl, seq_len, True, None)
 
 
-def get_seq_chunks(seq_file, chunk_size=1048576):
-    """Chunks of at most `chunk_size` records (reference seq_encoder.py:75-87), as `Chunk` arrays."""
+def get_seq_chunks_numpy(seq_file, chunk_size=1048576):
+    """numpy implementation of the chunk reader (kept as an independent cross-check of the native one in tests)."""
     fh, fmt = _open_binary(seq_file)
     with fh:
         if fmt.startswith("fq"):
             yield from _fastq_chunks(fh, chunk_size)
         else:
             yield from _fasta_chunks(fh, chunk_size)
+
+
+class NativeReader:
+    """librd_host.so reader: records are parsed in C++ straight into (pinned) buffers that go to the GPU as they are."""
+
+    def __init__(self, path, est_record_bytes=320):
+        import torch
+        self._torch = torch
+        self._pin = torch.cuda.is_available()
+        fmt = get_seq_format(path)                  # raises ValueError like the reference for unknown extensions
+        self.h = C.c_void_p()
+        N.host_check(N.host_lib().rd_reader_open(str(path).encode(), 1 if fmt.startswith("fa") else 0, C.byref(self.h)), "rd_reader_open")
+        self.est = est_record_bytes
+        self.eof = False
+
+    def close(self):
+        if self.h:
+            N.host_lib().rd_reader_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def _alloc(self, nbytes, nrec):
+        t = self._torch
+        kw = dict(pin_memory=True) if self._pin else {}
+        return (t.empty(nbytes, dtype=t.uint8, **kw), t.empty(nrec + 1, dtype=t.int64, **kw), t.empty(nrec, dtype=t.int64, **kw),
+                t.empty(nrec, dtype=t.int32, **kw))
+
+    def read(self, want):
+        """Exactly `want` records unless the file ends first; buffers grow as needed. Returns a Chunk or None at EOF."""
+        if self.eof:
+            return None
+        L = N.host_lib()
+        buf, rs, so, sl = self._alloc(max(1 << 16, want * self.est), want)
+        n_tot, b_tot = 0, 0
+        n, nb = C.c_int64(0), C.c_int64(0)
+        while n_tot < want:
+            rc = L.rd_reader_next(self.h, want - n_tot, buf.data_ptr() + b_tot, buf.numel() - b_tot, rs.data_ptr() + 8 * n_tot,
+                                  so.data_ptr() + 8 * n_tot, sl.data_ptr() + 4 * n_tot, C.byref(n), C.byref(nb))
+            if rc < 0:
+                N.host_check(rc, "rd_reader_next")
+            if n.value:
+                if b_tot:                               # offsets of this call are relative to its own buffer start
+                    rs[n_tot:n_tot + n.value + 1] += b_tot
+                    so[n_tot:n_tot + n.value] += b_tot
+                n_tot += n.value
+                b_tot += nb.value
+                self.est = max(self.est, int(1.1 * b_tot / n_tot) + 16)
+            if rc == 1:
+                self.eof = True
+                break
+            if n_tot < want:                            # buffer full before `want` records: grow and continue
+                grown = self._alloc(max(2 * buf.numel(), b_tot + (want - n_tot) * self.est + (1 << 16)), want)
+                grown[0][:b_tot] = buf[:b_tot]
+                grown[1][:n_tot + 1] = rs[:n_tot + 1]
+                grown[2][:n_tot] = so[:n_tot]
+                grown[3][:n_tot] = sl[:n_tot]
+                buf, rs, so, sl = grown
+        if n_tot == 0:
+            return None
+        return Chunk(buf[:b_tot].numpy(), rs[:n_tot + 1].numpy(), so[:n_tot].numpy(), sl[:n_tot].numpy(), True, None,
+                     (buf[:b_tot], so[:n_tot], sl[:n_tot]))
+
+
+def get_seq_chunks(seq_file, chunk_size=1048576):
+    """Chunks of at most `chunk_size` records (reference seq_encoder.py:75-87), as `Chunk` arrays, parsed by librd_host.so."""
+    r = NativeReader(seq_file)
+    try:
+        while True:
+            c = r.read(chunk_size)
+            if c is None:
+                return
+            yield c
+    finally:
+        r.close()
 
 
 def get_pairedread_chunks(r1_seq_file, r2_seq_file, chunk_size=1048576):
@@ -209,8 +289,28 @@ def select_records(chunk, mask):
     return chunk.buf[keep].tobytes()
 
 
+class NativeWriter:
+    """librd_host.so writer: gzip level 5 when the name ends with 'gz', else plain (reference detect.py:729-741)."""
+
+    def __init__(self, path):
+        self.h = C.c_void_p()
+        N.host_check(N.host_lib().rd_writer_open(str(path).encode(), C.byref(self.h)), "rd_writer_open")
+
+    def write_selected(self, chunk, labels, want):
+        """append the records of `chunk` whose label == want, in input order (reference detect.py:485-492)"""
+        if not chunk.verbatim:
+            raise ValueError("write_selected needs a chunk with normalised record text")
+        labels = np.ascontiguousarray(labels, dtype=np.int8)
+        buf = np.ascontiguousarray(chunk.buf)
+        rs = np.ascontiguousarray(chunk.rec_start, dtype=np.int64)
+        N.host_check(N.host_lib().rd_writer_write_selected(self.h, buf.ctypes.data, rs.ctypes.data, len(labels), labels.ctypes.data,
+                                                           int(want)), "rd_writer_write_selected")
+
+    def close(self):
+        if self.h:
+            N.host_check(N.host_lib().rd_writer_close(self.h), "rd_writer_close")
+            self.h = None
+
+
 def open_for_write(read_file):
-    """gzip level 5 when the name ends with 'gz', else plain (reference detect.py:729-741)."""
-    if read_file.endswith("gz"):
-        return gzip.open(read_file, mode="wb", compresslevel=5)
-    return open(read_file, "wb")
+    return NativeWriter(read_file)

@@ -87,14 +87,15 @@ class Predictor:
 
     # ---- classification of one chunk ------------------------------------------------------------------
     def _to_device(self, chunk, lo, hi, stream):
-        """pinned staging + async H2D of records [lo, hi) of a chunk: only the bytes spanning those reads travel."""
+        """async H2D of records [lo, hi) of a chunk: only the bytes spanning those reads travel. The native reader parsed
+        straight into pinned buffers, so there is no staging copy."""
         b0 = int(chunk.rec_start[lo])
         b1 = int(chunk.rec_start[hi])
+        tbuf, toff, tlen = chunk.tensors
         with torch.cuda.stream(stream):
-            host = torch.from_numpy(chunk.buf[b0:b1]) if chunk.buf.flags.writeable else torch.from_numpy(chunk.buf[b0:b1].copy())
-            arena = host.pin_memory().to(self.device, non_blocking=True) if b1 > b0 else torch.zeros(1, dtype=torch.uint8, device=self.device)
-            off = torch.from_numpy(chunk.seq_off[lo:hi] - b0).pin_memory().to(self.device, non_blocking=True)
-            ln = torch.from_numpy(np.ascontiguousarray(chunk.seq_len[lo:hi])).pin_memory().to(self.device, non_blocking=True)
+            arena = tbuf[b0:b1].to(self.device, non_blocking=True) if b1 > b0 else torch.zeros(1, dtype=torch.uint8, device=self.device)
+            off = toff[lo:hi].to(self.device, non_blocking=True) - b0
+            ln = tlen[lo:hi].to(self.device, non_blocking=True)
         return arena, off, ln
 
     def classify_chunk(self, chunks):
@@ -175,10 +176,8 @@ class Predictor:
                 num_rrna += int((labels == 1).sum())
                 num_unknown += int((labels == -1).sum())
                 for lab, handles in fhs.items():
-                    mask = labels == lab
-                    if mask.any():
-                        for e, fh in zip(ends, handles):
-                            fh.write(fx.select_records(chunks[e], mask))
+                    for e, fh in zip(ends, handles):
+                        fh.write_selected(chunks[e], labels, lab)
                 self.logger.info('{}{}{} sequences finished!'.format(colors.OKGREEN, num_read, colors.ENDC))
         if writer:
             self.logger.info('Processed {}{}{}{} sequences in total'.format(colors.BOLD, colors.OKCYAN, num_read, colors.ENDC))

@@ -28,6 +28,17 @@ def test_header_symbols_exported():
     assert b"gfx950" in N.lib().rd_version()
 
 
+def test_host_library_symbols():
+    from ribodetector_amd import _native as N
+    src = open(os.path.join(ROOT, "include", "ribodetector_amd_host.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(rd_[a-z0-9_]+)\s*\(", src)))
+    lib = ctypes.CDLL(N.HOST_LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), "librd_host.so does not export %s" % name
+    assert sorted(N.HOST_SYMBOLS) == declared
+
+
 def test_missing_extension_fails_loudly(monkeypatch):
     from ribodetector_amd import _native as N
     monkeypatch.setattr(N, "_lib", None)

@@ -26,19 +26,32 @@ def test_get_seq_format():
         fx.get_seq_format("reads.fq.bz2")
 
 
+READERS = [fx.get_seq_chunks, fx.get_seq_chunks_numpy]     # native (librd_host.so) and the numpy cross-check
+
+
+def _write(path, chunk, mask):
+    w = fx.open_for_write(path)
+    w.write_selected(chunk, mask.astype(np.int8), 1)
+    w.close()
+    op = gzip.open if path.endswith("gz") else open
+    with op(path, "rb") as fh:
+        return fh.read()
+
+
 def _records(chunk):
     b = chunk.buf.tobytes()
     return [b[chunk.seq_off[i]:chunk.seq_off[i] + chunk.seq_len[i]].decode() for i in range(len(chunk.seq_len))]
 
 
+@pytest.mark.parametrize("reader", READERS)
 @pytest.mark.parametrize("suffix", ["fq", "fq.gz"])
-def test_fastq_chunks(tmp_path, suffix, golden):
+def test_fastq_chunks(tmp_path, suffix, golden, reader):
     arena, off, lens = synth.reads_numpy(1000, (30, 150), seed=2)
     p = str(tmp_path / ("r." + suffix))
     synth.write_fastq(p, arena, off, mate=1)
     want = synth.as_strings(arena, off)
     got, total = [], 0
-    for c in fx.get_seq_chunks(p, chunk_size=333):
+    for c in reader(p, chunk_size=333):
         assert len(c.seq_len) <= 333 and c.verbatim
         got += _records(c)
         total += len(c.seq_len)
@@ -51,41 +64,50 @@ def test_fastq_chunks(tmp_path, suffix, golden):
         ref = list(fx.seq_parser(fh, "fastq"))
     assert [r[1] for r in ref] == want
     # label partition: selecting a mask yields exactly those records, in order, newline terminated
-    chunks = list(fx.get_seq_chunks(p, chunk_size=1000))
+    chunks = list(reader(p, chunk_size=1000))
     mask = np.random.default_rng(1).random(1000) < 0.3
-    sel = fx.select_records(chunks[0], mask).decode()
-    assert sel == "".join("\n".join(r) + "\n" for r, m in zip(ref, mask) if m)
+    want = "".join("\n".join(r) + "\n" for r, m in zip(ref, mask) if m)
+    assert fx.select_records(chunks[0], mask).decode() == want
     assert fx.select_records(chunks[0], np.zeros(1000, bool)) == b""
+    # native writer, plain and gzip (level 5 like the reference), same bytes
+    assert _write(str(tmp_path / "sel.fq"), chunks[0], mask).decode() == want
+    assert _write(str(tmp_path / "sel.fq.gz"), chunks[0], mask).decode() == want
+    assert _write(str(tmp_path / "none.fq"), chunks[0], np.zeros(1000, bool)) == b""
 
 
-def test_fastq_edge_framing(tmp_path, golden):
+@pytest.mark.parametrize("reader", READERS)
+def test_fastq_edge_framing(tmp_path, golden, reader):
     g = golden.json("parser")
     p = str(tmp_path / "odd.fastq")
     # CRLF endings, trailing blanks, '@' as first quality char, no final newline
     text = g["fastq_text"].replace("\n", "\r\n").rstrip("\r\n")
     with open(p, "w", newline="") as fh:
         fh.write(text)
-    cs = list(fx.get_seq_chunks(p, chunk_size=2))
+    cs = list(reader(p, chunk_size=2))
     assert [len(c.seq_len) for c in cs] == [2, 1]
     assert sum((_records(c) for c in cs), []) == [r[1] for r in g["fastq_records"]]
-    assert not cs[0].verbatim
     out = b"".join(fx.select_records(c, np.ones(len(c.seq_len), bool)) for c in cs).decode()
     assert out == "".join("\n".join(r) + "\n" for r in g["fastq_records"])
     with open(p, "w") as fh:
         fh.write("@a\nACGT\n+\n")
     with pytest.raises(ValueError):
-        list(fx.get_seq_chunks(p, 10))
+        list(reader(p, 10))
     with open(p, "w") as fh:
         fh.write("a\nACGT\n+\nIIII\n")
     with pytest.raises(ValueError):
-        list(fx.get_seq_chunks(p, 10))
+        list(reader(p, 10))
+    if reader is fx.get_seq_chunks:                # trailing blank lines (the reference crashes on them) are not a record
+        with open(p, "w") as fh:
+            fh.write("@a\nACGT\n+\nIIII\n\n\n")
+        assert sum(len(c.seq_len) for c in reader(p, 10)) == 1
 
 
-def test_fasta_chunks(tmp_path, golden):
+@pytest.mark.parametrize("reader", READERS)
+def test_fasta_chunks(tmp_path, golden, reader):
     g = golden.json("parser")
     p = str(tmp_path / "x.fa")
     open(p, "w").write(g["fasta_text"])
-    cs = list(fx.get_seq_chunks(p, chunk_size=2))
+    cs = list(reader(p, chunk_size=2))
     assert sum((_records(c) for c in cs), []) == [r[1] for r in g["fasta_records"]]
     out = b"".join(fx.select_records(c, np.ones(len(c.seq_len), bool)) for c in cs).decode()
     assert out == "".join("\n".join(r) + "\n" for r in g["fasta_records"])
@@ -102,3 +124,31 @@ def test_paired_chunks(tmp_path):
         assert len(c1.seq_len) == len(c2.seq_len)
         n += len(c1.seq_len)
     assert n == 100
+
+
+def test_native_reader_small_buffers_and_growth(tmp_path):
+    """records that do not fit the first buffer estimate: the reader hands back what fits, the wrapper grows and continues"""
+    rng = np.random.default_rng(3)
+    recs = []
+    for i in range(300):
+        L = int(rng.integers(1, 3000))
+        s = "".join("ACGT"[k] for k in rng.integers(0, 4, L))
+        recs.append(("@r%d some description" % i, s, "+", "I" * L))
+    p = str(tmp_path / "big.fastq.gz")
+    with gzip.open(p, "wt") as fh:
+        for r in recs:
+            fh.write("\n".join(r) + "\n")
+    r = fx.NativeReader(p, est_record_bytes=8)       # deliberately tiny estimate
+    got = []
+    while True:
+        c = r.read(77)
+        if c is None:
+            break
+        assert len(c.seq_len) == 77 or r.eof
+        b = c.buf.tobytes()
+        for i in range(len(c.seq_len)):
+            got.append(tuple(b[c.rec_start[i]:c.rec_start[i + 1]].decode().rstrip("\n").split("\n")))
+            assert b[c.seq_off[i]:c.seq_off[i] + c.seq_len[i]].decode() == got[-1][1]
+    assert got == recs
+    with pytest.raises(ValueError):
+        fx.NativeReader(str(tmp_path / "reads.txt"))
