@@ -191,6 +191,8 @@ def get_seq_chunks_numpy(seq_file, chunk_size=1048576):
 class NativeReader:
     """librd_host.so reader: records are parsed in C++ straight into (pinned) buffers that go to the GPU as they are."""
 
+    h = None
+
     def __init__(self, path, est_record_bytes=320):
         import torch
         self._torch = torch
