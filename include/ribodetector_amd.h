@@ -47,6 +47,11 @@ extern "C" {
 #define RD_VARIANT_MFMA_F16X3_T32 4 /* the same on v_mfma_f32_32x32x16_f16, 32-read tiles, hand-interleaved gate math */
 /* ids >= 10 are A/B and diagnostic builds used by bench.py --variant; not part of the stable ABI */
 
+/* output-row semantics (rd_set_semantics) */
+#define RD_SEM_PACKED 0 /* reference GPU product: PackedSequence, gather at timestep min(len,max_len)-1 (model/model.py:32-37)  */
+#define RD_SEM_PADDED 1 /* reference CPU product `ribodetector_cpu`: input zero-padded to max_len rows, BiLSTM over all rows,
+                           gather at the last non-zero row (model/model_cpu.py:29-37,57-62, detect_cpu.py:699-700)            */
+
 typedef struct rd_model rd_model; /* opaque: device-resident, pre-packed weights */
 
 /* Host pointers to the 10 tensors of the reference state_dict (reference model/model.py:16-24; names as in
@@ -70,6 +75,10 @@ void rd_model_destroy(rd_model *m);
 
 /* Select the recurrence kernel (RD_VARIANT_*); default AUTO = MFMA_F16X3_T32. */
 int rd_set_variant(rd_model *m, int variant);
+
+/* Select which of the reference's two products rd_classify reproduces (RD_SEM_*); default RD_SEM_PACKED. The two differ
+ * only for reads shorter than max_len or ending in non-ACGT bases. */
+int rd_set_semantics(rd_model *m, int semantics);
 
 /* Bytes of [dev] scratch rd_classify needs for n reads with truncation length max_len. */
 size_t rd_classify_workspace_bytes(int64_t n, int32_t max_len);

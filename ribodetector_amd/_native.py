@@ -9,6 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "librd_hip.so")
 
 ENSURE_MODES = {"none": 0, "rrna": 1, "norrna": 2, "both": 3}
+SEMANTICS = {"packed": 0, "gpu": 0, "padded": 1, "cpu": 1}
 VARIANTS = {"auto": 0, "mfma_f32": 1, "simple": 2, "mfma_f16x3": 3, "mfma_f16x3_t32": 4,
             # A/B builds of the fp32 kernel (activation form x schedule), see rd_kernels.hip
             "mfma_f32_a0s0": 10, "mfma_f32_a1s0": 11, "mfma_f32_a0s1": 12, "mfma_f32_a1s1": 13,
@@ -18,7 +19,7 @@ VARIANTS = {"auto": 0, "mfma_f32": 1, "simple": 2, "mfma_f16x3": 3, "mfma_f16x3_
 
 # every symbol include/ribodetector_amd.h declares (tests/test_abi.py checks the .so exports all of them)
 SYMBOLS = [
-    "rd_model_create", "rd_model_destroy", "rd_set_variant", "rd_classify_workspace_bytes", "rd_classify",
+    "rd_model_create", "rd_model_destroy", "rd_set_variant", "rd_set_semantics", "rd_classify_workspace_bytes", "rd_classify",
     "rd_pair_fuse", "rd_count_labels", "rd_encode_codes", "rd_encode_onehot_padded", "rd_pack_plan",
     "rd_pack_onehot", "rd_profile_enable", "rd_profile_read", "rd_last_error", "rd_version",
 ]
@@ -49,6 +50,7 @@ def lib():
     L.rd_model_destroy.argtypes = [vp]
     L.rd_model_destroy.restype = None
     L.rd_set_variant.argtypes = [vp, C.c_int]
+    L.rd_set_semantics.argtypes = [vp, C.c_int]
     L.rd_classify_workspace_bytes.argtypes = [i64, i32]
     L.rd_classify_workspace_bytes.restype = sz
     L.rd_classify.argtypes = [vp, vp, vp, vp, i64, i32, vp, vp, vp, sz, vp]

@@ -58,6 +58,12 @@ __device__ __forceinline__ int rd_code(unsigned ch) {
     return ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : (ch == 'T' || ch == 'U') ? 3 : 4;
 }
 
+__device__ __forceinline__ int rd_T(const int32_t *len, int64_t i, int max_len) {
+    int t = len[i];
+    t = t < 0 ? 0 : t;
+    return t < max_len ? t : max_len;
+}
+
 // ------------------------------------------------------------------------------------------------
 // activations. v_exp_f32 evaluates 2^x to ~1 ulp; the argument x*log2(e) is formed with an FMA-compensated
 // product so the result stays within ~2 ulp of expf over the whole range (SURVEY §7 "transcendental accuracy").
@@ -92,6 +98,7 @@ struct DevModel {
     float *b_out;     // [2]
     uint32_t *wpack16;  // f16x3 16x16x32 A operand (hi/lo halves), see rd_prep_kernel
     uint32_t *wpack16b; // f16x3 32x32x16 A operand
+    float *rev_tab;     // padded (ribodetector_cpu) semantics: [max_len][5][2] reverse-direction logit terms, see rd_revtab_kernel
 };
 
 }  // namespace
@@ -99,6 +106,8 @@ struct DevModel {
 struct rd_model {
     int device;
     int variant;
+    int semantics;      // RD_SEM_PACKED / RD_SEM_PADDED
+    int rev_tab_len;    // max_len the padded-semantics table was built for (0 = none)
     DevModel d;
     // profiling of the recurrence kernel (bench.py roofline)
     int prof_enabled;
@@ -186,6 +195,48 @@ __global__ void rd_prep_kernel(DevModel d) {
     }
 }
 
+// Padded (ribodetector_cpu) semantics, reverse half. The output row pos of a read is preceded, in the reverse direction, by
+// max_len-1-pos all-zero rows (padding / trailing non-ACGT bases): the reverse state there does not depend on the read.
+// tab[k][code][cls] = W_out[cls, 128:] . h_rev  where h_rev = cell(state after k zero-input steps from zero, input `code`).
+// One workgroup, max_len sequential cell steps of a 128 x 512 mat-vec: microseconds, built once per max_len.
+__global__ __launch_bounds__(512) void rd_revtab_kernel(DevModel d, int max_len) {
+    __shared__ float h[HID], c[HID], g[G4], hc[5][HID], hn[HID], cn[HID];
+    const float *raw = d.raw;
+    const int tid = threadIdx.x;
+    if (tid < HID) { h[tid] = 0.0f; c[tid] = 0.0f; }
+    __syncthreads();
+    for (int k = 0; k < max_len; ++k) {
+        float a = raw[OFF_BIHR + tid] + raw[OFF_BHHR + tid];
+        for (int u = 0; u < HID; ++u) a = __builtin_fmaf(raw[OFF_WHHR + tid * HID + u], h[u], a);
+        g[tid] = a;
+        __syncthreads();
+        for (int cell = tid; cell < 5 * HID; cell += 512) {
+            const int code = cell / HID, u = cell % HID;
+            float gi = g[u], gf = g[HID + u], gg = g[2 * HID + u], go = g[3 * HID + u];
+            if (code < 4) {
+                gi += raw[OFF_WIHR + u * 4 + code];
+                gf += raw[OFF_WIHR + (HID + u) * 4 + code];
+                gg += raw[OFF_WIHR + (2 * HID + u) * 4 + code];
+                go += raw[OFF_WIHR + (3 * HID + u) * 4 + code];
+            }
+            const float ig = 1.0f / (1.0f + expf(-gi)), fg = 1.0f / (1.0f + expf(-gf)), og = 1.0f / (1.0f + expf(-go));
+            const float c2 = fg * c[u] + ig * tanhf(gg);
+            const float h2 = og * tanhf(c2);
+            hc[code][u] = h2;
+            if (code == 4) { hn[u] = h2; cn[u] = c2; }   // the state advances over a zero row
+        }
+        __syncthreads();
+        if (tid < 10) {
+            const int code = tid >> 1, cls = tid & 1;
+            float s = 0.0f;
+            for (int u = 0; u < HID; ++u) s += raw[OFF_WOUT + cls * 256 + HID + u] * hc[code][u];
+            d.rev_tab[(k * 5 + code) * 2 + cls] = s;
+        }
+        if (tid < HID) { h[tid] = hn[tid]; c[tid] = cn[tid]; }
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // length bucketing: order[] = read indices sorted by T = min(len,max_len) descending (pack_sequence's sort,
 // detect.py:685). Ties are ordered by input index (stable) so that the order is deterministic.
@@ -194,11 +245,6 @@ __global__ void rd_prep_kernel(DevModel d) {
 constexpr int SORT_BLOCK = 256;
 constexpr int SORT_ITEMS = 2048;   // reads per block
 
-__device__ __forceinline__ int rd_T(const int32_t *len, int64_t i, int max_len) {
-    int t = len[i];
-    t = t < 0 ? 0 : t;
-    return t < max_len ? t : max_len;
-}
 
 // hist[(T)*(nblk) + blk] = number of reads of truncated length T in block blk
 __global__ void rd_len_hist_kernel(const int32_t *__restrict__ len, int64_t n, int max_len, int nblk,
@@ -317,24 +363,53 @@ struct ReadBatch {
     const uint8_t *arena;
     const int64_t *off;
     const int32_t *len;
+    const int32_t *steps;   // timesteps the forward recurrence runs for each read (rd_steps_kernel)
     const int32_t *order;   // sorted position -> read index (nullptr = identity)
     int64_t n;
     int max_len;
+    int sem;                // RD_SEM_PACKED: gather at step len-1 (reference GPU path); RD_SEM_PADDED: ribodetector_cpu
+    const float *rev_tab;   // padded semantics only
 };
+
+// Per-read number of forward steps.
+//   packed (model.py:32-37 + detect.py:682): T = min(len, max_len).
+//   padded (model_cpu.py:29-37,57-62): the input is zero-padded to max_len rows and the output row is the LAST NON-ZERO row,
+//     pos = L-1-argmax(flip(rowsum)); if every row is zero, argmax = 0 and pos = L-1. T = pos + 1.
+__global__ void rd_steps_kernel(const uint8_t *__restrict__ arena, const int64_t *__restrict__ off, const int32_t *__restrict__ len,
+                                int64_t n, int max_len, int sem, int32_t *__restrict__ steps) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int lr = rd_T(len, i, max_len);
+        int T = lr;
+        if (sem == RD_SEM_PADDED) {
+            const uint8_t *p = arena + off[i];
+            int pos = lr - 1;
+            while (pos >= 0 && rd_code(p[pos]) == 4) --pos;
+            T = pos >= 0 ? pos + 1 : max_len;
+        }
+        steps[i] = T;
+    }
+}
 
 // FC + argmax epilogue for one workgroup's reads. hl(row,u) = captured last forward hidden state.
 // logits = b_out + W_out[:, :128] . h_fwd + rev_lut[last base]   (model.py:36; reverse half folded, see header)
 template <typename HL>
-__device__ __forceinline__ void rd_fc_epilogue(int nrows, HL hl, const int *Trow, const long long *offrow, const int *origrow,
-                                               const float *s_wout, const DevModel &d, const ReadBatch &rb, float *logits,
-                                               uint8_t *labels) {
+__device__ __forceinline__ void rd_fc_epilogue(int nrows, HL hl, const int *Trow, const int *Lrow, const long long *offrow,
+                                               const int *origrow, const float *s_wout, const DevModel &d, const ReadBatch &rb,
+                                               float *logits, uint8_t *labels) {
     const int tid = threadIdx.x;
     if (tid < 2 * nrows) {
         const int row = tid >> 1, k = tid & 1;
         float s = d.b_out[k];
         for (int u = 0; u < HID; ++u) s = __builtin_fmaf(s_wout[k * HID + u], hl(row, u), s);
         const int T = Trow[row];
-        if (T > 0) s += d.rev_lut[rd_code(rb.arena[offrow[row] + T - 1]) * 2 + k];
+        if (rb.sem == RD_SEM_PADDED && T > 0) {   // (T == 0 only for the filler rows of the last workgroup)
+            // reverse half of output row pos = T-1: the reverse LSTM has walked max_len-1-pos zero rows, then x[pos]
+            const int pos = T - 1;
+            const int code = pos < Lrow[row] ? rd_code(rb.arena[offrow[row] + pos]) : 4;
+            s += rb.rev_tab[((rb.max_len - 1 - pos) * 5 + code) * 2 + k];
+        } else if (rb.sem != RD_SEM_PADDED && T > 0) {
+            s += d.rev_lut[rd_code(rb.arena[offrow[row] + T - 1]) * 2 + k];
+        }
         const float other = __shfl_xor(s, 1);
         const int orig = origrow[row];
         if (orig >= 0) {
@@ -366,6 +441,7 @@ struct __attribute__((aligned(16))) LstmSmem {
     float dummy[256];              // sink of predicated-off Hl stores (keeps the phase body branch-free)
     uint8_t codes[2][TC][BT];      // double-buffered code chunks, [t][row]
     int T[BT];
+    int Lr[BT];       // readable bytes of the read = min(len, max_len)
     long long off[BT];
     int orig[BT];
     int tmax;
@@ -377,7 +453,7 @@ __device__ __forceinline__ void rd_stage_codes(LstmSmem &S, const ReadBatch &rb,
     for (int idx = threadIdx.x; idx < BT * TC; idx += 256) {
         const int row = idx / TC, tt = idx % TC, t = t0 + tt;
         int code = 4;
-        if (t < S.T[row]) code = rd_code(rb.arena[S.off[row] + t]);
+        if (t < S.Lr[row]) code = rd_code(rb.arena[S.off[row] + t]);
         dst[tt][row] = (uint8_t)code;
     }
 }
@@ -410,14 +486,15 @@ __global__ __launch_bounds__(256, 1) void rd_lstm_mfma_f32_kernel(DevModel d, Re
     // ---- per-read metadata, zero state ---------------------------------------------------------
     if (tid < BT) {
         const int64_t g = (int64_t)blockIdx.x * BT + tid;
-        int T = 0, orig = -1;
+        int T = 0, lr = 0, orig = -1;
         long long off = 0;
         if (g < rb.n) {
             orig = rb.order ? rb.order[g] : (int)g;
-            T = rd_T(rb.len, orig, rb.max_len);
+            T = rd_T(rb.steps, orig, rb.max_len);
+            lr = rd_T(rb.len, orig, rb.max_len);
             off = rb.off[orig];
         }
-        S.T[tid] = T; S.off[tid] = off; S.orig[tid] = orig;
+        S.T[tid] = T; S.Lr[tid] = lr; S.off[tid] = off; S.orig[tid] = orig;
     }
     if (tid == 0) S.tmax = 0;
     for (int i = tid; i < NT * 16 * HSTR; i += 256) { (&S.Hs[0][0][0])[i] = 0.0f; (&S.Hl[0][0][0])[i] = 0.0f; }
@@ -576,7 +653,7 @@ __global__ __launch_bounds__(256, 1) void rd_lstm_mfma_f32_kernel(DevModel d, Re
     }
     // ---- epilogue: FC + reverse table + argmax ----------------------------------------------------
     rd_fc_epilogue(
-        BT, [&](int row, int u) { return S.Hl[row >> 4][row & 15][u]; }, S.T, S.off, S.orig, &S.wout[0][0], d, rb, logits, labels);
+        BT, [&](int row, int u) { return S.Hl[row >> 4][row & 15][u]; }, S.T, S.Lr, S.off, S.orig, &S.wout[0][0], d, rb, logits, labels);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -587,15 +664,15 @@ constexpr int SB = 8;
 __global__ __launch_bounds__(512) void rd_lstm_simple_kernel(DevModel d, ReadBatch rb, float *__restrict__ logits,
                                                              uint8_t *__restrict__ labels) {
     __shared__ float h[SB][HID], c[SB][HID], hl[SB][HID], g[SB][G4], s_wout[2 * HID];
-    __shared__ int T[SB], orig[SB], tmax_s;
+    __shared__ int T[SB], Lr[SB], orig[SB], tmax_s;
     __shared__ long long off[SB];
     const int tid = threadIdx.x;
     if (tid < SB) {
         const int64_t gi = (int64_t)blockIdx.x * SB + tid;
-        int Ti = 0, o = -1;
+        int Ti = 0, li = 0, o = -1;
         long long of = 0;
-        if (gi < rb.n) { o = rb.order ? rb.order[gi] : (int)gi; Ti = rd_T(rb.len, o, rb.max_len); of = rb.off[o]; }
-        T[tid] = Ti; orig[tid] = o; off[tid] = of;
+        if (gi < rb.n) { o = rb.order ? rb.order[gi] : (int)gi; Ti = rd_T(rb.steps, o, rb.max_len); li = rd_T(rb.len, o, rb.max_len); of = rb.off[o]; }
+        T[tid] = Ti; Lr[tid] = li; orig[tid] = o; off[tid] = of;
     }
     if (tid == 0) tmax_s = 0;
     for (int i = tid; i < SB * HID; i += 512) { (&h[0][0])[i] = 0; (&c[0][0])[i] = 0; (&hl[0][0])[i] = 0; }
@@ -609,7 +686,7 @@ __global__ __launch_bounds__(512) void rd_lstm_simple_kernel(DevModel d, ReadBat
 #pragma unroll
         for (int r = 0; r < SB; ++r) {
             int code = 4;
-            if (t < T[r]) code = rd_code(rb.arena[off[r] + t]);
+            if (t < Lr[r]) code = rd_code(rb.arena[off[r] + t]);
             a[r] = d.in_lut[code * G4 + tid];
         }
         for (int k = 0; k < HID; ++k) {
@@ -632,7 +709,7 @@ __global__ __launch_bounds__(512) void rd_lstm_simple_kernel(DevModel d, ReadBat
         __syncthreads();
     }
     rd_fc_epilogue(
-        SB, [&](int row, int u) { return hl[row][u]; }, T, off, orig, s_wout, d, rb, logits, labels);
+        SB, [&](int row, int u) { return hl[row][u]; }, T, Lr, off, orig, s_wout, d, rb, logits, labels);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -674,6 +751,7 @@ struct __attribute__((aligned(16))) Lstm16Smem {
     float wout[2][HID];
     uint8_t codes[2][TC16][BT];
     int T[BT];
+    int Lr[BT];       // readable bytes of the read = min(len, max_len)
     long long off[BT];
     int orig[BT];
     int tmax;
@@ -685,7 +763,7 @@ __device__ __forceinline__ void rd_stage_codes16(Lstm16Smem &S, const ReadBatch 
     for (int idx = threadIdx.x; idx < BT * TC16; idx += 256) {
         const int row = idx / TC16, tt = idx % TC16, t = t0 + tt;
         int code = 4;
-        if (t < S.T[row]) code = rd_code(rb.arena[S.off[row] + t]);
+        if (t < S.Lr[row]) code = rd_code(rb.arena[S.off[row] + t]);
         dst[tt][row] = (uint8_t)code;
     }
 }
@@ -703,14 +781,15 @@ __global__ __launch_bounds__(256, 1) void rd_lstm_mfma_f16x3_kernel(DevModel d, 
 
     if (tid < BT) {
         const int64_t g = (int64_t)blockIdx.x * BT + tid;
-        int T = 0, orig = -1;
+        int T = 0, lr = 0, orig = -1;
         long long off = 0;
         if (g < rb.n) {
             orig = rb.order ? rb.order[g] : (int)g;
-            T = rd_T(rb.len, orig, rb.max_len);
+            T = rd_T(rb.steps, orig, rb.max_len);
+            lr = rd_T(rb.len, orig, rb.max_len);
             off = rb.off[orig];
         }
-        S.T[tid] = T; S.off[tid] = off; S.orig[tid] = orig;
+        S.T[tid] = T; S.Lr[tid] = lr; S.off[tid] = off; S.orig[tid] = orig;
     }
     if (tid == 0) S.tmax = 0;
     for (int i = tid; i < 3 * NT * 16 * H16STR / 2; i += 256) (reinterpret_cast<uint32_t *>(&S.H1s[0][0][0]))[i] = 0u;
@@ -864,7 +943,7 @@ __global__ __launch_bounds__(256, 1) void rd_lstm_mfma_f16x3_kernel(DevModel d, 
     }
 
     rd_fc_epilogue(
-        BT, [&](int row, int u) { return S.Hl[row >> 4][row & 15][u]; }, S.T, S.off, S.orig, &S.wout[0][0], d, rb, logits, labels);
+        BT, [&](int row, int u) { return S.Hl[row >> 4][row & 15][u]; }, S.T, S.Lr, S.off, S.orig, &S.wout[0][0], d, rb, logits, labels);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -897,6 +976,7 @@ struct __attribute__((aligned(16))) Lstm16bSmem {
     float wout[2][HID];
     uint8_t codes[2][TC16][64];
     int T[64];
+    int Lr[64];       // readable bytes of the read = min(len, max_len)
     long long off[64];
     int orig[64];
     int tmax;
@@ -908,7 +988,7 @@ __device__ __forceinline__ void rd_stage_codes16b(Lstm16bSmem &S, const ReadBatc
     for (int idx = threadIdx.x; idx < 64 * TC16; idx += 256) {
         const int row = idx / TC16, tt = idx % TC16, t = t0 + tt;
         int code = 4;
-        if (t < S.T[row]) code = rd_code(rb.arena[S.off[row] + t]);
+        if (t < S.Lr[row]) code = rd_code(rb.arena[S.off[row] + t]);
         dst[tt][row] = (uint8_t)code;
     }
 }
@@ -1070,14 +1150,15 @@ __global__ __launch_bounds__(256, 1) void rd_lstm_mfma_f16x3_t32_kernel(DevModel
 
     if (tid < 64) {
         const int64_t g = (int64_t)blockIdx.x * 64 + tid;
-        int T = 0, orig = -1;
+        int T = 0, lr = 0, orig = -1;
         long long off = 0;
         if (g < rb.n) {
             orig = rb.order ? rb.order[g] : (int)g;
-            T = rd_T(rb.len, orig, rb.max_len);
+            T = rd_T(rb.steps, orig, rb.max_len);
+            lr = rd_T(rb.len, orig, rb.max_len);
             off = rb.off[orig];
         }
-        S.T[tid] = T; S.off[tid] = off; S.orig[tid] = orig;
+        S.T[tid] = T; S.Lr[tid] = lr; S.off[tid] = off; S.orig[tid] = orig;
     }
     if (tid == 0) S.tmax = 0;
     for (int i = tid; i < 3 * 2 * 32 * H16STR / 2; i += 256) (reinterpret_cast<uint32_t *>(&S.H1s[0][0][0]))[i] = 0u;
@@ -1146,7 +1227,7 @@ __global__ __launch_bounds__(256, 1) void rd_lstm_mfma_f16x3_t32_kernel(DevModel
     }
 
     rd_fc_epilogue(
-        64, [&](int row, int u) { return S.Hl[row][u]; }, S.T, S.off, S.orig, &S.wout[0][0], d, rb, logits, labels);
+        64, [&](int row, int u) { return S.Hl[row][u]; }, S.T, S.Lr, S.off, S.orig, &S.wout[0][0], d, rb, logits, labels);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1252,7 +1333,7 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 struct SortPlan {
     int nblk;
-    size_t hist_bytes, order_bytes, lenstart_bytes, total;
+    size_t hist_bytes, order_bytes, lenstart_bytes, steps_bytes, total;
 };
 inline SortPlan sort_plan(int64_t n, int max_len) {
     SortPlan p;
@@ -1261,7 +1342,8 @@ inline SortPlan sort_plan(int64_t n, int max_len) {
     p.hist_bytes = align_up((size_t)(max_len + 1) * p.nblk * sizeof(uint32_t), 256);
     p.order_bytes = align_up((size_t)(n > 0 ? n : 1) * sizeof(int32_t), 256);
     p.lenstart_bytes = align_up((size_t)(max_len + 1) * sizeof(int64_t) * 2, 256);   // len_start + cum scratch
-    p.total = p.hist_bytes + p.order_bytes + p.lenstart_bytes;
+    p.steps_bytes = align_up((size_t)(n > 0 ? n : 1) * sizeof(int32_t), 256);
+    p.total = p.hist_bytes + p.order_bytes + p.lenstart_bytes + p.steps_bytes;
     return p;
 }
 
@@ -1321,6 +1403,7 @@ int rd_model_create(const rd_weights *w, int device, rd_model **out) {
     A((void **)&m->d.wpack16b, sizeof(uint16_t) * 4 * 2 * 4 * 8 * 64 * 8);
     A((void **)&m->d.in_lut, sizeof(float) * 5 * G4);
     A((void **)&m->d.rev_lut, sizeof(float) * 10);
+    A((void **)&m->d.rev_tab, sizeof(float) * (size_t)MAX_LEN_LIMIT * 10);
     A((void **)&m->d.w_out, sizeof(float) * 512);
     A((void **)&m->d.b_out, sizeof(float) * 2);
     if (e == hipSuccess) e = hipMemcpy(m->d.raw, host, sizeof(float) * RAW_FLOATS, hipMemcpyHostToDevice);
@@ -1343,7 +1426,7 @@ void rd_model_destroy(rd_model *m) {
     if (!m) return;
     hipSetDevice(m->device);
     hipFree(m->d.raw); hipFree(m->d.wpack32); hipFree(m->d.wt_hh); hipFree(m->d.in_lut);
-    hipFree(m->d.rev_lut); hipFree(m->d.w_out); hipFree(m->d.b_out);
+    hipFree(m->d.rev_lut); hipFree(m->d.rev_tab); hipFree(m->d.w_out); hipFree(m->d.b_out);
     if (m->d.wpack16) hipFree(m->d.wpack16);
     if (m->d.wpack16b) hipFree(m->d.wpack16b);
     for (int i = 0; i < 2 * 512; ++i)
@@ -1357,6 +1440,13 @@ int rd_set_variant(rd_model *m, int variant) {
     if (variant != RD_VARIANT_MFMA_F32 && variant != RD_VARIANT_SIMPLE && variant != RD_VARIANT_MFMA_F16X3 && variant != RD_VARIANT_MFMA_F16X3_T32 && !(variant >= 10 && variant <= 42))
         RD_FAIL(RD_E_UNSUPPORTED, "rd_set_variant: variant %d not available in this build", variant);
     m->variant = variant;
+    return RD_OK;
+}
+
+int rd_set_semantics(rd_model *m, int semantics) {
+    if (!m) RD_FAIL(RD_E_INVALID, "rd_set_semantics: null model");
+    if (semantics != RD_SEM_PACKED && semantics != RD_SEM_PADDED) RD_FAIL(RD_E_INVALID, "rd_set_semantics: unknown semantics %d", semantics);
+    m->semantics = semantics;
     return RD_OK;
 }
 
@@ -1404,11 +1494,23 @@ int rd_classify(const rd_model *cm, const uint8_t *arena, const int64_t *seq_off
     if (n == 0) return RD_OK;
     if (!arena || !seq_off || !seq_len || !workspace) RD_FAIL(RD_E_INVALID, "rd_classify: null input pointer");
     hipStream_t st = (hipStream_t)stream;
+    const SortPlan sp = sort_plan(n, max_len);
+    if (workspace_bytes < sp.total) RD_FAIL(RD_E_WORKSPACE, "workspace too small: %zu < %zu", workspace_bytes, sp.total);
+    int32_t *steps = (int32_t *)((char *)workspace + sp.total - sp.steps_bytes);
+    {
+        int64_t nb = (n + 255) / 256;
+        if (nb > 4096) nb = 4096;
+        hipLaunchKernelGGL(rd_steps_kernel, dim3((unsigned)nb), dim3(256), 0, st, arena, seq_off, seq_len, n, max_len, m->semantics, steps);
+    }
+    if (m->semantics == RD_SEM_PADDED && m->rev_tab_len != max_len) {
+        hipLaunchKernelGGL(rd_revtab_kernel, dim3(1), dim3(512), 0, st, m->d, max_len);
+        m->rev_tab_len = max_len;
+    }
     int32_t *order = nullptr;
     int64_t *len_start = nullptr;
-    int rc = run_sort(seq_len, n, max_len, workspace, workspace_bytes, order, nullptr, nullptr, nullptr, nullptr, len_start, st);
+    int rc = run_sort(steps, n, max_len, workspace, workspace_bytes, order, nullptr, nullptr, nullptr, nullptr, len_start, st);
     if (rc) return rc;
-    ReadBatch rb{arena, seq_off, seq_len, order, n, max_len};
+    ReadBatch rb{arena, seq_off, seq_len, steps, order, n, max_len, m->semantics, m->d.rev_tab};
     hipEvent_t *ev = nullptr;
     if (m->prof_enabled) {
         if (m->prof_count == 512) { rc = rd_profile_drain(m); if (rc) return rc; }

@@ -46,6 +46,7 @@ class SeqModel:
         self._handle = None
         self.device = None
         self._variant = "auto"
+        self._semantics = "packed"
         self._ws = None
         self.training = True
 
@@ -90,6 +91,7 @@ class SeqModel:
         N.check(N.lib().rd_model_create(C.byref(w), idx, C.byref(h)), "rd_model_create")
         self._handle = h
         self.set_variant(self._variant)
+        self.set_semantics(self._semantics)
 
     def to(self, device, non_blocking=False):
         device = torch.device(device)
@@ -113,6 +115,15 @@ class SeqModel:
         self._variant = name
         if self._handle is not None:
             N.check(N.lib().rd_set_variant(self._handle, N.VARIANTS[name]), "rd_set_variant")
+        return self
+
+    def set_semantics(self, name):
+        """'packed' (default): the reference GPU product, forward1 over min(len, max_len) real timesteps.
+        'padded': the reference CPU product `ribodetector_cpu` (model_cpu.forward_last): zero-padded input, gather at the
+        last non-zero row. The two differ only for reads shorter than max_len or ending in non-ACGT bases."""
+        self._semantics = name
+        if self._handle is not None:
+            N.check(N.lib().rd_set_semantics(self._handle, N.SEMANTICS[name]), "rd_set_semantics")
         return self
 
     def __del__(self):

@@ -199,3 +199,31 @@ def test_full_size_batch_properties(gpu_model, oracle):
     # the reference batch (32,768) as one call gives the same rows
     lg32, _ = gpu_model.classify_bytes(arena, off[:32768].contiguous(), lens[:32768].contiguous(), 100)
     assert torch.equal(lg32, lg[:32768])
+
+
+@pytest.mark.parametrize("variant", ["auto", "simple", "mfma_f32"])
+def test_padded_cpu_product_semantics(gpu_model, golden, oracle, variant):
+    """RD_SEM_PADDED reproduces the reference's CPU product (model_cpu.forward_last: zero-padded input, gather at the last
+    non-zero row) - golden `cpu_logits` come from the reference's model_cpu.SeqModel itself."""
+    gpu_model.set_variant(variant)
+    gpu_model.set_semantics("padded")
+    try:
+        d = golden.npz("se100")
+        lg, lab = _run(gpu_model, d["arena"], d["offsets"], d["lens"], 100)
+        _check(lg, lab, d["cpu_logits"], "padded se100")
+        d = golden.npz("varlen")
+        lg, lab = _run(gpu_model, d["arena"], d["offsets"], d["lens"], 170)
+        _check(lg, lab, d["cpu_logits_l170"], "padded varlen170")
+        # short reads, trailing / all N, lowercase, empty: against the oracle's restatement of the CPU product
+        e = golden.npz("edge")
+        for L in (100, 64, 301):
+            ref = oracle.forward_padded(e["arena"], e["offsets"], e["lens"], L)
+            lg, lab = _run(gpu_model, e["arena"], e["offsets"], e["lens"], L)
+            _check(lg, lab, ref, "padded edge L=%d" % L)
+        # and it really differs from the packed semantics on short reads (SURVEY §3.4), so the switch is live
+        gpu_model.set_semantics("packed")
+        lgp, _ = _run(gpu_model, e["arena"], e["offsets"], e["lens"], 100)
+        assert np.abs(lgp - ref[: len(lgp)] if False else lgp - oracle.forward_padded(e["arena"], e["offsets"], e["lens"], 100)).max() > 1e-2
+    finally:
+        gpu_model.set_semantics("packed")
+        gpu_model.set_variant("auto")
