@@ -43,6 +43,10 @@ void rd_reader_close(rd_reader *r);
 int rd_reader_next(rd_reader *r, int64_t max_records, uint8_t *buf, int64_t buf_cap, int64_t *rec_start, int64_t *seq_off,
                    int32_t *seq_len, int64_t *n, int64_t *nbytes);
 
+/* Worker threads for gzip output (independent level-5 members compressed in parallel); 0 = auto (usable cores, <= 32).
+ * Mirrors the reference's -t/--threads flag (detect.py:787). */
+int rd_host_set_threads(int threads);
+
 int rd_writer_open(const char *path, rd_writer **out);
 /* append, in input order, every record i of the chunk with labels[i] == want */
 int rd_writer_write_selected(rd_writer *w, const uint8_t *buf, const int64_t *rec_start, int64_t n, const int8_t *labels,

@@ -7,7 +7,9 @@
 #include <string.h>
 #include <zlib.h>
 
+#include <algorithm>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/ribodetector_amd_host.h"
@@ -84,10 +86,76 @@ struct rd_reader {
     }
 };
 
+// gzip output is written as a sequence of independent gzip members (RFC 1952 allows concatenation; zcat, Python's gzip and
+// the reference's own readers accept it), each compressed at level 5 by its own thread: the reference's single-threaded
+// gzip.open(..., compresslevel=5) is the slowest stage of its pipeline ("2 times slower to write gz files").
 struct rd_writer {
-    gzFile gz;
     FILE *fp;
+    bool gz;
+    int threads;
+    std::vector<uint8_t> pending;   // gz only: selected record bytes not yet compressed
 };
+
+int g_threads = 0;                  // 0 = auto
+
+int usable_threads() {
+    if (g_threads > 0) return g_threads;
+    int n = (int)std::thread::hardware_concurrency();
+    if (n < 1) n = 1;
+    FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r");   // containers: quota / period
+    if (f) {
+        char q[64];
+        long long period = 0;
+        if (fscanf(f, "%63s %lld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+            long long quota = atoll(q);
+            int c = (int)std::max<long long>(1, quota / period);
+            n = std::min(n, c);
+        }
+        fclose(f);
+    }
+    return std::min(n, 32);
+}
+
+constexpr size_t GZ_BLOCK = 4u << 20;   // uncompressed bytes per gzip member
+
+bool gz_member(const uint8_t *src, size_t len, std::vector<uint8_t> &out) {
+    z_stream zs;
+    memset(&zs, 0, sizeof(zs));
+    if (deflateInit2(&zs, 5, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+    out.resize(deflateBound(&zs, (uLong)len) + 64);
+    zs.next_in = const_cast<Bytef *>(src);
+    zs.avail_in = (uInt)len;
+    zs.next_out = out.data();
+    zs.avail_out = (uInt)out.size();
+    const int rc = deflate(&zs, Z_FINISH);
+    const size_t produced = out.size() - zs.avail_out;
+    deflateEnd(&zs);
+    if (rc != Z_STREAM_END) return false;
+    out.resize(produced);
+    return true;
+}
+
+// compress w->pending[0, upto) as members of GZ_BLOCK bytes, `threads` at a time, and write them in order
+int gz_flush(rd_writer *w, size_t upto) {
+    size_t nblk = (upto + GZ_BLOCK - 1) / GZ_BLOCK;
+    for (size_t b0 = 0; b0 < nblk; b0 += (size_t)w->threads) {
+        const size_t nb = std::min<size_t>((size_t)w->threads, nblk - b0);
+        std::vector<std::vector<uint8_t>> outs(nb);
+        std::vector<char> ok(nb, 0);
+        std::vector<std::thread> th;
+        for (size_t k = 0; k < nb; ++k) {
+            const size_t off = (b0 + k) * GZ_BLOCK, len = std::min(GZ_BLOCK, upto - off);
+            th.emplace_back([w, off, len, k, &outs, &ok]() { ok[k] = gz_member(w->pending.data() + off, len, outs[k]) ? 1 : 0; });
+        }
+        for (auto &t : th) t.join();
+        for (size_t k = 0; k < nb; ++k) {
+            if (!ok[k]) return -1;
+            if (fwrite(outs[k].data(), 1, outs[k].size(), w->fp) != outs[k].size()) return -1;
+        }
+    }
+    w->pending.erase(w->pending.begin(), w->pending.begin() + (ptrdiff_t)upto);
+    return 0;
+}
 
 extern "C" {
 
@@ -222,23 +290,23 @@ int rd_reader_next(rd_reader *r, int64_t max_records, uint8_t *buf, int64_t buf_
     return at_eof ? 1 : 0;
 }
 
+int rd_host_set_threads(int threads) {
+    g_threads = threads > 0 ? threads : 0;
+    return 0;
+}
+
 int rd_writer_open(const char *path, rd_writer **out) {
     if (!path || !out) RDH_FAIL("rd_writer_open: null argument");
     rd_writer *w = new rd_writer();
-    w->gz = nullptr;
-    w->fp = nullptr;
     std::string p(path);
-    if (ends_with(p, "gz")) {
-        w->gz = gzopen(path, "wb5");   // compresslevel=5, detect.py:739
-        if (w->gz) gzbuffer(w->gz, 1 << 20);
-    } else {
-        w->fp = fopen(path, "wb");
-        if (w->fp) setvbuf(w->fp, nullptr, _IOFBF, 4 << 20);
-    }
-    if (!w->gz && !w->fp) {
+    w->gz = ends_with(p, "gz");            // reference detect.py:738: read_file.endswith('gz')
+    w->threads = usable_threads();
+    w->fp = fopen(path, "wb");
+    if (!w->fp) {
         delete w;
         RDH_FAIL("cannot open %s for writing", path);
     }
+    setvbuf(w->fp, nullptr, _IOFBF, 4 << 20);
     *out = w;
     return 0;
 }
@@ -250,20 +318,19 @@ int rd_writer_write_selected(rd_writer *w, const uint8_t *buf, const int64_t *re
     while (i < n) {
         if (labels[i] != want) { ++i; continue; }
         int64_t j = i + 1;
-        while (j < n && labels[j] == want) ++j;   // one write per run of consecutive selected records
+        while (j < n && labels[j] == want) ++j;   // one copy/write per run of consecutive selected records
         const uint8_t *p = buf + rec_start[i];
-        int64_t len = rec_start[j] - rec_start[i];
-        while (len > 0) {
-            unsigned chunk = (unsigned)std::min<int64_t>(len, 1 << 30);
-            if (w->gz) {
-                if (gzwrite(w->gz, p, chunk) != (int)chunk) RDH_FAIL("gzwrite failed");
-            } else if (fwrite(p, 1, chunk, w->fp) != chunk) {
-                RDH_FAIL("fwrite failed");
-            }
-            p += chunk;
-            len -= chunk;
+        const size_t len = (size_t)(rec_start[j] - rec_start[i]);
+        if (w->gz) {
+            w->pending.insert(w->pending.end(), p, p + len);
+        } else if (fwrite(p, 1, len, w->fp) != len) {
+            RDH_FAIL("fwrite failed");
         }
         i = j;
+    }
+    if (w->gz) {
+        const size_t full = (w->pending.size() / GZ_BLOCK) * GZ_BLOCK;
+        if (full >= GZ_BLOCK * (size_t)w->threads && gz_flush(w, full) != 0) RDH_FAIL("gzip compression/write failed");
     }
     return 0;
 }
@@ -271,8 +338,14 @@ int rd_writer_write_selected(rd_writer *w, const uint8_t *buf, const int64_t *re
 int rd_writer_close(rd_writer *w) {
     if (!w) return 0;
     int rc = 0;
-    if (w->gz) rc = gzclose(w->gz) == Z_OK ? 0 : -1;
-    if (w->fp) rc = fclose(w->fp) == 0 ? 0 : -1;
+    if (w->gz) {
+        if (!w->pending.empty()) rc = gz_flush(w, w->pending.size());
+        else if (ftell(w->fp) == 0) {   // an empty .gz must still be a valid gzip file (one empty member)
+            std::vector<uint8_t> m;
+            rc = gz_member(nullptr, 0, m) && fwrite(m.data(), 1, m.size(), w->fp) == m.size() ? 0 : -1;
+        }
+    }
+    if (fclose(w->fp) != 0) rc = -1;
     delete w;
     if (rc) RDH_FAIL("close failed");
     return 0;

@@ -168,6 +168,8 @@ class Predictor:
                 self.logger.info('Writing unclassified sequences into file: {}{}{}'.format(
                     colors.OKYELLOW, ", ".join(unclf), colors.ENDC))
         num_read = num_nonrrna = num_rrna = num_unknown = 0
+        from . import _native
+        _native.host_lib().rd_host_set_threads(int(self.args.threads))   # -t/--threads: gzip output workers
         self._copy_stream = torch.cuda.Stream(self.device)
         for chunks in self._prefetching(self._chunk_stream(chunk_reads)):
             labels = self.classify_chunk(chunks)

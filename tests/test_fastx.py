@@ -152,3 +152,30 @@ def test_native_reader_small_buffers_and_growth(tmp_path):
     assert got == recs
     with pytest.raises(ValueError):
         fx.NativeReader(str(tmp_path / "reads.txt"))
+
+
+def test_gzip_writer_members(tmp_path):
+    """gz output = concatenated independent gzip members (parallel level-5 compression): must round-trip, also when empty
+    and when the selection spans several 4 MiB members and several write calls."""
+    arena, off, lens = synth.reads_numpy(30000, 150, seed=8)
+    p = str(tmp_path / "big.fq")
+    synth.write_fastq(p, arena, off, mate=1)
+    chunks = list(fx.get_seq_chunks(p, chunk_size=7000))
+    out = str(tmp_path / "sel.fastq.gz")
+    w = fx.open_for_write(out)
+    want = b""
+    rng = np.random.default_rng(0)
+    for c in chunks:
+        lab = (rng.random(len(c.seq_len)) < 0.8).astype(np.int8)
+        w.write_selected(c, lab, 1)
+        want += fx.select_records(c, lab == 1)
+    w.close()
+    assert len(want) > (5 << 20)              # spans more than one 4 MiB member
+    with gzip.open(out, "rb") as fh:
+        assert fh.read() == want
+    empty = str(tmp_path / "empty.fq.gz")
+    w = fx.open_for_write(empty)
+    w.write_selected(chunks[0], np.zeros(len(chunks[0].seq_len), np.int8), 1)
+    w.close()
+    with gzip.open(empty, "rb") as fh:
+        assert fh.read() == b""
