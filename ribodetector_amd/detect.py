@@ -83,7 +83,9 @@ class Predictor:
         self.logger.info('Model using {} for read length {}{}{}{} loaded'.format(
             self.device, colors.BOLD, colors.OKCYAN, self.len, colors.ENDC))
         self.model = model.to(self.device)
-        self.model.set_semantics(getattr(self.args, 'semantics', 'gpu'))
+        kcfg = dict(self.config.config.get('kernel', {}))
+        self.model.set_variant(kcfg.get('variant', 'auto'))
+        self.model.set_semantics(getattr(self.args, 'semantics', None) or kcfg.get('semantics', 'gpu'))
         self.model.eval()
 
     # ---- classification of one chunk ------------------------------------------------------------------
@@ -268,7 +270,7 @@ none: give label based on the mean probability of read pair.
                           'Not needed when free RAM >=5 * your_file_size (uncompressed, sum of paired ends)',
                           'When chunk_size=256, memory=16 it will load 256 * 16 * 1024 reads each chunk (use ~20 GB for 100bp paired end)'))
     args.add_argument('--log', default=None, type=str, help='Log file name')
-    args.add_argument('--semantics', default='gpu', choices=['gpu', 'cpu'],
+    args.add_argument('--semantics', default=None, choices=['gpu', 'cpu'],
                       help='(extension) which reference product to reproduce for reads shorter than --len or ending in N:\n'
                            'gpu = ribodetector (packed sequences, default); cpu = ribodetector_cpu (zero-padded input).')
     args.add_argument('-v', '--version', action='version', version='%(prog)s {version}'.format(version=__version__))
