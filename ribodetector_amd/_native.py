@@ -43,6 +43,9 @@ def lib():
         raise RuntimeError(
             "ribodetector_amd: HIP extension %s is missing - run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(there is no CPU fallback)" % LIB_PATH)
+    # torch first: librd_hip.so must bind to the HIP runtime torch ships and initialises (its bundled libamdhip64), not to a
+    # second copy from /opt/rocm - with two runtimes in one process the second one sees no device.
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     vp, i64, i32, sz = C.c_void_p, C.c_int64, C.c_int32, C.c_size_t
     L.rd_model_create.argtypes = [C.POINTER(RdWeights), C.c_int, C.POINTER(vp)]

@@ -223,7 +223,50 @@ def test_padded_cpu_product_semantics(gpu_model, golden, oracle, variant):
         # and it really differs from the packed semantics on short reads, so the switch is live
         gpu_model.set_semantics("packed")
         lgp, _ = _run(gpu_model, e["arena"], e["offsets"], e["lens"], 100)
-        assert np.abs(lgp - ref[: len(lgp)] if False else lgp - oracle.forward_padded(e["arena"], e["offsets"], e["lens"], 100)).max() > 1e-2
+        assert np.abs(lgp - oracle.forward_padded(e["arena"], e["offsets"], e["lens"], 100)).max() > 1e-2
     finally:
         gpu_model.set_semantics("packed")
         gpu_model.set_variant("auto")
+
+
+def test_config_c_and_d_shapes_properties(gpu_model, oracle):
+    """BASELINE configs[3]/[4] shapes on one GPU's shard: 150 bp pairs with --ensure both, and 40-300 bp reads with -l 300:
+    determinism, order equivariance under length bucketing, label consistency, spot checks against the oracle."""
+    from ribodetector_amd import synth
+    from ribodetector_amd.data_loader import seq_encoder as E
+    from ribodetector_amd.model import model as M
+    # configs[4]: variable length, the bucketing permutation is non-trivial
+    n = 200000
+    arena, off, lens = synth.reads_numpy(n, (40, 300), seed=44)
+    b = E.batch_from_numpy(arena, off, lens, "cuda")
+    lg, lab = gpu_model.classify_bytes(b.arena, b.offsets, b.lens, 300)
+    lg2, lab2 = gpu_model.classify_bytes(b.arena, b.offsets, b.lens, 300)
+    torch.cuda.synchronize()
+    assert torch.equal(lg, lg2) and torch.equal(lab, lab2)
+    perm = torch.randperm(n, device="cuda")
+    lgp, labp = gpu_model.classify_bytes(b.arena, b.offsets[perm].contiguous(), b.lens[perm].contiguous(), 300)
+    assert torch.equal(lgp, lg[perm]) and torch.equal(labp, lab[perm])
+    idx = np.arange(0, n, n // 96)[:96]
+    ref = oracle.forward_packed(arena, off[idx], lens[idx], 300)
+    _check(lg[idx].cpu().numpy(), lab[idx].cpu().numpy(), ref, "configs[4] spot check")
+    # truncation: -l 170 on the same reads equals classifying the 170-prefixes
+    lgt, _ = gpu_model.classify_bytes(b.arena, b.offsets, b.lens, 170)
+    lgc, _ = gpu_model.classify_bytes(b.arena, b.offsets, torch.clamp(b.lens, max=170), 300)
+    assert torch.equal(lgt, lgc)
+    # configs[3]: 150 bp pairs, all four modes consistent with the per-mate labels
+    n = 100000
+    a1, o1, l1 = synth.reads_numpy(n, 150, seed=45, rrna_frac=0.3)
+    a2, o2, l2 = synth.reads_numpy(n, 150, seed=46, rrna_frac=0.3)
+    b1, b2 = E.batch_from_numpy(a1, o1, l1, "cuda"), E.batch_from_numpy(a2, o2, l2, "cuda")
+    g1, lab1 = gpu_model.classify_bytes(b1.arena, b1.offsets, b1.lens, 150)
+    g2, lab2 = gpu_model.classify_bytes(b2.arena, b2.offsets, b2.lens, 150)
+    both = M.pair_fuse(g1, g2, "both")
+    assert torch.equal(both == 1, (lab1 == 1) & (lab2 == 1)) and torch.equal(both == 0, (lab1 == 0) & (lab2 == 0))
+    assert torch.equal(M.pair_fuse(g1, g2, "rrna") == 1, both == 1) and torch.equal(M.pair_fuse(g1, g2, "norrna") == 0, both == 0)
+    none = M.pair_fuse(g1, g2, "none")
+    conc = both >= 0
+    assert torch.equal(none[conc], both[conc])          # concordant pairs: the logit sum agrees with both mates
+    assert (both == -1).any() and (none[~conc] == 0).any() and (none[~conc] == 1).any()
+    idx = np.arange(0, n, n // 64)[:64]
+    ref = oracle.forward_packed(a1, o1[idx], l1[idx], 150)
+    _check(g1[idx].cpu().numpy(), lab1[idx].cpu().numpy(), ref, "configs[3] spot check")
