@@ -120,34 +120,42 @@ class Predictor:
         return labels.cpu().numpy()
 
     # ---- drivers ----------------------------------------------------------------------------------------
-    def _chunk_stream(self, chunk_reads):
-        if self.is_paired:
-            yield from fx.get_pairedread_chunks(*self.input, chunk_size=chunk_reads)
-        else:
-            for c in fx.get_seq_chunks(*self.input, chunk_size=chunk_reads):
-                yield (c,)
+    # Host pipeline: one parser thread per input file -> GPU (main thread) -> one writer thread per mate. The C++ reader,
+    # the kernels and the C++ writer all release the GIL, so the three stages overlap (the reference parses the two mates
+    # with Pool(2), detect.py:131-132, but encodes, classifies and writes in lock-step).
+    @staticmethod
+    def _spawn(target, *a):
+        th = threading.Thread(target=target, args=a, daemon=True)
+        th.start()
+        return th
 
-    def _prefetching(self, it, depth=2):
-        """parse chunk k+1 on a host thread while chunk k is on the GPU"""
+    def _reader_queue(self, path, chunk_reads, depth=2):
         q = queue.Queue(maxsize=depth)
-        END = object()
 
         def work():
             try:
-                for x in it:
-                    q.put(x)
-                q.put(END)
-            except BaseException as e:  # surface parser errors on the main thread
+                for c in fx.get_seq_chunks(path, chunk_size=chunk_reads):
+                    q.put(c)
+                q.put(None)
+            except BaseException as e:      # surface parser errors on the main thread
                 q.put(e)
-        th = threading.Thread(target=work, daemon=True)
-        th.start()
+        self._spawn(work)
+        return q
+
+    def _chunk_stream(self, chunk_reads):
+        qs = [self._reader_queue(p, chunk_reads) for p in self.input]
         while True:
-            x = q.get()
-            if x is END:
+            cs = []
+            for q in qs:
+                c = q.get()
+                if isinstance(c, BaseException):
+                    raise c
+                cs.append(c)
+            if all(c is None for c in cs):
                 return
-            if isinstance(x, BaseException):
-                raise x
-            yield x
+            if any(c is None for c in cs) or len({len(c.seq_len) for c in cs}) != 1:
+                raise ValueError("paired-end files have different numbers of records")
+            yield tuple(cs)
 
     def run_with_chunks(self, chunk_reads=None):
         """Classify the input in chunks and write the outputs (reference detect.py:326-523)."""
@@ -173,17 +181,47 @@ class Predictor:
         from . import _native
         _native.host_lib().rd_host_set_threads(int(self.args.threads))   # -t/--threads: gzip output workers
         self._copy_stream = torch.cuda.Stream(self.device)
-        for chunks in self._prefetching(self._chunk_stream(chunk_reads)):
-            labels = self.classify_chunk(chunks)
-            num_read += len(chunks[0].seq_len)
-            if writer:
-                num_nonrrna += int((labels == 0).sum())
-                num_rrna += int((labels == 1).sum())
-                num_unknown += int((labels == -1).sum())
-                for lab, handles in fhs.items():
-                    for e, fh in zip(ends, handles):
-                        fh.write_selected(chunks[e], labels, lab)
-                self.logger.info('{}{}{} sequences finished!'.format(colors.OKGREEN, num_read, colors.ENDC))
+
+        # writer threads (rank 0): one per mate, records of every label file in input order
+        wq, werr, wth = [], [], []
+        if writer:
+            def write_end(e, q):
+                try:
+                    while True:
+                        item = q.get()
+                        if item is None:
+                            return
+                        chunk, labels = item
+                        for lab, handles in fhs.items():
+                            handles[e].write_selected(chunk, labels, lab)
+                except BaseException as ex:
+                    werr.append(ex)
+                    while q.get() is not None:   # keep draining so that the producer never blocks
+                        pass
+            for e in ends:
+                q = queue.Queue(maxsize=2)
+                wq.append(q)
+                wth.append(self._spawn(write_end, e, q))
+        try:
+            for chunks in self._chunk_stream(chunk_reads):
+                labels = self.classify_chunk(chunks)
+                num_read += len(chunks[0].seq_len)
+                if writer:
+                    if werr:
+                        raise werr[0]
+                    num_nonrrna += int((labels == 0).sum())
+                    num_rrna += int((labels == 1).sum())
+                    num_unknown += int((labels == -1).sum())
+                    for e in ends:
+                        wq[e].put((chunks[e], labels))
+                    self.logger.info('{}{}{} sequences finished!'.format(colors.OKGREEN, num_read, colors.ENDC))
+        finally:
+            for q in wq:
+                q.put(None)
+            for th in wth:
+                th.join()
+        if werr:
+            raise werr[0]
         if writer:
             self.logger.info('Processed {}{}{}{} sequences in total'.format(colors.BOLD, colors.OKCYAN, num_read, colors.ENDC))
             self.logger.info('Detected {}{}{}{} non-rRNA sequences'.format(colors.BOLD, colors.OKCYAN, num_nonrrna, colors.ENDC))
