@@ -964,6 +964,7 @@ __global__ __launch_bounds__(256, 1) void rd_lstm_mfma_f16x3_kernel(DevModel d, 
 // ------------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct __attribute__((aligned(16))) Lstm16bSmem {
     _Float16 H1s[2][32][H16STR];
@@ -1008,7 +1009,7 @@ constexpr unsigned char EW_STAGE[EW_NU] = {0,1,2,3,4,5,6,0,7,1,8,2,9,3,10,4,11,5
 //  the same stage; stage 13 = stores of a finished row-tile; generated offline, units are dealt out in this order)
 struct EwRegs {
     f32x4 kc[2];        // table rows of the cells in flight, by cell parity
-    float v[2][4];      // gate pipeline values, by cell parity
+    f32x2 v[2][2];      // gate pipeline values by cell parity: {i,f} and {g,o} as register pairs (packed fp32 math)
     float y[2], og[2], hs[2];
     _Float16 p16[2];
     f32x4 cs[2], hv[2]; // per row-tile, by row-tile parity
@@ -1028,26 +1029,29 @@ __device__ __forceinline__ void rd_ew_unit(Lstm16bSmem &S, EwRegs &R, const f32x
         constexpr int nc = cell + 1;
         if constexpr (nc < 16) R.kc[k ^ 1] = S.lut[c.wave][c.half][nc >> 2][nc & 3][c.codeEW];
         if constexpr (b == 0) R.cs[ap] = S.cS[TP][a][c.tid];
-    } else if constexpr (stage == 1) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) R.v[k][g] = __builtin_fmaf(accP[a][4 * b + g], (g == 2 ? KT : KS) / G_SCALE, R.kc[k][g]);
+    } else if constexpr (stage == 1) {   // exp2 arguments, two per packed instruction (gates i,f use KS; g uses KT)
+        const f32x2 g01 = {accP[a][4 * b + 0], accP[a][4 * b + 1]}, g23 = {accP[a][4 * b + 2], accP[a][4 * b + 3]};
+        const f32x2 k01 = {KS / G_SCALE, KS / G_SCALE}, k23 = {KT / G_SCALE, KS / G_SCALE};
+        R.v[k][0] = g01 * k01 + f32x2{R.kc[k][0], R.kc[k][1]};
+        R.v[k][1] = g23 * k23 + f32x2{R.kc[k][2], R.kc[k][3]};
     } else if constexpr (stage == 2) {
-        R.v[k][0] = __builtin_amdgcn_exp2f(R.v[k][0]); R.v[k][1] = __builtin_amdgcn_exp2f(R.v[k][1]);
+        R.v[k][0][0] = __builtin_amdgcn_exp2f(R.v[k][0][0]); R.v[k][0][1] = __builtin_amdgcn_exp2f(R.v[k][0][1]);
     } else if constexpr (stage == 3) {
-        R.v[k][2] = __builtin_amdgcn_exp2f(R.v[k][2]); R.v[k][3] = __builtin_amdgcn_exp2f(R.v[k][3]);
+        R.v[k][1][0] = __builtin_amdgcn_exp2f(R.v[k][1][0]); R.v[k][1][1] = __builtin_amdgcn_exp2f(R.v[k][1][1]);
     } else if constexpr (stage == 4) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) R.v[k][g] = 1.0f + R.v[k][g];
+        const f32x2 one = {1.0f, 1.0f};
+        R.v[k][0] += one;
+        R.v[k][1] += one;
     } else if constexpr (stage == 5) {
-        R.v[k][0] = __builtin_amdgcn_rcpf(R.v[k][0]); R.v[k][1] = __builtin_amdgcn_rcpf(R.v[k][1]);
+        R.v[k][0][0] = __builtin_amdgcn_rcpf(R.v[k][0][0]); R.v[k][0][1] = __builtin_amdgcn_rcpf(R.v[k][0][1]);
     } else if constexpr (stage == 6) {
-        R.v[k][2] = __builtin_amdgcn_rcpf(R.v[k][2]); R.v[k][3] = __builtin_amdgcn_rcpf(R.v[k][3]);
+        R.v[k][1][0] = __builtin_amdgcn_rcpf(R.v[k][1][0]); R.v[k][1][1] = __builtin_amdgcn_rcpf(R.v[k][1][1]);
     } else if constexpr (stage == 7) {
-        const float gg = __builtin_fmaf(-2.0f, R.v[k][2], 1.0f);
-        const float cn = __builtin_fmaf(R.v[k][1], R.cs[ap][b], R.v[k][0] * gg);
+        const float gg = __builtin_fmaf(-2.0f, R.v[k][1][0], 1.0f);
+        const float cn = __builtin_fmaf(R.v[k][0][1], R.cs[ap][b], R.v[k][0][0] * gg);
         R.cs[ap][b] = cn;
         R.y[k] = cn * KT;
-        R.og[k] = R.v[k][3];
+        R.og[k] = R.v[k][1][1];
     } else if constexpr (stage == 8) {
         R.y[k] = __builtin_amdgcn_exp2f(R.y[k]);
     } else if constexpr (stage == 9) {

@@ -270,3 +270,33 @@ def test_config_c_and_d_shapes_properties(gpu_model, oracle):
     idx = np.arange(0, n, n // 64)[:64]
     ref = oracle.forward_packed(a1, o1[idx], l1[idx], 150)
     _check(g1[idx].cpu().numpy(), lab1[idx].cpu().numpy(), ref, "configs[3] spot check")
+
+
+def test_abi_error_paths_on_device(gpu_model):
+    """status codes + rd_last_error through the C ABI with a live model (no exception crosses the boundary)"""
+    import ctypes as C
+    from ribodetector_amd import _native as N
+    L = N.lib()
+    h = gpu_model._handle
+    arena = torch.zeros(400, dtype=torch.uint8, device="cuda")
+    off = torch.arange(4, dtype=torch.int64, device="cuda") * 100
+    ln = torch.full((4,), 100, dtype=torch.int32, device="cuda")
+    lg = torch.empty((4, 2), dtype=torch.float32, device="cuda")
+    ws = torch.empty(1 << 16, dtype=torch.uint8, device="cuda")
+    st = N.stream_ptr()
+    args = lambda n, L_, wsb: (h, N.ptr(arena), N.ptr(off), N.ptr(ln), n, L_, N.ptr(lg), None, N.ptr(ws), wsb, st)
+    assert L.rd_classify(*args(4, 100, ws.numel())) == 0
+    assert L.rd_classify(*args(0, 100, ws.numel())) == 0                       # empty batch is fine
+    assert L.rd_classify(*args(4, 100, 16)) == -4 and b"workspace" in L.rd_last_error()
+    assert L.rd_classify(*args(4, 0, ws.numel())) == -1 and b"max_len" in L.rd_last_error()
+    assert L.rd_classify(*args(4, 20000, ws.numel())) == -1
+    assert L.rd_classify(*args(-1, 100, ws.numel())) == -1
+    assert L.rd_set_variant(h, 99) == -3 and L.rd_set_semantics(h, 7) == -1
+    with pytest.raises(KeyError):
+        gpu_model.set_variant("nope")
+    with pytest.raises(TypeError):
+        gpu_model.classify_bytes(arena.cpu(), off, ln, 100)
+    torch.cuda.synchronize()
+    # the model still works after the failed calls
+    lg2, _ = gpu_model.classify_bytes(arena + ord("A"), off, ln, 100)
+    assert torch.isfinite(lg2).all()
