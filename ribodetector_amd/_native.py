@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "librd_hip.so")
+LIB_PATH = os.environ.get("RD_HIP_LIB") or os.path.join(_HERE, "csrc", "librd_hip.so")   # env override: A/B of two builds
 
 ENSURE_MODES = {"none": 0, "rrna": 1, "norrna": 2, "both": 3}
 SEMANTICS = {"packed": 0, "gpu": 0, "padded": 1, "cpu": 1}

@@ -168,7 +168,7 @@ __global__ void rd_prep_kernel(DevModel d) {
         int col = g * HID + 32 * w + 16 * hf + 4 * a + b;
         float x = 16.0f * raw[OFF_WHH + col * HID + 16 * s + 8 * kh + e];
         _Float16 hi = (_Float16)x;
-        _Float16 lo = (_Float16)((x - (float)hi) * 2048.0f);
+        _Float16 lo = (_Float16)(x - (float)hi);      // unscaled: multiplied with H1s = 2^11 h_hi it carries the common 2^15
         _Float16 *base = reinterpret_cast<_Float16 *>(d.wpack16b);
         base[((((size_t)(w * 2 + 0) * 4 + a) * 8 + s) * 64 + lane) * 8 + e] = hi;
         base[((((size_t)(w * 2 + 1) * 4 + a) * 8 + s) * 64 + lane) * 8 + e] = lo;
@@ -960,16 +960,17 @@ __global__ __launch_bounds__(256, 1) void rd_lstm_mfma_f16x3_kernel(DevModel d, 
 //   * A = weights: row-tile a (0..3) of 32 rows = 8 units x (i,f,g,o); row 8b + 4hf + g  <->  gate g of unit
 //     32w + 16hf + 4a + b.  With the 32x32 C/D layout (col = lane&31, row = (reg&3) + 8(reg>>2) + 4(lane>>5)) lane
 //     (read j, half) holds in acc[a][4b + g] the four gates of unit 32w + 16half + 4a + b: 16 contiguous units/lane;
-//   * the dummy gate pass before t = 0 uses an all-zero table row (code 5): sigmoid -> 1/2, tanh -> 0 => c = h = 0.
+//   * the dummy gate pass before t = 0 uses an all-zero table row (code 5): sigmoid -> 1/2, tanh -> 0 => c = h = 0;
+//   * only two B arrays: W2 is kept as the UNSCALED fp16 residual of 16 w, so W2 . H1s carries the same 2^15 as W1 . H1s and
+//     W1 . H2 - the separate unscaled copy of h_hi (H1) of the 16x16 kernel is gone (8 LDS reads, 4 stores, 8 VALU per phase).
 // ------------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct __attribute__((aligned(16))) Lstm16bSmem {
-    _Float16 H1s[2][32][H16STR];
-    _Float16 H1[2][32][H16STR];
-    _Float16 H2[2][32][H16STR];
+    _Float16 H1s[2][32][H16STR];   // 2^11 h_hi   (B operand of the W1 and of the unscaled-W2 products)
+    _Float16 H2[2][32][H16STR];    // 2^11 h - H1s
     float Hl[64][HSTR];            // h captured at t == T-1
     f32x4 cS[2][4][256];           // cell state [tile][row-tile a][tid] -> units b = 0..3
     f32x4 lut[4][2][4][4][6];      // [wave][half][a][b][code] -> exp2-argument constants of (i,f,g,o); code 5 = zeros
@@ -1013,7 +1014,7 @@ struct EwRegs {
     float y[2], og[2], hs[2];
     _Float16 p16[2];
     f32x4 cs[2], hv[2]; // per row-tile, by row-tile parity
-    f16x4 o1s[2], o1[2], o2[2];
+    f16x4 o1s[2], o2[2];
 };
 
 struct PhaseCtx {       // per-lane constants of a phase
@@ -1065,12 +1066,10 @@ __device__ __forceinline__ void rd_ew_unit(Lstm16bSmem &S, EwRegs &R, const f32x
         R.p16[k] = (_Float16)R.hs[k];                                // 2^11 h_hi'
     } else if constexpr (stage == 12) {
         R.o1s[ap][b] = R.p16[k];
-        R.o1[ap][b] = R.p16[k] * (_Float16)(1.0f / H_SCALE);         // exact power-of-two scaling
         R.o2[ap][b] = (_Float16)(R.hs[k] - (float)R.p16[k]);         // exact residual, rounded once
     } else {   // 13: the row-tile's 4 cells are complete
         const int wo = c.j * H16STR + 32 * c.wave + 16 * c.half + 4 * a;
         *reinterpret_cast<f16x4 *>(&S.H1s[TP][0][0] + wo) = R.o1s[ap];
-        *reinterpret_cast<f16x4 *>(&S.H1[TP][0][0] + wo) = R.o1[ap];
         *reinterpret_cast<f16x4 *>(&S.H2[TP][0][0] + wo) = R.o2[ap];
         S.cS[TP][a][c.tid] = R.cs[ap];
         f32x4 *dst = c.last ? reinterpret_cast<f32x4 *>(&S.Hl[TP * 32 + c.j][32 * c.wave + 16 * c.half + 4 * a]) : &S.dummy[c.tid];
@@ -1089,29 +1088,30 @@ __device__ __forceinline__ void rd_ew_units(Lstm16bSmem &S, EwRegs &R, const f32
 // slot M = MFMA number M (k-step s = M/12, product (M%12)/4, row-tile M%4) followed by its share of gate-math units
 template <int TL, int FILL, int M>
 __device__ __forceinline__ void rd_slots(Lstm16bSmem &S, const f16x8 (&W1)[4][8], const f16x8 (&W2)[4][8], f32x16 (&accC)[4],
-                                         const f32x16 (&accP)[4], f16x8 (&Bf)[2][3], EwRegs &R, const PhaseCtx &c,
-                                         const _Float16 *h1s, const _Float16 *h1, const _Float16 *h2) {
+                                         const f32x16 (&accP)[4], f16x8 (&Bf)[2][2], EwRegs &R, const PhaseCtx &c,
+                                         const _Float16 *h1s, const _Float16 *h2) {
     if constexpr (M < 96) {
         constexpr int s = M / 12, pr = (M % 12) / 4, a = M % 4;
         if constexpr (M % 12 == 0 && s < 7) {       // B fragments of the next k-step stream in behind this one's MFMAs
             Bf[(s + 1) & 1][0] = *reinterpret_cast<const f16x8 *>(h1s + 16 * (s + 1));
-            Bf[(s + 1) & 1][1] = *reinterpret_cast<const f16x8 *>(h1 + 16 * (s + 1));
-            Bf[(s + 1) & 1][2] = *reinterpret_cast<const f16x8 *>(h2 + 16 * (s + 1));
+            Bf[(s + 1) & 1][1] = *reinterpret_cast<const f16x8 *>(h2 + 16 * (s + 1));
         }
+        // products: W1.H1s, W2.H1s (W2 = unscaled residual of 16 w, so this pair also carries 2^15), W1.H2
         const f16x8 A = pr == 1 ? W2[a][s] : W1[a][s];
+        const f16x8 B = Bf[s & 1][pr == 2 ? 1 : 0];
         if constexpr (M < 4) {
             f32x16 z;
 #pragma unroll
             for (int r = 0; r < 16; ++r) z[r] = 0.0f;
-            accC[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, Bf[s & 1][pr], z, 0, 0, 0);
+            accC[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, z, 0, 0, 0);
         } else {
-            accC[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, Bf[s & 1][pr], accC[a], 0, 0, 0);
+            accC[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, accC[a], 0, 0, 0);
         }
         if constexpr (FILL > 0) {
             rd_ew_units<TL ^ 1, (M * EW_NU) / 96, ((M + 1) * EW_NU) / 96>(S, R, accP, c);
             __builtin_amdgcn_sched_barrier(0);
         }
-        rd_slots<TL, FILL, M + 1>(S, W1, W2, accC, accP, Bf, R, c, h1s, h1, h2);
+        rd_slots<TL, FILL, M + 1>(S, W1, W2, accC, accP, Bf, R, c, h1s, h2);
     }
 }
 
@@ -1128,18 +1128,17 @@ __device__ __forceinline__ void rd_phase_t32(Lstm16bSmem &S, const f16x8 (&W1)[4
                                              f32x16 (&accP)[4], int tEW, int codeEW, int wave, int half, int j, int tid) {
     constexpr int TP = TL ^ 1;
     const int boff = j * H16STR + 8 * half;     // this lane's B fragment: row j, k = 16s + 8half + e
-    const _Float16 *h1s = &S.H1s[TL][0][0] + boff, *h1 = &S.H1[TL][0][0] + boff, *h2 = &S.H2[TL][0][0] + boff;
-    f16x8 Bf[2][3];
+    const _Float16 *h1s = &S.H1s[TL][0][0] + boff, *h2 = &S.H2[TL][0][0] + boff;
+    f16x8 Bf[2][2];
     Bf[0][0] = *reinterpret_cast<const f16x8 *>(h1s);
-    Bf[0][1] = *reinterpret_cast<const f16x8 *>(h1);
-    Bf[0][2] = *reinterpret_cast<const f16x8 *>(h2);
+    Bf[0][1] = *reinterpret_cast<const f16x8 *>(h2);
     PhaseCtx c;
     c.codeEW = codeEW; c.wave = wave; c.half = half; c.j = j; c.tid = tid;
     c.last = (tEW == S.T[TP * 32 + j] - 1);
     EwRegs R;
     R.kc[0] = S.lut[wave][half][0][0][codeEW];
     if (FILL > 0) __builtin_amdgcn_sched_barrier(0);
-    rd_slots<TL, (FILL > 0 ? FILL : 0), 0>(S, W1, W2, accC, accP, Bf, R, c, h1s, h1, h2);
+    rd_slots<TL, (FILL > 0 ? FILL : 0), 0>(S, W1, W2, accC, accP, Bf, R, c, h1s, h2);
     if constexpr (FILL == 0) rd_ew_units<TP, 0, EW_NU>(S, R, accP, c);
     if constexpr (FILL < 0) {   // bench diagnosis only (wrong results): no gate math, keep the accumulators live
         if (accC[0][0] + accC[1][5] + accC[2][9] + accC[3][15] == 123.456f) S.Hl[TP * 32 + j][tid & 127] = accC[0][1];
@@ -1168,7 +1167,7 @@ __global__ __launch_bounds__(256, 1) void rd_lstm_mfma_f16x3_t32_kernel(DevModel
         S.T[tid] = T; S.Lr[tid] = lr; S.off[tid] = off; S.orig[tid] = orig;
     }
     if (tid == 0) S.tmax = 0;
-    for (int i = tid; i < 3 * 2 * 32 * H16STR / 2; i += 256) (reinterpret_cast<uint32_t *>(&S.H1s[0][0][0]))[i] = 0u;
+    for (int i = tid; i < 2 * 2 * 32 * H16STR / 2; i += 256) (reinterpret_cast<uint32_t *>(&S.H1s[0][0][0]))[i] = 0u;
     for (int i = tid; i < 64 * HSTR; i += 256) (&S.Hl[0][0])[i] = 0.0f;
     for (int i = tid; i < 2 * 4 * 256; i += 256) (&S.cS[0][0][0])[i] = f32x4{0, 0, 0, 0};
     for (int i = tid; i < 4 * 2 * 4 * 4 * 6 * 4; i += 256) {   // i = ((((w*2 + hf)*4 + a)*4 + b)*6 + code)*4 + gate
@@ -1183,7 +1182,7 @@ __global__ __launch_bounds__(256, 1) void rd_lstm_mfma_f16x3_t32_kernel(DevModel
     if (tid < 64) atomicMax(&S.tmax, S.T[tid]);
     rd_stage_codes16b(S, rb, 0);
     if (FILL < 0) {   // diagnosis: realistic (pseudo-random) B operands that are never updated
-        for (int i = tid; i < 3 * 2 * 32 * H16STR / 2; i += 256) {
+        for (int i = tid; i < 2 * 2 * 32 * H16STR / 2; i += 256) {
             uint32_t x = (uint32_t)i * 2654435761u + blockIdx.x * 40503u;
             x ^= x >> 15; x *= 2246822519u; x ^= x >> 13;
             (reinterpret_cast<uint32_t *>(&S.H1s[0][0][0]))[i] = (x & 0x83ff83ffu) | 0x34003400u;   // |v| in [0.25, 0.5), random sign+mantissa
