@@ -10,7 +10,7 @@ LIB_PATH = os.environ.get("RD_HIP_LIB") or os.path.join(_HERE, "csrc", "librd_hi
 
 ENSURE_MODES = {"none": 0, "rrna": 1, "norrna": 2, "both": 3}
 SEMANTICS = {"packed": 0, "gpu": 0, "padded": 1, "cpu": 1}
-VARIANTS = {"auto": 0, "mfma_f32": 1, "simple": 2, "mfma_f16x3": 3, "mfma_f16x3_t32": 4,
+VARIANTS = {"auto": 0, "mfma_f32": 1, "simple": 2, "mfma_f16x3": 3, "mfma_f16x3_t32": 4, "mfma_f16x3_w8": 5,
             # A/B builds of the fp32 kernel (activation form x schedule), see rd_kernels.hip
             "mfma_f32_a0s0": 10, "mfma_f32_a1s0": 11, "mfma_f32_a0s1": 12, "mfma_f32_a1s1": 13,
             "mfma_f32_diag_noew": 20, "mfma_f32_diag_nomfma": 21, "mfma_f32_diag_mfmaonly": 22,

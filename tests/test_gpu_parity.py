@@ -9,7 +9,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
-VARIANTS = ["mfma_f32", "simple", "mfma_f32_a0s0", "mfma_f16x3", "mfma_f16x3_t32"]
+VARIANTS = ["mfma_f32", "simple", "mfma_f32_a0s0", "mfma_f16x3", "mfma_f16x3_t32", "mfma_f16x3_w8"]
 
 
 def _run(model, arena, offsets, lens, max_len):
