@@ -1063,10 +1063,11 @@ __device__ __forceinline__ void rd_ew_unit(Lstm16bSmem &S, EwRegs &R, const f32x
     } else if constexpr (stage == 6) {
         R.v[k][1][0] = __builtin_amdgcn_rcpf(R.v[k][1][0]); R.v[k][1][1] = __builtin_amdgcn_rcpf(R.v[k][1][1]);
     } else if constexpr (stage == 7) {
-        const float gg = __builtin_fmaf(-2.0f, R.v[k][1][0], 1.0f);
+        // the cell state is kept pre-multiplied by KT (c' = KT c): c' = f c'_old + i (KT tanh g), and tanh(c) = 1 - 2/(1 + 2^c')
+        const float gg = __builtin_fmaf(-2.0f * KT, R.v[k][1][0], KT);
         const float cn = __builtin_fmaf(R.v[k][0][1], R.cs[ap][b], R.v[k][0][0] * gg);
         R.cs[ap][b] = cn;
-        R.y[k] = cn * KT;
+        R.y[k] = cn;
         R.og[k] = R.v[k][1][1];
     } else if constexpr (stage == 8) {
         R.y[k] = __builtin_amdgcn_exp2f(R.y[k]);
@@ -1075,9 +1076,8 @@ __device__ __forceinline__ void rd_ew_unit(Lstm16bSmem &S, EwRegs &R, const f32x
     } else if constexpr (stage == 10) {
         R.y[k] = __builtin_amdgcn_rcpf(R.y[k]);
     } else if constexpr (stage == 11) {
-        const float h = R.og[k] * __builtin_fmaf(-2.0f, R.y[k], 1.0f);
-        R.hv[ap][b] = h;
-        R.hs[k] = h * H_SCALE;
+        R.hs[k] = R.og[k] * __builtin_fmaf(-2.0f * H_SCALE, R.y[k], H_SCALE);   // 2^11 h = 2^11 o tanh(c)
+        R.hv[ap][b] = R.hs[k];                                       // captured state is kept at scale 2^11 (epilogue divides)
         R.p16[k] = (_Float16)R.hs[k];                                // 2^11 h_hi'
     } else if constexpr (stage == 12) {
         R.o1s[ap][b] = R.p16[k];
@@ -1255,7 +1255,8 @@ __global__ __launch_bounds__(256, 1) void rd_lstm_mfma_f16x3_t32_kernel(DevModel
     }
 
     rd_fc_epilogue(
-        64, [&](int row, int u) { return S.Hl[row][u]; }, S.T, S.Lr, S.off, S.orig, &S.wout[0][0], d, rb, logits, labels);
+        64, [&](int row, int u) { return S.Hl[row][u] * (1.0f / H_SCALE); }, S.T, S.Lr, S.off, S.orig, &S.wout[0][0], d, rb, logits,
+        labels);
 }
 
 // ------------------------------------------------------------------------------------------------
