@@ -1045,19 +1045,20 @@ __device__ __forceinline__ void rd_ew_unit(Lstm16bSmem &S, EwRegs &R, const f32x
         constexpr int nc = cell + 1;
         if constexpr (nc < 16) R.kc[k ^ 1] = S.lut[c.wave][c.half][nc >> 2][nc & 3][c.codeEW];
         if constexpr (b == 0) R.cs[ap] = S.cS[TP][a][c.tid];
-    } else if constexpr (stage == 1) {   // exp2 arguments, two per packed instruction (gates i,f use KS; g uses KT)
-        const f32x2 g01 = {accP[a][4 * b + 0], accP[a][4 * b + 1]}, g23 = {accP[a][4 * b + 2], accP[a][4 * b + 3]};
-        const f32x2 k01 = {KS / G_SCALE, KS / G_SCALE}, k23 = {KT / G_SCALE, KS / G_SCALE};
-        R.v[k][0] = g01 * k01 + f32x2{R.kc[k][0], R.kc[k][1]};
-        R.v[k][1] = g23 * k23 + f32x2{R.kc[k][2], R.kc[k][3]};
+    } else if constexpr (stage == 1) {
+        // exp2 arguments. Scalar FMAs on purpose: packed fp32 ops (v_pk_fma_f32 / v_pk_add_f32) cost ~10 cycles each beside
+        // f16 MFMAs against ~1 for a scalar op (tools/ubench/mfma_fill.hip), so the build also passes -fno-slp-vectorize.
+        R.v[k][0][0] = __builtin_fmaf(accP[a][4 * b + 0], KS / G_SCALE, R.kc[k][0]);
+        R.v[k][0][1] = __builtin_fmaf(accP[a][4 * b + 1], KS / G_SCALE, R.kc[k][1]);
+        R.v[k][1][0] = __builtin_fmaf(accP[a][4 * b + 2], KT / G_SCALE, R.kc[k][2]);
+        R.v[k][1][1] = __builtin_fmaf(accP[a][4 * b + 3], KS / G_SCALE, R.kc[k][3]);
     } else if constexpr (stage == 2) {
         R.v[k][0][0] = __builtin_amdgcn_exp2f(R.v[k][0][0]); R.v[k][0][1] = __builtin_amdgcn_exp2f(R.v[k][0][1]);
     } else if constexpr (stage == 3) {
         R.v[k][1][0] = __builtin_amdgcn_exp2f(R.v[k][1][0]); R.v[k][1][1] = __builtin_amdgcn_exp2f(R.v[k][1][1]);
     } else if constexpr (stage == 4) {
-        const f32x2 one = {1.0f, 1.0f};
-        R.v[k][0] += one;
-        R.v[k][1] += one;
+        R.v[k][0][0] += 1.0f; R.v[k][0][1] += 1.0f;
+        R.v[k][1][0] += 1.0f; R.v[k][1][1] += 1.0f;
     } else if constexpr (stage == 5) {
         R.v[k][0][0] = __builtin_amdgcn_rcpf(R.v[k][0][0]); R.v[k][0][1] = __builtin_amdgcn_rcpf(R.v[k][0][1]);
     } else if constexpr (stage == 6) {
@@ -1077,11 +1078,16 @@ __device__ __forceinline__ void rd_ew_unit(Lstm16bSmem &S, EwRegs &R, const f32x
         R.y[k] = __builtin_amdgcn_rcpf(R.y[k]);
     } else if constexpr (stage == 11) {
         R.hs[k] = R.og[k] * __builtin_fmaf(-2.0f * H_SCALE, R.y[k], H_SCALE);   // 2^11 h = 2^11 o tanh(c)
+        // keep the fp32 value opaque: without this the compiler fuses the multiply into v_fma_mixlo_f16 conversions, and that
+        // form measurably loses accuracy in the hi/lo split (logit error 2.5e-5 -> 1.2e-4 on the known-answer reads)
+        asm volatile("" : "+v"(R.hs[k]));
         R.hv[ap][b] = R.hs[k];                                       // captured state is kept at scale 2^11 (epilogue divides)
         R.p16[k] = (_Float16)R.hs[k];                                // 2^11 h_hi'
     } else if constexpr (stage == 12) {
         R.o1s[ap][b] = R.p16[k];
-        R.o2[ap][b] = (_Float16)(R.hs[k] - (float)R.p16[k]);         // exact residual, rounded once
+        float res = R.hs[k] - (float)R.p16[k];                       // exact residual
+        asm volatile("" : "+v"(res));
+        R.o2[ap][b] = (_Float16)res;                                 // rounded once
     } else {   // 13: the row-tile's 4 cells are complete
         const int wo = c.j * H16STR + 32 * c.wave + 16 * c.half + 4 * a;
         *reinterpret_cast<f16x4 *>(&S.H1s[TP][0][0] + wo) = R.o1s[ap];
@@ -1427,10 +1433,13 @@ __global__ __launch_bounds__(512, 2) void rd_lstm_mfma_f16x3_w8_kernel(DevModel 
                         const float cn = __builtin_fmaf(fg, cs[b], ig * __builtin_fmaf(-2.0f, gr, 1.0f));
                         cs[b] = cn;
                         const float yc = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(cn * KT));
-                        const float hs = og * __builtin_fmaf(-2.0f * H_SCALE, yc, H_SCALE);     // 2^11 h
+                        float hs = og * __builtin_fmaf(-2.0f * H_SCALE, yc, H_SCALE);     // 2^11 h
+                        asm volatile("" : "+v"(hs));             // no v_fma_mix fusion (see rd_ew_unit)
                         const _Float16 p16 = (_Float16)hs;
+                        float res = hs - (float)p16;
+                        asm volatile("" : "+v"(res));
                         v1[4 * a + b] = p16;
-                        v2[4 * a + b] = (_Float16)(hs - (float)p16);
+                        v2[4 * a + b] = (_Float16)res;
                         hsv[4 * a + b] = hs;
                     }
                     S.cS[tile][a][tid] = cs;

@@ -40,6 +40,9 @@ __global__ __launch_bounds__(256, 1) void kern32(float *out, int iters) {
     f32x16 acc[4];
     float v[8];
     f32x4 l[8];
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 pk[4], pka = {1.0f + threadIdx.x, 0.5f}, pkb = {1.0001f, 0.9999f};
+    for (int i = 0; i < 4; ++i) pk[i] = f32x2{(float)i, (float)threadIdx.x};
     for (int i = 0; i < 4; ++i) for (int j = 0; j < 16; ++j) acc[i][j] = 0;
     for (int i = 0; i < 8; ++i) { v[i] = threadIdx.x * 0.001f + i; l[i] = f32x4{0,0,0,0}; }
     float a = threadIdx.x * 1e-3f, b = 1.0f + threadIdx.x * 1e-4f;
@@ -65,6 +68,10 @@ __global__ __launch_bounds__(256, 1) void kern32(float *out, int iters) {
                         if (k == 0) asm volatile("v_exp_f32 %0, %0" : "+v"(v[(c + k) & 7]));
                         else if (k == 1) asm volatile("v_rcp_f32 %0, %0" : "+v"(v[(c + k) & 7]));
                         else asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[(c + k) & 7]) : "v"(b), "v"(a));
+                    } else if (FILL == 6) {   // packed fp32 fma (two lanes-worth of work per instruction)
+                        asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(pk[(c + k) & 3]) : "v"(pkb), "v"(pka));
+                    } else if (FILL == 7) {   // packed fp32 add
+                        asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(pk[(c + k) & 3]) : "v"(pkb));
                     } else if (FILL == 5) {   // one trans + rest fma
                         if (k == 0) asm volatile("v_exp_f32 %0, %0" : "+v"(v[(c + k) & 7]));
                         else asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[(c + k) & 7]) : "v"(b), "v"(a));
@@ -78,6 +85,7 @@ __global__ __launch_bounds__(256, 1) void kern32(float *out, int iters) {
     float s = 0;
     for (int i = 0; i < 4; ++i) for (int j = 0; j < 16; ++j) s += acc[i][j];
     for (int i = 0; i < 8; ++i) s += v[i] + l[i][0];
+    for (int i = 0; i < 4; ++i) s += pk[i][0] + pk[i][1];
     pad[threadIdx.x] = s;
     out[blockIdx.x * 256 + threadIdx.x] = pad[threadIdx.x];
 }
@@ -127,6 +135,8 @@ int main() {
     run32<4, 3>(d, "f16 32x32x16 +2exp+fma"); run32<5, 3>(d, "f16 32x32x16 +2exp+fma"); run32<6, 3>(d, "f16 32x32x16 +2exp+fma"); run32<7, 3>(d, "f16 32x32x16 +2exp+fma");
     run32<5, 4>(d, "f16 32x32x16 +exp+rcp+fma"); run32<6, 4>(d, "f16 32x32x16 +exp+rcp+fma");
     run32<4, 5>(d, "f16 32x32x16 +1exp+fma"); run32<5, 5>(d, "f16 32x32x16 +1exp+fma"); run32<6, 5>(d, "f16 32x32x16 +1exp+fma");
+    run32<2, 6>(d, "f16 32x32x16 +pk_fma"); run32<4, 6>(d, "f16 32x32x16 +pk_fma"); run32<6, 6>(d, "f16 32x32x16 +pk_fma");
+    run32<2, 7>(d, "f16 32x32x16 +pk_add"); run32<4, 7>(d, "f16 32x32x16 +pk_add");
     run32<1, 2>(d, "f16 32x32x16 +ds_read_b128"); run32<2, 2>(d, "f16 32x32x16 +ds_read_b128");
     return 0;
 }
