@@ -984,11 +984,13 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct __attribute__((aligned(16))) Lstm16bSmem {
+    // hot arrays first: everything the phase loop touches per cell sits below 64 KiB, so its LDS addresses are one base
+    // register + a 16-bit immediate offset (no per-access address arithmetic)
+    f32x4 lut[4][2][4][4][6];      // [wave][half][a][b][code] -> exp2-argument constants of (i,f,g,o); code 5 = zeros
     _Float16 H1s[2][32][H16STR];   // 2^11 h_hi   (B operand of the W1 and of the unscaled-W2 products)
     _Float16 H2[2][32][H16STR];    // 2^11 h - H1s
-    float Hl[64][HSTR];            // h captured at t == T-1
     f32x4 cS[2][4][256];           // cell state [tile][row-tile a][tid] -> units b = 0..3
-    f32x4 lut[4][2][4][4][6];      // [wave][half][a][b][code] -> exp2-argument constants of (i,f,g,o); code 5 = zeros
+    float Hl[64][HSTR];            // h captured at t == T-1
     f32x4 dummy[256];              // sink of predicated-off Hl stores
     float wout[2][HID];
     uint8_t codes[2][TC16][64];
@@ -1188,7 +1190,7 @@ __global__ __launch_bounds__(256, 1) void rd_lstm_mfma_f16x3_t32_kernel(DevModel
         S.T[tid] = T; S.Lr[tid] = lr; S.off[tid] = off; S.orig[tid] = orig;
     }
     if (tid == 0) S.tmax = 0;
-    for (int i = tid; i < 2 * 2 * 32 * H16STR / 2; i += 256) (reinterpret_cast<uint32_t *>(&S.H1s[0][0][0]))[i] = 0u;
+    for (int i = tid; i < 2 * 32 * H16STR / 2; i += 256) { (reinterpret_cast<uint32_t *>(&S.H1s[0][0][0]))[i] = 0u; (reinterpret_cast<uint32_t *>(&S.H2[0][0][0]))[i] = 0u; }
     for (int i = tid; i < 64 * HSTR; i += 256) (&S.Hl[0][0])[i] = 0.0f;
     for (int i = tid; i < 2 * 4 * 256; i += 256) (&S.cS[0][0][0])[i] = f32x4{0, 0, 0, 0};
     for (int i = tid; i < 4 * 2 * 4 * 4 * 6 * 4; i += 256) {   // i = ((((w*2 + hf)*4 + a)*4 + b)*6 + code)*4 + gate
@@ -1203,10 +1205,11 @@ __global__ __launch_bounds__(256, 1) void rd_lstm_mfma_f16x3_t32_kernel(DevModel
     if (tid < 64) atomicMax(&S.tmax, S.T[tid]);
     rd_stage_codes16b(S, rb, 0);
     if (FILL < 0) {   // diagnosis: realistic (pseudo-random) B operands that are never updated
-        for (int i = tid; i < 2 * 2 * 32 * H16STR / 2; i += 256) {
+        for (int i = tid; i < 2 * 32 * H16STR / 2; i += 256) {
             uint32_t x = (uint32_t)i * 2654435761u + blockIdx.x * 40503u;
             x ^= x >> 15; x *= 2246822519u; x ^= x >> 13;
             (reinterpret_cast<uint32_t *>(&S.H1s[0][0][0]))[i] = (x & 0x83ff83ffu) | 0x34003400u;   // |v| in [0.25, 0.5), random sign+mantissa
+            (reinterpret_cast<uint32_t *>(&S.H2[0][0][0]))[i] = ((x * 31u) & 0x83ff83ffu) | 0x34003400u;
         }
     }
 
