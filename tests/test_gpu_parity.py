@@ -300,3 +300,26 @@ def test_abi_error_paths_on_device(gpu_model):
     # the model still works after the failed calls
     lg2, _ = gpu_model.classify_bytes(arena + ord("A"), off, ln, 100)
     assert torch.isfinite(lg2).all()
+
+
+def test_random_bytes_and_lengths_stress(gpu_model, oracle):
+    """arbitrary byte values (0x00..0xFF), ragged lengths around tile and chunk boundaries, overlapping / unordered offsets:
+    the HIP path must agree with the oracle and never read outside [off, off+len)"""
+    rng = np.random.default_rng(99)
+    for trial, (n, maxlen) in enumerate([(129, 67), (200, 130), (77, 300), (513, 100)]):
+        lens = rng.integers(0, maxlen + 40, n).astype(np.int32)
+        total = int(lens.sum())
+        arena = rng.integers(0, 256, total + 8, dtype=np.uint8)
+        # mostly valid bases so that the recurrence is exercised, with arbitrary bytes sprinkled in
+        valid = np.frombuffer(b"ACGTU", dtype=np.uint8)[rng.integers(0, 5, total + 8)]
+        arena = np.where(rng.random(total + 8) < 0.9, valid, arena).astype(np.uint8)
+        off = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(lens, out=off[1:])
+        perm = rng.permutation(n)                       # reads handed over in a different order than they lie in the arena
+        o2, l2 = off[:-1][perm], lens[perm]
+        ref = oracle.forward_packed(arena, np.concatenate([o2, [0]]), l2, maxlen)
+        from ribodetector_amd.data_loader import seq_encoder as E
+        b = E.batch_from_numpy(arena, o2, l2, "cuda")
+        lg, lab = gpu_model.classify_bytes(b.arena, b.offsets, b.lens, maxlen)
+        torch.cuda.synchronize()
+        _check(lg.cpu().numpy(), lab.cpu().numpy(), ref, "stress %d" % trial)
