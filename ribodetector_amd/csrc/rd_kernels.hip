@@ -1029,7 +1029,6 @@ struct EwRegs {
     f32x4 kc[2];        // table rows of the cells in flight, by cell parity
     f32x2 v[2][2];      // gate pipeline values by cell parity: {i,f} and {g,o} as register pairs (packed fp32 math)
     float y[2], og[2], hs[2];
-    _Float16 p16[2];
     f32x4 cs[2], hv[2]; // per row-tile, by row-tile parity
     f16x4 o1s[2], o2[2];
 };
@@ -1080,16 +1079,24 @@ __device__ __forceinline__ void rd_ew_unit(Lstm16bSmem &S, EwRegs &R, const f32x
         R.y[k] = __builtin_amdgcn_rcpf(R.y[k]);
     } else if constexpr (stage == 11) {
         R.hs[k] = R.og[k] * __builtin_fmaf(-2.0f * H_SCALE, R.y[k], H_SCALE);   // 2^11 h = 2^11 o tanh(c)
-        // keep the fp32 value opaque: without this the compiler fuses the multiply into v_fma_mixlo_f16 conversions, and that
-        // form measurably loses accuracy in the hi/lo split (logit error 2.5e-5 -> 1.2e-4 on the known-answer reads)
-        asm volatile("" : "+v"(R.hs[k]));
         R.hv[ap][b] = R.hs[k];                                       // captured state is kept at scale 2^11 (epilogue divides)
-        R.p16[k] = (_Float16)R.hs[k];                                // 2^11 h_hi'
     } else if constexpr (stage == 12) {
-        R.o1s[ap][b] = R.p16[k];
-        float res = R.hs[k] - (float)R.p16[k];                       // exact residual
-        asm volatile("" : "+v"(res));
-        R.o2[ap][b] = (_Float16)res;                                 // rounded once
+        // hi/lo split, two cells at a time (cells 2i and 2i+1 of a row-tile; the even cell's 2^11 h waits in R.hs[0]):
+        //   P  = {fp16(hs0), fp16(hs1)}                 one v_cvt_pk_f16_f32
+        //   r  = hs - fp32(P.half)  (exact, in fp32)    one v_fma_mix_f32 each (fp32 result: the fp16-output form
+        //                                               v_fma_mixlo_f16 measurably loses accuracy)
+        //   O2 = {fp16(r0), fp16(r1)}                   one v_cvt_pk_f16_f32
+        if constexpr (k == 1) {
+            typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+            const f16x2 P = {(_Float16)R.hs[0], (_Float16)R.hs[1]};
+            unsigned pbits = __builtin_bit_cast(unsigned, P);
+            float r0, r1;
+            asm volatile("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(R.hs[0]), "v"(pbits));
+            asm volatile("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(R.hs[1]), "v"(pbits));
+            const f16x2 O = {(_Float16)r0, (_Float16)r1};
+            R.o1s[ap][b - 1] = P[0]; R.o1s[ap][b] = P[1];
+            R.o2[ap][b - 1] = O[0]; R.o2[ap][b] = O[1];
+        }
     } else {   // 13: the row-tile's 4 cells are complete
         const int wo = c.j * H16STR + 32 * c.wave + 16 * c.half + 4 * a;
         *reinterpret_cast<f16x4 *>(&S.H1s[TP][0][0] + wo) = R.o1s[ap];
