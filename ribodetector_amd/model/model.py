@@ -155,6 +155,10 @@ class SeqModel:
         if want_labels and labels is None:
             labels = torch.empty((n,), dtype=torch.uint8, device=self.device)
         ws = self._workspace(n, max_len)
+        with torch.cuda.device(self.device):        # the kernels launch on the calling thread's current HIP device
+            return self._classify_launch(arena, offsets, lens, n, max_len, logits, labels, want_labels, ws)
+
+    def _classify_launch(self, arena, offsets, lens, n, max_len, logits, labels, want_labels, ws):
         N.check(N.lib().rd_classify(self._handle, N.ptr(arena), N.ptr(offsets), N.ptr(lens), n, int(max_len), N.ptr(logits),
                                     N.ptr(labels if want_labels else None), N.ptr(ws), ws.numel(), N.stream_ptr(self.device)),
                 "rd_classify")
@@ -216,6 +220,11 @@ def pair_fuse(logits1, logits2, ensure, counts=None):
     `counts` (uint64... stored as int64[3] tensor) is added to when given."""
     n = int(logits1.shape[0])
     out = torch.empty((n,), dtype=torch.int8, device=logits1.device)
+    with torch.cuda.device(logits1.device):
+        return _pair_fuse_launch(logits1, logits2, n, ensure, out, counts)
+
+
+def _pair_fuse_launch(logits1, logits2, n, ensure, out, counts):
     N.check(N.lib().rd_pair_fuse(N.ptr(logits1), N.ptr(logits2), n, N.ENSURE_MODES[ensure], N.ptr(out), N.ptr(counts),
                                  N.stream_ptr(logits1.device)), "rd_pair_fuse")
     return out
@@ -223,6 +232,7 @@ def pair_fuse(logits1, logits2, ensure, counts=None):
 
 def count_labels(labels, counts):
     """counts int64[3] device tensor (non-rRNA, rRNA, unclassified), added to (reference detect.py:485-486)."""
-    N.check(N.lib().rd_count_labels(N.ptr(labels), int(labels.numel()), N.ptr(counts), N.stream_ptr(labels.device)),
-            "rd_count_labels")
+    with torch.cuda.device(labels.device):
+        N.check(N.lib().rd_count_labels(N.ptr(labels), int(labels.numel()), N.ptr(counts), N.stream_ptr(labels.device)),
+                "rd_count_labels")
     return counts

@@ -77,3 +77,24 @@ def test_cli_argument_errors(tmp_path):
         detect.main(["-l", "100", "-i", "a.fq", "b.fq", "-o", "x.fq"])
     with pytest.raises(RuntimeError):
         detect.main(["-l", "100", "-i", "a.fq", "-o", "x.fq", "-r", "r1.fq", "r2.fq"])
+
+
+def test_cli_fasta_and_cpu_semantics(tmp_path, oracle):
+    """FASTA input (multi-line, lower-case -> upper-cased by the parser, like the reference) and the --semantics cpu switch"""
+    from ribodetector_amd import detect, synth
+    arena, off, lens = synth.reads_numpy(2000, (50, 140), seed=77)
+    seqs = synth.as_strings(arena, off)
+    inp = str(tmp_path / "in.fa")
+    with open(inp, "w") as fh:
+        for i, s in enumerate(seqs):
+            s2 = s.lower() if i % 3 == 0 else s
+            fh.write(">seq%d some text\n%s\n%s\n" % (i, s2[:60], s2[60:]))
+    for sem, fwd in (("gpu", oracle.forward_packed), ("cpu", oracle.forward_padded)):
+        out = str(tmp_path / ("out_%s.fa" % sem))
+        p = detect.main(["-l", "100", "-i", inp, "-o", out, "--semantics", sem])
+        ref = fwd(arena, off, lens, 100)          # the parser upper-cases FASTA, so the original upper-case reads are what is classified
+        lab = oracle.argmax(ref)
+        assert np.abs(ref[:, 1] - ref[:, 0]).min() > 2e-4
+        assert p.num_rrna == int(lab.sum())
+        want = "".join(">seq%d some text\n%s\n" % (i, seqs[i]) for i in np.flatnonzero(lab == 0))
+        assert _read(out) == want
