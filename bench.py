@@ -94,7 +94,7 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if args.gpus > 1 and world == 1:
         raise SystemExit("for --gpus N>1 launch with python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
-    dev = torch.device("cuda", local)
+    dev = torch.device("cuda", int(os.environ.get("RD_LOCAL_DEVICE", local)))   # override: several ranks on one GPU (tests only)
     torch.cuda.set_device(dev)
 
     cfg = ConfigParser.from_json(os.path.join(ROOT, "ribodetector_amd", "config.json"))
@@ -167,7 +167,7 @@ def main():
     launches, kms = model.profile_read()
     model.profile_enable(False)
     rdist.reduce_counts(counts)
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev if world == 1 or dist.get_backend() == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())

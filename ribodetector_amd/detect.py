@@ -77,7 +77,11 @@ class Predictor:
             self.logger.error('{}No visible GPU devices!{} This build runs the HIP kernels only; the CPU product of the '
                               'reference is ribodetector_cpu'.format(colors.FAIL, colors.ENDC))
             raise RuntimeError("Set HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES or use CPU inference.")
-        self.device = torch.device('cuda', self.local_rank if self.world > 1 else torch.cuda.current_device())
+        if self.world > 1:                       # one process per GPU; RD_LOCAL_DEVICE pins a rank elsewhere (ranks sharing a GPU)
+            self.device = torch.device('cuda', int(os.environ.get('RD_LOCAL_DEVICE', self.local_rank)))
+            torch.cuda.set_device(self.device)
+        else:
+            self.device = torch.device('cuda', torch.cuda.current_device())
         self.has_cuda = True
         model.load_state_dict(self.config.load_state_dict(self.state_key))
         self.logger.info('Model using {} for read length {}{}{}{} loaded'.format(
@@ -104,7 +108,11 @@ class Predictor:
     def classify_chunk(self, chunks):
         """chunks: (c1,) or (c1, c2). Returns the int8 labels of the whole chunk on rank 0 (numpy), None elsewhere."""
         n = len(chunks[0].seq_len)
-        lo, hi = rdist.shard_range(n, self.rank, self.world)
+        bounds = None
+        if self.world > 1:                       # equal bases (= recurrence steps) per rank, not equal read counts
+            work = sum(np.minimum(np.asarray(c.seq_len, dtype=np.int64), self.len) for c in chunks)
+            bounds = rdist.shard_bounds(n, self.world, work)
+        lo, hi = (0, n) if bounds is None else (bounds[self.rank], bounds[self.rank + 1])
         cs = self._copy_stream
         dev_in = [self._to_device(c, lo, hi, cs) for c in chunks]
         torch.cuda.current_stream(self.device).wait_stream(cs)
@@ -114,7 +122,7 @@ class Predictor:
         else:
             labels = outs[0][1].view(torch.int8)
         if self.world > 1:
-            labels = rdist.gather_labels(labels, n, dst=0)
+            labels = rdist.gather_labels(labels, n, dst=0, bounds=bounds)
             if self.rank != 0:
                 return None
         return labels.cpu().numpy()

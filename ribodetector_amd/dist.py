@@ -21,8 +21,8 @@ def init_from_env(backend=None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend is None:                      # RD_DIST_BACKEND=gloo: label exchange over host memory (e.g. several ranks
+            backend = os.environ.get("RD_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")   # sharing one GPU)
         if backend == "nccl":
             torch.cuda.set_device(local)
             dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
@@ -40,19 +40,39 @@ def shard_sizes(n, world):
     return [shard_range(n, r, world)[1] - shard_range(n, r, world)[0] for r in range(world)]
 
 
-def gather_labels(local_labels, n_total, dst=0, group=None, async_op=False, out=None):
+def shard_bounds(n, world, weights=None):
+    """W+1 boundaries of the contiguous shards of n reads. Without weights: r*n//W (equal read counts). With weights
+    (per-read work, e.g. min(len, max_len) summed over the mates): equal total work per rank, which is what balances the
+    ranks on variable-length input. Deterministic in (n, world, weights), so every rank computes
+    the same split from its own copy of the chunk."""
+    if weights is None or n == 0:
+        return [(r * n) // world for r in range(world + 1)]
+    import numpy as np
+    cs = np.cumsum(np.asarray(weights, dtype=np.int64))
+    total = int(cs[-1])
+    b = [0] + [int(np.searchsorted(cs, (r * total) // world, side="right")) for r in range(1, world)] + [n]
+    for r in range(1, world + 1):
+        b[r] = max(b[r], b[r - 1])
+    return b
+
+
+def gather_labels(local_labels, n_total, dst=0, group=None, async_op=False, out=None, bounds=None):
     """Gather the per-rank label vectors (int8/uint8, 1 B per read or pair) to rank `dst`, in input order.
 
-    Every rank passes its shard's labels (length shard_range(n_total, rank, world)). Returns the [n_total] tensor on
-    `dst` (None elsewhere); with async_op=True returns (tensor_or_None, finish) where finish() waits and trims."""
+    Every rank passes its shard's labels (length shard_range(n_total, rank, world), or bounds[rank+1]-bounds[rank] when the
+    shard_bounds() of a weighted split are given). Returns the [n_total] tensor on `dst` (None elsewhere); with
+    async_op=True returns (tensor_or_None, finish) where finish() waits and trims."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return (local_labels, (lambda: local_labels)) if async_op else local_labels
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    sizes = shard_sizes(n_total, world)
+    if local_labels.is_cuda and dist.get_backend(group) == "gloo":
+        local_labels, out = local_labels.cpu(), None
+    sizes = shard_sizes(n_total, world) if bounds is None else [bounds[r + 1] - bounds[r] for r in range(world)]
+    assert sum(sizes) == n_total
     assert local_labels.numel() == sizes[rank], (local_labels.numel(), sizes[rank])
     mx = max(sizes)
     send = local_labels
-    if send.numel() != mx:                       # shards differ by at most one element: pad to the common size
+    if send.numel() != mx:                       # pad to the common size (1 B per read: the padding is noise)
         send = torch.zeros(mx, dtype=local_labels.dtype, device=local_labels.device)
         send[: local_labels.numel()] = local_labels
     recv = None
@@ -76,5 +96,10 @@ def gather_labels(local_labels, n_total, dst=0, group=None, async_op=False, out=
 def reduce_counts(counts, group=None):
     """all-reduce(SUM) of the int64[3] counters; every rank gets the totals."""
     if dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
+        if counts.is_cuda and dist.get_backend(group) == "gloo":
+            host = counts.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            counts.copy_(host)
+        else:
+            dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
     return counts

@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n, ensure, tmp):
+def _worker(rank, world, port, n, ensure, tmp, weighted=False):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     from oracle import oracle as O
@@ -33,14 +33,19 @@ def _worker(rank, world, port, n, ensure, tmp):
     ora = O.load_default()
     a1, o1, l1 = synth.reads_numpy(n, (50, 110), seed=5)
     a2, o2, l2 = synth.reads_numpy(n, (50, 110), seed=6)
-    lo, hi = rdist.shard_range(n, rank, world)
+    bounds = None
+    if weighted:                                  # equal bases per rank (what detect.py does under torchrun)
+        bounds = rdist.shard_bounds(n, world, np.minimum(l1, 100).astype(np.int64) + np.minimum(l2, 100))
+        lo, hi = bounds[rank], bounds[rank + 1]
+    else:
+        lo, hi = rdist.shard_range(n, rank, world)
     # per-rank classifier = the CPU oracle on this rank's contiguous shard of the pairs
     g1 = ora.forward_packed(a1, o1[lo:hi + 1], l1[lo:hi], 100)
     g2 = ora.forward_packed(a2, o2[lo:hi + 1], l2[lo:hi], 100)
     lab = torch.from_numpy(ora.pair_fuse(g1, g2, ensure))
     counts = torch.tensor(ora.count_labels(lab.numpy()), dtype=torch.int64)
-    full = rdist.gather_labels(lab, n, dst=0)
-    _, fin = rdist.gather_labels(lab, n, dst=0, async_op=True)
+    full = rdist.gather_labels(lab, n, dst=0, bounds=bounds)
+    _, fin = rdist.gather_labels(lab, n, dst=0, async_op=True, bounds=bounds)
     full2 = fin()
     rdist.reduce_counts(counts)
     if rank == 0:
@@ -51,11 +56,11 @@ def _worker(rank, world, port, n, ensure, tmp):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n,ensure", [(101, "both"), (64, "rrna")])
-def test_two_rank_gather_matches_single(tmp_path, oracle, n, ensure):
+@pytest.mark.parametrize("n,ensure,weighted", [(101, "both", False), (64, "rrna", False), (97, "none", True)])
+def test_two_rank_gather_matches_single(tmp_path, oracle, n, ensure, weighted):
     from ribodetector_amd import synth
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, n, ensure, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, n, ensure, str(tmp_path), weighted), nprocs=2, join=True)
     a1, o1, l1 = synth.reads_numpy(n, (50, 110), seed=5)
     a2, o2, l2 = synth.reads_numpy(n, (50, 110), seed=6)
     want = oracle.pair_fuse(oracle.forward_packed(a1, o1, l1, 100), oracle.forward_packed(a2, o2, l2, 100), ensure)
@@ -75,6 +80,21 @@ def test_shard_ranges_cover_and_order():
             assert all(rs[i][1] == rs[i + 1][0] for i in range(w - 1))
             sz = rdist.shard_sizes(n, w)
             assert sum(sz) == n and max(sz) - min(sz) <= 1
+
+
+def test_weighted_bounds_balance_bases():
+    from ribodetector_amd import dist as rdist
+    rng = np.random.default_rng(3)
+    for n, w in ((1000, 8), (17, 3), (5, 8), (0, 4), (1, 2)):
+        lens = rng.integers(0, 301, n)
+        lens[: n // 2] = np.sort(lens[: n // 2])              # a sorted stretch: equal read counts would be unbalanced
+        b = rdist.shard_bounds(n, w, lens)
+        assert b[0] == 0 and b[-1] == n and all(b[i] <= b[i + 1] for i in range(w))
+        if n >= 100:
+            per = [int(lens[b[r]:b[r + 1]].sum()) for r in range(w)]
+            assert max(per) - min(per) <= 2 * 300, per         # within one or two reads' worth of bases
+    assert rdist.shard_bounds(10, 2) == [0, 5, 10]
+    assert rdist.shard_bounds(4, 2, [0, 0, 0, 0]) in ([0, 4, 4], [0, 0, 4])   # all-empty reads: any monotone split
 
 
 def test_single_process_passthrough():

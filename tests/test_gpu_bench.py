@@ -1,0 +1,52 @@
+"""bench.py contract on the GPU: one JSON line with every field the driver reads, at N=1 and under torchrun x2.
+The x2 case shares this box's single GPU (RD_LOCAL_DEVICE=0) and exchanges labels over gloo - it checks the multi-rank
+code path (shard seeds, async label gather, counter all-reduce, max-over-ranks timing), not the speed."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+        "dtype", "data", "config", "roofline")         # cpu_baseline is skipped here (--no-cpu-baseline): it takes ~20 s
+
+
+def _line(out):
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_single_gpu_contract():
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--pairs-per-step", "65536", "--no-alt",
+                        "--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _line(r.stdout)
+    for k in KEYS:
+        assert k in j, k
+    assert j["n_gpus"] == 1 and j["steps"] == 3 and j["warmup"] == 1 and j["unit"] == "reads/s" and j["scaling"] == "weak"
+    assert j["metric"] == "reads/sec classified, 100 bp paired-end" and j["higher_is_better"] is True
+    assert j["value"] > 1e6 and abs(j["value"] - 2 * 65536 * 3 / (j["ms_per_step"] * 3e-3)) < 1e-6 * j["value"]
+    rf = j["roofline"]
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    assert "workload" in j["config"] and "model" not in j["config"]
+
+
+def test_bench_two_ranks_one_gpu():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, RD_DIST_BACKEND="gloo", RD_LOCAL_DEVICE="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--pairs-per-step", "65536",
+           "--no-alt", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    j = _line(r.stdout)
+    assert j["n_gpus"] == 2 and j["value"] > 1e6
+    assert abs(j["value"] - 2 * 2 * 65536 * 3 / (j["ms_per_step"] * 3e-3)) < 1e-6 * j["value"]     # whole-job aggregate

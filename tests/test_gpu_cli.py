@@ -98,3 +98,36 @@ def test_cli_fasta_and_cpu_semantics(tmp_path, oracle):
         assert p.num_rrna == int(lab.sum())
         want = "".join(">seq%d some text\n%s\n" % (i, seqs[i]) for i in np.flatnonzero(lab == 0))
         assert _read(out) == want
+
+
+def test_cli_two_ranks_match_one(tmp_path):
+    """torchrun x2 (both ranks on this box's one GPU, labels exchanged over gloo) must write the same files as one process:
+    exercises the sharded path of the CLI - work-balanced bounds, sub-range H2D, label gather, rank-0-only output."""
+    import socket
+    import subprocess
+    import sys
+    from ribodetector_amd import detect, synth
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    n = 5000
+    a1, o1, _ = synth.reads_numpy(n, (40, 160), seed=51, rrna_frac=0.3)
+    a2, o2, _ = synth.reads_numpy(n, (40, 160), seed=52, rrna_frac=0.3)
+    i1, i2 = str(tmp_path / "r_1.fq"), str(tmp_path / "r_2.fq")
+    synth.write_fastq(i1, a1, o1, 1)
+    synth.write_fastq(i2, a2, o2, 2)
+    one = [str(tmp_path / x) for x in ("a1.fq", "a2.fq", "ar1.fq", "ar2.fq")]
+    p = detect.main(["-l", "120", "-i", i1, i2, "-o", *one[:2], "-r", *one[2:], "-e", "both", "--chunk_size", "1", "-m", "3"])
+    two = [str(tmp_path / x) for x in ("b1.fq", "b2.fq", "br1.fq", "br2.fq")]
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, RD_DIST_BACKEND="gloo", RD_LOCAL_DEVICE="0", PYTHONPATH=root)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "-m", "ribodetector_amd.detect", "-l", "120", "-i", i1, i2, "-o", *two[:2], "-r", *two[2:],
+           "-e", "both", "--chunk_size", "1", "-m", "3"]
+    r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert p.num_read == n and p.num_unknown > 0
+    for a, b in zip(one, two):
+        assert _read(a) == _read(b) and len(_read(a)) > 0
+    assert _read(one[0] + ".unclassified.gz") == _read(two[0] + ".unclassified.gz")
