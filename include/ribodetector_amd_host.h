@@ -43,6 +43,11 @@ void rd_reader_close(rd_reader *r);
 int rd_reader_next(rd_reader *r, int64_t max_records, uint8_t *buf, int64_t buf_cap, int64_t *rec_start, int64_t *seq_off,
                    int32_t *seq_len, int64_t *n, int64_t *nbytes);
 
+/* Decompress a whole gzip file (all members) into out[0..cap) with the reader's own DEFLATE decoder (csrc/rd_inflate.h);
+ * *n = bytes produced. Errors follow Python's gzip module, which the reference reads .gz input with: truncated stream,
+ * CRC / length mismatch, bad magic -> -1 + message. Used by the tests and for small side files. */
+int rd_host_gunzip(const char *path, uint8_t *out, int64_t cap, int64_t *n);
+
 /* Worker threads for gzip output (independent level-5 members compressed in parallel); 0 = auto (usable cores, <= 32).
  * Mirrors the reference's -t/--threads flag (detect.py:787). */
 int rd_host_set_threads(int threads);

@@ -93,7 +93,7 @@ def ptr(t):
 # ---- host ingest library (librd_host.so: C++ + zlib, no GPU) -------------------------------------------------------
 HOST_LIB_PATH = os.path.join(_HERE, "csrc", "librd_host.so")
 HOST_SYMBOLS = ["rd_reader_open", "rd_reader_close", "rd_reader_next", "rd_writer_open", "rd_writer_write_selected",
-                "rd_writer_close", "rd_host_last_error", "rd_host_set_threads"]
+                "rd_writer_close", "rd_host_last_error", "rd_host_set_threads", "rd_host_gunzip"]
 _host = None
 
 
@@ -114,6 +114,7 @@ def host_lib():
     L.rd_writer_write_selected.argtypes = [vp, vp, vp, i64, vp, C.c_int32]
     L.rd_writer_close.argtypes = [vp]
     L.rd_host_set_threads.argtypes = [C.c_int]
+    L.rd_host_gunzip.argtypes = [C.c_char_p, vp, i64, C.POINTER(i64)]
     L.rd_host_last_error.restype = C.c_char_p
     _host = L
     return L

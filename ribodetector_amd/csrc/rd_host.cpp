@@ -8,11 +8,15 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
 
 #include "../../include/ribodetector_amd_host.h"
+#include "rd_inflate.h"
 
 namespace {
 
@@ -33,8 +37,78 @@ inline bool is_ws(unsigned char c) { return c == ' ' || (c >= 9 && c <= 13) || c
 
 }  // namespace
 
+// Decompression runs ahead of the parser in its own thread: blocks of decompressed text wait in a short queue.
+struct rd_prefetch {
+    static constexpr size_t BLOCK = 4u << 20, DEPTH = 3;
+    rdz::GzipStream *gz;
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<std::vector<uint8_t>> ready, spare;
+    bool done = false, stop = false, failed = false;
+    std::string err;
+
+    explicit rd_prefetch(rdz::GzipStream *g) : gz(g) {
+        th = std::thread([this]() { run(); });
+    }
+    ~rd_prefetch() {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            stop = true;
+        }
+        cv.notify_all();
+        th.join();
+    }
+    void run() {
+        for (;;) {
+            std::vector<uint8_t> blk;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [this]() { return stop || ready.size() < DEPTH; });
+                if (stop) return;
+                if (!spare.empty()) {
+                    blk.swap(spare.front());
+                    spare.pop_front();
+                }
+            }
+            blk.resize(BLOCK);
+            const long got = gz->read(blk.data(), BLOCK);
+            std::lock_guard<std::mutex> lk(m);
+            if (got <= 0) {
+                failed = got < 0;
+                if (failed) err = gz->err;
+                done = true;
+                cv.notify_all();
+                return;
+            }
+            blk.resize((size_t)got);
+            ready.push_back(std::move(blk));
+            cv.notify_all();
+        }
+    }
+    // next block (empty = end of stream or error, see failed); `used` = the previous block, recycled
+    std::vector<uint8_t> next(std::vector<uint8_t> &&used) {
+        std::unique_lock<std::mutex> lk(m);
+        if (used.capacity()) spare.push_back(std::move(used));
+        cv.wait(lk, [this]() { return done || !ready.empty(); });
+        std::vector<uint8_t> blk;
+        if (!ready.empty()) {
+            blk.swap(ready.front());
+            ready.pop_front();
+            cv.notify_all();
+        }
+        return blk;
+    }
+};
+
 struct rd_reader {
-    gzFile fh;
+    FILE *fp = nullptr;
+    rdz::GzipStream *gz = nullptr;   // set when the file starts with the gzip magic; plain bytes otherwise
+    rd_prefetch *pf = nullptr;
+    std::vector<uint8_t> blk;        // gz: block being copied into the window, from blk_off
+    size_t blk_off = 0;
+    bool failed = false;             // decompression error: message in err
+    std::string err;
     int fasta;
     std::vector<uint8_t> in;     // raw input window
     size_t pos, end;             // unconsumed bytes are in[pos, end)
@@ -76,7 +150,22 @@ struct rd_reader {
             pos = 0;
         }
         if (end == in.size()) in.resize(in.size() * 2);
-        int got = gzread(fh, in.data() + end, (unsigned)std::min<size_t>(in.size() - end, 1u << 30));
+        long got;
+        if (gz) {
+            if (blk_off == blk.size()) {
+                blk = pf->next(std::move(blk));
+                blk_off = 0;
+            }
+            got = (long)std::min(in.size() - end, blk.size() - blk_off);
+            memcpy(in.data() + end, blk.data() + blk_off, (size_t)got);
+            blk_off += (size_t)got;
+            if (got == 0 && pf->failed) {   // set before the empty block was handed over
+                failed = true;
+                err = pf->err;
+            }
+        } else {
+            got = (long)fread(in.data() + end, 1, in.size() - end, fp);
+        }
         if (got <= 0) {
             eof = true;
             return false;
@@ -171,14 +260,24 @@ int rd_reader_open(const char *path, int format, rd_reader **out) {
         else if (ends_with(stem, ".fasta") || ends_with(stem, ".fa") || ends_with(stem, ".fna") || ends_with(stem, ".fas")) format = 1;
         else RDH_FAIL("Unknown extension of %s. Only fastq and fasta sequence formats are supported.", path);
     }
-    gzFile fh = gzopen(path, "rb");   // transparently reads plain files too
-    if (!fh) RDH_FAIL("cannot open %s", path);
-    gzbuffer(fh, 1 << 20);
+    FILE *fp = fopen(path, "rb");
+    if (!fp) RDH_FAIL("cannot open %s", path);
+    setvbuf(fp, nullptr, _IONBF, 0);   // both paths read in MiB-sized pieces themselves
     rd_reader *r = new rd_reader();
-    r->fh = fh;
+    r->fp = fp;
     r->fasta = format;
     r->in.resize(8 << 20);
     r->pos = r->end = 0;
+    // gzip is recognised by its magic, like zlib's gzopen (a superset of the reference's by-extension rule)
+    uint8_t magic[2];
+    const size_t got = fread(magic, 1, 2, fp);
+    if (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
+        r->gz = new rdz::GzipStream(fp, magic, 2);
+        r->pf = new rd_prefetch(r->gz);
+    } else {
+        memcpy(r->in.data(), magic, got);
+        r->end = got;
+    }
     r->eof = false;
     r->scan_next = 0;
     *out = r;
@@ -187,7 +286,9 @@ int rd_reader_open(const char *path, int format, rd_reader **out) {
 
 void rd_reader_close(rd_reader *r) {
     if (!r) return;
-    gzclose(r->fh);
+    delete r->pf;   // joins the decompression thread first
+    delete r->gz;
+    fclose(r->fp);
     delete r;
 }
 
@@ -201,6 +302,7 @@ int rd_reader_next(rd_reader *r, int64_t max_records, uint8_t *buf, int64_t buf_
         while (n < max_records) {
             size_t lb[4], le[4];
             const int got = r->scan_lines(4, lb, le);
+            if (r->failed) RDH_FAIL("%s", r->err.c_str());
             if (got == 0) { at_eof = true; break; }   // clean end of file
             if (got < 4) {
                 bool blank = true;   // tolerate trailing blank lines only
@@ -253,7 +355,9 @@ int rd_reader_next(rd_reader *r, int64_t max_records, uint8_t *buf, int64_t buf_
         };
         while (n < max_records) {
             size_t lb, le;
-            if (r->scan_lines(1, &lb, &le) == 0) {   // end of input
+            const int got = r->scan_lines(1, &lb, &le);
+            if (r->failed) RDH_FAIL("%s", r->err.c_str());
+            if (got == 0) {   // end of input
                 if (!r->pending_seq.empty()) {
                     int rc = emit();
                     if (rc < 0) return -1;
@@ -288,6 +392,37 @@ int rd_reader_next(rd_reader *r, int64_t max_records, uint8_t *buf, int64_t buf_
     *n_out = n;
     *nbytes_out = w;
     return at_eof ? 1 : 0;
+}
+
+int rd_host_gunzip(const char *path, uint8_t *out, int64_t cap, int64_t *n_out) {
+    if (!path || !out || !n_out) RDH_FAIL("rd_host_gunzip: null argument");
+    FILE *fp = fopen(path, "rb");
+    if (!fp) RDH_FAIL("cannot open %s", path);
+    setvbuf(fp, nullptr, _IONBF, 0);
+    int64_t n = 0;
+    int rc = 0;
+    {
+        rdz::GzipStream gz(fp, nullptr, 0);
+        for (;;) {
+            uint8_t extra;
+            const long got = n < cap ? gz.read(out + n, (size_t)(cap - n)) : gz.read(&extra, 1);
+            if (got < 0) {
+                snprintf(g_err, sizeof(g_err), "%s", gz.err.c_str());
+                rc = -1;
+                break;
+            }
+            if (got == 0) break;
+            if (n >= cap) {
+                snprintf(g_err, sizeof(g_err), "rd_host_gunzip: output exceeds the buffer (%lld bytes)", (long long)cap);
+                rc = -1;
+                break;
+            }
+            n += got;
+        }
+    }
+    fclose(fp);
+    *n_out = n;
+    return rc;
 }
 
 int rd_host_set_threads(int threads) {

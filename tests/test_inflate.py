@@ -1,0 +1,164 @@
+"""The reader's own gzip/DEFLATE decoder (ribodetector_amd/csrc/rd_inflate.h) against zlib/Python's gzip - which is what
+the reference reads .gz input with (data_loader/fastx_parser.py, seq_encoder.py:75-92): identical bytes for every block
+type and framing feature, and an error (not silent truncation) for damaged files."""
+import ctypes as C
+import gzip
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+from ribodetector_amd import _native as N
+from ribodetector_amd import synth
+from ribodetector_amd.data_loader import fastx_parser as fx
+
+
+def gunzip(path, cap):
+    L = N.host_lib()
+    out = np.empty(max(cap, 1), dtype=np.uint8)
+    n = C.c_int64(0)
+    rc = L.rd_host_gunzip(str(path).encode(), out.ctypes.data, cap, C.byref(n))
+    return rc, out[: n.value].tobytes(), L.rd_host_last_error().decode()
+
+
+def member(data, level=5, strategy=zlib.Z_DEFAULT_STRATEGY, flags=0, mem=8, wbits=15):
+    """one gzip member built by hand so that header flags and deflate strategies can be chosen"""
+    co = zlib.compressobj(level, zlib.DEFLATED, -wbits, mem, strategy)
+    body = co.compress(data) + co.flush()
+    hdr = b"\x1f\x8b\x08" + bytes([flags]) + b"\0\0\0\0\x02\xff"
+    if flags & 4:
+        hdr += struct.pack("<H", 7) + b"EXTRA!!"
+    if flags & 8:
+        hdr += b"reads_1.fastq\0"
+    if flags & 16:
+        hdr += b"a comment\0"
+    if flags & 2:
+        hdr += struct.pack("<H", zlib.crc32(hdr) & 0xffff)
+    return hdr + body + struct.pack("<II", zlib.crc32(data) & 0xffffffff, len(data) & 0xffffffff)
+
+
+def fastq_bytes(n, seed=3):
+    arena, off, _ = synth.reads_numpy(n, (60, 150), seed=seed)
+    b = arena.tobytes()
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        s = b[off[i]:off[i + 1]]
+        q = bytes(rng.integers(35, 74, len(s), dtype=np.uint8))
+        out.append(b"@read.%d/1 lane=3\n%s\n+\n%s\n" % (i, s, q))
+    return b"".join(out)
+
+
+RNG = np.random.default_rng(11)
+PAYLOADS = {
+    "empty": b"",
+    "one": b"A",
+    "fastq": fastq_bytes(20000),                                           # ~6 MB: several output blocks, input refills
+    "random": RNG.integers(0, 256, 3 << 20, dtype=np.uint8).tobytes(),     # incompressible: stored blocks / long codes
+    "zeros": bytes(5 << 20),                                               # distance-1 matches of length 258
+    "period3": b"ACG" * 900001,                                            # overlapping copies with distance < 8
+    "period7": b"ACGTTGA" * 400000,
+    "skewed": bytes(RNG.choice(np.arange(256, dtype=np.uint8), 2 << 20, p=np.r_[0.7, np.full(255, 0.3 / 255)])),  # long Huffman codes
+}
+
+
+@pytest.mark.parametrize("name", list(PAYLOADS))
+@pytest.mark.parametrize("level,strategy", [(0, zlib.Z_DEFAULT_STRATEGY), (1, zlib.Z_DEFAULT_STRATEGY), (5, zlib.Z_DEFAULT_STRATEGY),
+                                            (9, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_FIXED), (6, zlib.Z_HUFFMAN_ONLY), (6, zlib.Z_RLE)])
+def test_inflate_matches_zlib(tmp_path, name, level, strategy):
+    data = PAYLOADS[name]
+    p = tmp_path / "x.gz"
+    p.write_bytes(member(data, level, strategy))
+    assert gzip.decompress(p.read_bytes()) == data                         # the fixture itself is valid gzip
+    rc, got, err = gunzip(p, len(data) + 16)
+    assert rc == 0, err
+    assert got == data
+
+
+def test_gzip_framing_features(tmp_path):
+    a, b, c = PAYLOADS["fastq"][:300000], b"second member\n" * 1000, PAYLOADS["random"][:70000]
+    blob = member(a, 5, flags=4 | 8 | 16 | 2) + member(b"", 6) + member(b, 9, flags=8) + bytes(37) + member(c, 1) + bytes(512)
+    p = tmp_path / "multi.gz"
+    p.write_bytes(blob)
+    assert gzip.decompress(blob) == a + b + c                              # Python's gzip: members concatenate, zero padding skipped
+    rc, got, err = gunzip(p, len(a + b + c) + 1)
+    assert rc == 0, err
+    assert got == a + b + c
+    # small windows / memory levels change the block structure, not the format
+    p.write_bytes(member(PAYLOADS["fastq"], 7, mem=1, wbits=9))
+    rc, got, err = gunzip(p, len(PAYLOADS["fastq"]))
+    assert rc == 0 and got == PAYLOADS["fastq"], err
+    # gzip module / command line produce the same thing
+    p.write_bytes(gzip.compress(a, 6))
+    assert gunzip(p, len(a))[1] == a
+
+
+def test_damaged_files_are_errors(tmp_path):
+    data = PAYLOADS["fastq"][:2000000]
+    good = member(data, 5)
+    p = tmp_path / "bad.gz"
+    for cut in (5, 11, 200, len(good) // 2, len(good) - 9, len(good) - 8, len(good) - 1):
+        p.write_bytes(good[:cut])
+        with pytest.raises(Exception):
+            gzip.decompress(good[:cut])                                    # the reference's reader fails on these too
+        rc, _, err = gunzip(p, len(data) + 16)
+        assert rc != 0 and "ended before the end-of-stream marker" in err, (cut, err)
+    crc_bad = bytearray(good)
+    crc_bad[-6] ^= 0x10
+    p.write_bytes(bytes(crc_bad))
+    rc, _, err = gunzip(p, len(data) + 16)
+    assert rc != 0 and "CRC check failed" in err
+    size_bad = bytearray(good)
+    size_bad[-2] ^= 0x01
+    p.write_bytes(bytes(size_bad))
+    rc, _, err = gunzip(p, len(data) + 16)
+    assert rc != 0 and "Incorrect length" in err
+    rng = np.random.default_rng(5)
+    detected = 0
+    for _ in range(40):                                                    # a flipped bit anywhere in the body is caught
+        x = bytearray(good)
+        x[int(rng.integers(10, len(good) - 8))] ^= 1 << int(rng.integers(0, 8))
+        p.write_bytes(bytes(x))
+        rc, got, err = gunzip(p, len(data) + 1024)
+        detected += rc != 0
+        assert rc != 0 or got == data
+    assert detected == 40
+    p.write_bytes(good + b"trailing garbage")
+    rc, _, err = gunzip(p, len(data) + 16)
+    assert rc != 0 and "Not a gzipped file" in err
+    p.write_bytes(good)
+    rc, _, err = gunzip(p, len(data) - 1)                                  # caller buffer too small
+    assert rc != 0 and "exceeds the buffer" in err
+
+
+def test_random_deflate_streams_never_crash(tmp_path):
+    """arbitrary bytes after a valid header: any outcome but a crash / out-of-bounds access is fine"""
+    rng = np.random.default_rng(9)
+    p = tmp_path / "fuzz.gz"
+    for i in range(300):
+        body = rng.integers(0, 256, int(rng.integers(1, 4000)), dtype=np.uint8).tobytes()
+        p.write_bytes(b"\x1f\x8b\x08\0\0\0\0\0\x02\xff" + body)
+        rc, got, err = gunzip(p, 1 << 20)
+        assert rc in (0, -1)
+    good = member(PAYLOADS["fastq"][:100000], 6)
+    for i in range(300):                                                   # mutate a valid stream: exercises deeper states
+        x = bytearray(good)
+        for _ in range(int(rng.integers(1, 4))):
+            x[int(rng.integers(10, len(x)))] = int(rng.integers(0, 256))
+        p.write_bytes(bytes(x))
+        rc, got, err = gunzip(p, 1 << 20)
+        assert rc in (0, -1)
+
+
+def test_reader_reports_truncated_gzip(tmp_path):
+    arena, off, _ = synth.reads_numpy(50000, 100, seed=8)
+    fq = tmp_path / "r.fq.gz"
+    synth.write_fastq(str(fq), arena, off, 1)
+    whole = fq.read_bytes()
+    assert sum(len(c.seq_len) for c in fx.get_seq_chunks(str(fq), 8192)) == 50000
+    cut = tmp_path / "cut.fq.gz"
+    cut.write_bytes(whole[: len(whole) * 2 // 3])
+    with pytest.raises(ValueError, match="ended before the end-of-stream marker"):
+        for _ in fx.get_seq_chunks(str(cut), 8192):
+            pass
