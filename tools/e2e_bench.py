@@ -1,0 +1,52 @@
+#!/usr/bin/env python
+"""End-to-end CLI rate on this machine's GPU: FASTQ file(s) in -> classified FASTQ file(s) out, wall clock around
+detect.main() (model load, parsing, H2D, kernels, D2H, writing). python tools/e2e_bench.py [--reads 4000000]"""
+import argparse
+import gzip
+import json
+import os
+import shutil
+import sys
+import tempfile
+import time
+
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
+from ribodetector_amd import detect, synth      # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reads", type=int, default=4000000)
+    a = ap.parse_args()
+    d = tempfile.mkdtemp(prefix="rde2e", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    files = {}
+    for mate, seed in ((1, 1), (2, 2)):
+        arena, off, _ = synth.reads_numpy(a.reads, 100, seed=seed)
+        p = os.path.join(d, "r_%d.fq" % mate)
+        synth.write_fastq(p, arena, off, mate)
+        with open(p, "rb") as fi, gzip.open(p + ".gz", "wb", compresslevel=5) as fo:
+            shutil.copyfileobj(fi, fo, 1 << 24)
+        files[mate] = p
+    out = {"reads_per_file": a.reads}
+
+    def run(tag, inputs, outputs, extra=()):
+        t = time.perf_counter()
+        p = detect.main(["-l", "100", "-i", *inputs, "-o", *outputs, *extra])      # default chunking: 1 Mi reads per chunk
+        dt = time.perf_counter() - t
+        out[tag] = {"reads_per_s": len(inputs) * a.reads / dt, "seconds": dt, "rrna": p.num_rrna, "non_rrna": p.num_nonrrna}
+
+    o = lambda n: os.path.join(d, n)     # noqa: E731
+    run("first_call_se_plain", [files[1]], [o("w.fq")])        # includes HIP start-up, model load, first pinned allocations
+    run("first_call_pe_plain", [files[1], files[2]], [o("w1.fq"), o("w2.fq")], ["-e", "rrna"])
+    run("se_plain_to_plain", [files[1]], [o("a.fq")])
+    run("se_gz_to_plain", [files[1] + ".gz"], [o("b.fq")])
+    run("se_gz_to_gz", [files[1] + ".gz"], [o("c.fq.gz")])
+    run("pe_plain_to_plain", [files[1], files[2]], [o("d1.fq"), o("d2.fq")], ["-e", "rrna"])
+    run("pe_gz_to_plain", [files[1] + ".gz", files[2] + ".gz"], [o("e1.fq"), o("e2.fq")], ["-e", "rrna"])
+    run("pe_gz_to_gz", [files[1] + ".gz", files[2] + ".gz"], [o("f1.fq.gz"), o("f2.fq.gz")], ["-e", "rrna"])
+    shutil.rmtree(d, ignore_errors=True)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
