@@ -48,7 +48,8 @@ int rd_reader_next(rd_reader *r, int64_t max_records, uint8_t *buf, int64_t buf_
  * CRC / length mismatch, bad magic -> -1 + message. Used by the tests and for small side files. */
 int rd_host_gunzip(const char *path, uint8_t *out, int64_t cap, int64_t *n);
 
-/* Worker threads for gzip output (independent level-5 members compressed in parallel); 0 = auto (usable cores, <= 32).
+/* Worker threads for gzip output (independent level-5 members compressed in parallel, by libdeflate.so.0 when the system
+ * has it - bound at run time - else zlib; RD_HOST_ZLIB=1 forces zlib); 0 = auto (usable cores, <= 32).
  * Mirrors the reference's -t/--threads flag (detect.py:787). */
 int rd_host_set_threads(int threads);
 

@@ -1,6 +1,7 @@
 // rd_host.cpp - host-side FASTQ/FASTA ingest and label-partitioned output (librd_host.so). See
 // include/ribodetector_amd_host.h for the reference interfaces this replaces.
 #include <ctype.h>
+#include <dlfcn.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -183,7 +184,36 @@ struct rd_writer {
     bool gz;
     int threads;
     std::vector<uint8_t> pending;   // gz only: selected record bytes not yet compressed
+    std::vector<void *> comp;       // gz only: one libdeflate compressor per worker slot (empty: zlib)
 };
+
+// libdeflate (a system library of this image, libdeflate0 1.10) compresses level 5 ~2.5x faster than zlib at the same
+// ratio; it is bound at run time so that the library still loads - and falls back to zlib - where it is absent.
+// RD_HOST_ZLIB=1 forces the zlib path.
+struct LibDeflate {
+    void *(*alloc)(int) = nullptr;
+    void (*release)(void *) = nullptr;
+    size_t (*gzip_compress)(void *, const void *, size_t, void *, size_t) = nullptr;
+    size_t (*gzip_bound)(void *, size_t) = nullptr;
+    bool ok = false;
+};
+
+const LibDeflate &libdeflate() {
+    static const LibDeflate L = []() {
+        LibDeflate l;
+        const char *force = getenv("RD_HOST_ZLIB");
+        if (force && force[0] == '1') return l;
+        void *h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+        if (!h) return l;
+        l.alloc = (void *(*)(int))dlsym(h, "libdeflate_alloc_compressor");
+        l.release = (void (*)(void *))dlsym(h, "libdeflate_free_compressor");
+        l.gzip_compress = (size_t(*)(void *, const void *, size_t, void *, size_t))dlsym(h, "libdeflate_gzip_compress");
+        l.gzip_bound = (size_t(*)(void *, size_t))dlsym(h, "libdeflate_gzip_compress_bound");
+        l.ok = l.alloc && l.release && l.gzip_compress && l.gzip_bound;
+        return l;
+    }();
+    return L;
+}
 
 int g_threads = 0;                  // 0 = auto
 
@@ -207,7 +237,16 @@ int usable_threads() {
 
 constexpr size_t GZ_BLOCK = 4u << 20;   // uncompressed bytes per gzip member
 
-bool gz_member(const uint8_t *src, size_t len, std::vector<uint8_t> &out) {
+bool gz_member(const uint8_t *src, size_t len, std::vector<uint8_t> &out, void *comp) {
+    if (comp) {
+        const LibDeflate &L = libdeflate();
+        out.resize(L.gzip_bound(comp, len));
+        const size_t n = L.gzip_compress(comp, src, len, out.data(), out.size());
+        if (n) {
+            out.resize(n);
+            return true;
+        }
+    }
     z_stream zs;
     memset(&zs, 0, sizeof(zs));
     if (deflateInit2(&zs, 5, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
@@ -224,26 +263,50 @@ bool gz_member(const uint8_t *src, size_t len, std::vector<uint8_t> &out) {
     return true;
 }
 
-// compress w->pending[0, upto) as members of GZ_BLOCK bytes, `threads` at a time, and write them in order
+// compress w->pending[0, upto) as members of GZ_BLOCK bytes and write them in order: the workers take blocks from a shared
+// counter (no barrier between batches), the calling thread writes each member as soon as it and its predecessors are done
 int gz_flush(rd_writer *w, size_t upto) {
-    size_t nblk = (upto + GZ_BLOCK - 1) / GZ_BLOCK;
-    for (size_t b0 = 0; b0 < nblk; b0 += (size_t)w->threads) {
-        const size_t nb = std::min<size_t>((size_t)w->threads, nblk - b0);
-        std::vector<std::vector<uint8_t>> outs(nb);
-        std::vector<char> ok(nb, 0);
-        std::vector<std::thread> th;
-        for (size_t k = 0; k < nb; ++k) {
-            const size_t off = (b0 + k) * GZ_BLOCK, len = std::min(GZ_BLOCK, upto - off);
-            th.emplace_back([w, off, len, k, &outs, &ok]() { ok[k] = gz_member(w->pending.data() + off, len, outs[k]) ? 1 : 0; });
-        }
-        for (auto &t : th) t.join();
-        for (size_t k = 0; k < nb; ++k) {
-            if (!ok[k]) return -1;
-            if (fwrite(outs[k].data(), 1, outs[k].size(), w->fp) != outs[k].size()) return -1;
-        }
+    const size_t nblk = (upto + GZ_BLOCK - 1) / GZ_BLOCK;
+    std::vector<std::vector<uint8_t>> outs(nblk);
+    std::vector<signed char> state(nblk, 0);   // 0 = pending, 1 = compressed, -1 = failed (guarded by m)
+    std::mutex m;
+    std::condition_variable cv;
+    size_t next = 0;
+    const size_t nthreads = std::min<size_t>((size_t)std::max(1, w->threads), nblk);
+    std::vector<std::thread> th;
+    for (size_t t = 0; t < nthreads; ++t) {
+        void *comp = t < w->comp.size() ? w->comp[t] : nullptr;
+        th.emplace_back([&, comp]() {
+            for (;;) {
+                size_t b;
+                {
+                    std::lock_guard<std::mutex> lk(m);
+                    if (next >= nblk) return;
+                    b = next++;
+                }
+                const size_t off = b * GZ_BLOCK, len = std::min(GZ_BLOCK, upto - off);
+                const bool ok = gz_member(w->pending.data() + off, len, outs[b], comp);
+                {
+                    std::lock_guard<std::mutex> lk(m);
+                    state[b] = ok ? 1 : -1;
+                }
+                cv.notify_all();
+            }
+        });
     }
+    int rc = 0;
+    for (size_t b = 0; b < nblk; ++b) {
+        {
+            std::unique_lock<std::mutex> lk(m);
+            cv.wait(lk, [&]() { return state[b] != 0; });
+            if (state[b] < 0) rc = -1;
+        }
+        if (rc == 0 && fwrite(outs[b].data(), 1, outs[b].size(), w->fp) != outs[b].size()) rc = -1;
+        std::vector<uint8_t>().swap(outs[b]);
+    }
+    for (auto &t : th) t.join();
     w->pending.erase(w->pending.begin(), w->pending.begin() + (ptrdiff_t)upto);
-    return 0;
+    return rc;
 }
 
 extern "C" {
@@ -442,6 +505,8 @@ int rd_writer_open(const char *path, rd_writer **out) {
         RDH_FAIL("cannot open %s for writing", path);
     }
     setvbuf(w->fp, nullptr, _IOFBF, 4 << 20);
+    if (w->gz && libdeflate().ok)
+        for (int k = 0; k < w->threads; ++k) w->comp.push_back(libdeflate().alloc(5));   // reference: compresslevel=5
     *out = w;
     return 0;
 }
@@ -477,9 +542,10 @@ int rd_writer_close(rd_writer *w) {
         if (!w->pending.empty()) rc = gz_flush(w, w->pending.size());
         else if (ftell(w->fp) == 0) {   // an empty .gz must still be a valid gzip file (one empty member)
             std::vector<uint8_t> m;
-            rc = gz_member(nullptr, 0, m) && fwrite(m.data(), 1, m.size(), w->fp) == m.size() ? 0 : -1;
+            rc = gz_member(nullptr, 0, m, nullptr) && fwrite(m.data(), 1, m.size(), w->fp) == m.size() ? 0 : -1;
         }
     }
+    for (void *c : w->comp) libdeflate().release(c);
     if (fclose(w->fp) != 0) rc = -1;
     delete w;
     if (rc) RDH_FAIL("close failed");

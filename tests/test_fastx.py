@@ -179,3 +179,29 @@ def test_gzip_writer_members(tmp_path):
     w.close()
     with gzip.open(empty, "rb") as fh:
         assert fh.read() == b""
+
+
+def test_gzip_writer_zlib_fallback(tmp_path):
+    """RD_HOST_ZLIB=1 (or a machine without libdeflate.so.0) takes the zlib path: same decompressed bytes, and the
+    library's own reader/decoder reads both back."""
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    arena, off, _ = synth.reads_numpy(40000, 120, seed=9)
+    src = str(tmp_path / "in.fq")
+    synth.write_fastq(src, arena, off, mate=1)
+    code = ("import sys, numpy as np; sys.path.insert(0, %r)\n"
+            "from ribodetector_amd.data_loader import fastx_parser as fx\n"
+            "w = fx.open_for_write(sys.argv[2])\n"
+            "for c in fx.get_seq_chunks(sys.argv[1], 9000):\n"
+            "    w.write_selected(c, (np.arange(len(c.seq_len)) %% 3 != 0).astype(np.int8), 1)\n"
+            "w.close()\n") % root
+    outs = {}
+    for tag, env in (("auto", {}), ("zlib", {"RD_HOST_ZLIB": "1"})):
+        out = str(tmp_path / ("o_%s.fq.gz" % tag))
+        subprocess.run([sys.executable, "-c", code, src, out], check=True, env=dict(os.environ, **env), timeout=300)
+        with gzip.open(out, "rb") as fh:
+            outs[tag] = fh.read()
+        got = b"".join(c.buf[c.rec_start[0]:c.rec_start[-1]].tobytes() for c in fx.get_seq_chunks(out, 5000))
+        assert got == outs[tag]
+    assert outs["auto"] == outs["zlib"] and outs["auto"].count(b"\n") == 4 * (40000 - 13334)
