@@ -28,6 +28,7 @@
 #include "../../include/ribodetector_amd.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -1473,57 +1474,154 @@ __global__ __launch_bounds__(512, 2) void rd_lstm_mfma_f16x3_w8_kernel(DevModel 
 // ------------------------------------------------------------------------------------------------
 // standalone encoders (reference tensor layouts). HBM-bound streaming kernels.
 // ------------------------------------------------------------------------------------------------
-// codes[n][stride] u8: one workgroup row-block per read group; consecutive lanes walk consecutive bases.
-__global__ void rd_encode_codes_kernel(const uint8_t *__restrict__ arena, const int64_t *__restrict__ off,
-                                       const int32_t *__restrict__ len, int64_t n, int max_len, int stride,
-                                       uint8_t *__restrict__ codes) {
-    // one wave per read, grid-stride over reads; 64 consecutive bytes per wave instruction
-    const int lane = threadIdx.x & 63;
-    const int64_t wave_id = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    for (int64_t i = wave_id; i < n; i += nwaves) {
-        const int T = rd_T(len, i, max_len);
-        const uint8_t *src = arena + off[i];
-        uint8_t *dst = codes + (size_t)i * stride;
-        for (int j = lane; j < stride; j += 64) dst[j] = (uint8_t)(j < T ? rd_code(src[j]) : 4);
+// All three give one workgroup a block of ENC_R reads whose output range is contiguous, stage the reads' offsets and
+// lengths in LDS once, and let consecutive lanes write consecutive 4-/16-byte pieces of that range, so every wave store
+// covers whole cache lines whatever the read length is.
+constexpr int ENC_R = 64;
+
+__device__ __forceinline__ f32x4 rd_onehot(int code) {
+    return f32x4{code == 0 ? 1.f : 0.f, code == 1 ? 1.f : 0.f, code == 2 ? 1.f : 0.f, code == 3 ? 1.f : 0.f};
+}
+
+// codes[n][stride] u8 (4 = pad / not ACGTU): 4 output bytes per lane and iteration, one aligned dword store when VEC
+template <bool VEC>
+__global__ __launch_bounds__(256) void rd_encode_codes_kernel(const uint8_t *__restrict__ arena, const int64_t *__restrict__ off,
+                                                              const int32_t *__restrict__ len, int64_t n, int max_len, int stride,
+                                                              uint8_t *__restrict__ codes) {
+    __shared__ int64_t s_off[ENC_R];
+    __shared__ int s_T[ENC_R];
+    for (int64_t r0 = (int64_t)blockIdx.x * ENC_R; r0 < n; r0 += (int64_t)gridDim.x * ENC_R) {
+        const int R = (int)(n - r0 < ENC_R ? n - r0 : ENC_R);
+        __syncthreads();
+        if ((int)threadIdx.x < R) {
+            s_off[threadIdx.x] = off[r0 + threadIdx.x];
+            s_T[threadIdx.x] = rd_T(len, r0 + threadIdx.x, max_len);
+        }
+        __syncthreads();
+        const unsigned total = (unsigned)R * (unsigned)stride;
+        uint8_t *dst = codes + (size_t)r0 * stride;
+        for (unsigned e = threadIdx.x * 4; e < total; e += 1024) {
+            unsigned i = e / (unsigned)stride, j = e - i * (unsigned)stride;
+            uint32_t w = 0;
+            if (j + 4 <= (unsigned)s_T[i]) {   // four bases of one read: one (unaligned) dword load
+                uint32_t raw;
+                __builtin_memcpy(&raw, arena + s_off[i] + j, 4);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) w |= (unsigned)rd_code((raw >> (8 * b)) & 0xff) << (8 * b);
+            } else {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    unsigned c = 4;
+                    if (e + b < total && j < (unsigned)s_T[i]) c = (unsigned)rd_code(arena[s_off[i] + j]);
+                    w |= c << (8 * b);
+                    if (++j == (unsigned)stride) {
+                        j = 0;
+                        ++i;
+                    }
+                }
+            }
+            if (VEC && e + 4 <= total) {
+                *(uint32_t *)(dst + e) = w;
+            } else {
+                for (int b = 0; b < 4 && e + b < total; ++b) dst[e + b] = (uint8_t)(w >> (8 * b));
+            }
+        }
     }
 }
 
-// onehot[n][max_len][4] fp32 (encode_variable_len_read): one lane per (read, base) -> one float4 store (16 B/lane)
-__global__ void rd_encode_onehot_padded_kernel(const uint8_t *__restrict__ arena, const int64_t *__restrict__ off,
-                                               const int32_t *__restrict__ len, int64_t n, int max_len,
-                                               f32x4 *__restrict__ out) {
-    const int64_t total = n * (int64_t)max_len;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t i = e / max_len;
-        const int j = (int)(e % max_len);
-        int code = 4;
-        if (j < rd_T(len, i, max_len)) code = rd_code(arena[off[i] + j]);
-        out[e] = f32x4{code == 0 ? 1.f : 0.f, code == 1 ? 1.f : 0.f, code == 2 ? 1.f : 0.f, code == 3 ? 1.f : 0.f};
+// onehot[n][max_len][4] fp32 (encode_variable_len_read): one 16-byte store per lane, consecutive lanes consecutive rows
+__global__ __launch_bounds__(256) void rd_encode_onehot_padded_kernel(const uint8_t *__restrict__ arena, const int64_t *__restrict__ off,
+                                                                      const int32_t *__restrict__ len, int64_t n, int max_len,
+                                                                      f32x4 *__restrict__ out) {
+    __shared__ int64_t s_off[ENC_R];
+    __shared__ int s_T[ENC_R];
+    const unsigned L = (unsigned)max_len, dq = 256u / L, dr = 256u % L;
+    for (int64_t r0 = (int64_t)blockIdx.x * ENC_R; r0 < n; r0 += (int64_t)gridDim.x * ENC_R) {
+        const int R = (int)(n - r0 < ENC_R ? n - r0 : ENC_R);
+        __syncthreads();
+        if ((int)threadIdx.x < R) {
+            s_off[threadIdx.x] = off[r0 + threadIdx.x];
+            s_T[threadIdx.x] = rd_T(len, r0 + threadIdx.x, max_len);
+        }
+        __syncthreads();
+        const unsigned total = (unsigned)R * L;
+        f32x4 *dst = out + (size_t)r0 * L;
+        unsigned i = threadIdx.x / L, j = threadIdx.x - i * L;
+        for (unsigned e = threadIdx.x; e < total; e += 256) {
+            int code = 4;
+            if (j < (unsigned)s_T[i]) code = rd_code(arena[s_off[i] + j]);
+            __builtin_nontemporal_store(rd_onehot(code), dst + e);
+            i += dq;
+            j += dr;
+            if (j >= L) {
+                j -= L;
+                ++i;
+            }
+        }
     }
 }
 
-// PackedSequence.data [sum T][4]: row(t, j) = cum[t] + j with cum[t] = sum_{t'<t} batch_sizes[t'].
-// One workgroup per timestep slab: lanes walk the sorted reads (coalesced 16-B stores).
-__global__ void rd_pack_onehot_kernel(const uint8_t *__restrict__ arena, const int64_t *__restrict__ off,
-                                      const int32_t *__restrict__ len, int max_len, const int64_t *__restrict__ sorted_idx,
-                                      const int64_t *__restrict__ batch_sizes, f32x4 *__restrict__ data) {
-    const int t = blockIdx.y;
-    const int64_t bs = batch_sizes[t];
-    __shared__ int64_t s_base;
-    if (threadIdx.x == 0) {
-        int64_t b = 0;
-        for (int tt = 0; tt < t; ++tt) b += batch_sizes[tt];
-        s_base = b;
+// PackedSequence.data [sum T][4]: row(t, j) = cum[t] + j, cum[t] = sum_{t'<t} batch_sizes[t'], j = position of the read in
+// the length-sorted order. A workgroup takes ENC_R consecutive sorted reads and walks the timesteps in chunks of PK_TC:
+// each read's bases are loaded once, as contiguous bytes, into an LDS tile; the tile is then written out transposed, one
+// timestep per wave instruction = 64 consecutive 16-byte rows. cum[] is carried from chunk to chunk.
+constexpr int PK_TC = 128;
+__global__ __launch_bounds__(256) void rd_pack_onehot_kernel(const uint8_t *__restrict__ arena, const int64_t *__restrict__ off,
+                                                             const int32_t *__restrict__ len, int64_t n, int max_len,
+                                                             const int64_t *__restrict__ sorted_idx,
+                                                             const int64_t *__restrict__ batch_sizes, f32x4 *__restrict__ data) {
+    __shared__ int64_t s_off[ENC_R];
+    __shared__ int s_T[ENC_R];
+    __shared__ int64_t s_bs[PK_TC], s_cum[PK_TC], s_scan[2][PK_TC];
+    __shared__ uint8_t s_code[ENC_R][PK_TC + 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t j0 = (int64_t)blockIdx.x * ENC_R;
+    const int R = (int)(n - j0 < ENC_R ? n - j0 : ENC_R);
+    if (tid < ENC_R) {
+        int T = 0;
+        int64_t o = 0;
+        if (tid < R) {
+            const int64_t i = sorted_idx[j0 + tid];
+            o = off[i];
+            T = rd_T(len, i, max_len);
+        }
+        s_off[tid] = o;
+        s_T[tid] = T;
     }
     __syncthreads();
-    const int64_t base = s_base;
-    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < bs; j += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t i = sorted_idx[j];
-        const int code = rd_code(arena[off[i] + t]);
-        data[base + j] = f32x4{code == 0 ? 1.f : 0.f, code == 1 ? 1.f : 0.f, code == 2 ? 1.f : 0.f, code == 3 ? 1.f : 0.f};
+    const int Tmax = s_T[0];   // sorted by length, descending: the first read of the block is its longest
+    int64_t carry = 0;         // cum[t0]
+    for (int t0 = 0; t0 < Tmax; t0 += PK_TC) {
+        const int TC = Tmax - t0 < PK_TC ? Tmax - t0 : PK_TC;
+        // batch_sizes of this chunk and their exclusive prefix sums (Hillis-Steele over PK_TC entries)
+        if (tid < PK_TC) {
+            const int64_t b = tid < TC ? batch_sizes[t0 + tid] : 0;
+            s_bs[tid] = b;
+            s_scan[0][tid] = b;
+        }
+        __syncthreads();
+        int cur = 0;
+        for (int d = 1; d < PK_TC; d <<= 1) {
+            if (tid < PK_TC) s_scan[cur ^ 1][tid] = s_scan[cur][tid] + (tid >= d ? s_scan[cur][tid - d] : 0);
+            cur ^= 1;
+            __syncthreads();
+        }
+        if (tid < PK_TC) s_cum[tid] = carry + s_scan[cur][tid] - s_bs[tid];
+        const int64_t chunk_total = s_scan[cur][PK_TC - 1];
+        // the reads' bases of this chunk -> LDS tile (16 reads per wave, 64 consecutive bytes per wave load)
+        for (int r = wave * 16; r < wave * 16 + 16; ++r) {
+            const int T = s_T[r];
+            const uint8_t *src = arena + s_off[r] + t0;
+            for (int tt = lane; tt < TC; tt += 64) s_code[r][tt] = (uint8_t)(t0 + tt < T ? rd_code(src[tt]) : 4);
+        }
+        __syncthreads();
+        for (int tt = wave; tt < TC; tt += 4) {
+            const int64_t bs = s_bs[tt];
+            if (j0 + lane < bs) __builtin_nontemporal_store(rd_onehot(s_code[lane][tt]), data + s_cum[tt] + j0 + lane);
+        }
+        carry += chunk_total;
+        __syncthreads();
     }
-    (void)len; (void)max_len;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1539,27 +1637,64 @@ __device__ __forceinline__ void rd_block_count3(unsigned c0, unsigned c1, unsign
     if (threadIdx.x < 3 && sh[threadIdx.x]) atomicAdd((unsigned long long *)&counts[threadIdx.x], (unsigned long long)sh[threadIdx.x]);
 }
 
-// detect.py:616-663
-__global__ void rd_pair_fuse_kernel(const float2 *__restrict__ l1, const float2 *__restrict__ l2, int64_t n, int mode,
-                                    int8_t *__restrict__ out, uint64_t *__restrict__ counts) {
+__device__ __forceinline__ int rd_fuse(float2 a, float2 b, int mode) {   // detect.py:616-663
+    const int la = a.y > a.x, lb = b.y > b.x;
+    if (mode == RD_ENSURE_RRNA) return la & lb;
+    if (mode == RD_ENSURE_NORRNA) return la | lb;
+    if (mode == RD_ENSURE_BOTH) return (la == lb) ? la : -1;
+    return __fadd_rn(a.y, b.y) > __fadd_rn(a.x, b.x) ? 1 : 0;   // argmax(r1_outs + r2_outs), :657
+}
+
+// VEC: two pairs per lane and iteration (16-byte loads; needs 16-byte aligned logits and 2-byte aligned labels)
+template <bool VEC>
+__global__ __launch_bounds__(256) void rd_pair_fuse_kernel(const float2 *__restrict__ l1, const float2 *__restrict__ l2, int64_t n, int mode,
+                                                           int8_t *__restrict__ out, uint64_t *__restrict__ counts) {
     unsigned c0 = 0, c1 = 0, c2 = 0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const float2 a = l1[i], b = l2[i];
-        const int la = a.y > a.x, lb = b.y > b.x;
-        int f;
-        if (mode == RD_ENSURE_RRNA) f = (la & lb);
-        else if (mode == RD_ENSURE_NORRNA) f = (la | lb);
-        else if (mode == RD_ENSURE_BOTH) f = (la == lb) ? la : -1;
-        else f = __fadd_rn(a.y, b.y) > __fadd_rn(a.x, b.x) ? 1 : 0;   // argmax(r1_outs + r2_outs), :657
-        out[i] = (int8_t)f;
-        c0 += f == 0; c1 += f == 1; c2 += f < 0;
+    const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, gsz = (int64_t)gridDim.x * blockDim.x;
+    if (VEC) {
+        const int64_t n2 = n >> 1;
+        for (int64_t i = gtid; i < n2; i += gsz) {
+            const f32x4 a = ((const f32x4 *)l1)[i], b = ((const f32x4 *)l2)[i];
+            const int f0 = rd_fuse(float2{a[0], a[1]}, float2{b[0], b[1]}, mode), f1 = rd_fuse(float2{a[2], a[3]}, float2{b[2], b[3]}, mode);
+            ((uint16_t *)out)[i] = (uint16_t)((f0 & 0xff) | ((f1 & 0xff) << 8));
+            c0 += (f0 == 0) + (f1 == 0); c1 += (f0 == 1) + (f1 == 1); c2 += (f0 < 0) + (f1 < 0);
+        }
+        if ((n & 1) && gtid == 0) {
+            const int f = rd_fuse(l1[n - 1], l2[n - 1], mode);
+            out[n - 1] = (int8_t)f;
+            c0 += f == 0; c1 += f == 1; c2 += f < 0;
+        }
+    } else {
+        for (int64_t i = gtid; i < n; i += gsz) {
+            const int f = rd_fuse(l1[i], l2[i], mode);
+            out[i] = (int8_t)f;
+            c0 += f == 0; c1 += f == 1; c2 += f < 0;
+        }
     }
     if (counts) rd_block_count3(c0, c1, c2, counts);
 }
 
-__global__ void rd_count_kernel(const uint8_t *__restrict__ labels, int64_t n, uint64_t *__restrict__ counts) {
+// VEC: 16 labels per lane and iteration (needs a 16-byte aligned pointer)
+template <bool VEC>
+__global__ __launch_bounds__(256) void rd_count_kernel(const uint8_t *__restrict__ labels, int64_t n, uint64_t *__restrict__ counts) {
     unsigned c0 = 0, c1 = 0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, gsz = (int64_t)gridDim.x * blockDim.x;
+    int64_t done = 0;
+    if (VEC) {
+        const int64_t n16 = n >> 4;
+        for (int64_t i = gtid; i < n16; i += gsz) {
+            const u32x4 v = ((const u32x4 *)labels)[i];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const unsigned f = (v[k] >> (8 * b)) & 0xff;
+                    c0 += f == 0; c1 += f == 1;
+                }
+        }
+        done = n16 << 4;
+    }
+    for (int64_t i = done + gtid; i < n; i += gsz) {
         const int f = labels[i];
         c0 += f == 0; c1 += f == 1;
     }
@@ -1797,10 +1932,16 @@ int rd_pair_fuse(const float *logits1, const float *logits2, int64_t n, int32_t 
     if (n < 0 || ensure_mode < 0 || ensure_mode > 3) RD_FAIL(RD_E_INVALID, "rd_pair_fuse: bad n or ensure_mode");
     if (n == 0) return RD_OK;
     if (!logits1 || !logits2 || !pair_labels) RD_FAIL(RD_E_INVALID, "rd_pair_fuse: null pointer");
-    int64_t nb = (n + 255) / 256;
-    if (nb > 2048) nb = 2048;
-    hipLaunchKernelGGL(rd_pair_fuse_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const float2 *)logits1,
-                       (const float2 *)logits2, n, ensure_mode, pair_labels, counts);
+    // few, fat workgroups: every workgroup ends with three global atomics on the same counters
+    int64_t nb = (n + 2047) / 2048;
+    if (nb > 1024) nb = 1024;
+    const bool vec = (((uintptr_t)logits1 | (uintptr_t)logits2) & 15) == 0 && ((uintptr_t)pair_labels & 1) == 0;
+    if (vec)
+        hipLaunchKernelGGL(rd_pair_fuse_kernel<true>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const float2 *)logits1,
+                           (const float2 *)logits2, n, ensure_mode, pair_labels, counts);
+    else
+        hipLaunchKernelGGL(rd_pair_fuse_kernel<false>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const float2 *)logits1,
+                           (const float2 *)logits2, n, ensure_mode, pair_labels, counts);
     RD_HIP(hipGetLastError());
     return RD_OK;
 }
@@ -1809,9 +1950,12 @@ int rd_count_labels(const uint8_t *labels, int64_t n, uint64_t *counts, void *st
     if (n < 0) RD_FAIL(RD_E_INVALID, "rd_count_labels: bad n");
     if (n == 0) return RD_OK;
     if (!labels || !counts) RD_FAIL(RD_E_INVALID, "rd_count_labels: null pointer");
-    int64_t nb = (n + 255) / 256;
-    if (nb > 2048) nb = 2048;
-    hipLaunchKernelGGL(rd_count_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, labels, n, counts);
+    int64_t nb = (n + 16383) / 16384;
+    if (nb > 1024) nb = 1024;
+    if (((uintptr_t)labels & 15) == 0)
+        hipLaunchKernelGGL(rd_count_kernel<true>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, labels, n, counts);
+    else
+        hipLaunchKernelGGL(rd_count_kernel<false>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, labels, n, counts);
     RD_HIP(hipGetLastError());
     return RD_OK;
 }
@@ -1821,10 +1965,15 @@ int rd_encode_codes(const uint8_t *arena, const int64_t *seq_off, const int32_t 
     if (n < 0 || max_len < 1 || stride < max_len) RD_FAIL(RD_E_INVALID, "rd_encode_codes: bad n/max_len/stride");
     if (n == 0) return RD_OK;
     if (!arena || !seq_off || !seq_len || !codes) RD_FAIL(RD_E_INVALID, "rd_encode_codes: null pointer");
-    int64_t nb = (n + 3) / 4;   // 4 waves (reads) per block per pass
-    if (nb > 256 * 32) nb = 256 * 32;
-    hipLaunchKernelGGL(rd_encode_codes_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, arena, seq_off, seq_len, n,
-                       max_len, stride, codes);
+    if ((int64_t)ENC_R * stride > 0x7fffffffLL) RD_FAIL(RD_E_INVALID, "rd_encode_codes: stride too large");
+    int64_t nb = (n + ENC_R - 1) / ENC_R;
+    if (nb > 256 * 64) nb = 256 * 64;
+    if (((uintptr_t)codes & 3) == 0)   // a block's output starts at r0 * stride with r0 a multiple of 64
+        hipLaunchKernelGGL(rd_encode_codes_kernel<true>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, arena, seq_off, seq_len,
+                           n, max_len, stride, codes);
+    else
+        hipLaunchKernelGGL(rd_encode_codes_kernel<false>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, arena, seq_off, seq_len,
+                           n, max_len, stride, codes);
     RD_HIP(hipGetLastError());
     return RD_OK;
 }
@@ -1834,8 +1983,9 @@ int rd_encode_onehot_padded(const uint8_t *arena, const int64_t *seq_off, const 
     if (n < 0 || max_len < 1) RD_FAIL(RD_E_INVALID, "rd_encode_onehot_padded: bad n/max_len");
     if (n == 0) return RD_OK;
     if (!arena || !seq_off || !seq_len || !onehot) RD_FAIL(RD_E_INVALID, "rd_encode_onehot_padded: null pointer");
-    int64_t nb = (n * max_len + 255) / 256;
-    if (nb > 256 * 32) nb = 256 * 32;
+    if (max_len > MAX_LEN_LIMIT) RD_FAIL(RD_E_INVALID, "rd_encode_onehot_padded: max_len=%d out of range [1,%d]", max_len, MAX_LEN_LIMIT);
+    int64_t nb = (n + ENC_R - 1) / ENC_R;
+    if (nb > 256 * 64) nb = 256 * 64;
     hipLaunchKernelGGL(rd_encode_onehot_padded_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, arena, seq_off,
                        seq_len, n, max_len, (f32x4 *)onehot);
     RD_HIP(hipGetLastError());
@@ -1858,10 +2008,10 @@ int rd_pack_onehot(const uint8_t *arena, const int64_t *seq_off, const int32_t *
     if (n < 1 || max_len < 1) RD_FAIL(RD_E_INVALID, "rd_pack_onehot: bad n/max_len");
     if (!arena || !seq_off || !seq_len || !sorted_idx || !batch_sizes || !data) RD_FAIL(RD_E_INVALID, "rd_pack_onehot: null pointer");
     hipStream_t st = (hipStream_t)stream;
-    int64_t nbx = (n + 255) / 256;
-    if (nbx > 1024) nbx = 1024;
-    hipLaunchKernelGGL(rd_pack_onehot_kernel, dim3((unsigned)nbx, (unsigned)max_len), dim3(256), 0, st, arena, seq_off, seq_len,
-                       max_len, sorted_idx, batch_sizes, (f32x4 *)data);
+    const int64_t nb = (n + ENC_R - 1) / ENC_R;
+    if (nb > 0x7fffffffLL) RD_FAIL(RD_E_INVALID, "rd_pack_onehot: n too large");
+    hipLaunchKernelGGL(rd_pack_onehot_kernel, dim3((unsigned)nb), dim3(256), 0, st, arena, seq_off, seq_len, n, max_len, sorted_idx,
+                       batch_sizes, (f32x4 *)data);
     RD_HIP(hipGetLastError());
     return RD_OK;
 }
