@@ -391,18 +391,107 @@ struct ReadBatch {
 //   packed (model.py:32-37 + detect.py:682): T = min(len, max_len).
 //   padded (model_cpu.py:29-37,57-62): the input is zero-padded to max_len rows and the output row is the LAST NON-ZERO row,
 //     pos = L-1-argmax(flip(rowsum)); if every row is zero, argmax = 0 and pos = L-1. T = pos + 1.
-__global__ void rd_steps_kernel(const uint8_t *__restrict__ arena, const int64_t *__restrict__ off, const int32_t *__restrict__ len,
-                                int64_t n, int max_len, int sem, int32_t *__restrict__ steps) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const int lr = rd_T(len, i, max_len);
-        int T = lr;
-        if (sem == RD_SEM_PADDED) {
-            const uint8_t *p = arena + off[i];
-            int pos = lr - 1;
-            while (pos >= 0 && rd_code(p[pos]) == 4) --pos;
-            T = pos >= 0 ? pos + 1 : max_len;
+// It also histograms the step counts (wave-aggregated LDS counters, flushed with one global atomic per non-empty bin and
+// workgroup) for the bucketing below.
+__device__ __forceinline__ uint32_t rd_bin_add(uint32_t *bins, int T, bool valid) {   // returns the rank inside the bin
+    const unsigned long long m = __ballot(valid);
+    if (!m) return 0;
+    const int lane = threadIdx.x & 63, first = __ffsll((long long)m) - 1;
+    const int T0 = __shfl(T, first);
+    if (__all(!valid || T == T0)) {   // the common case (fixed-length reads): one atomic per wave
+        uint32_t base = 0;
+        if (lane == first) base = atomicAdd(&bins[T0], (uint32_t)__popcll(m));
+        return __shfl(base, first) + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+    }
+    return valid ? atomicAdd(&bins[T], 1u) : 0;
+}
+
+__global__ __launch_bounds__(256) void rd_steps_kernel(const uint8_t *__restrict__ arena, const int64_t *__restrict__ off,
+                                                       const int32_t *__restrict__ len, int64_t n, int max_len, int sem,
+                                                       int32_t *__restrict__ steps, uint32_t *__restrict__ ghist) {
+    extern __shared__ uint32_t sh_bins[];   // max_len+1
+    for (int i = threadIdx.x; i <= max_len; i += 256) sh_bins[i] = 0;
+    __syncthreads();
+    for (int64_t base = (int64_t)blockIdx.x * 256; base < n; base += (int64_t)gridDim.x * 256) {
+        const int64_t i = base + threadIdx.x;
+        const bool valid = i < n;
+        int T = 0;
+        if (valid) {
+            const int lr = rd_T(len, i, max_len);
+            T = lr;
+            if (sem == RD_SEM_PADDED) {
+                const uint8_t *p = arena + off[i];
+                int pos = lr - 1;
+                while (pos >= 0 && rd_code(p[pos]) == 4) --pos;
+                T = pos >= 0 ? pos + 1 : max_len;
+            }
+            steps[i] = T;
         }
-        steps[i] = T;
+        rd_bin_add(sh_bins, T, valid);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i <= max_len; i += 256)
+        if (sh_bins[i]) atomicAdd(&ghist[i], sh_bins[i]);
+}
+
+// Length bucketing for rd_classify: order[] = read indices grouped by step count, longest first, so that the reads of a
+// tile run (nearly) the same number of steps. Every read is computed independently of its tile mates, so the order INSIDE
+// a bucket does not matter and is left to the atomics (rd_pack_plan, whose output order is visible, uses the stable sort
+// above). cursor[T] = first position of bucket T = number of reads with more than T steps.
+__global__ __launch_bounds__(256) void rd_bucket_scan_kernel(const uint32_t *__restrict__ ghist, int max_len,
+                                                             uint32_t *__restrict__ cursor) {
+    __shared__ uint32_t part[256];
+    const int tid = threadIdx.x, nb = max_len + 1, per = (nb + 255) / 256;
+    uint32_t s = 0;
+    for (int k = 0; k < per; ++k) {
+        const int e = tid * per + k;   // scan position e <-> T = max_len - e
+        if (e < nb) s += ghist[max_len - e];
+    }
+    part[tid] = s;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        const uint32_t v = tid >= d ? part[tid - d] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[tid] - s;
+    for (int k = 0; k < per; ++k) {
+        const int e = tid * per + k;
+        if (e < nb) {
+            cursor[max_len - e] = run;
+            run += ghist[max_len - e];
+        }
+    }
+}
+
+constexpr int BK_ITEMS = 2048;   // reads per workgroup and pass
+__global__ __launch_bounds__(256) void rd_bucket_scatter_kernel(const int32_t *__restrict__ steps, int64_t n, int max_len,
+                                                                uint32_t *__restrict__ cursor, int32_t *__restrict__ order) {
+    extern __shared__ uint32_t sh_bins[];   // max_len+1: counts of this pass, then the buckets' reserved start positions
+    for (int64_t b0 = (int64_t)blockIdx.x * BK_ITEMS; b0 < n; b0 += (int64_t)gridDim.x * BK_ITEMS) {
+        __syncthreads();
+        for (int i = threadIdx.x; i <= max_len; i += 256) sh_bins[i] = 0;
+        __syncthreads();
+        int Tk[BK_ITEMS / 256];
+        uint32_t rk[BK_ITEMS / 256];
+#pragma unroll
+        for (int k = 0; k < BK_ITEMS / 256; ++k) {
+            const int64_t i = b0 + k * 256 + threadIdx.x;
+            const bool valid = i < n;
+            const int T = valid ? steps[i] : 0;
+            rk[k] = rd_bin_add(sh_bins, T, valid);
+            Tk[k] = valid ? T : -1;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i <= max_len; i += 256) {
+            const uint32_t c = sh_bins[i];
+            if (c) sh_bins[i] = atomicAdd(&cursor[i], c);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < BK_ITEMS / 256; ++k)
+            if (Tk[k] >= 0) order[sh_bins[Tk[k]] + rk[k]] = (int32_t)(b0 + k * 256 + threadIdx.x);
     }
 }
 
@@ -1743,6 +1832,29 @@ int run_sort(const int32_t *seq_len, int64_t n, int max_len, void *workspace, si
     return RD_OK;
 }
 
+// steps[] + order[] for rd_classify: steps kernel (with histogram) -> bucket starts -> scatter
+int run_steps_and_buckets(const uint8_t *arena, const int64_t *seq_off, const int32_t *seq_len, int64_t n, int max_len, int sem,
+                          void *workspace, size_t wbytes, int32_t *&steps, int32_t *&order, hipStream_t st) {
+    SortPlan p = sort_plan(n, max_len);
+    if (wbytes < p.total) RD_FAIL(RD_E_WORKSPACE, "workspace too small: %zu < %zu", wbytes, p.total);
+    char *w = (char *)workspace;
+    uint32_t *ghist = (uint32_t *)w;                                          // (max_len+1) u32 fit in hist_bytes
+    order = (int32_t *)(w + p.hist_bytes);
+    uint32_t *cursor = (uint32_t *)(w + p.hist_bytes + p.order_bytes);        // (max_len+1) u32 fit in lenstart_bytes
+    steps = (int32_t *)(w + p.total - p.steps_bytes);
+    const size_t sh = (size_t)(max_len + 1) * sizeof(uint32_t);
+    RD_HIP(hipMemsetAsync(ghist, 0, sh, st));
+    int64_t nb = (n + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(rd_steps_kernel, dim3((unsigned)nb), dim3(256), sh, st, arena, seq_off, seq_len, n, max_len, sem, steps, ghist);
+    hipLaunchKernelGGL(rd_bucket_scan_kernel, dim3(1), dim3(256), 0, st, ghist, max_len, cursor);
+    int64_t nbs = (n + BK_ITEMS - 1) / BK_ITEMS;
+    if (nbs > 2048) nbs = 2048;
+    hipLaunchKernelGGL(rd_bucket_scatter_kernel, dim3((unsigned)nbs), dim3(256), sh, st, steps, n, max_len, cursor, order);
+    RD_HIP(hipGetLastError());
+    return RD_OK;
+}
+
 }  // namespace
 
 // ================================================================================================
@@ -1873,19 +1985,12 @@ int rd_classify(const rd_model *cm, const uint8_t *arena, const int64_t *seq_off
     hipStream_t st = (hipStream_t)stream;
     const SortPlan sp = sort_plan(n, max_len);
     if (workspace_bytes < sp.total) RD_FAIL(RD_E_WORKSPACE, "workspace too small: %zu < %zu", workspace_bytes, sp.total);
-    int32_t *steps = (int32_t *)((char *)workspace + sp.total - sp.steps_bytes);
-    {
-        int64_t nb = (n + 255) / 256;
-        if (nb > 4096) nb = 4096;
-        hipLaunchKernelGGL(rd_steps_kernel, dim3((unsigned)nb), dim3(256), 0, st, arena, seq_off, seq_len, n, max_len, m->semantics, steps);
-    }
     if (m->semantics == RD_SEM_PADDED && m->rev_tab_len != max_len) {
         hipLaunchKernelGGL(rd_revtab_kernel, dim3(1), dim3(512), 0, st, m->d, max_len);
         m->rev_tab_len = max_len;
     }
-    int32_t *order = nullptr;
-    int64_t *len_start = nullptr;
-    int rc = run_sort(steps, n, max_len, workspace, workspace_bytes, order, nullptr, nullptr, nullptr, nullptr, len_start, st);
+    int32_t *steps = nullptr, *order = nullptr;
+    int rc = run_steps_and_buckets(arena, seq_off, seq_len, n, max_len, m->semantics, workspace, workspace_bytes, steps, order, st);
     if (rc) return rc;
     ReadBatch rb{arena, seq_off, seq_len, steps, order, n, max_len, m->semantics, m->d.rev_tab};
     hipEvent_t *ev = nullptr;
