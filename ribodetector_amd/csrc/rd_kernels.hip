@@ -1844,12 +1844,14 @@ int run_steps_and_buckets(const uint8_t *arena, const int64_t *seq_off, const in
     steps = (int32_t *)(w + p.total - p.steps_bytes);
     const size_t sh = (size_t)(max_len + 1) * sizeof(uint32_t);
     RD_HIP(hipMemsetAsync(ghist, 0, sh, st));
+    // one workgroup per CU at most: every workgroup ends with one global atomic per non-empty bin, and with fixed-length
+    // reads they all hit the same bin
     int64_t nb = (n + 255) / 256;
-    if (nb > 2048) nb = 2048;
+    if (nb > 256) nb = 256;
     hipLaunchKernelGGL(rd_steps_kernel, dim3((unsigned)nb), dim3(256), sh, st, arena, seq_off, seq_len, n, max_len, sem, steps, ghist);
     hipLaunchKernelGGL(rd_bucket_scan_kernel, dim3(1), dim3(256), 0, st, ghist, max_len, cursor);
     int64_t nbs = (n + BK_ITEMS - 1) / BK_ITEMS;
-    if (nbs > 2048) nbs = 2048;
+    if (nbs > 256) nbs = 256;
     hipLaunchKernelGGL(rd_bucket_scatter_kernel, dim3((unsigned)nbs), dim3(256), sh, st, steps, n, max_len, cursor, order);
     RD_HIP(hipGetLastError());
     return RD_OK;
