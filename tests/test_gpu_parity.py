@@ -274,7 +274,6 @@ def test_config_c_and_d_shapes_properties(gpu_model, oracle):
 
 def test_abi_error_paths_on_device(gpu_model):
     """status codes + rd_last_error through the C ABI with a live model (no exception crosses the boundary)"""
-    import ctypes as C
     from ribodetector_amd import _native as N
     L = N.lib()
     h = gpu_model._handle

@@ -2,7 +2,6 @@
 (tests/golden/make_golden.py). Logit tolerance 5e-5 (observed 1.2e-5: fp32 reassociation vs torch/oneDNN);
 labels, indices and integer layouts are exact."""
 import numpy as np
-import pytest
 
 TOL = 5e-5
 

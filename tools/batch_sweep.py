@@ -1,0 +1,43 @@
+#!/usr/bin/env python
+"""reads/s of SeqModel.classify_bytes as a function of the reads per call (100 bp, inputs in HBM): where launch overhead
+and the 256-workgroup fill of the chip start to matter. python tools/batch_sweep.py"""
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
+from ribodetector_amd import synth                                    # noqa: E402
+from ribodetector_amd.model import model as M                         # noqa: E402
+from ribodetector_amd.parse_config import ConfigParser                # noqa: E402
+
+
+def main():
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    cfg = ConfigParser.from_json(os.path.join(root, "ribodetector_amd", "config.json"))
+    model = cfg.init_obj("arch", M)
+    model.load_state_dict(cfg.load_state_dict("mcc"))
+    model.to("cuda:0").eval()
+    out = {}
+    for n in (1024, 4096, 16384, 32768, 65536, 262144, 1048576):
+        arena, off, lens = synth.reads_torch(n, 100, seed=3, device=torch.device("cuda", 0))
+        offs = off[:-1].contiguous()
+        logits = torch.empty((n, 2), dtype=torch.float32, device="cuda:0")
+        labels = torch.empty((n,), dtype=torch.uint8, device="cuda:0")
+        reps = max(3, min(200, (1 << 22) // n))
+        for _ in range(3):
+            model.classify_bytes(arena, offs, lens, 100, logits=logits, labels=labels)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(reps):
+            model.classify_bytes(arena, offs, lens, 100, logits=logits, labels=labels)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t) / reps
+        out[n] = {"us_per_call": dt * 1e6, "reads_per_s": n / dt}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
