@@ -1,0 +1,39 @@
+"""float64 evaluation of the reference's forward1 (model/model.py:32-37: BiLSTM over the packed reads, hidden state at the
+last base, Linear) - the yardstick for how far ANY fp32 implementation (the reference's own torch/cuDNN arithmetic, the
+oracle, the HIP kernels) is from the exact value of the same recurrence. Test helper, numpy only."""
+import numpy as np
+
+
+def f64_forward(sd, arena, off, lens, max_len):
+    """float64 evaluation of forward1 (packed semantics), vectorised over reads"""
+    g = lambda k: np.asarray(sd[k], dtype=np.float64) if isinstance(sd[k], np.ndarray) else sd[k].double().numpy()   # noqa: E731
+    wih, whh, b = g("rnn.weight_ih_l0"), g("rnn.weight_hh_l0"), g("rnn.bias_ih_l0") + g("rnn.bias_hh_l0")
+    wihr, br = g("rnn.weight_ih_l0_reverse"), g("rnn.bias_ih_l0_reverse") + g("rnn.bias_hh_l0_reverse")
+    wout, bout = g("out.weight"), g("out.bias")
+    n = len(lens)
+    T = np.minimum(lens, max_len).astype(np.int64)
+    lut = np.full(256, 4, dtype=np.int64)
+    for ch, c in ((b"A", 0), (b"C", 1), (b"G", 2), (b"T", 3), (b"U", 3)):
+        lut[ch[0]] = c
+    inl = np.concatenate([wih.T + b, b[None, :]], 0)                # [5, 512]
+    inr = np.concatenate([wihr.T + br, br[None, :]], 0)
+    sig = lambda x: 1.0 / (1.0 + np.exp(-x))                         # noqa: E731
+    h = np.zeros((n, 128)); c = np.zeros((n, 128))
+    order = np.argsort(-T, kind="stable")
+    Ts = T[order]
+    for t in range(int(T.max()) if n else 0):
+        m = int((Ts > t).sum())
+        idx = order[:m]
+        code = lut[arena[off[idx] + t]]
+        gates = inl[code] + h[idx] @ whh.T
+        i, f, gg, o = sig(gates[:, :128]), sig(gates[:, 128:256]), np.tanh(gates[:, 256:384]), sig(gates[:, 384:])
+        c[idx] = f * c[idx] + i * gg
+        h[idx] = o * np.tanh(c[idx])
+    last = np.where(T > 0, lut[arena[np.minimum(off[:-1] + np.maximum(T, 1) - 1, len(arena) - 1)]], 4)
+    gr = inr[last]
+    cr = sig(gr[:, :128]) * np.tanh(gr[:, 256:384])
+    hr = sig(gr[:, 384:]) * np.tanh(cr)
+    hr[T == 0] = 0.0
+    return np.concatenate([h, hr], 1) @ wout.T + bout
+
+

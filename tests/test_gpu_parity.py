@@ -322,3 +322,78 @@ def test_random_bytes_and_lengths_stress(gpu_model, oracle):
         lg, lab = gpu_model.classify_bytes(b.arena, b.offsets, b.lens, maxlen)
         torch.cuda.synchronize()
         _check(lg.cpu().numpy(), lab.cpu().numpy(), ref, "stress %d" % trial)
+
+
+def _check_tail(lg, lab, ref_logits, maxlen, what):
+    """Like _check for reads of up to 100 steps. Beyond that the recurrence amplifies fp32 rounding noise so far that no two
+    fp32 implementations agree to 1e-4 on every read (tests/diag_error_tail.py: over 100,000 reads of <= 300 bp the oracle
+    itself is up to 2.6e-4 from a float64 evaluation, 3 reads beyond 1e-4): there the bar is 1e-4 for 99.9 % of the reads,
+    5e-5 for 99 %, 1e-3 for all, and labels equal wherever the reference's own margin exceeds the observed error."""
+    if maxlen <= 100:
+        return _check(lg, lab, ref_logits, what)
+    e = np.abs(lg - ref_logits).max(axis=1)
+    assert np.quantile(e, 0.999) < TOL and np.quantile(e, 0.99) < 5e-5 and e.max() < 1e-3, \
+        "%s: logit error max %.3g p99.9 %.3g p99 %.3g" % (what, e.max(), np.quantile(e, 0.999), np.quantile(e, 0.99))
+    ref_lab = (ref_logits[:, 1] > ref_logits[:, 0]).astype(np.uint8)
+    bad = np.flatnonzero(lab != ref_lab)
+    margin = np.abs(ref_logits[:, 1] - ref_logits[:, 0])
+    assert (margin[bad] < 2 * e[bad] + 2e-4).all(), "%s: label mismatch at margins %s" % (what, margin[bad])
+    assert ((lg[:, 1] > lg[:, 0]).astype(np.uint8) == lab).all(), what
+    return float(e.max())
+
+
+def test_error_against_float64_truth(gpu_model, oracle, report):
+    """The HIP kernels are as close to the exact (float64) value of the recurrence as the reference's fp32 arithmetic is:
+    same median and 99th-percentile error as the fp32 oracle, for every kernel variant, at 100 and at 300 steps."""
+    import os
+    import sys
+    from ribodetector_amd import synth
+    from ribodetector_amd.data_loader import seq_encoder as E
+    from ribodetector_amd.parse_config import ConfigParser
+    sys.path.insert(0, os.path.dirname(__file__))
+    from f64_truth import f64_forward
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    sd = ConfigParser.from_json(os.path.join(root, "ribodetector_amd", "config.json")).load_state_dict("mcc")
+    out = {}
+    try:
+        for maxlen, n in ((100, 6000), (300, 3000)):
+            arena, off, lens = synth.reads_numpy(n, (maxlen - 60, maxlen + 20), seed=77 + maxlen, rrna_frac=0.3, n_rate=0.01)
+            truth = f64_forward(sd, arena, off, lens, maxlen)
+            eo = np.abs(oracle.forward_packed(arena, off, lens, maxlen) - truth).max(axis=1)
+            b = E.batch_from_numpy(arena, off[:-1], lens, "cuda")
+            for v in ("auto", "mfma_f32", "simple"):
+                gpu_model.set_variant(v)
+                lg, _ = gpu_model.classify_bytes(b.arena, b.offsets, b.lens, maxlen)
+                ek = np.abs(lg.cpu().numpy().astype(np.float64) - truth).max(axis=1)
+                out["%s@%d" % (v, maxlen)] = {"median": float(np.median(ek)), "p99": float(np.quantile(ek, 0.99)), "max": float(ek.max())}
+                assert np.median(ek) < 1.5 * np.median(eo) + 2e-7, (v, maxlen, np.median(ek), np.median(eo))
+                assert np.quantile(ek, 0.99) < 2.0 * np.quantile(eo, 0.99) + 1e-6, (v, maxlen)
+                assert ek.max() < 4 * eo.max() + 2e-5, (v, maxlen, ek.max(), eo.max())
+            out["oracle_fp32@%d" % maxlen] = {"median": float(np.median(eo)), "p99": float(np.quantile(eo, 0.99)), "max": float(eo.max())}
+    finally:
+        gpu_model.set_variant("auto")
+    report["error_vs_float64"] = out
+
+
+@pytest.mark.parametrize("sem", ["packed", "padded"])
+def test_soak_random_reads(gpu_model, oracle, report, sem):
+    """differential soak against the oracle: RD_SOAK_READS reads per case (default 4,000; the round-1 evidence run used
+    200,000), lengths 0..max_len+40, rRNA-like / random / non-ACGT content mixed, several max_len values"""
+    import os
+    from ribodetector_amd import synth
+    from ribodetector_amd.data_loader import seq_encoder as E
+    n = int(os.environ.get("RD_SOAK_READS", "4000"))
+    gpu_model.set_variant("auto")
+    gpu_model.set_semantics(sem)
+    worst = 0.0
+    try:
+        for k, maxlen in enumerate((100, 1, 37, 150, 300)):
+            arena, off, lens = synth.reads_numpy(n, (0, maxlen + 40), seed=1000 + k, rrna_frac=0.3, n_rate=0.02)
+            ref = (oracle.forward_packed if sem == "packed" else oracle.forward_padded)(arena, off, lens, maxlen)
+            b = E.batch_from_numpy(arena, off[:-1], lens, "cuda")
+            lg, lab = gpu_model.classify_bytes(b.arena, b.offsets, b.lens, maxlen)
+            torch.cuda.synchronize()
+            worst = max(worst, _check_tail(lg.cpu().numpy(), lab.cpu().numpy(), ref, maxlen, "soak %s -l %d" % (sem, maxlen)))
+    finally:
+        gpu_model.set_semantics("packed")
+    report["soak_%s" % sem] = {"reads_per_case": n, "cases": 5, "max_abs_logit_err": float(worst)}

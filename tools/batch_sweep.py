@@ -15,27 +15,33 @@ from ribodetector_amd.parse_config import ConfigParser                # noqa: E4
 
 
 def main():
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--len", type=int, default=100)
+    ap.add_argument("--sizes", type=int, nargs="*", default=[1024, 4096, 16384, 32768, 65536, 262144, 1048576])
+    a = ap.parse_args()
+    L = a.len
     root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
     cfg = ConfigParser.from_json(os.path.join(root, "ribodetector_amd", "config.json"))
     model = cfg.init_obj("arch", M)
     model.load_state_dict(cfg.load_state_dict("mcc"))
     model.to("cuda:0").eval()
     out = {}
-    for n in (1024, 4096, 16384, 32768, 65536, 262144, 1048576):
-        arena, off, lens = synth.reads_torch(n, 100, seed=3, device=torch.device("cuda", 0))
+    for n in a.sizes:
+        arena, off, lens = synth.reads_torch(n, L, seed=3, device=torch.device("cuda", 0))
         offs = off[:-1].contiguous()
         logits = torch.empty((n, 2), dtype=torch.float32, device="cuda:0")
         labels = torch.empty((n,), dtype=torch.uint8, device="cuda:0")
         reps = max(3, min(200, (1 << 22) // n))
         for _ in range(3):
-            model.classify_bytes(arena, offs, lens, 100, logits=logits, labels=labels)
+            model.classify_bytes(arena, offs, lens, L, logits=logits, labels=labels)
         torch.cuda.synchronize()
         t = time.perf_counter()
         for _ in range(reps):
-            model.classify_bytes(arena, offs, lens, 100, logits=logits, labels=labels)
+            model.classify_bytes(arena, offs, lens, L, logits=logits, labels=labels)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t) / reps
-        out[n] = {"us_per_call": dt * 1e6, "reads_per_s": n / dt}
+        out[n] = {"us_per_call": dt * 1e6, "reads_per_s": n / dt, "read_steps_per_s": n * L / dt}
     print(json.dumps(out))
 
 
