@@ -131,3 +131,24 @@ def test_cli_two_ranks_match_one(tmp_path):
     for a, b in zip(one, two):
         assert _read(a) == _read(b) and len(_read(a)) > 0
     assert _read(one[0] + ".unclassified.gz") == _read(two[0] + ".unclassified.gz")
+
+
+def test_cli_damaged_input_is_an_error(tmp_path):
+    """a truncated .gz (or a FASTQ cut inside a record) stops the run with an error instead of writing a short output"""
+    from ribodetector_amd import detect, synth
+    arena, off, _ = synth.reads_numpy(30000, 100, seed=61)
+    good = str(tmp_path / "r.fq.gz")
+    synth.write_fastq(good, arena, off, 1)
+    blob = open(good, "rb").read()
+    cut = str(tmp_path / "cut.fq.gz")
+    with open(cut, "wb") as fh:
+        fh.write(blob[: len(blob) // 2])
+    with pytest.raises(ValueError, match="ended before the end-of-stream marker"):
+        detect.main(["-l", "100", "-i", cut, "-o", str(tmp_path / "o.fq"), "--chunk_size", "4", "-m", "3"])
+    plain = str(tmp_path / "cut.fq")
+    text = gzip.decompress(blob)
+    lines = text.split(b"\n")
+    with open(plain, "wb") as fh:               # ends inside the sequence line of record 10,000: 2 of 4 lines present
+        fh.write(b"\n".join(lines[:40001]) + b"\n" + lines[40001][:25])
+    with pytest.raises(ValueError, match="truncated FASTQ record"):
+        detect.main(["-l", "100", "-i", plain, "-o", str(tmp_path / "o2.fq")])
