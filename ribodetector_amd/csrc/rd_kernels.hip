@@ -13,12 +13,16 @@
 //   * the input is one-hot/zero, so W_ih x + b_ih + b_hh is a 5-row table (in_lut) - a gather, not a GEMM.
 //   => the only dense work is the forward recurrence h[B,128] . W_hh^T[128,512] per timestep.
 //
-// Kernel inventory
-//   rd_prep_kernel            weight pre-packing (once per model)
-//   rd_len_hist/scan/scatter  length bucketing = pack_sequence's sort (descending length)
-//   rd_lstm_mfma_f32_kernel   persistent-weight fp32-MFMA recurrence + fused encoder/FC/argmax epilogue
-//   rd_lstm_simple_kernel     plain-FMA cross-check of the same function
-//   rd_encode_* / rd_pack_*   standalone encoder kernels (reference tensor layouts), HBM-bound
+// Kernel inventory (DESIGN.md §3 has the roofline of each)
+//   rd_prep_kernel, rd_revtab_kernel   weight pre-packing (once per model); reverse-half table of the padded semantics
+//   rd_steps_kernel, rd_bucket_scan/scatter_kernel   steps per read + length bucketing for rd_classify (longest first)
+//   rd_len_hist/scan/scatter_kernel    stable counting sort = pack_sequence's sort, for rd_pack_plan
+//   rd_lstm_mfma_f16x3_t32_kernel      DEFAULT recurrence: split-precision f16 MFMA 32x32x16, weights resident in AGPRs,
+//                                      hand-interleaved gate math; fused encoder + FC + argmax epilogue
+//   rd_lstm_mfma_f16x3_kernel, rd_lstm_mfma_f16x3_w8_kernel   earlier / experimental tilings of the same arithmetic
+//   rd_lstm_mfma_f32_kernel            exact-fp32 MFMA recurrence (A/B reference for the split-precision kernels)
+//   rd_lstm_simple_kernel              plain-FMA cross-check of the same function
+//   rd_encode_* / rd_pack_onehot       standalone encoder kernels (reference tensor layouts), HBM-bound
 //   rd_pair_fuse_kernel, rd_count_kernel
 #include <hip/hip_runtime.h>
 #include <stdint.h>
