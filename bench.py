@@ -57,9 +57,9 @@ def cpu_baseline(arena_np, n_reads, target_s=15.0):
     rate = probe / max(time.time() - t0, 1e-6)
     n = int(min(n_reads, max(1024 * cores, (rate * target_s) // (1024 * cores) * 1024 * cores)))
     t0 = time.time()
-    ora.forward_padded(arena_np, off[:n], lens[:n], READ_LEN, batched=True, batch=1024, nthreads=cores)
+    cpu_logits = ora.forward_padded(arena_np, off[:n], lens[:n], READ_LEN, batched=True, batch=1024, nthreads=cores)
     dt = time.time() - t0
-    return {"value": n / dt, "unit": "reads/s", "cores": cores, "kind": "port",
+    return {"logits": cpu_logits, "n": n, "value": n / dt, "unit": "reads/s", "cores": cores, "kind": "port",
             "sample": "first %d reads of the rank-0 R1 stream (100 bp), oracle rdo_forward_padded_batched = ribodetector_cpu "
                       "algorithm (padded BiLSTM over all 100 steps x 2 directions, batch 1024, one batch per thread, "
                       "%d OpenMP threads = usable cores of this container; os.cpu_count() = %d), %.1f s; onnxruntime is not installed, so this C port "
@@ -209,7 +209,11 @@ def main():
                                    % (P, "pairs" if paired else "reads", args.steps, total_pairs / 1e6),
                        "pairs_per_s": (total_pairs / dt) if paired else None, "per_step_per_gpu": P, "read_len": RL if args.workload != "var300" else "40-300",
                        "ensure": args.ensure if paired else None,
-                       "kernel_variant": variant, "parallelism": "reads sharded x%d, RCCL label gather" % world,
+                       "kernel_variant": variant,
+                       "precision": ("every fp32 product h*w is formed as three f16 MFMA products of hi/lo parts with fp32 accumulation; "
+                                     "logit error against a float64 evaluation equals the fp32 reference's own (DESIGN.md 4, "
+                                     "tests/test_gpu_parity.py::test_error_against_float64_truth); parity_sample below is this run's check"
+                                     if variant.startswith("mfma_f16x3") else "fp32"), "parallelism": "reads sharded x%d, RCCL label gather" % world,
                        "label_counts": {"non_rrna": c[0], "rrna": c[1], "unclassified": c[2]}},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": (achieved / peak) if achieved else None, "traffic": traffic,
@@ -266,8 +270,24 @@ def main():
         if not args.no_cpu_baseline and world == 1 and args.workload in ("pe100", "se100"):
             try:
                 nb = min(P, 400000)
-                out["cpu_baseline"] = cpu_baseline(r1[0][0][: nb * READ_LEN].cpu().numpy(), nb)
-                out["config"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+                cb = cpu_baseline(r1[0][0][: nb * READ_LEN].cpu().numpy(), nb)
+                cpu_logits, ns = cb.pop("logits"), cb.pop("n")
+                out["cpu_baseline"] = cb
+                out["config"]["gpu_over_cpu"] = out["value"] / cb["value"]
+                # the baseline's logits double as a parity check of the timed kernel on the same reads (same semantics:
+                # ribodetector_cpu's padded input = the 'padded' switch of the HIP path)
+                import numpy as np
+                model.set_semantics("padded")
+                g_logits, g_labels = model.classify_bytes(r1[0][0], offs[:ns].contiguous(), lens[:ns].contiguous(), MAXLEN)
+                model.set_semantics("packed")
+                g_logits = g_logits.cpu().numpy()
+                err = np.abs(g_logits - cpu_logits).max(axis=1)
+                margin = np.abs(cpu_logits[:, 1] - cpu_logits[:, 0])
+                diff = np.flatnonzero(g_labels.cpu().numpy() != (cpu_logits[:, 1] > cpu_logits[:, 0]))
+                out["parity_sample"] = {"reads": int(ns), "vs": "cpu_baseline logits (fp32 C port of ribodetector_cpu), same reads",
+                                        "max_abs_logit_err": float(err.max()), "p9999_abs_logit_err": float(np.quantile(err, 0.9999)),
+                                        "label_mismatches": int(len(diff)),
+                                        "largest_margin_among_mismatches": float(margin[diff].max()) if len(diff) else None}
             except Exception as e:  # the checker is not the product: report, don't hide
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out))
