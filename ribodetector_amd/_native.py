@@ -15,7 +15,8 @@ VARIANTS = {"auto": 0, "mfma_f32": 1, "simple": 2, "mfma_f16x3": 3, "mfma_f16x3_
             "mfma_f32_a0s0": 10, "mfma_f32_a1s0": 11, "mfma_f32_a0s1": 12, "mfma_f32_a1s1": 13,
             "mfma_f32_diag_noew": 20, "mfma_f32_diag_nomfma": 21, "mfma_f32_diag_mfmaonly": 22,
             "mfma_f32_diag_mfmabar": 23, "mfma_f16x3_fill0": 30, "mfma_f16x3_fill3": 31, "mfma_f16x3_fill4": 32,
-            "mfma_f16x3_t32_fill0": 40, "mfma_f16x3_t32_diag_mfmaonly": 41}
+            "mfma_f16x3_t32_fill0": 40, "mfma_f16x3_t32_diag_mfmaonly": 41,
+            "mfma_f16x3_t32_diag_nobarrier": 42}
 
 # every symbol include/ribodetector_amd.h declares (tests/test_abi.py checks the .so exports all of them)
 SYMBOLS = [

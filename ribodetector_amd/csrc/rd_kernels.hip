@@ -1267,7 +1267,7 @@ __device__ __forceinline__ void rd_phase_t32(Lstm16bSmem &S, const f16x8 (&W1)[4
     if constexpr (FILL < 0) {   // bench diagnosis only (wrong results): no gate math, keep the accumulators live
         if (accC[0][0] + accC[1][5] + accC[2][9] + accC[3][15] == 123.456f) S.Hl[TP * 32 + j][tid & 127] = accC[0][1];
     }
-    __syncthreads();
+    if constexpr (FILL != 7) __syncthreads();   // FILL 7: bench diagnosis only (racy, wrong results): what the barrier costs
 }
 
 template <int FILL>
@@ -2024,6 +2024,7 @@ int rd_classify(const rd_model *cm, const uint8_t *arena, const int64_t *seq_off
         case RD_VARIANT_MFMA_F16X3: hipLaunchKernelGGL(rd_lstm_mfma_f16x3_kernel<2>, dim3((unsigned)nwg), dim3(256), 0, st, m->d, rb, logits, labels); break;
         case RD_VARIANT_MFMA_F16X3_T32: hipLaunchKernelGGL(rd_lstm_mfma_f16x3_t32_kernel<6>, dim3((unsigned)nwg), dim3(256), 0, st, m->d, rb, logits, labels); break;
         case 5: hipLaunchKernelGGL(rd_lstm_mfma_f16x3_w8_kernel, dim3((unsigned)nwg), dim3(512), 0, st, m->d, rb, logits, labels); break;
+        case 42: hipLaunchKernelGGL(rd_lstm_mfma_f16x3_t32_kernel<7>, dim3((unsigned)nwg), dim3(256), 0, st, m->d, rb, logits, labels); break;
         case 41: hipLaunchKernelGGL(rd_lstm_mfma_f16x3_t32_kernel<-1>, dim3((unsigned)nwg), dim3(256), 0, st, m->d, rb, logits, labels); break;
         case 40: hipLaunchKernelGGL(rd_lstm_mfma_f16x3_t32_kernel<0>, dim3((unsigned)nwg), dim3(256), 0, st, m->d, rb, logits, labels); break;
         case 30: hipLaunchKernelGGL(rd_lstm_mfma_f16x3_kernel<0>, dim3((unsigned)nwg), dim3(256), 0, st, m->d, rb, logits, labels); break;
