@@ -397,3 +397,32 @@ def test_soak_random_reads(gpu_model, oracle, report, sem):
     finally:
         gpu_model.set_semantics("packed")
     report["soak_%s" % sem] = {"reads_per_case": n, "cases": 5, "max_abs_logit_err": float(worst)}
+
+
+def test_integration_md_binding_runs(gpu_model, oracle):
+    """The ctypes stub INTEGRATION.md shows a reference maintainer (`ribodetector/hip_backend.py`) is executed as written
+    (only the library path is made absolute) and must classify like the package's own wrapper."""
+    import os
+    import re
+    from ribodetector_amd import _native as N
+    from ribodetector_amd import synth
+    from ribodetector_amd.data_loader import seq_encoder as E
+    from ribodetector_amd.parse_config import ConfigParser
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    md = open(os.path.join(root, "INTEGRATION.md")).read()
+    block = re.search(r"```python\n(# ribodetector/hip_backend\.py.*?)```", md, re.S).group(1)
+    block = block.replace('C.CDLL("librd_hip.so")', "C.CDLL(%r)" % N.LIB_PATH)
+    ns = {}
+    exec(compile(block, "INTEGRATION.md:hip_backend", "exec"), ns)
+    sd = ConfigParser.from_json(os.path.join(root, "ribodetector_amd", "config.json")).load_state_dict("mcc")
+    sd = {k: torch.as_tensor(np.asarray(v)) for k, v in sd.items()}
+    hm = ns["HipModel"](sd, device=0)
+    arena, off, lens = synth.reads_numpy(3000, (30, 130), seed=12, rrna_frac=0.3)
+    b = E.batch_from_numpy(arena, off[:-1], lens, "cuda")
+    logits, labels = hm.classify(b.arena, b.offsets, b.lens, 100)
+    want, wlab = gpu_model.classify_bytes(b.arena, b.offsets, b.lens, 100)
+    torch.cuda.synchronize()
+    assert torch.equal(logits, want) and torch.equal(labels, wlab)
+    _check(logits.cpu().numpy(), labels.cpu().numpy(), oracle.forward_packed(arena, off, lens, 100), "INTEGRATION.md stub")
+    fused = hm.pair_labels(logits, logits.flip(0).contiguous(), "both")
+    assert fused.dtype == torch.int8 and set(fused.unique().tolist()) <= {-1, 0, 1}
