@@ -1,0 +1,61 @@
+// rd_recurrence.hpp - what the recurrence kernels share: the read batch descriptor, the fused FC + argmax epilogue, the split-precision scales
+// Part of the single translation unit rd_kernels.hip (included from there, in order); see that file for the kernel
+// inventory and DESIGN.md §3 for the roofline of each kernel.
+#pragma once
+#include "rd_common.hpp"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// shared pieces of the recurrence kernels
+// ------------------------------------------------------------------------------------------------
+struct ReadBatch {
+    const uint8_t *arena;
+    const int64_t *off;
+    const int32_t *len;
+    const int32_t *steps;   // timesteps the forward recurrence runs for each read (rd_steps_kernel)
+    const int32_t *order;   // sorted position -> read index (nullptr = identity)
+    int64_t n;
+    int max_len;
+    int sem;                // RD_SEM_PACKED: gather at step len-1 (reference GPU path); RD_SEM_PADDED: ribodetector_cpu
+    const float *rev_tab;   // padded semantics only
+};
+
+// FC + argmax epilogue for one workgroup's reads. hl(row,u) = captured last forward hidden state.
+// logits = b_out + W_out[:, :128] . h_fwd + rev_lut[last base]   (model.py:36; reverse half folded, see header)
+template <typename HL>
+__device__ __forceinline__ void rd_fc_epilogue(int nrows, HL hl, const int *Trow, const int *Lrow, const long long *offrow,
+                                               const int *origrow, const float *s_wout, const DevModel &d, const ReadBatch &rb,
+                                               float *logits, uint8_t *labels) {
+    const int tid = threadIdx.x;
+    if (tid < 2 * nrows) {
+        const int row = tid >> 1, k = tid & 1;
+        float s = d.b_out[k];
+        for (int u = 0; u < HID; ++u) s = __builtin_fmaf(s_wout[k * HID + u], hl(row, u), s);
+        const int T = Trow[row];
+        if (rb.sem == RD_SEM_PADDED && T > 0) {   // (T == 0 only for the filler rows of the last workgroup)
+            // reverse half of output row pos = T-1: the reverse LSTM has walked max_len-1-pos zero rows, then x[pos]
+            const int pos = T - 1;
+            const int code = pos < Lrow[row] ? rd_code(rb.arena[offrow[row] + pos]) : 4;
+            s += rb.rev_tab[((rb.max_len - 1 - pos) * 5 + code) * 2 + k];
+        } else if (rb.sem != RD_SEM_PADDED && T > 0) {
+            s += d.rev_lut[rd_code(rb.arena[offrow[row] + T - 1]) * 2 + k];
+        }
+        const float other = __shfl_xor(s, 1);
+        const int orig = origrow[row];
+        if (orig >= 0) {
+            logits[(size_t)orig * 2 + k] = s;
+            if (labels && k == 0) labels[orig] = other > s ? 1 : 0;   // torch.argmax: first max wins ties -> 0
+        }
+    }
+}
+
+// split-precision (f16x3) kernels: operand layout and scales, see rd_lstm_f16x3.hpp
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+constexpr int H16STR = 136;   // f16 per LDS row: 128 + 8 pad = 272 B -> conflict-free ds_read_b128 over 16 rows
+constexpr int TC16 = 64;      // timesteps per staged code chunk
+constexpr float W_SCALE = 16.0f, H_SCALE = 2048.0f, G_SCALE = 32768.0f;   // 2^4, 2^11, 2^15
+// sigmoid(x) = 1 / (1 + 2^(KS x)),  tanh(x) = 1 - 2 / (1 + 2^(KT x))
+constexpr float KS = -1.44269504088896341f, KT = 2.88539008177792681f;
+
+}  // namespace

@@ -1,0 +1,303 @@
+// rd_sort.hpp - steps per read, length bucketing for rd_classify, the stable sort behind rd_pack_plan, and their host-side launch helpers
+// Part of the single translation unit rd_kernels.hip (included from there, in order); see that file for the kernel
+// inventory and DESIGN.md §3 for the roofline of each kernel.
+#pragma once
+#include "rd_common.hpp"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// length bucketing: order[] = read indices sorted by T = min(len,max_len) descending (pack_sequence's sort,
+// detect.py:685). Ties are ordered by input index (stable) so that the order is deterministic.
+// Three kernels: per-block histograms -> exclusive scan over (length desc, block asc) -> stable scatter.
+// ------------------------------------------------------------------------------------------------
+constexpr int SORT_BLOCK = 256;
+constexpr int SORT_ITEMS = 2048;   // reads per block
+
+
+// hist[(T)*(nblk) + blk] = number of reads of truncated length T in block blk
+__global__ void rd_len_hist_kernel(const int32_t *__restrict__ len, int64_t n, int max_len, int nblk,
+                                   uint32_t *__restrict__ hist) {
+    extern __shared__ uint32_t sh[];   // max_len+1
+    for (int i = threadIdx.x; i <= max_len; i += blockDim.x) sh[i] = 0;
+    __syncthreads();
+    int64_t base = (int64_t)blockIdx.x * SORT_ITEMS;
+    for (int k = threadIdx.x; k < SORT_ITEMS; k += blockDim.x) {
+        int64_t i = base + k;
+        if (i < n) atomicAdd(&sh[rd_T(len, i, max_len)], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i <= max_len; i += blockDim.x) hist[(size_t)i * nblk + blockIdx.x] = sh[i];
+}
+
+// single block: exclusive scan of hist in the order (T descending, blk ascending); also per-length totals:
+// len_start[T] = first sorted position of length T; batch_sizes[t] = #reads with T > t; total_steps.
+__global__ void rd_len_scan_kernel(uint32_t *__restrict__ hist, int max_len, int nblk, int64_t *__restrict__ len_start,
+                                   int64_t *__restrict__ batch_sizes, int64_t *__restrict__ total_steps) {
+    __shared__ unsigned long long carry;
+    __shared__ unsigned long long wsum[SORT_BLOCK / 64];
+    const int tid = threadIdx.x;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    const int64_t total = (int64_t)(max_len + 1) * nblk;
+    unsigned long long steps = 0;
+    for (int64_t base = 0; base < total; base += SORT_BLOCK) {
+        int64_t e = base + tid;               // element in scan order
+        unsigned v = 0;
+        int T = 0;
+        if (e < total) {
+            T = max_len - (int)(e / nblk);
+            v = hist[(size_t)T * nblk + (e % nblk)];
+        }
+        // inclusive scan within the block
+        unsigned long long x = v;
+        for (int o = 1; o < 64; o <<= 1) {
+            unsigned long long y = __shfl_up(x, o);
+            if ((tid & 63) >= o) x += y;
+        }
+        if ((tid & 63) == 63) wsum[tid >> 6] = x;
+        __syncthreads();
+        unsigned long long pre = carry;
+        for (int w = 0; w < (tid >> 6); ++w) pre += wsum[w];
+        unsigned long long excl = pre + x - v;
+        if (e < total) {
+            hist[(size_t)T * nblk + (e % nblk)] = (uint32_t)excl;   // n < 2^31
+            if ((e % nblk) == 0 && len_start) len_start[T] = (int64_t)excl;
+        }
+        __syncthreads();
+        if (tid == SORT_BLOCK - 1) carry = pre + x;
+        __syncthreads();
+    }
+    (void)steps;
+    if (batch_sizes || total_steps) {
+        // batch_sizes[t] = #reads with T >= t+1 = len_start[t] (start of the first length <= t) ... computed from len_start:
+        // reads with T > t occupy sorted positions [0, len_start[t]) because lengths are descending.
+        __syncthreads();
+        unsigned long long acc = 0;
+        for (int t = tid; t < max_len; t += SORT_BLOCK) {
+            int64_t bs = len_start[t];
+            if (batch_sizes) batch_sizes[t] = bs;
+            acc += (unsigned long long)bs;
+        }
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+        if ((tid & 63) == 0) wsum[tid >> 6] = acc;
+        __syncthreads();
+        if (tid == 0 && total_steps) {
+            unsigned long long s = 0;
+            for (int w = 0; w < SORT_BLOCK / 64; ++w) s += wsum[w];
+            *total_steps = (int64_t)s;
+        }
+    }
+}
+
+// stable scatter: one wave-serial pass per block keeps input order inside a length bucket.
+__global__ void rd_len_scatter_kernel(const int32_t *__restrict__ len, int64_t n, int max_len, int nblk,
+                                      const uint32_t *__restrict__ hist, int32_t *__restrict__ order,
+                                      int64_t *__restrict__ sorted_idx, int64_t *__restrict__ unsorted_idx) {
+    extern __shared__ uint32_t cur[];   // max_len+1 running cursors of this block
+    for (int i = threadIdx.x; i <= max_len; i += blockDim.x) cur[i] = hist[(size_t)i * nblk + blockIdx.x];
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * SORT_ITEMS;
+    // process 64 reads at a time with wave 0 only (stability needs an order; the work is a few bytes per read)
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        for (int k0 = 0; k0 < SORT_ITEMS; k0 += 64) {
+            int64_t i = base + k0 + lane;
+            bool valid = i < n;
+            int T = valid ? rd_T(len, i, max_len) : -1;
+            // rank among earlier lanes with the same T
+            unsigned rank = 0, cnt = 0;
+            for (int o = 0; o < 64; ++o) {
+                int To = __shfl(T, o);
+                if (To == T) { cnt++; if (o < lane) rank++; }
+            }
+            uint32_t pos = 0;
+            if (valid) pos = cur[T] + rank;
+            __builtin_amdgcn_wave_barrier();
+            if (valid && rank == cnt - 1) cur[T] = pos + 1;   // last lane of each group advances the cursor
+            __builtin_amdgcn_wave_barrier();
+            if (valid) {
+                if (order) order[pos] = (int32_t)i;
+                if (sorted_idx) sorted_idx[pos] = i;
+                if (unsorted_idx) unsorted_idx[i] = pos;
+            }
+        }
+    }
+}
+
+// Per-read number of forward steps.
+//   packed (model.py:32-37 + detect.py:682): T = min(len, max_len).
+//   padded (model_cpu.py:29-37,57-62): the input is zero-padded to max_len rows and the output row is the LAST NON-ZERO row,
+//     pos = L-1-argmax(flip(rowsum)); if every row is zero, argmax = 0 and pos = L-1. T = pos + 1.
+// It also histograms the step counts (wave-aggregated LDS counters, flushed with one global atomic per non-empty bin and
+// workgroup) for the bucketing below.
+__device__ __forceinline__ uint32_t rd_bin_add(uint32_t *bins, int T, bool valid) {   // returns the rank inside the bin
+    const unsigned long long m = __ballot(valid);
+    if (!m) return 0;
+    const int lane = threadIdx.x & 63, first = __ffsll((long long)m) - 1;
+    const int T0 = __shfl(T, first);
+    if (__all(!valid || T == T0)) {   // the common case (fixed-length reads): one atomic per wave
+        uint32_t base = 0;
+        if (lane == first) base = atomicAdd(&bins[T0], (uint32_t)__popcll(m));
+        return __shfl(base, first) + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+    }
+    return valid ? atomicAdd(&bins[T], 1u) : 0;
+}
+
+__global__ __launch_bounds__(256) void rd_steps_kernel(const uint8_t *__restrict__ arena, const int64_t *__restrict__ off,
+                                                       const int32_t *__restrict__ len, int64_t n, int max_len, int sem,
+                                                       int32_t *__restrict__ steps, uint32_t *__restrict__ ghist) {
+    extern __shared__ uint32_t sh_bins[];   // max_len+1
+    for (int i = threadIdx.x; i <= max_len; i += 256) sh_bins[i] = 0;
+    __syncthreads();
+    for (int64_t base = (int64_t)blockIdx.x * 256; base < n; base += (int64_t)gridDim.x * 256) {
+        const int64_t i = base + threadIdx.x;
+        const bool valid = i < n;
+        int T = 0;
+        if (valid) {
+            const int lr = rd_T(len, i, max_len);
+            T = lr;
+            if (sem == RD_SEM_PADDED) {
+                const uint8_t *p = arena + off[i];
+                int pos = lr - 1;
+                while (pos >= 0 && rd_code(p[pos]) == 4) --pos;
+                T = pos >= 0 ? pos + 1 : max_len;
+            }
+            steps[i] = T;
+        }
+        rd_bin_add(sh_bins, T, valid);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i <= max_len; i += 256)
+        if (sh_bins[i]) atomicAdd(&ghist[i], sh_bins[i]);
+}
+
+// Length bucketing for rd_classify: order[] = read indices grouped by step count, longest first, so that the reads of a
+// tile run (nearly) the same number of steps. Every read is computed independently of its tile mates, so the order INSIDE
+// a bucket does not matter and is left to the atomics (rd_pack_plan, whose output order is visible, uses the stable sort
+// above). cursor[T] = first position of bucket T = number of reads with more than T steps.
+__global__ __launch_bounds__(256) void rd_bucket_scan_kernel(const uint32_t *__restrict__ ghist, int max_len,
+                                                             uint32_t *__restrict__ cursor) {
+    __shared__ uint32_t part[256];
+    const int tid = threadIdx.x, nb = max_len + 1, per = (nb + 255) / 256;
+    uint32_t s = 0;
+    for (int k = 0; k < per; ++k) {
+        const int e = tid * per + k;   // scan position e <-> T = max_len - e
+        if (e < nb) s += ghist[max_len - e];
+    }
+    part[tid] = s;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        const uint32_t v = tid >= d ? part[tid - d] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[tid] - s;
+    for (int k = 0; k < per; ++k) {
+        const int e = tid * per + k;
+        if (e < nb) {
+            cursor[max_len - e] = run;
+            run += ghist[max_len - e];
+        }
+    }
+}
+
+constexpr int BK_ITEMS = 2048;   // reads per workgroup and pass
+__global__ __launch_bounds__(256) void rd_bucket_scatter_kernel(const int32_t *__restrict__ steps, int64_t n, int max_len,
+                                                                uint32_t *__restrict__ cursor, int32_t *__restrict__ order) {
+    extern __shared__ uint32_t sh_bins[];   // max_len+1: counts of this pass, then the buckets' reserved start positions
+    for (int64_t b0 = (int64_t)blockIdx.x * BK_ITEMS; b0 < n; b0 += (int64_t)gridDim.x * BK_ITEMS) {
+        __syncthreads();
+        for (int i = threadIdx.x; i <= max_len; i += 256) sh_bins[i] = 0;
+        __syncthreads();
+        int Tk[BK_ITEMS / 256];
+        uint32_t rk[BK_ITEMS / 256];
+#pragma unroll
+        for (int k = 0; k < BK_ITEMS / 256; ++k) {
+            const int64_t i = b0 + k * 256 + threadIdx.x;
+            const bool valid = i < n;
+            const int T = valid ? steps[i] : 0;
+            rk[k] = rd_bin_add(sh_bins, T, valid);
+            Tk[k] = valid ? T : -1;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i <= max_len; i += 256) {
+            const uint32_t c = sh_bins[i];
+            if (c) sh_bins[i] = atomicAdd(&cursor[i], c);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < BK_ITEMS / 256; ++k)
+            if (Tk[k] >= 0) order[sh_bins[Tk[k]] + rk[k]] = (int32_t)(b0 + k * 256 + threadIdx.x);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host helpers
+// ------------------------------------------------------------------------------------------------
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+struct SortPlan {
+    int nblk;
+    size_t hist_bytes, order_bytes, lenstart_bytes, steps_bytes, total;
+};
+inline SortPlan sort_plan(int64_t n, int max_len) {
+    SortPlan p;
+    p.nblk = (int)((n + SORT_ITEMS - 1) / SORT_ITEMS);
+    if (p.nblk < 1) p.nblk = 1;
+    p.hist_bytes = align_up((size_t)(max_len + 1) * p.nblk * sizeof(uint32_t), 256);
+    p.order_bytes = align_up((size_t)(n > 0 ? n : 1) * sizeof(int32_t), 256);
+    p.lenstart_bytes = align_up((size_t)(max_len + 1) * sizeof(int64_t) * 2, 256);   // len_start + cum scratch
+    p.steps_bytes = align_up((size_t)(n > 0 ? n : 1) * sizeof(int32_t), 256);
+    p.total = p.hist_bytes + p.order_bytes + p.lenstart_bytes + p.steps_bytes;
+    return p;
+}
+
+constexpr int MAX_LEN_LIMIT = 16000;   // LDS histogram of max_len+1 uint32 must fit in 64 KB
+
+int run_sort(const int32_t *seq_len, int64_t n, int max_len, void *workspace, size_t wbytes, int32_t *&order,
+             int64_t *sorted_idx, int64_t *unsorted_idx, int64_t *batch_sizes, int64_t *total_steps, int64_t *&len_start,
+             hipStream_t st) {
+    SortPlan p = sort_plan(n, max_len);
+    if (wbytes < p.total) RD_FAIL(RD_E_WORKSPACE, "workspace too small: %zu < %zu", wbytes, p.total);
+    char *w = (char *)workspace;
+    uint32_t *hist = (uint32_t *)w;
+    order = (int32_t *)(w + p.hist_bytes);
+    len_start = (int64_t *)(w + p.hist_bytes + p.order_bytes);
+    const size_t sh = (size_t)(max_len + 1) * sizeof(uint32_t);
+    hipLaunchKernelGGL(rd_len_hist_kernel, dim3(p.nblk), dim3(SORT_BLOCK), sh, st, seq_len, n, max_len, p.nblk, hist);
+    hipLaunchKernelGGL(rd_len_scan_kernel, dim3(1), dim3(SORT_BLOCK), 0, st, hist, max_len, p.nblk, len_start, batch_sizes,
+                       total_steps);
+    hipLaunchKernelGGL(rd_len_scatter_kernel, dim3(p.nblk), dim3(SORT_BLOCK), sh, st, seq_len, n, max_len, p.nblk, hist, order,
+                       sorted_idx, unsorted_idx);
+    RD_HIP(hipGetLastError());
+    return RD_OK;
+}
+
+// steps[] + order[] for rd_classify: steps kernel (with histogram) -> bucket starts -> scatter
+int run_steps_and_buckets(const uint8_t *arena, const int64_t *seq_off, const int32_t *seq_len, int64_t n, int max_len, int sem,
+                          void *workspace, size_t wbytes, int32_t *&steps, int32_t *&order, hipStream_t st) {
+    SortPlan p = sort_plan(n, max_len);
+    if (wbytes < p.total) RD_FAIL(RD_E_WORKSPACE, "workspace too small: %zu < %zu", wbytes, p.total);
+    char *w = (char *)workspace;
+    uint32_t *ghist = (uint32_t *)w;                                          // (max_len+1) u32 fit in hist_bytes
+    order = (int32_t *)(w + p.hist_bytes);
+    uint32_t *cursor = (uint32_t *)(w + p.hist_bytes + p.order_bytes);        // (max_len+1) u32 fit in lenstart_bytes
+    steps = (int32_t *)(w + p.total - p.steps_bytes);
+    const size_t sh = (size_t)(max_len + 1) * sizeof(uint32_t);
+    RD_HIP(hipMemsetAsync(ghist, 0, sh, st));
+    // one workgroup per CU at most: every workgroup ends with one global atomic per non-empty bin, and with fixed-length
+    // reads they all hit the same bin
+    int64_t nb = (n + 255) / 256;
+    if (nb > 256) nb = 256;
+    hipLaunchKernelGGL(rd_steps_kernel, dim3((unsigned)nb), dim3(256), sh, st, arena, seq_off, seq_len, n, max_len, sem, steps, ghist);
+    hipLaunchKernelGGL(rd_bucket_scan_kernel, dim3(1), dim3(256), 0, st, ghist, max_len, cursor);
+    int64_t nbs = (n + BK_ITEMS - 1) / BK_ITEMS;
+    if (nbs > 256) nbs = 256;
+    hipLaunchKernelGGL(rd_bucket_scatter_kernel, dim3((unsigned)nbs), dim3(256), sh, st, steps, n, max_len, cursor, order);
+    RD_HIP(hipGetLastError());
+    return RD_OK;
+}
+
+}  // namespace
