@@ -15,6 +15,7 @@ import argparse
 import math
 import os
 import threading
+import time
 import queue
 from argparse import RawTextHelpFormatter
 
@@ -105,8 +106,10 @@ class Predictor:
             ln = tlen[lo:hi].to(self.device, non_blocking=True)
         return arena, off, ln
 
-    def classify_chunk(self, chunks):
-        """chunks: (c1,) or (c1, c2). Returns the int8 labels of the whole chunk on rank 0 (numpy), None elsewhere."""
+    def submit_chunk(self, chunks):
+        """Enqueue one chunk: H2D on the copy stream, kernels on the compute stream, D2H of the labels into pinned memory.
+        Nothing here waits for the GPU, so the next chunk's H2D overlaps this chunk's kernels. Returns a ticket for
+        collect_chunk()."""
         n = len(chunks[0].seq_len)
         bounds = None
         if self.world > 1:                       # equal bases (= recurrence steps) per rank, not equal read counts
@@ -115,17 +118,32 @@ class Predictor:
         lo, hi = (0, n) if bounds is None else (bounds[self.rank], bounds[self.rank + 1])
         cs = self._copy_stream
         dev_in = [self._to_device(c, lo, hi, cs) for c in chunks]
-        torch.cuda.current_stream(self.device).wait_stream(cs)
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_stream(cs)
         outs = [self.model.classify_bytes(a, o, l, self.len, want_labels=not self.is_paired) for a, o, l in dev_in]
         if self.is_paired:
             labels = module_arch.pair_fuse(outs[0][0], outs[1][0], self.args.ensure)
         else:
             labels = outs[0][1].view(torch.int8)
+        host = None
+        if self.world == 1:
+            host = torch.empty(labels.shape, dtype=torch.int8, pin_memory=True)
+            host.copy_(labels, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record(cur)
+        return {"n": n, "bounds": bounds, "labels": labels, "host": host, "done": done, "keep": (dev_in, outs)}
+
+    def collect_chunk(self, tk):
+        """Labels of a submitted chunk: int8 numpy on rank 0 (whole chunk, input order), None elsewhere."""
         if self.world > 1:
-            labels = rdist.gather_labels(labels, n, dst=0, bounds=bounds)
-            if self.rank != 0:
-                return None
-        return labels.cpu().numpy()
+            labels = rdist.gather_labels(tk["labels"], tk["n"], dst=0, bounds=tk["bounds"])
+            return None if self.rank != 0 else labels.cpu().numpy()
+        tk["done"].synchronize()
+        return tk["host"].numpy()
+
+    def classify_chunk(self, chunks):
+        """chunks: (c1,) or (c1, c2). Returns the int8 labels of the whole chunk on rank 0 (numpy), None elsewhere."""
+        return self.collect_chunk(self.submit_chunk(chunks))
 
     # ---- drivers ----------------------------------------------------------------------------------------
     # Host pipeline: one parser thread per input file -> GPU (main thread) -> one writer thread per mate. The C++ reader,
@@ -155,7 +173,9 @@ class Predictor:
         while True:
             cs = []
             for q in qs:
+                t0 = time.perf_counter()
                 c = q.get()
+                self._stage_s["wait_reader"] += time.perf_counter() - t0
                 if isinstance(c, BaseException):
                     raise c
                 cs.append(c)
@@ -186,6 +206,7 @@ class Predictor:
                 self.logger.info('Writing unclassified sequences into file: {}{}{}'.format(
                     colors.OKYELLOW, ", ".join(unclf), colors.ENDC))
         num_read = num_nonrrna = num_rrna = num_unknown = 0
+        self._stage_s = {"wait_reader": 0.0, "classify": 0.0, "wait_writer": 0.0}   # main-thread seconds per pipeline stage
         from . import _native
         _native.host_lib().rd_host_set_threads(int(self.args.threads))   # -t/--threads: gzip output workers
         self._copy_stream = torch.cuda.Stream(self.device)
@@ -210,9 +231,23 @@ class Predictor:
                 q = queue.Queue(maxsize=2)
                 wq.append(q)
                 wth.append(self._spawn(write_end, e, q))
+        def in_flight(stream):
+            """chunk k+1 is submitted (its H2D starts) before the labels of chunk k are waited for"""
+            prev = None
+            for chunks in stream:
+                t0 = time.perf_counter()
+                tk = self.submit_chunk(chunks)
+                self._stage_s["classify"] += time.perf_counter() - t0
+                if prev is not None:
+                    yield prev
+                prev = (chunks, tk)
+            if prev is not None:
+                yield prev
         try:
-            for chunks in self._chunk_stream(chunk_reads):
-                labels = self.classify_chunk(chunks)
+            for chunks, tk in in_flight(self._chunk_stream(chunk_reads)):
+                t0 = time.perf_counter()
+                labels = self.collect_chunk(tk)
+                self._stage_s["classify"] += time.perf_counter() - t0
                 num_read += len(chunks[0].seq_len)
                 if writer:
                     if werr:
@@ -220,8 +255,10 @@ class Predictor:
                     num_nonrrna += int((labels == 0).sum())
                     num_rrna += int((labels == 1).sum())
                     num_unknown += int((labels == -1).sum())
+                    t0 = time.perf_counter()
                     for e in ends:
                         wq[e].put((chunks[e], labels))
+                    self._stage_s["wait_writer"] += time.perf_counter() - t0
                     self.logger.info('{}{}{} sequences finished!'.format(colors.OKGREEN, num_read, colors.ENDC))
         finally:
             for q in wq:
