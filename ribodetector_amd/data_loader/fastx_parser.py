@@ -236,7 +236,7 @@ class NativeReader:
                     so[n_tot:n_tot + n.value] += b_tot
                 n_tot += n.value
                 b_tot += nb.value
-                self.est = max(self.est, int(1.1 * b_tot / n_tot) + 16)
+                self.est = int(1.08 * b_tot / n_tot) + 16          # bytes per record seen so far: sizes the next pinned buffer
             if rc == 1:
                 self.eof = True
                 break
