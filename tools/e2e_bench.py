@@ -23,7 +23,7 @@ def main():
     for mate, seed in ((1, 1), (2, 2)):
         arena, off, _ = synth.reads_numpy(a.reads, 100, seed=seed)
         p = os.path.join(d, "r_%d.fq" % mate)
-        synth.write_fastq(p, arena, off, mate)
+        synth.write_fastq_realistic(p, arena, off, mate, seed=seed)
         with open(p, "rb") as fi, gzip.open(p + ".gz", "wb", compresslevel=5) as fo:
             shutil.copyfileobj(fi, fo, 1 << 24)
         files[mate] = p

@@ -35,7 +35,7 @@ def main():
     d = tempfile.mkdtemp(prefix="rdhost")
     arena, off, _ = synth.reads_numpy(a.reads, 100, seed=1)
     plain, gz = os.path.join(d, "r.fq"), os.path.join(d, "r.fq.gz")
-    synth.write_fastq(plain, arena, off, 1)
+    synth.write_fastq_realistic(plain, arena, off, 1, seed=1)
     with open(plain, "rb") as fi, gzip.open(gz, "wb", compresslevel=5) as fo:
         fo.write(fi.read())
     out = {"reads": a.reads, "plain_MB": os.path.getsize(plain) / 1e6, "gz_MB": os.path.getsize(gz) / 1e6}
