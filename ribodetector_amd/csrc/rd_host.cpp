@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/uio.h>
 #include <unistd.h>
 #include <zlib.h>
 
@@ -538,42 +539,34 @@ int rd_writer_open(const char *path, rd_writer **out) {
     return 0;
 }
 
-// One run = consecutive selected records = one contiguous byte range of the chunk.
-struct rd_run {
-    const uint8_t *p;
-    size_t len;
-};
-
-// write runs[r0, r1) at file offset off: short runs are staged into a 1 MiB buffer, long ones go out directly
-bool write_runs(int fd, const rd_run *runs, size_t r0, size_t r1, int64_t off) {
-    constexpr size_t STAGE = 1u << 20, DIRECT = 256u << 10;
-    std::vector<uint8_t> stage;
-    stage.reserve(STAGE);
-    for (size_t r = r0; r < r1; ++r) {
-        if (runs[r].len >= DIRECT) {
-            if (!stage.empty()) {
-                if (!pwrite_all(fd, stage.data(), stage.size(), off)) return false;
-                off += (int64_t)stage.size();
-                stage.clear();
+// One run = consecutive selected records = one contiguous byte range of the chunk. Plain output is one pwritev() per
+// 1,024 runs straight from the chunk buffer: a single copy into the page cache, by one thread - writes to one file
+// serialise on the inode lock anyway (tmpfs on the GPU box: 6.1 GB/s from one thread, 4.2 GB/s from eight pwrite()rs).
+bool write_runs(int fd, std::vector<struct iovec> &iov, int64_t off) {
+    size_t k = 0;
+    while (k < iov.size()) {
+        const int cnt = (int)std::min<size_t>(iov.size() - k, 1024);
+        ssize_t got = pwritev(fd, iov.data() + k, cnt, (off_t)off);
+        if (got <= 0) return false;
+        off += got;
+        while (got > 0 && k < iov.size()) {   // advance past what was written (a short write can end inside a run)
+            if ((size_t)got >= iov[k].iov_len) {
+                got -= (ssize_t)iov[k].iov_len;
+                ++k;
+            } else {
+                iov[k].iov_base = (char *)iov[k].iov_base + got;
+                iov[k].iov_len -= (size_t)got;
+                got = 0;
             }
-            if (!pwrite_all(fd, runs[r].p, runs[r].len, off)) return false;
-            off += (int64_t)runs[r].len;
-            continue;
         }
-        if (stage.size() + runs[r].len > STAGE) {
-            if (!pwrite_all(fd, stage.data(), stage.size(), off)) return false;
-            off += (int64_t)stage.size();
-            stage.clear();
-        }
-        stage.insert(stage.end(), runs[r].p, runs[r].p + runs[r].len);
     }
-    return stage.empty() || pwrite_all(fd, stage.data(), stage.size(), off);
+    return true;
 }
 
 int rd_writer_write_selected(rd_writer *w, const uint8_t *buf, const int64_t *rec_start, int64_t n, const int8_t *labels,
                              int32_t want) {
     if (!w || !buf || !rec_start || !labels) RDH_FAIL("rd_writer_write_selected: null argument");
-    std::vector<rd_run> runs;
+    std::vector<struct iovec> iov;
     size_t total = 0;
     int64_t i = 0;
     while (i < n) {
@@ -583,7 +576,7 @@ int rd_writer_write_selected(rd_writer *w, const uint8_t *buf, const int64_t *re
         const uint8_t *p = buf + rec_start[i];
         const size_t len = (size_t)(rec_start[j] - rec_start[i]);
         if (w->gz) w->pending.insert(w->pending.end(), p, p + len);
-        else runs.push_back(rd_run{p, len});
+        else if (len) iov.push_back(iovec{const_cast<uint8_t *>(p), len});
         total += len;
         i = j;
     }
@@ -592,34 +585,7 @@ int rd_writer_write_selected(rd_writer *w, const uint8_t *buf, const int64_t *re
         if (full >= GZ_BLOCK * (size_t)w->threads && gz_flush(w, full) != 0) RDH_FAIL("gzip compression/write failed");
         return 0;
     }
-    // plain output: the copy into the page cache is what costs (~3 GB/s per thread), so large selections are cut into
-    // byte-balanced slices that several threads pwrite() at their final offsets
-    const size_t nthreads = std::min<size_t>({(size_t)std::max(1, w->threads), (size_t)8, total / (8u << 20) + 1, runs.size()});
-    if (nthreads <= 1) {
-        if (!write_runs(w->fd, runs.data(), 0, runs.size(), w->off)) RDH_FAIL("write failed");
-    } else {
-        std::vector<size_t> cut(nthreads + 1, runs.size());
-        std::vector<int64_t> offs(nthreads + 1, 0);
-        cut[0] = 0;
-        offs[0] = w->off;
-        size_t acc = 0, t = 1;
-        for (size_t r = 0; r < runs.size() && t < nthreads; ++r) {
-            acc += runs[r].len;
-            if (acc >= total * t / nthreads) {
-                cut[t] = r + 1;
-                offs[t] = w->off + (int64_t)acc;
-                ++t;
-            }
-        }
-        for (; t < nthreads; ++t) { cut[t] = runs.size(); offs[t] = w->off + (int64_t)total; }
-        std::vector<char> ok(nthreads, 1);
-        std::vector<std::thread> th;
-        for (size_t k = 0; k < nthreads; ++k)
-            th.emplace_back([&, k]() { ok[k] = write_runs(w->fd, runs.data(), cut[k], cut[k + 1], offs[k]) ? 1 : 0; });
-        for (auto &x : th) x.join();
-        for (char o : ok)
-            if (!o) RDH_FAIL("write failed");
-    }
+    if (!write_runs(w->fd, iov, w->off)) RDH_FAIL("write failed");
     w->off += (int64_t)total;
     return 0;
 }

@@ -207,9 +207,9 @@ def test_gzip_writer_zlib_fallback(tmp_path):
     assert outs["auto"] == outs["zlib"] and outs["auto"].count(b"\n") == 4 * (40000 - 13334)
 
 
-def test_plain_writer_parallel_slices(tmp_path):
-    """plain output above 8 MiB per call is written by several threads at precomputed offsets: same bytes as a serial
-    write, for dense, sparse and alternating selections, across several calls on one file"""
+def test_plain_writer_vectored(tmp_path):
+    """plain output is written with pwritev straight from the chunk buffer, 1,024 runs per call: right bytes for dense,
+    sparse and alternating selections (tens of thousands of runs), across several calls on one file"""
     arena, off, _ = synth.reads_numpy(90000, 150, seed=10)
     p = str(tmp_path / "big.fq")
     synth.write_fastq(p, arena, off, mate=1)
