@@ -4,7 +4,7 @@
 // data_loader/seq_encoder.py:75-92 open the file by extension); zlib's inflate decodes ~0.3 GB/s here, i.e. ~1.3 M reads/s,
 // an order of magnitude below what the kernels consume. This decoder is built for long runs of literals and short matches
 // (FASTQ text): a 64-bit bit buffer refilled once per length/distance pair, packed 32-bit table entries with an 11-bit
-// (literal/length) and 8-bit (distance) first level, up to three literals per refill, 8-byte match copies into a buffer
+// (literal/length) and 10-bit (distance) first level, up to three literals per refill, 8-byte match copies into a buffer
 // with slack. The member CRC-32 and ISIZE are verified like gzip.GzipFile does (a mismatch is an error, zero padding
 // between/after members is skipped); the CRC is folded 64 bytes at a time with carry-less multiplies (PCLMULQDQ,
 // ~10 GB/s, against ~1 GB/s for zlib 1.2.11's table-driven crc32, which would cost more than the decoding itself).
@@ -22,7 +22,7 @@
 namespace rdz {
 
 constexpr uint32_t F_LIT = 1u << 31, F_EOB = 1u << 30, F_SUB = 1u << 29, F_BAD = 1u << 28;
-constexpr int LIT_BITS = 11, DIST_BITS = 8, PRE_BITS = 7;
+constexpr int LIT_BITS = 11, DIST_BITS = 10, PRE_BITS = 7;   // FASTQ matches reach far back: long distance codes are common
 constexpr size_t WIN = 32768, CHUNK = 2u << 20, OSLACK = 258 + 64, OSAFE = WIN + CHUNK;
 constexpr size_t IN_CAP = 1u << 20, IN_PAD = 128;
 
@@ -587,13 +587,21 @@ class GzipStream {
             const uint8_t *src = dst - dist;
             op += len;
             if (dist >= 8) {
-                long left = (long)len;
-                do {
-                    memcpy(dst, src, 8);
-                    dst += 8;
-                    src += 8;
-                    left -= 8;
-                } while (left > 0);
+                // most matches in FASTQ text are 4-16 bytes: two unconditional 8-byte copies (in order, so a distance of
+                // 8..15 still reads what the first one wrote), a loop only beyond that; the slack behind OSAFE absorbs the overshoot
+                memcpy(dst, src, 8);
+                memcpy(dst + 8, src + 8, 8);
+                if (len > 16) {
+                    long left = (long)len - 16;
+                    dst += 16;
+                    src += 16;
+                    do {
+                        memcpy(dst, src, 8);
+                        dst += 8;
+                        src += 8;
+                        left -= 8;
+                    } while (left > 0);
+                }
             } else if (dist == 1) {
                 memset(dst, *src, len);
             } else {
