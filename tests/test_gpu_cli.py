@@ -152,3 +152,33 @@ def test_cli_damaged_input_is_an_error(tmp_path):
         fh.write(b"\n".join(lines[:40001]) + b"\n" + lines[40001][:25])
     with pytest.raises(ValueError, match="truncated FASTQ record"):
         detect.main(["-l", "100", "-i", plain, "-o", str(tmp_path / "o2.fq")])
+
+
+def test_cpp_example_over_the_c_abi(tmp_path, gpu_model):
+    """examples/classify_fastq (C++, no Python/torch: librd_host.so reader + librd_hip.so classifier through the two C
+    ABIs) must give the labels the package gives for the same file."""
+    import subprocess
+    import torch
+    from ribodetector_amd import synth
+    from ribodetector_amd.data_loader import seq_encoder as E
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    exe = os.path.join(root, "examples", "classify_fastq")
+    if not os.path.exists(exe):
+        import __graft_entry__ as g
+        g.build()
+    arena, off, lens = synth.reads_numpy(20000, (40, 140), seed=71, rrna_frac=0.3)
+    fq = str(tmp_path / "r.fq.gz")
+    synth.write_fastq(fq, arena, off, 1)
+    lab_file = str(tmp_path / "labels.txt")
+    weights = os.path.join(root, "ribodetector_amd", "data", "ribodetector_600k_variable_len70_101_epoch47.safetensors")
+    r = subprocess.run([exe, weights, fq, "100", lab_file], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = np.array([int(x) for x in open(lab_file).read().split()], dtype=np.uint8)
+    b = E.batch_from_numpy(arena, off[:-1], lens, "cuda")
+    gpu_model.set_variant("auto")
+    _, lab = gpu_model.classify_bytes(b.arena, b.offsets, b.lens, 100)
+    torch.cuda.synchronize()
+    want = lab.cpu().numpy()
+    assert got.shape == want.shape and (got == want).all()
+    assert "Processed 20000 sequences in total" in r.stdout
+    assert "Detected %d rRNA sequences" % int(want.sum()) in r.stdout and "Detected %d non-rRNA sequences" % int((want == 0).sum()) in r.stdout
