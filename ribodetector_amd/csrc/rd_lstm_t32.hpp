@@ -68,7 +68,7 @@ __device__ __forceinline__ void rd_stage_codes16b(Lstm16bSmem &S, const ReadBatc
 constexpr int EW_NU = 212;
 constexpr unsigned char EW_CELL[EW_NU] = {0,0,0,0,0,0,0,1,0,1,0,1,0,1,0,1,0,1,0,1,1,2,1,2,1,2,1,2,1,2,1,2,2,3,2,3,2,3,2,3,2,3,2,3,2,3,3,4,3,4,3,4,3,4,3,4,3,4,3,4,5,4,5,4,5,4,5,4,5,4,5,4,5,5,6,5,6,5,6,5,6,5,6,5,6,6,7,6,7,6,7,6,7,6,7,6,7,6,7,7,8,7,8,7,8,7,8,7,8,7,8,7,8,9,8,9,8,9,8,9,8,9,8,9,8,9,9,10,9,10,9,10,9,10,9,10,9,10,10,11,10,11,10,11,10,11,10,11,10,11,10,11,11,12,11,12,11,12,11,12,11,12,11,12,11,12,13,12,13,12,13,12,13,12,13,12,13,12,13,13,14,13,14,13,14,13,14,13,14,13,14,14,15,14,15,14,15,14,15,14,15,14,15,14,15,15,15,15,15,15,15,15};
 constexpr unsigned char EW_STAGE[EW_NU] = {0,1,2,3,4,5,6,0,7,1,8,2,9,3,10,4,11,5,12,6,7,0,8,1,9,2,10,3,11,4,12,5,6,0,7,1,8,2,9,3,10,4,11,5,12,6,7,0,8,1,9,2,10,3,11,4,12,5,13,6,0,7,1,8,2,9,3,10,4,11,5,12,6,7,0,8,1,9,2,10,3,11,4,12,5,6,0,7,1,8,2,9,3,10,4,11,5,12,6,7,0,8,1,9,2,10,3,11,4,12,5,13,6,0,7,1,8,2,9,3,10,4,11,5,12,6,7,0,8,1,9,2,10,3,11,4,12,5,6,0,7,1,8,2,9,3,10,4,11,5,12,6,7,0,8,1,9,2,10,3,11,4,12,5,13,6,0,7,1,8,2,9,3,10,4,11,5,12,6,7,0,8,1,9,2,10,3,11,4,12,5,6,0,7,1,8,2,9,3,10,4,11,5,12,6,7,8,9,10,11,12,13};
-// (schedule above: 16 cells x 13 stages, cell c starts at step floor(6.5 c) so that two cells are in flight and never in
+// (schedule above, generated by tools/gen_ew_schedule.py: 16 cells x 13 stages, cell c starts at step floor(6.5 c) so that two cells are in flight and never in
 //  the same stage; stage 13 = stores of a finished row-tile; generated offline, units are dealt out in this order)
 struct EwRegs {
     f32x4 kc[2];        // table rows of the cells in flight, by cell parity

@@ -71,3 +71,12 @@ def test_synth_deterministic():
     assert set(np.unique(a1)) <= set(b"ACGTN")
     a3, _, _ = synth.reads_numpy(500, 100, seed=4)
     assert abs((a3 == ord("N")).mean() - 0.001) < 0.002
+
+
+def test_gate_math_schedule_is_reproducible():
+    """the hand-interleave tables of the default kernel (EW_CELL / EW_STAGE) are what tools/gen_ew_schedule.py generates"""
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "gen_ew_schedule.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
