@@ -182,3 +182,23 @@ def test_cpp_example_over_the_c_abi(tmp_path, gpu_model):
     assert got.shape == want.shape and (got == want).all()
     assert "Processed 20000 sequences in total" in r.stdout
     assert "Detected %d rRNA sequences" % int(want.sum()) in r.stdout and "Detected %d non-rRNA sequences" % int((want == 0).sum()) in r.stdout
+
+
+def test_cli_empty_and_tiny_inputs(tmp_path):
+    """an empty file, a single read and a single pair go through the whole pipeline (no chunk, one-element chunks)"""
+    from ribodetector_amd import detect
+    empty = str(tmp_path / "empty.fq")
+    open(empty, "w").close()
+    out = str(tmp_path / "o.fq")
+    p = detect.main(["-l", "100", "-i", empty, "-o", out])
+    assert p.num_read == 0 and _read(out) == ""
+    one = str(tmp_path / "one.fq")
+    rec = "@r1\n" + "ACGT" * 25 + "\n+\n" + "I" * 100 + "\n"
+    with open(one, "w") as fh:
+        fh.write(rec)
+    p = detect.main(["-l", "100", "-i", one, "-o", out, "-r", str(tmp_path / "r.fq")])
+    assert p.num_read == 1 and p.num_nonrrna + p.num_rrna == 1
+    assert _read(out) + _read(str(tmp_path / "r.fq")) == rec
+    o1, o2 = str(tmp_path / "p1.fq.gz"), str(tmp_path / "p2.fq.gz")
+    p = detect.main(["-l", "100", "-i", one, one, "-o", o1, o2, "-e", "both"])
+    assert p.num_read == 1 and p.num_unknown == 0 and _read(o1) == _read(o2)
