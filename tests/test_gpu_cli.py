@@ -202,3 +202,25 @@ def test_cli_empty_and_tiny_inputs(tmp_path):
     o1, o2 = str(tmp_path / "p1.fq.gz"), str(tmp_path / "p2.fq.gz")
     p = detect.main(["-l", "100", "-i", one, one, "-o", o1, o2, "-e", "both"])
     assert p.num_read == 1 and p.num_unknown == 0 and _read(o1) == _read(o2)
+
+
+def test_cli_mismatched_pairs_and_fasta_gz(tmp_path, oracle):
+    from ribodetector_amd import detect, synth
+    arena, off, lens = synth.reads_numpy(1500, (60, 120), seed=81, rrna_frac=0.4)
+    seqs = synth.as_strings(arena, off)
+    fa = str(tmp_path / "in.fasta.gz")
+    with gzip.open(fa, "wt") as fh:
+        for i, s in enumerate(seqs):
+            fh.write(">s%d\r\n%s\r\n" % (i, s))                         # CRLF line ends: stripped like the reference's rstrip/strip
+    out, rr = str(tmp_path / "o.fa.gz"), str(tmp_path / "r.fa")
+    p = detect.main(["-l", "100", "-i", fa, "-o", out, "-r", rr, "-e", "norrna"])
+    lab = oracle.argmax(oracle.forward_packed(arena, off, lens, 100))
+    assert p.num_rrna == int(lab.sum())
+    assert _read(out) == "".join(">s%d\n%s\n" % (i, seqs[i]) for i in np.flatnonzero(lab == 0))
+    assert _read(rr) == "".join(">s%d\n%s\n" % (i, seqs[i]) for i in np.flatnonzero(lab == 1))
+    # R2 one record short
+    f1, f2 = str(tmp_path / "a_1.fq"), str(tmp_path / "a_2.fq")
+    synth.write_fastq(f1, arena, off, 1)
+    synth.write_fastq(f2, arena[: off[-2]], off[:-1], 2)
+    with pytest.raises(ValueError, match="different numbers of records"):
+        detect.main(["-l", "100", "-i", f1, f2, "-o", str(tmp_path / "x1.fq"), str(tmp_path / "x2.fq")])
