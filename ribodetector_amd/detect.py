@@ -125,18 +125,20 @@ class Predictor:
             labels = module_arch.pair_fuse(outs[0][0], outs[1][0], self.args.ensure)
         else:
             labels = outs[0][1].view(torch.int8)
-        host = None
+        host = finish = None
         if self.world == 1:
             host = torch.empty(labels.shape, dtype=torch.int8, pin_memory=True)
             host.copy_(labels, non_blocking=True)
+        else:                                    # label gather (1 B per read) queued behind the kernels, collected later
+            _, finish = rdist.gather_labels(labels, n, dst=0, bounds=bounds, async_op=True)
         done = torch.cuda.Event()
         done.record(cur)
-        return {"n": n, "bounds": bounds, "labels": labels, "host": host, "done": done, "keep": (dev_in, outs)}
+        return {"n": n, "bounds": bounds, "labels": labels, "host": host, "finish": finish, "done": done, "keep": (dev_in, outs)}
 
     def collect_chunk(self, tk):
         """Labels of a submitted chunk: int8 numpy on rank 0 (whole chunk, input order), None elsewhere."""
         if self.world > 1:
-            labels = rdist.gather_labels(tk["labels"], tk["n"], dst=0, bounds=tk["bounds"])
+            labels = tk["finish"]()
             return None if self.rank != 0 else labels.cpu().numpy()
         tk["done"].synchronize()
         return tk["host"].numpy()
