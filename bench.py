@@ -1,22 +1,32 @@
 #!/usr/bin/env python3
 """bench.py - reads/s classified, 100 bp paired-end (BASELINE.json metric) on N MI355X of one node.
 
-A "step" = one pass of the hot path over one batch of synthetic read pairs that is already resident in HBM:
-    rd_classify(R1) + rd_classify(R2)  (length bucketing, fused encoder, LSTM recurrence, FC, argmax)
-    rd_pair_fuse(--ensure rrna) + counters, and for N>1 the RCCL gather of the 1-byte pair labels to rank 0.
+A "step" = one pass of the hot path over one batch of synthetic read pairs (timed region (ii)):
+    read bytes in PINNED HOST memory -> H2D on a copy stream (double buffered: the bytes of step k+1 travel while step k
+    computes) -> rd_classify(R1) + rd_classify(R2) (length bucketing, fused encoder, LSTM recurrence, FC, argmax)
+    -> rd_pair_fuse(--ensure rrna) + counters -> D2H of the 1-byte pair labels into pinned host memory,
+    and for N>1 the RCCL gather of the labels to rank 0.
 Workload = BASELINE.json configs[2] ("10M paired-end 100 bp reads with --ensure rrna, 1 MI355X"): with the default
 --steps 10 x 1,048,576 pairs/step = 10.5 M pairs (21 M reads) are classified inside the timed region.
 For N>1 every rank gets its own shard of the same size (weak scaling), as the reads shard embarrassingly.
+`python bench.py --gpus N` with N>1 and no WORLD_SIZE in the environment re-launches itself under
+torch.distributed.run with N ranks (backend nccl = RCCL); launched under torchrun it uses the environment as is.
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus
-  roofline     - the recurrence kernel against the fp32-MFMA peak: algorithmic FLOPs (T*131072+1024 per read)
-                 / average launch duration measured with hipEvents on the launch stream (C ABI rd_profile_*)
+  config.kernel_only_reads_per_s - timed region (i): the same steps with the read bytes already resident in HBM
+  roofline     - the recurrence kernel against the dense MFMA peak: algorithmic FLOPs (T*131072+1024 per read)
+                 / average launch duration measured with hipEvents on the launch stream inside the timed region
+                 (C ABI rd_profile_*); traffic = HBM bytes per launch from FETCH_SIZE/WRITE_SIZE collected by rocprofv3
+                 --pmc passes over a child run of this same command (gfx950 correction: FETCH_SIZE x2)
+  encoder      - the standalone HBM-bound encoder kernels (reference tensor layouts): achieved GB/s against 8 TB/s
   cpu_baseline - the CPU oracle's restatement of ribodetector_cpu (padded BiLSTM over all L steps, batch 1024,
                  one batch per thread) timed on this box's host cores on a bounded sample of the same reads.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,10 +34,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 READ_LEN = 100
-FLOPS_PER_READ = READ_LEN * 131072 + 1024        # forward recurrence h.W_hh^T + FC
-BYTES_PER_READ = READ_LEN + 4 + 8 + 8 + 1        # ASCII + len + offset + logits + label
-PEAKS = {"mfma_f32": 157.3, "simple": 157.3, "mfma_f16x3": 2500.0, "mfma_f16x3_t32": 2500.0}   # dense TFLOP/s, MI355X_MICROARCH.md
-MFMA_FLOPS_PER_ALGO_FLOP = {"mfma_f32": 1, "simple": 1, "mfma_f16x3": 3, "mfma_f16x3_t32": 3}   # f16x3 issues three f16 products per fp32 product
+PEAKS = {"mfma_f32": 157.3, "simple": 157.3, "mfma_f16x3_t32": 2500.0}   # dense TFLOP/s, MI355X_MICROARCH.md
+MFMA_FLOPS_PER_ALGO_FLOP = {"mfma_f32": 1, "simple": 1, "mfma_f16x3_t32": 3}   # f16x3 issues three f16 products per fp32 product
+HBM_PEAK_GBPS = 8000.0
+WORKLOADS = {"pe100": (True, 100, 100), "se100": (False, 100, 100), "pe150": (True, 150, 150), "var300": (False, 300, 300)}
 
 
 def usable_cores():
@@ -43,8 +53,11 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(arena_np, n_reads, target_s=15.0):
-    """Time the oracle's batched ribodetector_cpu restatement on all usable host cores; bounded to ~target_s seconds."""
+def cpu_baseline(arena_np, n_reads, target_s=12.0):
+    """Time the oracle's batched ribodetector_cpu restatement on all usable host cores; bounded to ~target_s seconds.
+    Two rates: model only (bytes -> logits; the base lookup is fused into the port's input gather) and encode + model (the
+    [1024, L, 4] fp32 one-hot tensor ribodetector_cpu feeds onnxruntime, detect_cpu.py:699-700, materialised by the C port
+    before the model runs - the reference builds it with Python list comprehensions, ~120 us per read and core)."""
     import numpy as np
     from oracle import oracle as O
     ora = O.load_default()
@@ -59,11 +72,125 @@ def cpu_baseline(arena_np, n_reads, target_s=15.0):
     t0 = time.time()
     cpu_logits = ora.forward_padded(arena_np, off[:n], lens[:n], READ_LEN, batched=True, batch=1024, nthreads=cores)
     dt = time.time() - t0
+    # encode leg: one-hot [n, L, 4] fp32 by the C port (single thread per call here; n/cores reads per thread equivalent)
+    ne = min(n, 65536)
+    t1 = time.time()
+    for i in range(0, ne, 1024):
+        ora.encode_padded_batch(arena_np, off[i:i + 1025], READ_LEN)
+    t_enc_per_read = (time.time() - t1) / ne / cores      # the encode parallelises over reads like the model does
+    enc_model = 1.0 / (1.0 / (n / dt) + t_enc_per_read)
     return {"logits": cpu_logits, "n": n, "value": n / dt, "unit": "reads/s", "cores": cores, "kind": "port",
-            "sample": "first %d reads of the rank-0 R1 stream (100 bp), oracle rdo_forward_padded_batched = ribodetector_cpu "
-                      "algorithm (padded BiLSTM over all 100 steps x 2 directions, batch 1024, one batch per thread, "
-                      "%d OpenMP threads = usable cores of this container; os.cpu_count() = %d), %.1f s; onnxruntime is not installed, so this C port "
-                      "stands in for it" % (n, cores, os.cpu_count() or 0, dt)}
+            "encode_plus_model_reads_per_s": enc_model, "os_cpu_count": os.cpu_count() or 0,
+            "sample": "first %d reads of the rank-0 R1 stream (100 bp); oracle rdo_forward_padded_batched = the ribodetector_cpu "
+                      "algorithm (padded BiLSTM over all 100 steps x 2 directions, batch 1024, one batch per thread) as a hand-vectorised "
+                      "AVX-512/AVX2 + OpenMP C port, %d threads = usable cores of this container (os.cpu_count() = %d), %.1f s. "
+                      "`value` is MODEL ONLY (ASCII bytes -> logits, base lookup fused); encode_plus_model adds materialising the "
+                      "[1024,100,4] fp32 one-hot input in C (the reference's Python encoder is ~100x slower than that and would "
+                      "dominate). onnxruntime is not installed, so this port stands in for ribodetector_cpu"
+                      % (n, cores, os.cpu_count() or 0, dt)}
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` (N>1) outside torchrun: start N ranks of this script under torch.distributed.run."""
+    import torch
+    shared = os.environ.get("RD_LOCAL_DEVICE")        # tests: several ranks share one GPU and exchange labels over gloo
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if shared is None and have < args.gpus:
+        sys.stderr.write("bench.py: --gpus %d needs %d visible devices, this box has %d (one rank per GPU over RCCL; for a functional "
+                         "run on fewer devices set RD_DIST_BACKEND=gloo RD_LOCAL_DEVICE=0)\n" % (args.gpus, args.gpus, have))
+        raise SystemExit(3)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, usable_cores() // args.gpus)))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def pmc_traffic(args, kernel_substr, timeout_s=240):
+    """HBM bytes per launch of the recurrence kernel: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; they do not fit one
+    pass) over a child run of this script (`--pmc-child`: same workload, same batch, resident inputs, 1 warm-up + 2 steps).
+    Counter collection only - no trace domain is combined with --pmc. Returns (dict | None, error | None)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    rp = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rp):
+        return None, "rocprofv3 not found"
+    out = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="rd_pmc_", dir="/tmp")
+        cmd = [rp, "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
+               "--pmc-child", "--workload", args.workload, "--variant", args.variant, "--pairs-per-step", str(args.pairs_per_step),
+               "--ensure", args.ensure]
+        env = dict(os.environ, TMPDIR="/tmp")
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            shutil.rmtree(d, ignore_errors=True)
+            return None, "rocprofv3 --pmc %s timed out" % ctr
+        vals = []
+        for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            with open(path) as fh:
+                for row in csv.DictReader(fh):
+                    if kernel_substr in row["Kernel_Name"] and row["Counter_Name"] == ctr:
+                        vals.append(float(row["Counter_Value"]))
+        shutil.rmtree(d, ignore_errors=True)
+        if not vals:
+            return None, "rocprofv3 --pmc %s: no rows for %s (rc %d): %s" % (ctr, kernel_substr, r.returncode, r.stdout.decode(errors="replace")[-300:])
+        out[ctr + "_KB"] = sum(vals) / len(vals)
+        out[ctr + "_launches"] = len(vals)
+    out["hbm_bytes_per_launch"] = (2.0 * out["FETCH_SIZE_KB"] + out["WRITE_SIZE_KB"]) * 1024.0
+    out["correction"] = "gfx950 FETCH_SIZE tallies 64 B per 128-B request: x2 (MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported; KB = 1024 B"
+    return out, None
+
+
+def encoder_record(torch, N, dev, arena, offs, lens, n, L):
+    """standalone encoder kernels on the first n reads: algorithmic bytes / kernel time (events on the launch stream)"""
+    lib, st = N.lib(), N.stream_ptr(dev)
+
+    def timed(fn, reps=10):
+        for _ in range(2):
+            fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        torch.cuda.synchronize(dev)
+        return a.elapsed_time(b) / reps * 1e-3
+
+    rec = {"reads": n, "read_len": L, "bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s", "kernels": {}}
+
+    def put(name, t, nbytes, what):
+        rec["kernels"][name] = {"ms": t * 1e3, "achieved": nbytes / t / 1e9, "frac": nbytes / t / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes": what}
+    codes = torch.empty((n, L), dtype=torch.uint8, device=dev)
+    t = timed(lambda: N.check(lib.rd_encode_codes(N.ptr(arena), N.ptr(offs), N.ptr(lens), n, L, L, N.ptr(codes), st), "rd_encode_codes"))
+    put("rd_encode_codes_kernel", t, n * (2 * L + 12), "L in + L out + 12 index per read")
+    del codes
+    oh = torch.empty((n, L, 4), dtype=torch.float32, device=dev)
+    t = timed(lambda: N.check(lib.rd_encode_onehot_padded(N.ptr(arena), N.ptr(offs), N.ptr(lens), n, L, N.ptr(oh), st), "rd_encode_onehot_padded"))
+    put("rd_encode_onehot_padded_kernel", t, n * (17 * L + 12), "L in + 16 L out + 12 index per read")
+    del oh
+    ws = torch.empty(int(lib.rd_classify_workspace_bytes(n, L)), dtype=torch.uint8, device=dev)
+    si = torch.empty(n, dtype=torch.int64, device=dev)
+    ui = torch.empty(n, dtype=torch.int64, device=dev)
+    bs = torch.empty(L, dtype=torch.int64, device=dev)
+    tot = torch.empty(1, dtype=torch.int64, device=dev)
+    N.check(lib.rd_pack_plan(N.ptr(lens), n, L, N.ptr(si), N.ptr(ui), N.ptr(bs), N.ptr(tot), N.ptr(ws), ws.numel(), st), "rd_pack_plan")
+    data = torch.empty((int(tot.item()), 4), dtype=torch.float32, device=dev)
+    t = timed(lambda: N.check(lib.rd_pack_onehot(N.ptr(arena), N.ptr(offs), N.ptr(lens), n, L, N.ptr(si), N.ptr(bs), N.ptr(data), st), "rd_pack_onehot"))
+    put("rd_pack_onehot_kernel", t, n * (17 * L + 16), "L in + 16 L out + 16 index per read")
+    return rec
 
 
 def main():
@@ -74,16 +201,24 @@ def main():
     ap.add_argument("--pairs-per-step", type=int, default=1 << 20)
     ap.add_argument("--variant", default="auto")
     ap.add_argument("--ensure", default="rrna")
-    ap.add_argument("--workload", default="pe100", choices=["pe100", "se100", "pe150", "var300"],
+    ap.add_argument("--workload", default="pe100", choices=sorted(WORKLOADS),
                     help="pe100 = BASELINE configs[2] (the metric's configuration, default); se100 = configs[1]; pe150 = the per-GPU "
                          "shard of configs[3]; var300 = the per-GPU shard of configs[4] (40-300 bp, -l 300)")
-    ap.add_argument("--pcie", action="store_true", help="also time the step with the read bytes starting in pinned host memory")
+    ap.add_argument("--resident-only", action="store_true", help="time region (i) only: read bytes resident in HBM (diagnostics)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the short extra measurement of the exact-fp32 MFMA kernel")
+    ap.add_argument("--no-encoder", action="store_true", help="skip the standalone encoder kernels")
+    ap.add_argument("--traffic", default="live", choices=["live", "off"],
+                    help="live: collect FETCH_SIZE/WRITE_SIZE with rocprofv3 --pmc over a child run of this command (adds ~40 s)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
 
     import torch
     import torch.distributed as dist
+    from ribodetector_amd import _native as N
     from ribodetector_amd import dist as rdist
     from ribodetector_amd import synth
     from ribodetector_amd.model import model as module_arch
@@ -92,10 +227,9 @@ def main():
     rank, world, local = rdist.init_from_env()
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N>1 launch with python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     dev = torch.device("cuda", int(os.environ.get("RD_LOCAL_DEVICE", local)))   # override: several ranks on one GPU (tests only)
     torch.cuda.set_device(dev)
+    backend = dist.get_backend() if world > 1 else None
 
     cfg = ConfigParser.from_json(os.path.join(ROOT, "ribodetector_amd", "config.json"))
     model = cfg.init_obj("arch", module_arch)
@@ -105,9 +239,9 @@ def main():
     variant = "mfma_f16x3_t32" if args.variant == "auto" else args.variant
 
     P = args.pairs_per_step
-    WL = {"pe100": (True, 100, 100), "se100": (False, 100, 100), "pe150": (True, 150, 150), "var300": (False, 300, 300)}[args.workload]
-    paired, RL, MAXLEN = WL
-    nslices = max(1, min(args.steps, 10))                 # distinct batches resident in HBM, reused cyclically
+    paired, RL, MAXLEN = WORKLOADS[args.workload]
+    steps = 2 if args.pmc_child else args.steps
+    nslices = max(1, min(steps, 4))                       # distinct batches, reused cyclically
     r1 = [synth.reads_torch(P, RL, seed=2000 + 100 * rank + i, device=dev) for i in range(nslices)]
     r2 = [synth.reads_torch(P, RL, seed=7000 + 100 * rank + i, device=dev) for i in range(nslices)] if paired else None
     offs = r1[0][1][:-1].contiguous()
@@ -118,24 +252,24 @@ def main():
         lens = torch.randint(40, 301, (P,), generator=g, device=dev, dtype=torch.int32)
     flops_per_launch = float((torch.clamp(lens, max=MAXLEN).to(torch.float64) * 131072 + 1024).sum().item())
     bytes_per_launch = float(lens.to(torch.float64).sum().item()) + P * (4 + 8 + 8 + 1)
-    lg1 = torch.empty((P, 2), dtype=torch.float32, device=dev)
-    lg2 = torch.empty((P, 2), dtype=torch.float32, device=dev)
+    nm = 2 if paired else 1
+    lg = [torch.empty((P, 2), dtype=torch.float32, device=dev) for _ in range(nm)]
     counts = torch.zeros(3, dtype=torch.int64, device=dev)
     gathered = torch.empty(P * world, dtype=torch.int8, device=dev) if (world > 1 and rank == 0) else None
-
     lab8 = torch.empty((P,), dtype=torch.uint8, device=dev)
+    cur = torch.cuda.current_stream(dev)
 
-    def step(i, a1=None, a2=None):
-        a1 = r1[i % nslices][0] if a1 is None else a1
+    def compute(a1, a2):
+        """kernels of one step on the current stream -> device labels int8[P]"""
         if paired:
-            a2 = r2[i % nslices][0] if a2 is None else a2
-            model.classify_bytes(a1, offs, lens, MAXLEN, want_labels=False, logits=lg1)
-            model.classify_bytes(a2, offs, lens, MAXLEN, want_labels=False, logits=lg2)
-            lab = module_arch.pair_fuse(lg1, lg2, args.ensure, counts)
-        else:
-            model.classify_bytes(a1, offs, lens, MAXLEN, want_labels=True, logits=lg1, labels=lab8)
-            module_arch.count_labels(lab8, counts)
-            lab = lab8.view(torch.int8)
+            model.classify_bytes(a1, offs, lens, MAXLEN, want_labels=False, logits=lg[0])
+            model.classify_bytes(a2, offs, lens, MAXLEN, want_labels=False, logits=lg[1])
+            return module_arch.pair_fuse(lg[0], lg[1], args.ensure, counts)
+        model.classify_bytes(a1, offs, lens, MAXLEN, want_labels=True, logits=lg[0], labels=lab8)
+        module_arch.count_labels(lab8, counts)
+        return lab8.view(torch.int8)
+
+    def exchange(lab):
         if world > 1:
             _, fin = rdist.gather_labels(lab, P * world, dst=0, async_op=True, out=gathered)
             return fin
@@ -147,50 +281,121 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    for i in range(args.warmup):
-        f = step(i)
-        if f:
+    def run_resident(nsteps):
+        """region (i): inputs resident in HBM"""
+        pend = []
+        for i in range(nsteps):
+            f = exchange(compute(r1[i % nslices][0], r2[i % nslices][0] if paired else None))
+            if f:
+                pend.append(f)
+        for f in pend:
             f()
+
+    if args.pmc_child:                                      # profiled by the parent's rocprofv3 --pmc passes; prints nothing
+        run_resident(3)
+        torch.cuda.synchronize(dev)
+        return
+
+    # ---- region (ii): pinned host bytes -> H2D (copy stream, double buffered) -> kernels -> labels D2H (pinned) ----------------
+    host_in = [[t[0].cpu().pin_memory() for t in r1]] + ([[t[0].cpu().pin_memory() for t in r2]] if paired else [])
+    cs = torch.cuda.Stream(dev)
+    dbuf = [[torch.empty_like(r1[0][0]) for _ in range(nm)] for _ in range(2)]
+    host_lab = [torch.empty((P,), dtype=torch.int8).pin_memory() for _ in range(2)]
+    ev_ready = [torch.cuda.Event() for _ in range(2)]      # H2D of the slot finished
+    ev_free = [None, None]                                 # kernels that read the slot finished
+    ev_lab = [None, None]                                  # labels of the slot are in host memory
+
+    def h2d(i):
+        s = i & 1
+        with torch.cuda.stream(cs):
+            if ev_free[s] is not None:
+                cs.wait_event(ev_free[s])
+            for m in range(nm):
+                dbuf[s][m].copy_(host_in[m][i % nslices], non_blocking=True)
+            ev_ready[s].record(cs)
+
+    def run_device_path(nsteps):
+        pend = []
+        h2d(0)
+        for i in range(nsteps):
+            s = i & 1
+            if i + 1 < nsteps:
+                h2d(i + 1)
+            cur.wait_event(ev_ready[s])
+            lab = compute(dbuf[s][0], dbuf[s][1] if paired else None)
+            ev_free[s] = torch.cuda.Event()
+            ev_free[s].record(cur)
+            if ev_lab[s] is not None:
+                ev_lab[s].synchronize()                    # the host consumed the labels of step i-2 (bounds the run-ahead)
+            host_lab[s].copy_(lab, non_blocking=True)
+            ev_lab[s] = torch.cuda.Event()
+            ev_lab[s].record(cur)
+            f = exchange(lab)
+            if f:
+                pend.append(f)
+        for f in pend:
+            f()
+
+    timed_path = run_resident if args.resident_only else run_device_path
+    timed_path(args.warmup)
+    sync()
     counts.zero_()
     model.profile_enable(True)
     sync()
     t0 = time.perf_counter()
-    pend = []
-    for i in range(args.steps):
-        f = step(i)
-        if f:
-            pend.append(f)
-    for f in pend:
-        f()
+    timed_path(args.steps)
     sync()
     dt = time.perf_counter() - t0
     launches, kms = model.profile_read()
     model.profile_enable(False)
     rdist.reduce_counts(counts)
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev if world == 1 or dist.get_backend() == "nccl" else "cpu")
+    on_dev = world == 1 or backend == "nccl"
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev if on_dev else "cpu")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     total_pairs = P * args.steps * world
     c = counts.cpu().tolist()
     assert c[0] + c[1] + c[2] == total_pairs, (c, total_pairs)
+    host_check = int((host_lab[(args.steps - 1) & 1] != 0).sum()) if not args.resident_only and args.steps > 0 else None
+
+    # ---- region (i): the same steps with the bytes resident in HBM -------------------------------------------------------------
+    dt_res = None
+    if not args.resident_only:
+        sync()
+        t1 = time.perf_counter()
+        run_resident(args.steps)
+        sync()
+        dt_res = time.perf_counter() - t1
+        tr = torch.tensor([dt_res], dtype=torch.float64, device=dev if on_dev else "cpu")
+        if world > 1:
+            dist.all_reduce(tr, op=dist.ReduceOp.MAX)
+        dt_res = float(tr.item())
 
     if rank == 0:
-        reads_per_launch = P
+        mult = 2.0 if paired else 1.0
         avg_ms = kms / max(launches, 1)
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if launches else None
-        base = ("mfma_f16x3_t32" if variant.startswith("mfma_f16x3_t32") else "mfma_f16x3" if variant.startswith("mfma_f16x3")
-                else "mfma_f32" if variant.startswith("mfma_f32") else variant)
+        base = "mfma_f16x3_t32" if variant.startswith("mfma_f16x3_t32") else "mfma_f32" if variant.startswith("mfma_f32") else variant
         peak = PEAKS[base]
-        traffic = None
-        try:   # HBM bytes per launch from the PMC passes of tools/profile_round.sh (bench.py cannot collect PMC itself)
-            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["rd_lstm_%s_kernel" % base]
-            traffic = tj["hbm_bytes_per_launch"] * bytes_per_launch / (tj["reads_per_launch"] * (tj["read_len"] + 21))
-        except Exception:
-            pass
+        kname = "rd_lstm_%s_kernel" % base
+        traffic, traffic_src = None, "not collected (--traffic off or N>1)"
+        if args.traffic == "live" and world == 1:
+            tj, err = pmc_traffic(args, "rd_lstm_")
+            if tj:
+                traffic = tj["hbm_bytes_per_launch"]
+                traffic_src = dict(tj, how="rocprofv3 --pmc passes over a child run of this command in this invocation")
+            else:
+                traffic_src = "failed: %s" % err
+        wl_text = {"pe100": "BASELINE configs[2]: paired-end 100 bp, --ensure %s" % args.ensure,
+                   "se100": "BASELINE configs[1]: single-end 100 bp",
+                   "pe150": "BASELINE configs[3] per-GPU shard: paired-end 150 bp, -l 150, --ensure %s" % args.ensure,
+                   "var300": "BASELINE configs[4] per-GPU shard: single-end 40-300 bp, -l 300, length-bucketed"}[args.workload]
+        region = ("read bytes resident in HBM (region i)" if args.resident_only else
+                  "read bytes start in pinned host memory, H2D double-buffered on a copy stream, labels D2H to pinned memory (SURVEY 8d region ii)")
         out = {
             "metric": "reads/sec classified, 100 bp paired-end" if args.workload == "pe100" else "reads/sec classified, " + args.workload,
-            "value": (2.0 if paired else 1.0) * total_pairs / dt,
+            "value": mult * total_pairs / dt,
             "unit": "reads/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -199,25 +404,27 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" if not variant.startswith("mfma_f16x3") else "f16x3-split (f32 accumulate)",
+            "dtype": "f32" if base != "mfma_f16x3_t32" else "f16x3-split (f32 accumulate)",
             "data": "synthetic",
-            "config": {"workload": {"pe100": "BASELINE configs[2]: paired-end 100 bp, --ensure %s" % args.ensure,
-                                    "se100": "BASELINE configs[1]: single-end 100 bp",
-                                    "pe150": "BASELINE configs[3] per-GPU shard: paired-end 150 bp, -l 150, --ensure %s" % args.ensure,
-                                    "var300": "BASELINE configs[4] per-GPU shard: single-end 40-300 bp, -l 300, length-bucketed"}[args.workload]
-                                   + ", %d %s/step/GPU x %d steps (%.1f M total), inputs resident in HBM"
-                                   % (P, "pairs" if paired else "reads", args.steps, total_pairs / 1e6),
-                       "pairs_per_s": (total_pairs / dt) if paired else None, "per_step_per_gpu": P, "read_len": RL if args.workload != "var300" else "40-300",
+            "config": {"workload": wl_text + ", %d %s/step/GPU x %d steps (%.1f M total); %s"
+                                   % (P, "pairs" if paired else "reads", args.steps, total_pairs / 1e6, region),
+                       "timed_region": "i" if args.resident_only else "ii",
+                       "kernel_only_reads_per_s": (mult * total_pairs / dt_res) if dt_res else None,
+                       "device_path_over_kernel_only": (dt_res / dt) if dt_res else None,
+                       "pairs_per_s": (total_pairs / dt) if paired else None, "per_step_per_gpu": P,
+                       "read_len": RL if args.workload != "var300" else "40-300",
                        "ensure": args.ensure if paired else None,
                        "kernel_variant": variant,
                        "precision": ("every fp32 product h*w is formed as three f16 MFMA products of hi/lo parts with fp32 accumulation; "
-                                     "logit error against a float64 evaluation equals the fp32 reference's own (DESIGN.md 4, "
-                                     "tests/test_gpu_parity.py::test_error_against_float64_truth); parity_sample below is this run's check"
-                                     if variant.startswith("mfma_f16x3") else "fp32"), "parallelism": "reads sharded x%d, RCCL label gather" % world,
-                       "label_counts": {"non_rrna": c[0], "rrna": c[1], "unclassified": c[2]}},
+                                     "parity_sample below is this run's check against the fp32 CPU port"
+                                     if base == "mfma_f16x3_t32" else "fp32"),
+                       "parallelism": "reads sharded x%d, label gather to rank 0" % world,
+                       "rccl_ranks": world, "dist_backend": backend,
+                       "label_counts": {"non_rrna": c[0], "rrna": c[1], "unclassified": c[2]},
+                       "host_labels_nonzero_last_step": host_check},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": (achieved / peak) if achieved else None, "traffic": traffic,
-                         "kernel": "rd_lstm_%s_kernel" % base, "launches": launches, "avg_launch_ms": avg_ms,
+                         "frac": (achieved / peak) if achieved else None, "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": kname, "launches": launches, "avg_launch_ms": avg_ms,
                          "algorithmic_flops_per_launch": flops_per_launch,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "mfma_flops_executed_per_algorithmic_flop": MFMA_FLOPS_PER_ALGO_FLOP[base],
@@ -229,44 +436,22 @@ def main():
             model.profile_enable(True)
             sync()
             t1 = time.perf_counter()
-            for i in range(2):
-                step(i)
+            run_resident(2)
             sync()
             d1 = time.perf_counter() - t1
             l2, k2 = model.profile_read()
             model.profile_enable(False)
             model.set_variant(args.variant)
             a2 = flops_per_launch / (k2 / max(l2, 1) * 1e-3) / 1e12
-            out["alt_fp32_kernel"] = {"kernel": "rd_lstm_mfma_f32_kernel", "value": (2.0 if paired else 1.0) * P * 2 / d1, "unit": "reads/s", "steps": 2,
+            out["alt_fp32_kernel"] = {"kernel": "rd_lstm_mfma_f32_kernel", "value": mult * P * 2 / d1, "unit": "reads/s", "steps": 2,
+                                      "timed_region": "i",
                                       "roofline": {"bound": "mfma", "achieved": a2, "peak": PEAKS["mfma_f32"], "unit": "TFLOP/s",
                                                    "frac": a2 / PEAKS["mfma_f32"], "avg_launch_ms": k2 / max(l2, 1)}}
-        if args.pcie and world == 1:
-            # same step, but every batch's bytes start in pinned host memory: H2D on a copy stream, double buffered
-            hosts = [[t[0].cpu().pin_memory() for t in (r1[:2] if not paired else r1[:2] + r2[:2])]]
-            h = hosts[0]
-            cs = torch.cuda.Stream(dev)
-            bufs = [[torch.empty_like(r1[0][0]) for _ in range(2 if paired else 1)] for _ in range(2)]
-            evs = [torch.cuda.Event() for _ in range(2)]
-            def h2d(i):
-                with torch.cuda.stream(cs):
-                    bufs[i & 1][0].copy_(h[i & 1], non_blocking=True)
-                    if paired:
-                        bufs[i & 1][1].copy_(h[2 + (i & 1)], non_blocking=True)
-                    evs[i & 1].record(cs)
-            counts.zero_()
-            sync()
-            t2 = time.perf_counter()
-            h2d(0)
-            for i in range(args.steps):
-                if i + 1 < args.steps:
-                    h2d(i + 1)
-                torch.cuda.current_stream(dev).wait_event(evs[i & 1])
-                step(i, bufs[i & 1][0], bufs[i & 1][1] if paired else None)
-                cs.wait_stream(torch.cuda.current_stream(dev))    # buffer (i&1) is reused by h2d(i+2)
-            lab_host = torch.empty((P,), dtype=torch.int8).pin_memory()
-            sync()
-            d2 = time.perf_counter() - t2
-            out["config"]["pcie_inclusive_reads_per_s"] = (2.0 if paired else 1.0) * P * args.steps / d2
+        if world == 1 and not args.no_encoder:
+            try:
+                out["encoder"] = encoder_record(torch, N, dev, r1[0][0], offs, lens, P, MAXLEN)
+            except Exception as e:
+                out["encoder"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1 and args.workload in ("pe100", "se100"):
             try:
                 nb = min(P, 400000)
@@ -291,6 +476,7 @@ def main():
             except Exception as e:  # the checker is not the product: report, don't hide
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out))
+        sys.stdout.flush()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

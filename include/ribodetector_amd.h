@@ -43,9 +43,11 @@ extern "C" {
 #define RD_VARIANT_AUTO 0       /* = MFMA_F16X3_T32                                                            */
 #define RD_VARIANT_MFMA_F32 1   /* persistent-weight fp32 MFMA recurrence (v_mfma_f32_16x16x4_f32)              */
 #define RD_VARIANT_SIMPLE 2     /* plain fp32 FMA kernel, correctness cross-check                              */
-#define RD_VARIANT_MFMA_F16X3 3 /* fp32 product as 3 fp16 MFMA products (hi*hi + hi*lo + lo*hi), fp32 accumulate */
-#define RD_VARIANT_MFMA_F16X3_T32 4 /* the same on v_mfma_f32_32x32x16_f16, 32-read tiles, hand-interleaved gate math */
-/* ids >= 10 are A/B and diagnostic builds used by bench.py --variant; not part of the stable ABI */
+/* id 3 (the first 16x16x32 tiling of the split-precision kernel) was removed in 0.2: RD_E_UNSUPPORTED          */
+#define RD_VARIANT_MFMA_F16X3_T32 4 /* fp32 product as 3 fp16 MFMA products (hi*hi + hi*lo + lo*hi) on v_mfma_f32_32x32x16_f16,
+                                       fp32 accumulate, 32-read tiles, hand-interleaved gate math                */
+/* Any other id is rejected with RD_E_UNSUPPORTED by librd_hip.so. The A/B and diagnostic instantiations used by tools/
+ * (ids >= 10, some of them wrong by design) exist only in the separately built librd_hip_diag.so (-DRD_DIAG). */
 
 /* output-row semantics (rd_set_semantics) */
 #define RD_SEM_PACKED 0 /* reference GPU product: PackedSequence, gather at timestep min(len,max_len)-1 (model/model.py:32-37)  */
@@ -73,8 +75,10 @@ typedef struct rd_weights {
 int rd_model_create(const rd_weights *w, int device, rd_model **out);
 void rd_model_destroy(rd_model *m);
 
-/* Select the recurrence kernel (RD_VARIANT_*); default AUTO = MFMA_F16X3_T32. */
+/* Select the recurrence kernel (RD_VARIANT_*); default AUTO = MFMA_F16X3_T32. Ids this build does not contain are
+ * refused with RD_E_UNSUPPORTED (the model keeps its current kernel). rd_variant_available: 1 if `variant` can be selected. */
 int rd_set_variant(rd_model *m, int variant);
+int rd_variant_available(int variant);
 
 /* Select which of the reference's two products rd_classify reproduces (RD_SEM_*); default RD_SEM_PACKED. The two differ
  * only for reads shorter than max_len or ending in non-ACGT bases. */

@@ -39,7 +39,9 @@ void rd_reader_close(rd_reader *r);
  *   rec_start int64[max_records+1], seq_off int64[max_records] (start of the bases in buf), seq_len int32[max_records]
  * Stops early when the next record would not fit into buf_cap (it is delivered by the next call).
  * *n = number of records delivered. Returns 1 when the end of the file was reached (no record follows those delivered),
- * 0 when more may follow (*n == 0 then means: the next record does not fit into the remaining buffer), <0 on error. */
+ * 0 when more may follow, <0 on error. *n == 0 with return 0 means: the next record does not fit into the remaining buffer;
+ * *nbytes then holds the bytes that record needs, so that the caller can grow the buffer (the reference parser has no
+ * record-size limit, fastx_parser.py:15-55). */
 int rd_reader_next(rd_reader *r, int64_t max_records, uint8_t *buf, int64_t buf_cap, int64_t *rec_start, int64_t *seq_off,
                    int32_t *seq_len, int64_t *n, int64_t *nbytes);
 
@@ -54,6 +56,8 @@ int rd_host_gunzip(const char *path, uint8_t *out, int64_t cap, int64_t *n);
 int rd_host_set_threads(int threads);
 
 int rd_writer_open(const char *path, rd_writer **out);
+/* compressor threads this writer was opened with (= the rd_host_set_threads value in force at rd_writer_open) */
+int rd_writer_threads(const rd_writer *w);
 /* append, in input order, every record i of the chunk with labels[i] == want */
 int rd_writer_write_selected(rd_writer *w, const uint8_t *buf, const int64_t *rec_start, int64_t n, const int8_t *labels,
                              int32_t want);

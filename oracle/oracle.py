@@ -77,6 +77,16 @@ class Oracle:
         self.lib.rdo_encode_padded(_p(a, C.c_uint8), C.c_int64(len(bytes(seq_bytes))), C.c_int(max_len), _fp(out))
         return out
 
+    def encode_padded_batch(self, arena, offsets, max_len):
+        """[n, max_len, 4] fp32 for the reads offsets[i]..offsets[i+1] (offsets has n+1 entries)"""
+        arena = np.ascontiguousarray(arena, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        n = len(offsets) - 1
+        out = np.empty((n, max_len, 4), dtype=np.float32)
+        if n > 0:
+            self.lib.rdo_encode_padded_batch(_p(arena, C.c_uint8), _p(offsets, C.c_int64), C.c_int64(n), C.c_int(max_len), _fp(out))
+        return out
+
     def pack_sequence(self, arena, offsets, lens, max_len):
         arena, offsets, lens = self._args(arena, offsets, lens)
         n = len(lens)

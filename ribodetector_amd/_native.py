@@ -10,17 +10,19 @@ LIB_PATH = os.environ.get("RD_HIP_LIB") or os.path.join(_HERE, "csrc", "librd_hi
 
 ENSURE_MODES = {"none": 0, "rrna": 1, "norrna": 2, "both": 3}
 SEMANTICS = {"packed": 0, "gpu": 0, "padded": 1, "cpu": 1}
-VARIANTS = {"auto": 0, "mfma_f32": 1, "simple": 2, "mfma_f16x3": 3, "mfma_f16x3_t32": 4, "mfma_f16x3_w8": 5,
-            # A/B builds of the fp32 kernel (activation form x schedule), see rd_kernels.hip
-            "mfma_f32_a0s0": 10, "mfma_f32_a1s0": 11, "mfma_f32_a0s1": 12, "mfma_f32_a1s1": 13,
-            "mfma_f32_diag_noew": 20, "mfma_f32_diag_nomfma": 21, "mfma_f32_diag_mfmaonly": 22,
-            "mfma_f32_diag_mfmabar": 23, "mfma_f16x3_fill0": 30, "mfma_f16x3_fill3": 31, "mfma_f16x3_fill4": 32,
-            "mfma_f16x3_t32_fill0": 40, "mfma_f16x3_t32_diag_mfmaonly": 41,
-            "mfma_f16x3_t32_diag_nobarrier": 42}
+VARIANTS = {"auto": 0, "mfma_f32": 1, "simple": 2, "mfma_f16x3_t32": 4}      # what librd_hip.so (the product build) accepts
+# A/B and diagnostic instantiations: only in librd_hip_diag.so (built with -DRD_DIAG by __graft_entry__.build_diag(), selected
+# with RD_HIP_LIB=.../librd_hip_diag.so by the scripts under tools/). Several compute wrong results by design.
+DIAG_VARIANTS = {"mfma_f32_a0s0": 10, "mfma_f32_a1s0": 11, "mfma_f32_a0s1": 12, "mfma_f32_a1s1": 13,
+                 "mfma_f32_diag_noew": 20, "mfma_f32_diag_nomfma": 21, "mfma_f32_diag_mfmaonly": 22, "mfma_f32_diag_mfmabar": 23,
+                 "mfma_f16x3_t32_fill0": 40, "mfma_f16x3_t32_diag_mfmaonly": 41, "mfma_f16x3_t32_diag_nobarrier": 42,
+                 "t32_x0": 50, "t32_x1": 51, "t32_x2": 52, "t32_x3": 53, "t32_x4": 54, "t32_x5": 55, "t32_x6": 56, "t32_x7": 57}
+if os.path.basename(LIB_PATH).startswith("librd_hip_diag"):
+    VARIANTS = dict(VARIANTS, **DIAG_VARIANTS)
 
 # every symbol include/ribodetector_amd.h declares (tests/test_abi.py checks the .so exports all of them)
 SYMBOLS = [
-    "rd_model_create", "rd_model_destroy", "rd_set_variant", "rd_set_semantics", "rd_classify_workspace_bytes", "rd_classify",
+    "rd_model_create", "rd_model_destroy", "rd_set_variant", "rd_variant_available", "rd_set_semantics", "rd_classify_workspace_bytes", "rd_classify",
     "rd_pair_fuse", "rd_count_labels", "rd_encode_codes", "rd_encode_onehot_padded", "rd_pack_plan",
     "rd_pack_onehot", "rd_profile_enable", "rd_profile_read", "rd_last_error", "rd_version",
 ]
@@ -54,6 +56,7 @@ def lib():
     L.rd_model_destroy.argtypes = [vp]
     L.rd_model_destroy.restype = None
     L.rd_set_variant.argtypes = [vp, C.c_int]
+    L.rd_variant_available.argtypes = [C.c_int]
     L.rd_set_semantics.argtypes = [vp, C.c_int]
     L.rd_classify_workspace_bytes.argtypes = [i64, i32]
     L.rd_classify_workspace_bytes.restype = sz
@@ -69,9 +72,7 @@ def lib():
     L.rd_last_error.restype = C.c_char_p
     L.rd_version.restype = C.c_char_p
     for name in SYMBOLS:
-        f = getattr(L, name)
-        if f.restype is C.c_int and name not in ("rd_last_error", "rd_version"):
-            pass
+        getattr(L, name)          # AttributeError here = the .so does not export a symbol the header declares
     _lib = L
     return L
 
@@ -94,7 +95,7 @@ def ptr(t):
 # ---- host ingest library (librd_host.so: C++ + zlib, no GPU) -------------------------------------------------------
 HOST_LIB_PATH = os.path.join(_HERE, "csrc", "librd_host.so")
 HOST_SYMBOLS = ["rd_reader_open", "rd_reader_close", "rd_reader_next", "rd_writer_open", "rd_writer_write_selected",
-                "rd_writer_close", "rd_host_last_error", "rd_host_set_threads", "rd_host_gunzip"]
+                "rd_writer_close", "rd_writer_threads", "rd_host_last_error", "rd_host_set_threads", "rd_host_gunzip"]
 _host = None
 
 
@@ -114,6 +115,7 @@ def host_lib():
     L.rd_writer_open.argtypes = [C.c_char_p, C.POINTER(vp)]
     L.rd_writer_write_selected.argtypes = [vp, vp, vp, i64, vp, C.c_int32]
     L.rd_writer_close.argtypes = [vp]
+    L.rd_writer_threads.argtypes = [vp]
     L.rd_host_set_threads.argtypes = [C.c_int]
     L.rd_host_gunzip.argtypes = [C.c_char_p, vp, i64, C.POINTER(i64)]
     L.rd_host_last_error.restype = C.c_char_p

@@ -78,9 +78,7 @@ struct DevModel {
     float *rev_lut;   // [5][2]      W_out[:,128:] . h_rev(one step from zero on `code`)
     float *w_out;     // [2][256]
     float *b_out;     // [2]
-    uint32_t *wpack16;  // f16x3 16x16x32 A operand (hi/lo halves), see rd_prep_kernel
     uint32_t *wpack16b; // f16x3 32x32x16 A operand
-    uint32_t *wpack16c; // f16x3 32x32x16 A operand of the 8-wave kernel
     float *rev_tab;     // padded (ribodetector_cpu) semantics: [max_len][5][2] reverse-direction logit terms, see rd_revtab_kernel
 };
 

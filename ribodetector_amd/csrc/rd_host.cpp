@@ -386,7 +386,7 @@ void rd_reader_close(rd_reader *r) {
 int rd_reader_next(rd_reader *r, int64_t max_records, uint8_t *buf, int64_t buf_cap, int64_t *rec_start, int64_t *seq_off,
                    int32_t *seq_len, int64_t *n_out, int64_t *nbytes_out) {
     if (!r || !buf || !rec_start || !seq_off || !seq_len || !n_out || !nbytes_out) RDH_FAIL("rd_reader_next: null argument");
-    int64_t n = 0, w = 0;
+    int64_t n = 0, w = 0, need_hint = 0;
     bool at_eof = false;
     if (!r->fasta) {
         // FASTQ: 4 lines per record, each rstrip()-ed (fastx_parser.py:18-37)
@@ -408,8 +408,10 @@ int rd_reader_next(rd_reader *r, int64_t max_records, uint8_t *buf, int64_t buf_
             if (le[0] == lb[0] || base[lb[0]] != '@') RDH_FAIL("FASTQ record does not start with '@'");
             int64_t need = 4;
             for (int k = 0; k < 4; ++k) need += (int64_t)(le[k] - lb[k]);
-            if (need > buf_cap) RDH_FAIL("rd_reader_next: one record (%lld bytes) exceeds the buffer", (long long)need);
-            if (w + need > buf_cap) break;   // does not fit: the record stays in the window for the next call
+            if (w + need > buf_cap) {        // does not fit: the record stays in the window for the next call
+                if (n == 0) need_hint = need;   // not even alone: tell the caller how much room this record takes
+                break;
+            }
             rec_start[n] = w;
             for (int k = 0; k < 4; ++k) {
                 const size_t len = le[k] - lb[k];
@@ -427,11 +429,11 @@ int rd_reader_next(rd_reader *r, int64_t max_records, uint8_t *buf, int64_t buf_
         // file if seq != '')
         auto emit = [&](void) -> int {   // 1 = emitted, 0 = does not fit, -1 = error
             int64_t need = (int64_t)r->pending_header.size() + 1 + (int64_t)r->pending_seq.size() + 1;
-            if (need > buf_cap) {
-                snprintf(g_err, sizeof(g_err), "rd_reader_next: one record (%lld bytes) exceeds the buffer", (long long)need);
-                return -1;
+            if (n >= max_records) return 0;
+            if (w + need > buf_cap) {
+                if (n == 0) need_hint = need;
+                return 0;
             }
-            if (w + need > buf_cap || n >= max_records) return 0;
             rec_start[n] = w;
             memcpy(buf + w, r->pending_header.data(), r->pending_header.size());
             w += (int64_t)r->pending_header.size();
@@ -481,7 +483,7 @@ int rd_reader_next(rd_reader *r, int64_t max_records, uint8_t *buf, int64_t buf_
     }
     rec_start[n] = w;
     *n_out = n;
-    *nbytes_out = w;
+    *nbytes_out = (n == 0 && !at_eof) ? need_hint : w;   // nothing delivered: bytes the next record needs (the reference has no record-size limit)
     return at_eof ? 1 : 0;
 }
 
@@ -515,6 +517,8 @@ int rd_host_gunzip(const char *path, uint8_t *out, int64_t cap, int64_t *n_out) 
     *n_out = n;
     return rc;
 }
+
+int rd_writer_threads(const rd_writer *w) { return w ? w->threads : -1; }
 
 int rd_host_set_threads(int threads) {
     g_threads = threads > 0 ? threads : 0;

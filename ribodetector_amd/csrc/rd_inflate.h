@@ -378,6 +378,7 @@ class GzipStream {
             ip_ += 2;
         }
         member_abs_ = base_abs_ + (op_ - WIN);
+        hist0_ = op_;     // a member's window starts empty: a distance reaching into the previous member is invalid (as in zlib)
         crc_ = 0;
         crc_from_ = op_;
         bitbuf_ = 0;

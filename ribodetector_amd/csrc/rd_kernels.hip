@@ -19,7 +19,6 @@
 //   rd_len_hist/scan/scatter_kernel    stable counting sort = pack_sequence's sort, for rd_pack_plan
 //   rd_lstm_mfma_f16x3_t32_kernel      DEFAULT recurrence: split-precision f16 MFMA 32x32x16, weights resident in AGPRs,
 //                                      hand-interleaved gate math; fused encoder + FC + argmax epilogue
-//   rd_lstm_mfma_f16x3_kernel, rd_lstm_mfma_f16x3_w8_kernel   earlier / experimental tilings of the same arithmetic
 //   rd_lstm_mfma_f32_kernel            exact-fp32 MFMA recurrence (A/B reference for the split-precision kernels)
 //   rd_lstm_simple_kernel              plain-FMA cross-check of the same function
 //   rd_encode_* / rd_pack_onehot       standalone encoder kernels (reference tensor layouts), HBM-bound
@@ -29,9 +28,7 @@
 #include "rd_recurrence.hpp"
 #include "rd_sort.hpp"
 #include "rd_lstm_f32.hpp"
-#include "rd_lstm_f16x3.hpp"
 #include "rd_lstm_t32.hpp"
-#include "rd_lstm_w8.hpp"
 #include "rd_encode.hpp"
 
 // ================================================================================================
@@ -63,9 +60,7 @@ int rd_model_create(const rd_weights *w, int device, rd_model **out) {
     A((void **)&m->d.raw, sizeof(float) * RAW_FLOATS);
     A((void **)&m->d.wpack32, sizeof(float) * 4 * 8 * 32 * 64);
     A((void **)&m->d.wt_hh, sizeof(float) * HID * G4);
-    A((void **)&m->d.wpack16, sizeof(uint16_t) * 4 * 2 * 8 * 4 * 64 * 8);
     A((void **)&m->d.wpack16b, sizeof(uint16_t) * 4 * 2 * 4 * 8 * 64 * 8);
-    A((void **)&m->d.wpack16c, sizeof(uint16_t) * 8 * 2 * 2 * 8 * 64 * 8);
     A((void **)&m->d.in_lut, sizeof(float) * 5 * G4);
     A((void **)&m->d.rev_lut, sizeof(float) * 10);
     A((void **)&m->d.rev_tab, sizeof(float) * (size_t)MAX_LEN_LIMIT * 10);
@@ -92,19 +87,34 @@ void rd_model_destroy(rd_model *m) {
     hipSetDevice(m->device);
     hipFree(m->d.raw); hipFree(m->d.wpack32); hipFree(m->d.wt_hh); hipFree(m->d.in_lut);
     hipFree(m->d.rev_lut); hipFree(m->d.rev_tab); hipFree(m->d.w_out); hipFree(m->d.b_out);
-    if (m->d.wpack16) hipFree(m->d.wpack16);
     if (m->d.wpack16b) hipFree(m->d.wpack16b);
-    if (m->d.wpack16c) hipFree(m->d.wpack16c);
     for (int i = 0; i < 2 * 512; ++i)
         if (m->prof_ev[i]) hipEventDestroy(m->prof_ev[i]);
     delete m;
 }
 
+// Product build: the three kernels that compute the function (AUTO = the split-precision MFMA kernel). The A/B and
+// diagnostic instantiations (ids >= 10; several of them compute WRONG results by design: gate math or MFMAs removed, barrier
+// removed) exist only in the -DRD_DIAG build (librd_hip_diag.so, tools/), never in librd_hip.so.
+static bool rd_variant_known(int v) {
+    if (v == RD_VARIANT_MFMA_F32 || v == RD_VARIANT_SIMPLE || v == RD_VARIANT_MFMA_F16X3_T32) return true;
+#ifdef RD_DIAG
+    switch (v) {
+    case 10: case 11: case 12: case 13: case 20: case 21: case 22: case 23: case 40: case 41: case 42:
+    case 50: case 51: case 52: case 53: case 54: case 55: case 56: case 57: return true;
+    default: break;
+    }
+#endif
+    return false;
+}
+
+int rd_variant_available(int variant) { return (variant == RD_VARIANT_AUTO || rd_variant_known(variant)) ? 1 : 0; }
+
 int rd_set_variant(rd_model *m, int variant) {
     if (!m) RD_FAIL(RD_E_INVALID, "rd_set_variant: null model");
     if (variant == RD_VARIANT_AUTO) variant = RD_VARIANT_MFMA_F16X3_T32;
-    if (variant != RD_VARIANT_MFMA_F32 && variant != RD_VARIANT_SIMPLE && variant != RD_VARIANT_MFMA_F16X3 && variant != RD_VARIANT_MFMA_F16X3_T32 && variant != 5 && !(variant >= 10 && variant <= 42))
-        RD_FAIL(RD_E_UNSUPPORTED, "rd_set_variant: variant %d not available in this build", variant);
+    if (!rd_variant_known(variant))
+        RD_FAIL(RD_E_UNSUPPORTED, "rd_set_variant: variant %d not available in this build (product build: 0 auto, 1 mfma_f32, 2 simple, 4 mfma_f16x3_t32)", variant);
     m->variant = variant;
     return RD_OK;
 }
@@ -183,26 +193,24 @@ int rd_classify(const rd_model *cm, const uint8_t *arena, const int64_t *seq_off
         hipLaunchKernelGGL(rd_lstm_simple_kernel, dim3((unsigned)nwg), dim3(512), 0, st, m->d, rb, logits, labels);
     } else {
         const int64_t nwg = (n + BT - 1) / BT;
+        const dim3 grid((unsigned)nwg), blk(256);
         switch (m->variant) {
-        case 10: hipLaunchKernelGGL((rd_lstm_mfma_f32_kernel<0, 0>), dim3((unsigned)nwg), dim3(256), 0, st, m->d, rb, logits, labels); break;
-        case 11: hipLaunchKernelGGL((rd_lstm_mfma_f32_kernel<1, 0>), dim3((unsigned)nwg), dim3(256), 0, st, m->d, rb, logits, labels); break;
-        case 12: hipLaunchKernelGGL((rd_lstm_mfma_f32_kernel<0, 1>), dim3((unsigned)nwg), dim3(256), 0, st, m->d, rb, logits, labels); break;
-        case 13: hipLaunchKernelGGL((rd_lstm_mfma_f32_kernel<1, 1>), dim3((unsigned)nwg), dim3(256), 0, st, m->d, rb, logits, labels); break;
-        case 20: hipLaunchKernelGGL((rd_lstm_mfma_f32_kernel<1, 0, 1>), dim3((unsigned)nwg), dim3(256), 0, st, m->d, rb, logits, labels); break;
-        case 21: hipLaunchKernelGGL((rd_lstm_mfma_f32_kernel<1, 0, 2>), dim3((unsigned)nwg), dim3(256), 0, st, m->d, rb, logits, labels); break;
-        case 22: hipLaunchKernelGGL((rd_lstm_mfma_f32_kernel<1, 0, 3>), dim3((unsigned)nwg), dim3(256), 0, st, m->d, rb, logits, labels); break;
-        case 23: hipLaunchKernelGGL((rd_lstm_mfma_f32_kernel<1, 0, 4>), dim3((unsigned)nwg), dim3(256), 0, st, m->d, rb, logits, labels); break;
-        case RD_VARIANT_MFMA_F16X3: hipLaunchKernelGGL(rd_lstm_mfma_f16x3_kernel<2>, dim3((unsigned)nwg), dim3(256), 0, st, m->d, rb, logits, labels); break;
-        case RD_VARIANT_MFMA_F16X3_T32: hipLaunchKernelGGL(rd_lstm_mfma_f16x3_t32_kernel<6>, dim3((unsigned)nwg), dim3(256), 0, st, m->d, rb, logits, labels); break;
-        case 5: hipLaunchKernelGGL(rd_lstm_mfma_f16x3_w8_kernel, dim3((unsigned)nwg), dim3(512), 0, st, m->d, rb, logits, labels); break;
-        case 42: hipLaunchKernelGGL(rd_lstm_mfma_f16x3_t32_kernel<7>, dim3((unsigned)nwg), dim3(256), 0, st, m->d, rb, logits, labels); break;
-        case 41: hipLaunchKernelGGL(rd_lstm_mfma_f16x3_t32_kernel<-1>, dim3((unsigned)nwg), dim3(256), 0, st, m->d, rb, logits, labels); break;
-        case 40: hipLaunchKernelGGL(rd_lstm_mfma_f16x3_t32_kernel<0>, dim3((unsigned)nwg), dim3(256), 0, st, m->d, rb, logits, labels); break;
-        case 30: hipLaunchKernelGGL(rd_lstm_mfma_f16x3_kernel<0>, dim3((unsigned)nwg), dim3(256), 0, st, m->d, rb, logits, labels); break;
-        case 31: hipLaunchKernelGGL(rd_lstm_mfma_f16x3_kernel<3>, dim3((unsigned)nwg), dim3(256), 0, st, m->d, rb, logits, labels); break;
-        case 32: hipLaunchKernelGGL(rd_lstm_mfma_f16x3_kernel<4>, dim3((unsigned)nwg), dim3(256), 0, st, m->d, rb, logits, labels); break;
-        case RD_VARIANT_MFMA_F32:
-        default: hipLaunchKernelGGL((rd_lstm_mfma_f32_kernel<1, 0>), dim3((unsigned)nwg), dim3(256), 0, st, m->d, rb, logits, labels); break;
+        case RD_VARIANT_MFMA_F16X3_T32: hipLaunchKernelGGL(rd_lstm_mfma_f16x3_t32_kernel<6>, grid, blk, 0, st, m->d, rb, logits, labels); break;
+        case RD_VARIANT_MFMA_F32: hipLaunchKernelGGL((rd_lstm_mfma_f32_kernel<1, 0>), grid, blk, 0, st, m->d, rb, logits, labels); break;
+#ifdef RD_DIAG
+        case 10: hipLaunchKernelGGL((rd_lstm_mfma_f32_kernel<0, 0>), grid, blk, 0, st, m->d, rb, logits, labels); break;
+        case 11: hipLaunchKernelGGL((rd_lstm_mfma_f32_kernel<1, 0>), grid, blk, 0, st, m->d, rb, logits, labels); break;
+        case 12: hipLaunchKernelGGL((rd_lstm_mfma_f32_kernel<0, 1>), grid, blk, 0, st, m->d, rb, logits, labels); break;
+        case 13: hipLaunchKernelGGL((rd_lstm_mfma_f32_kernel<1, 1>), grid, blk, 0, st, m->d, rb, logits, labels); break;
+        case 20: hipLaunchKernelGGL((rd_lstm_mfma_f32_kernel<1, 0, 1>), grid, blk, 0, st, m->d, rb, logits, labels); break;
+        case 21: hipLaunchKernelGGL((rd_lstm_mfma_f32_kernel<1, 0, 2>), grid, blk, 0, st, m->d, rb, logits, labels); break;
+        case 22: hipLaunchKernelGGL((rd_lstm_mfma_f32_kernel<1, 0, 3>), grid, blk, 0, st, m->d, rb, logits, labels); break;
+        case 23: hipLaunchKernelGGL((rd_lstm_mfma_f32_kernel<1, 0, 4>), grid, blk, 0, st, m->d, rb, logits, labels); break;
+        case 40: hipLaunchKernelGGL(rd_lstm_mfma_f16x3_t32_kernel<0>, grid, blk, 0, st, m->d, rb, logits, labels); break;
+        case 41: hipLaunchKernelGGL(rd_lstm_mfma_f16x3_t32_kernel<-1>, grid, blk, 0, st, m->d, rb, logits, labels); break;
+        case 42: hipLaunchKernelGGL(rd_lstm_mfma_f16x3_t32_kernel<7>, grid, blk, 0, st, m->d, rb, logits, labels); break;
+#endif
+        default: RD_FAIL(RD_E_UNSUPPORTED, "rd_classify: variant %d not available in this build", m->variant);
         }
     }
     RD_HIP(hipGetLastError());

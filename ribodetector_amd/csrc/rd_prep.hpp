@@ -28,19 +28,6 @@ __global__ void rd_prep_kernel(DevModel d) {
         int k = i / G4, col = i % G4;
         d.wt_hh[i] = raw[OFF_WHH + col * HID + k];
     }
-    // f16x3 A operand: [wave][W1|W2][tile a][k-step s][lane][8 halves]; lane (i = lane&15, q): row i of tile a is
-    // gate i&3 of unit 32w + 8(i>>2) + a; element e is hidden index 32s + 8q + e.  W1 = fp16(16 w), W2 = fp16(2^11 (16 w - W1)).
-    for (int i = tid; i < 4 * 8 * 4 * 64 * 8; i += nth) {
-        int e = i & 7, lane = (i >> 3) & 63, s = (i >> 9) & 3, a = (i >> 11) & 7, w = i >> 14;
-        int row = lane & 15, q = lane >> 4;
-        int col = (row & 3) * HID + 32 * w + 8 * (row >> 2) + a;
-        float x = 16.0f * raw[OFF_WHH + col * HID + 32 * s + 8 * q + e];
-        _Float16 hi = (_Float16)x;
-        _Float16 lo = (_Float16)((x - (float)hi) * 2048.0f);
-        _Float16 *base = reinterpret_cast<_Float16 *>(d.wpack16);
-        base[((((size_t)(w * 2 + 0) * 8 + a) * 4 + s) * 64 + lane) * 8 + e] = hi;
-        base[((((size_t)(w * 2 + 1) * 8 + a) * 4 + s) * 64 + lane) * 8 + e] = lo;
-    }
     for (int i = tid; i < 5 * G4; i += nth) {
         int code = i / G4, col = i % G4;
         float b = raw[OFF_BIH + col] + raw[OFF_BHH + col];
@@ -59,20 +46,6 @@ __global__ void rd_prep_kernel(DevModel d) {
         _Float16 *base = reinterpret_cast<_Float16 *>(d.wpack16b);
         base[((((size_t)(w * 2 + 0) * 4 + a) * 8 + s) * 64 + lane) * 8 + e] = hi;
         base[((((size_t)(w * 2 + 1) * 4 + a) * 8 + s) * 64 + lane) * 8 + e] = lo;
-    }
-    // w8 kernel A operand: [wave(8)][W1|W2][row-tile a(2)][k-step s][lane][8 halves]; row i = 8b + 4hf + g is gate g of unit
-    // 16w + 8hf + 4a + b; W2 = unscaled fp16 residual of 16 w.
-    for (int i = tid; i < 8 * 2 * 8 * 64 * 8; i += nth) {
-        int e = i & 7, lane = (i >> 3) & 63, s = (i >> 9) & 7, a = (i >> 12) & 1, w = i >> 13;
-        int row = lane & 31, kh = lane >> 5;
-        int g = row & 3, hf = (row >> 2) & 1, b = row >> 3;
-        int col = g * HID + 16 * w + 8 * hf + 4 * a + b;
-        float x = 16.0f * raw[OFF_WHH + col * HID + 16 * s + 8 * kh + e];
-        _Float16 hi = (_Float16)x;
-        _Float16 lo = (_Float16)(x - (float)hi);
-        _Float16 *base = reinterpret_cast<_Float16 *>(d.wpack16c);
-        base[((((size_t)(w * 2 + 0) * 2 + a) * 8 + s) * 64 + lane) * 8 + e] = hi;
-        base[((((size_t)(w * 2 + 1) * 2 + a) * 8 + s) * 64 + lane) * 8 + e] = lo;
     }
     for (int i = tid; i < 512; i += nth) d.w_out[i] = raw[OFF_WOUT + i];
     if (tid < 2) d.b_out[tid] = raw[OFF_BOUT + tid];

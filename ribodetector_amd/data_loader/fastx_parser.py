@@ -230,6 +230,7 @@ class NativeReader:
                                   so.data_ptr() + 8 * n_tot, sl.data_ptr() + 4 * n_tot, C.byref(n), C.byref(nb))
             if rc < 0:
                 N.host_check(rc, "rd_reader_next")
+            hint = 0 if n.value else int(nb.value)        # nothing delivered: the bytes the next record needs
             if n.value:
                 if b_tot:                               # offsets of this call are relative to its own buffer start
                     rs[n_tot:n_tot + n.value + 1] += b_tot
@@ -241,7 +242,7 @@ class NativeReader:
                 self.eof = True
                 break
             if n_tot < want:                            # buffer full before `want` records: grow and continue
-                grown = self._alloc(max(2 * buf.numel(), b_tot + (want - n_tot) * self.est + (1 << 16)), want)
+                grown = self._alloc(max(2 * buf.numel(), b_tot + (want - n_tot) * self.est + (1 << 16), b_tot + hint + (1 << 16)), want)
                 grown[0][:b_tot] = buf[:b_tot]
                 grown[1][:n_tot + 1] = rs[:n_tot + 1]
                 grown[2][:n_tot] = so[:n_tot]
@@ -297,6 +298,11 @@ class NativeWriter:
     def __init__(self, path):
         self.h = C.c_void_p()
         N.host_check(N.host_lib().rd_writer_open(str(path).encode(), C.byref(self.h)), "rd_writer_open")
+
+    @property
+    def threads(self):
+        """compressor threads of this writer (the -t/--threads value in force when it was opened)"""
+        return int(N.host_lib().rd_writer_threads(self.h))
 
     def write_selected(self, chunk, labels, want):
         """append the records of `chunk` whose label == want, in input order (reference detect.py:485-492)"""

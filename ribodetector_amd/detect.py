@@ -89,7 +89,10 @@ class Predictor:
             self.device, colors.BOLD, colors.OKCYAN, self.len, colors.ENDC))
         self.model = model.to(self.device)
         kcfg = dict(self.config.config.get('kernel', {}))
-        self.model.set_variant(kcfg.get('variant', 'auto'))
+        variant = kcfg.get('variant', 'auto')
+        if variant not in ('auto', 'mfma_f32', 'simple', 'mfma_f16x3_t32'):
+            raise RuntimeError("config.json kernel.variant must be one of auto, mfma_f16x3_t32, mfma_f32, simple; got %r" % (variant,))
+        self.model.set_variant(variant)
         self.model.set_semantics(getattr(self.args, 'semantics', None) or kcfg.get('semantics', 'gpu'))
         self.model.eval()
 
@@ -194,6 +197,8 @@ class Predictor:
         writer = self.rank == 0
         ends = (0, 1) if self.is_paired else (0,)
         fhs = {}
+        from . import _native
+        _native.host_lib().rd_host_set_threads(int(self.args.threads))   # -t/--threads: gzip workers; read when a writer is opened
         if writer:
             if self.rrna is not None:
                 self.logger.info('Writing output rRNA sequences into file: {}{}{}'.format(
@@ -209,8 +214,6 @@ class Predictor:
                     colors.OKYELLOW, ", ".join(unclf), colors.ENDC))
         num_read = num_nonrrna = num_rrna = num_unknown = 0
         self._stage_s = {"wait_reader": 0.0, "classify": 0.0, "wait_writer": 0.0}   # main-thread seconds per pipeline stage
-        from . import _native
-        _native.host_lib().rd_host_set_threads(int(self.args.threads))   # -t/--threads: gzip output workers
         self._copy_stream = torch.cuda.Stream(self.device)
 
         # writer threads (rank 0): one per mate, records of every label file in input order
@@ -276,6 +279,7 @@ class Predictor:
             if self.is_paired and self.args.ensure == 'both':
                 self.logger.info('Discarded {}{}{}{} unclassified sequences'.format(
                     colors.BOLD, colors.OKCYAN, num_unknown, colors.ENDC))
+            self.writer_threads = sorted({fh.threads for handles in fhs.values() for fh in handles})
             for handles in fhs.values():
                 for fh in handles:
                     fh.close()

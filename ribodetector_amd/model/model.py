@@ -112,6 +112,8 @@ class SeqModel:
         return self
 
     def set_variant(self, name):
+        if name not in N.VARIANTS:
+            raise RuntimeError("SeqModel.set_variant: unknown kernel variant %r (this build has: %s)" % (name, ", ".join(sorted(N.VARIANTS))))
         self._variant = name
         if self._handle is not None:
             N.check(N.lib().rd_set_variant(self._handle, N.VARIANTS[name]), "rd_set_variant")

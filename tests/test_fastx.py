@@ -228,3 +228,46 @@ def test_plain_writer_vectored(tmp_path):
         assert len(want) > (8 << 20) or name == "sparse"
         with open(out, "rb") as fh:
             assert fh.read() == want, name
+
+
+def test_long_record_with_small_chunk(tmp_path):
+    """one record far larger than the first buffer (a 120 kb FASTA sequence, a 300 kb FASTQ read) with a tiny chunk_size: the
+    reader reports the bytes it needs and the wrapper grows - the reference parser has no record-size limit"""
+    rng = np.random.default_rng(11)
+    big = "".join("ACGT"[k] for k in rng.integers(0, 4, 120000))
+    fa = str(tmp_path / "long.fa")
+    with open(fa, "w") as fh:
+        fh.write(">short1\nACGT\n>big one\n")
+        for i in range(0, len(big), 60):
+            fh.write(big[i:i + 60].lower() + "\n")
+        fh.write(">short2\nGGCC\n")
+    recs = []
+    for c in fx.get_seq_chunks(fa, chunk_size=2):
+        b = c.buf.tobytes()
+        recs += [b[c.seq_off[i]:c.seq_off[i] + c.seq_len[i]].decode() for i in range(len(c.seq_len))]
+    assert recs == ["ACGT", big, "GGCC"]
+    fq = str(tmp_path / "long.fq")
+    big2 = big * 2 + big[:60000]
+    with open(fq, "w") as fh:
+        fh.write("@a\nAC\n+\nII\n@b\n%s\n+\n%s\n@c\nGT\n+\nII\n" % (big2, "I" * len(big2)))
+    r = fx.NativeReader(fq, est_record_bytes=8)
+    c = r.read(3)
+    assert list(c.seq_len) == [2, len(big2), 2] and r.read(3) is None
+    assert c.buf.tobytes()[c.seq_off[1]:c.seq_off[1] + c.seq_len[1]].decode() == big2
+
+
+def test_writer_threads_follow_set_threads(tmp_path):
+    """rd_writer_open takes the thread count in force when it is called: -t must be applied before the writers are opened"""
+    from ribodetector_amd import _native as N
+    L = N.host_lib()
+    try:
+        for t in (3, 1, 7):
+            L.rd_host_set_threads(t)
+            w = fx.open_for_write(str(tmp_path / ("t%d.fq.gz" % t)))
+            assert w.threads == t
+            w.close()
+    finally:
+        L.rd_host_set_threads(0)
+    w = fx.open_for_write(str(tmp_path / "auto.fq.gz"))
+    assert 1 <= w.threads <= 32
+    w.close()

@@ -36,6 +36,7 @@ def test_cli_single_end_10k(tmp_path, oracle):
     margin = np.abs(ref[:, 1] - ref[:, 0])
     assert margin.min() > 2e-4                                          # no borderline read in this fixture
     assert p.num_read == 10000 and p.num_rrna == int(lab.sum()) and p.num_nonrrna == int((lab == 0).sum())
+    assert p.writer_threads == [2]                                      # -t reaches the gzip writers
     assert _read(out) == _fastq_text(arena, off, 1, np.flatnonzero(lab == 0))
     assert _read(rr) == _fastq_text(arena, off, 1, np.flatnonzero(lab == 1))
     # whole-file mode gives the same files

@@ -9,7 +9,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
-VARIANTS = ["mfma_f32", "simple", "mfma_f32_a0s0", "mfma_f16x3", "mfma_f16x3_t32", "mfma_f16x3_w8"]
+VARIANTS = ["mfma_f32", "simple", "mfma_f16x3_t32"]
 
 
 def _run(model, arena, offsets, lens, max_len):
@@ -291,7 +291,9 @@ def test_abi_error_paths_on_device(gpu_model):
     assert L.rd_classify(*args(4, 20000, ws.numel())) == -1
     assert L.rd_classify(*args(-1, 100, ws.numel())) == -1
     assert L.rd_set_variant(h, 99) == -3 and L.rd_set_semantics(h, 7) == -1
-    with pytest.raises(KeyError):
+    for diag_id in (41, 42, 22, 10, 3, 5, 14):        # diagnostic / removed / never-defined ids: refused by the product build
+        assert L.rd_set_variant(h, diag_id) == -3 and b"not available" in L.rd_last_error()
+    with pytest.raises(RuntimeError):
         gpu_model.set_variant("nope")
     with pytest.raises(TypeError):
         gpu_model.classify_bytes(arena.cpu(), off, ln, 100)

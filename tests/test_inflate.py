@@ -162,3 +162,32 @@ def test_reader_reports_truncated_gzip(tmp_path):
     with pytest.raises(ValueError, match="ended before the end-of-stream marker"):
         for _ in fx.get_seq_chunks(str(cut), 8192):
             pass
+
+
+def test_match_must_not_reach_into_previous_member(tmp_path):
+    """a distance that points before the start of its own gzip member is invalid (zlib: 'invalid distance too far back'),
+    even when an earlier member left bytes in the window"""
+    import struct
+    import zlib
+    first = member(b"ABCDEFGHIJKLMNOPQRSTUVWXYZ" * 40, 5)
+    # second member: fixed-Huffman block whose first symbol is a match (length 3, distance 1) - there is no history yet
+    bits = []
+
+    def put(v, n, msb=False):
+        for i in (range(n - 1, -1, -1) if msb else range(n)):
+            bits.append((v >> i) & 1)
+    put(1, 1)
+    put(1, 2)                    # BFINAL, BTYPE = 01 (fixed)
+    put(0b0000001, 7, msb=True)  # length code 257 (length 3)
+    put(0, 5, msb=True)          # distance code 0 (distance 1)
+    put(0, 7, msb=True)          # end of block
+    while len(bits) % 8:
+        bits.append(0)
+    body = bytes(sum(b << k for k, b in enumerate(bits[i:i + 8])) for i in range(0, len(bits), 8))
+    with pytest.raises(zlib.error):
+        zlib.decompressobj(-15).decompress(body)
+    bad = first + b"\x1f\x8b\x08\x00\x00\x00\x00\x00\x00\xff" + body + struct.pack("<II", 0, 3)
+    p = tmp_path / "cross.gz"
+    p.write_bytes(bad)
+    rc, _, err = gunzip(p, 1 << 16)
+    assert rc != 0 and "distance" in err.lower(), err
