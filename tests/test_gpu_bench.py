@@ -23,7 +23,7 @@ def _line(out):
 
 def test_bench_single_gpu_contract():
     r = subprocess.run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--pairs-per-step", "65536", "--no-alt",
-                        "--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+                        "--no-cpu-baseline", "--traffic", "off"], cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     j = _line(r.stdout)
     for k in KEYS:
@@ -34,19 +34,64 @@ def test_bench_single_gpu_contract():
     rf = j["roofline"]
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
     assert "workload" in j["config"] and "model" not in j["config"]
+    # the timed region is SURVEY 8d (ii): pinned host bytes -> H2D -> kernels -> labels D2H; (i) rides along
+    assert j["config"]["timed_region"] == "ii" and j["config"]["kernel_only_reads_per_s"] > 1e6
+    assert j["config"]["host_labels_nonzero_last_step"] > 0           # the labels really arrived in host memory
+    assert j["ms_per_step"] >= 2 * rf["avg_launch_ms"] * 0.999        # a step = two launches of the recurrence kernel
+    enc = j["encoder"]["kernels"]
+    assert set(enc) == {"rd_encode_codes_kernel", "rd_encode_onehot_padded_kernel", "rd_pack_onehot_kernel"}
+    assert all(v["achieved"] > 50 for v in enc.values())
 
 
-def test_bench_two_ranks_one_gpu():
+def test_bench_self_launches_two_ranks_one_gpu():
+    """`python bench.py --gpus 2` with no WORLD_SIZE: bench.py starts its own two ranks (torch.distributed.run). Here they
+    share the one GPU and exchange labels over gloo; on an N-GPU node the same path runs one rank per GPU over RCCL."""
+    env = dict(os.environ, RD_DIST_BACKEND="gloo", RD_LOCAL_DEVICE="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--pairs-per-step", "65536", "--no-alt",
+           "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    j = _line(r.stdout)
+    assert j["n_gpus"] == 2 and j["value"] > 1e6 and j["config"]["rccl_ranks"] == 2 and j["config"]["dist_backend"] == "gloo"
+    assert abs(j["value"] - 2 * 2 * 65536 * 3 / (j["ms_per_step"] * 3e-3)) < 1e-6 * j["value"]     # whole-job aggregate
+
+
+def test_bench_under_torchrun_two_ranks_one_gpu():
+    """the driver's own launch form: python -m torch.distributed.run ... bench.py --gpus 2"""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     env = dict(os.environ, RD_DIST_BACKEND="gloo", RD_LOCAL_DEVICE="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--pairs-per-step", "65536",
+           "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--pairs-per-step", "65536",
            "--no-alt", "--no-cpu-baseline"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     j = _line(r.stdout)
     assert j["n_gpus"] == 2 and j["value"] > 1e6
-    assert abs(j["value"] - 2 * 2 * 65536 * 3 / (j["ms_per_step"] * 3e-3)) < 1e-6 * j["value"]     # whole-job aggregate
+
+
+def test_bench_needs_n_devices():
+    """--gpus 2 on a box with one device (and no shared-GPU override) stops with a clear message, before any rank starts"""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("box has >= 2 devices")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "RD_LOCAL_DEVICE", "RD_DIST_BACKEND")}
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "3"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 3 and "needs 2 visible devices" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_two_gpu_rccl_when_available():
+    """one rank per GPU over RCCL (backend nccl): only on a box with >= 2 devices"""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "RD_LOCAL_DEVICE", "RD_DIST_BACKEND")}
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-alt", "--no-cpu-baseline"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    j = _line(r.stdout)
+    assert j["n_gpus"] == 2 and j["config"]["dist_backend"] == "nccl"
