@@ -264,6 +264,9 @@ def main():
         if paired:
             model.classify_bytes(a1, offs, lens, MAXLEN, want_labels=False, logits=lg[0])
             model.classify_bytes(a2, offs, lens, MAXLEN, want_labels=False, logits=lg[1])
+            if args.ensure == "none":
+                model.refine_pairs(a1, offs, lens, MAXLEN, lg[0], lg[1])
+                model.refine_pairs(a2, offs, lens, MAXLEN, lg[1], lg[0])
             return module_arch.pair_fuse(lg[0], lg[1], args.ensure, counts)
         model.classify_bytes(a1, offs, lens, MAXLEN, want_labels=True, logits=lg[0], labels=lab8)
         module_arch.count_labels(lab8, counts)
@@ -376,7 +379,7 @@ def main():
         mult = 2.0 if paired else 1.0
         avg_ms = kms / max(launches, 1)
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if launches else None
-        base = "mfma_f16x3_t32" if variant.startswith("mfma_f16x3_t32") else "mfma_f32" if variant.startswith("mfma_f32") else variant
+        base = ("mfma_f16x3_t32" if variant.startswith(("mfma_f16x3_t32", "t32_")) else "mfma_f32" if variant.startswith("mfma_f32") else variant)
         peak = PEAKS[base]
         kname = "rd_lstm_%s_kernel" % base
         traffic, traffic_src = None, "not collected (--traffic off or N>1)"

@@ -33,6 +33,20 @@ typedef struct rd_writer rd_writer;
 int rd_reader_open(const char *path, int format, rd_reader **out);
 void rd_reader_close(rd_reader *r);
 
+/* Byte-range ingest for the multi-rank CLI (one process per GPU): every rank parses only its own part of a PLAIN input file.
+ *   rd_host_file_info          size in bytes; is_gzip = 1 if the file starts with the gzip magic (no byte ranges then)
+ *   rd_host_find_record_start  first record boundary at or after byte pos (FASTQ: a line starting with '@' whose second-next
+ *                              line starts with '+'; FASTA: a line starting with '>'); the file size if none follows
+ *   rd_host_count_records      records starting in [start, end), start being a boundary
+ *   rd_host_skip_records       the boundary k records after the boundary `start`
+ *   rd_reader_open_range       a reader over [start, end) (both boundaries): parses exactly like a file holding those bytes
+ * Record semantics stay those of the reference parser (fastx_parser.py:15-55). */
+int rd_host_file_info(const char *path, int64_t *size, int32_t *is_gzip);
+int rd_host_find_record_start(const char *path, int format, int64_t pos, int64_t *out);
+int rd_host_count_records(const char *path, int format, int64_t start, int64_t end, int64_t *n);
+int rd_host_skip_records(const char *path, int format, int64_t start, int64_t k, int64_t *out);
+int rd_reader_open_range(const char *path, int format, int64_t start, int64_t end, rd_reader **out);
+
 /* Parse up to max_records records into caller buffers.
  *   buf[0 .. *nbytes)      normalised record text: for record i, buf[rec_start[i] .. rec_start[i+1]) is exactly
  *                          '\n'.join(record_lines) + '\n' as the reference would write it

@@ -16,13 +16,15 @@ VARIANTS = {"auto": 0, "mfma_f32": 1, "simple": 2, "mfma_f16x3_t32": 4}      # w
 DIAG_VARIANTS = {"mfma_f32_a0s0": 10, "mfma_f32_a1s0": 11, "mfma_f32_a0s1": 12, "mfma_f32_a1s1": 13,
                  "mfma_f32_diag_noew": 20, "mfma_f32_diag_nomfma": 21, "mfma_f32_diag_mfmaonly": 22, "mfma_f32_diag_mfmabar": 23,
                  "mfma_f16x3_t32_fill0": 40, "mfma_f16x3_t32_diag_mfmaonly": 41, "mfma_f16x3_t32_diag_nobarrier": 42,
-                 "t32_x0": 50, "t32_x1": 51, "t32_x2": 52, "t32_x3": 53, "t32_x4": 54, "t32_x5": 55, "t32_x6": 56, "t32_x7": 57}
+                 # accuracy experiments on the default kernel (rd_lstm_t32.hpp ACC bits): id = 50 + ACC
+                 "t32_acc0": 50, "t32_acc1_4prod": 51, "t32_acc2_smallfirst": 52, "t32_acc4_exparg": 54, "t32_acc8_newton": 58,
+                 "t32_acc15_all": 65, "t32_acc16_ops24": 66, "t32_acc32_creg": 82, "t32_acc48_ops24_creg": 98}
 if os.path.basename(LIB_PATH).startswith("librd_hip_diag"):
     VARIANTS = dict(VARIANTS, **DIAG_VARIANTS)
 
 # every symbol include/ribodetector_amd.h declares (tests/test_abi.py checks the .so exports all of them)
 SYMBOLS = [
-    "rd_model_create", "rd_model_destroy", "rd_set_variant", "rd_variant_available", "rd_set_semantics", "rd_classify_workspace_bytes", "rd_classify",
+    "rd_model_create", "rd_model_destroy", "rd_set_variant", "rd_variant_available", "rd_set_semantics", "rd_set_refine", "rd_refine", "rd_classify_workspace_bytes", "rd_classify",
     "rd_pair_fuse", "rd_count_labels", "rd_encode_codes", "rd_encode_onehot_padded", "rd_pack_plan",
     "rd_pack_onehot", "rd_profile_enable", "rd_profile_read", "rd_last_error", "rd_version",
 ]
@@ -58,6 +60,8 @@ def lib():
     L.rd_set_variant.argtypes = [vp, C.c_int]
     L.rd_variant_available.argtypes = [C.c_int]
     L.rd_set_semantics.argtypes = [vp, C.c_int]
+    L.rd_set_refine.argtypes = [vp, C.c_float]
+    L.rd_refine.argtypes = [vp, vp, vp, vp, i64, i32, vp, vp, vp, vp]
     L.rd_classify_workspace_bytes.argtypes = [i64, i32]
     L.rd_classify_workspace_bytes.restype = sz
     L.rd_classify.argtypes = [vp, vp, vp, vp, i64, i32, vp, vp, vp, sz, vp]
@@ -94,7 +98,8 @@ def ptr(t):
 
 # ---- host ingest library (librd_host.so: C++ + zlib, no GPU) -------------------------------------------------------
 HOST_LIB_PATH = os.path.join(_HERE, "csrc", "librd_host.so")
-HOST_SYMBOLS = ["rd_reader_open", "rd_reader_close", "rd_reader_next", "rd_writer_open", "rd_writer_write_selected",
+HOST_SYMBOLS = ["rd_reader_open", "rd_reader_close", "rd_reader_next", "rd_host_file_info", "rd_host_find_record_start",
+                "rd_host_count_records", "rd_host_skip_records", "rd_reader_open_range", "rd_writer_open", "rd_writer_write_selected",
                 "rd_writer_close", "rd_writer_threads", "rd_host_last_error", "rd_host_set_threads", "rd_host_gunzip"]
 _host = None
 
@@ -110,6 +115,11 @@ def host_lib():
     vp, i64 = C.c_void_p, C.c_int64
     L.rd_reader_open.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
     L.rd_reader_close.argtypes = [vp]
+    L.rd_host_file_info.argtypes = [C.c_char_p, C.POINTER(i64), C.POINTER(C.c_int32)]
+    L.rd_host_find_record_start.argtypes = [C.c_char_p, C.c_int, i64, C.POINTER(i64)]
+    L.rd_host_count_records.argtypes = [C.c_char_p, C.c_int, i64, i64, C.POINTER(i64)]
+    L.rd_host_skip_records.argtypes = [C.c_char_p, C.c_int, i64, i64, C.POINTER(i64)]
+    L.rd_reader_open_range.argtypes = [C.c_char_p, C.c_int, i64, i64, C.POINTER(vp)]
     L.rd_reader_close.restype = None
     L.rd_reader_next.argtypes = [vp, i64, vp, i64, vp, vp, vp, C.POINTER(i64), C.POINTER(i64)]
     L.rd_writer_open.argtypes = [C.c_char_p, C.POINTER(vp)]

@@ -89,6 +89,7 @@ struct rd_model {
     int variant;
     int semantics;      // RD_SEM_PACKED / RD_SEM_PADDED
     int rev_tab_len;    // max_len the padded-semantics table was built for (0 = none)
+    float refine_thresh;  // margin below which a read is re-evaluated in float64 (rd_refine.hpp); 0 = off
     DevModel d;
     // profiling of the recurrence kernel (bench.py roofline)
     int prof_enabled;

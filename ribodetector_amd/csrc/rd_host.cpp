@@ -15,6 +15,7 @@
 #include <condition_variable>
 #include <deque>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -369,6 +370,192 @@ int rd_reader_open(const char *path, int format, rd_reader **out) {
             },
             []() { return std::string("read error"); });
     }
+    r->eof = false;
+    r->scan_next = 0;
+    *out = r;
+    return 0;
+}
+
+// ---- byte-range readers for the multi-rank CLI: every rank parses only its own part of a PLAIN file -------------------------
+namespace {
+
+struct RangeFile {
+    int fd = -1;
+    int64_t size = 0;
+    std::vector<uint8_t> buf;
+    int64_t base = 0, len = 0;   // buf holds file bytes [base, base + len)
+    bool open_path(const char *path) {
+        fd = open(path, O_RDONLY);
+        if (fd < 0) return false;
+        size = (int64_t)lseek(fd, 0, SEEK_END);
+        buf.resize(4u << 20);
+        return true;
+    }
+    ~RangeFile() { if (fd >= 0) close(fd); }
+    bool load(int64_t at) {   // buf <- file bytes from `at`
+        base = at;
+        len = 0;
+        while (len < (int64_t)buf.size() && base + len < size) {
+            const ssize_t k = pread(fd, buf.data() + len, buf.size() - (size_t)len, (off_t)(base + len));
+            if (k < 0) return false;
+            if (k == 0) break;
+            len += k;
+        }
+        return true;
+    }
+    // offset of the first byte after the next '\n' at or after `at` (= start of the next line), or size when there is none
+    int64_t next_line(int64_t at) {
+        for (;;) {
+            if (at >= size) return size;
+            if (at < base || at >= base + len) { if (!load(at)) return -1; }
+            const uint8_t *p = buf.data() + (at - base);
+            const uint8_t *nl = (const uint8_t *)memchr(p, '\n', (size_t)(base + len - at));
+            if (nl) return base + (nl - buf.data()) + 1;
+            at = base + len;
+        }
+    }
+    int byte_at(int64_t at) {   // -1 past the end
+        if (at >= size) return -1;
+        if (at < base || at >= base + len) { if (!load(at)) return -2; }
+        return buf[(size_t)(at - base)];
+    }
+};
+
+int range_format(const char *path, int format) {
+    std::string p(path);
+    if (format >= 0) return format;
+    if (ends_with(p, ".fq") || ends_with(p, ".fastq")) return 0;
+    if (ends_with(p, ".fasta") || ends_with(p, ".fa") || ends_with(p, ".fna") || ends_with(p, ".fas")) return 1;
+    return -1;
+}
+
+}  // namespace
+
+int rd_host_file_info(const char *path, int64_t *size, int32_t *is_gzip) {
+    if (!path || !size || !is_gzip) RDH_FAIL("rd_host_file_info: null argument");
+    RangeFile f;
+    if (!f.open_path(path)) RDH_FAIL("cannot open %s", path);
+    *size = f.size;
+    *is_gzip = (f.byte_at(0) == 0x1f && f.byte_at(1) == 0x8b) ? 1 : 0;
+    return 0;
+}
+
+// First record boundary at or after byte `pos` of a plain file. FASTQ (4-line records, fastx_parser.py:18-37): a line that
+// starts with '@' whose second-next line starts with '+' - a quality line may start with '@' too, but then the second-next
+// line is a sequence line, which never starts with '+'. FASTA: a line that starts with '>'. Returns the file size when no
+// record starts after pos.
+int rd_host_find_record_start(const char *path, int format, int64_t pos, int64_t *out) {
+    if (!path || !out) RDH_FAIL("rd_host_find_record_start: null argument");
+    format = range_format(path, format);
+    if (format < 0) RDH_FAIL("Unknown extension of %s. Only fastq and fasta sequence formats are supported.", path);
+    RangeFile f;
+    if (!f.open_path(path)) RDH_FAIL("cannot open %s", path);
+    if (pos <= 0) { *out = 0; return 0; }
+    if (pos >= f.size) { *out = f.size; return 0; }
+    int64_t line = (f.byte_at(pos - 1) == '\n') ? pos : f.next_line(pos);
+    while (line >= 0 && line < f.size) {
+        const int c = f.byte_at(line);
+        if (format == 1) {
+            if (c == '>') { *out = line; return 0; }
+        } else if (c == '@') {
+            const int64_t l1 = f.next_line(line), l2 = l1 >= 0 ? f.next_line(l1) : -1;
+            if (l2 < 0) break;
+            if (l2 < f.size && f.byte_at(l2) == '+') { *out = line; return 0; }
+        }
+        line = f.next_line(line);
+    }
+    if (line < 0) RDH_FAIL("read error in %s", path);
+    *out = f.size;
+    return 0;
+}
+
+// Records that start in [start, end) (start = a record boundary): FASTQ = lines / 4, FASTA = lines starting with '>'.
+int rd_host_count_records(const char *path, int format, int64_t start, int64_t end, int64_t *n_out) {
+    if (!path || !n_out) RDH_FAIL("rd_host_count_records: null argument");
+    format = range_format(path, format);
+    if (format < 0) RDH_FAIL("Unknown extension of %s. Only fastq and fasta sequence formats are supported.", path);
+    RangeFile f;
+    if (!f.open_path(path)) RDH_FAIL("cannot open %s", path);
+    if (end > f.size) end = f.size;
+    int64_t lines = 0, headers = 0, at = start;
+    bool line_start = true;
+    while (at < end) {
+        if (!f.load(at)) RDH_FAIL("read error in %s", path);
+        const int64_t m = std::min(f.len, end - at);
+        if (m <= 0) break;
+        const uint8_t *p = f.buf.data(), *e = p + m;
+        while (p < e) {
+            if (line_start && *p == '>') ++headers;
+            const uint8_t *nl = (const uint8_t *)memchr(p, '\n', (size_t)(e - p));
+            if (!nl) { line_start = false; break; }
+            ++lines;
+            line_start = true;
+            p = nl + 1;
+        }
+        at += m;
+    }
+    if (!line_start) ++lines;   // last line without terminator
+    *n_out = format == 1 ? headers : lines / 4;
+    return 0;
+}
+
+// Byte offset of the record boundary `k` records after the boundary `start` (the file size if fewer records follow).
+int rd_host_skip_records(const char *path, int format, int64_t start, int64_t k, int64_t *out) {
+    if (!path || !out || k < 0) RDH_FAIL("rd_host_skip_records: bad argument");
+    format = range_format(path, format);
+    if (format < 0) RDH_FAIL("Unknown extension of %s. Only fastq and fasta sequence formats are supported.", path);
+    RangeFile f;
+    if (!f.open_path(path)) RDH_FAIL("cannot open %s", path);
+    int64_t at = start;
+    if (format == 0) {
+        for (int64_t i = 0; i < 4 * k && at < f.size; ++i) {
+            at = f.next_line(at);
+            if (at < 0) RDH_FAIL("read error in %s", path);
+        }
+    } else {
+        for (int64_t i = 0; i < k && at < f.size; ++i) {   // from one header to the next
+            do {
+                at = f.next_line(at);
+                if (at < 0) RDH_FAIL("read error in %s", path);
+            } while (at < f.size && f.byte_at(at) != '>');
+        }
+    }
+    *out = at;
+    return 0;
+}
+
+// Reader over the bytes [start, end) of a plain (not gzip) file; both offsets must be record boundaries
+// (rd_host_find_record_start / rd_host_skip_records), so the range parses exactly like a file of its own.
+int rd_reader_open_range(const char *path, int format, int64_t start, int64_t end, rd_reader **out) {
+    if (!path || !out || start < 0 || end < start) RDH_FAIL("rd_reader_open_range: bad argument");
+    format = range_format(path, format);
+    if (format < 0) RDH_FAIL("Unknown extension of %s. Only fastq and fasta sequence formats are supported.", path);
+    FILE *fp = fopen(path, "rb");
+    if (!fp) RDH_FAIL("cannot open %s", path);
+    setvbuf(fp, nullptr, _IONBF, 0);
+    uint8_t magic[2];
+    if (fread(magic, 1, 2, fp) == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
+        fclose(fp);
+        RDH_FAIL("rd_reader_open_range: %s is gzip-compressed; byte ranges need a plain file", path);
+    }
+    if (fseeko(fp, (off_t)start, SEEK_SET) != 0) {
+        fclose(fp);
+        RDH_FAIL("cannot seek in %s", path);
+    }
+    rd_reader *r = new rd_reader();
+    r->fp = fp;
+    r->fasta = format;
+    r->in.resize(8 << 20);
+    r->pos = r->end = 0;
+    auto left = std::make_shared<int64_t>(end - start);
+    r->pf = new rd_prefetch(
+        [fp, left](uint8_t *dst, size_t cap) {
+            if (*left <= 0) return 0L;
+            const size_t k = fread(dst, 1, (size_t)std::min<int64_t>((int64_t)cap, *left), fp);
+            *left -= (int64_t)k;
+            return (k == 0 && ferror(fp)) ? -1L : (long)k;
+        },
+        []() { return std::string("read error"); });
     r->eof = false;
     r->scan_next = 0;
     *out = r;

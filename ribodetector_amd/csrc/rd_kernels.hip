@@ -21,6 +21,7 @@
 //                                      hand-interleaved gate math; fused encoder + FC + argmax epilogue
 //   rd_lstm_mfma_f32_kernel            exact-fp32 MFMA recurrence (A/B reference for the split-precision kernels)
 //   rd_lstm_simple_kernel              plain-FMA cross-check of the same function
+//   rd_refine_kernel                   float64 re-evaluation of the reads whose margin is inside the fp32 noise band
 //   rd_encode_* / rd_pack_onehot       standalone encoder kernels (reference tensor layouts), HBM-bound
 //   rd_pair_fuse_kernel, rd_count_kernel
 #include "rd_common.hpp"
@@ -29,6 +30,7 @@
 #include "rd_sort.hpp"
 #include "rd_lstm_f32.hpp"
 #include "rd_lstm_t32.hpp"
+#include "rd_refine.hpp"
 #include "rd_encode.hpp"
 
 // ================================================================================================
@@ -53,6 +55,7 @@ int rd_model_create(const rd_weights *w, int device, rd_model **out) {
     memset(m, 0, sizeof(*m));
     m->device = device;
     m->variant = RD_VARIANT_MFMA_F16X3_T32;
+    m->refine_thresh = RD_REFINE_DEFAULT;
     float *host = new float[RAW_FLOATS];
     for (int i = 0; i < 10; ++i) memcpy(host + offs[i], src[i], sizeof(float) * (size_t)(offs[i + 1] - offs[i]));
     hipError_t e = hipSuccess;
@@ -101,7 +104,7 @@ static bool rd_variant_known(int v) {
 #ifdef RD_DIAG
     switch (v) {
     case 10: case 11: case 12: case 13: case 20: case 21: case 22: case 23: case 40: case 41: case 42:
-    case 50: case 51: case 52: case 53: case 54: case 55: case 56: case 57: return true;
+    case 50: case 51: case 52: case 54: case 58: case 65: case 66: case 82: case 98: return true;
     default: break;
     }
 #endif
@@ -124,6 +127,38 @@ int rd_set_semantics(rd_model *m, int semantics) {
     if (semantics != RD_SEM_PACKED && semantics != RD_SEM_PADDED) RD_FAIL(RD_E_INVALID, "rd_set_semantics: unknown semantics %d", semantics);
     m->semantics = semantics;
     return RD_OK;
+}
+
+int rd_set_refine(rd_model *m, float thresh) {
+    if (!m) RD_FAIL(RD_E_INVALID, "rd_set_refine: null model");
+    if (!(thresh >= 0.0f) || thresh > 1.0f) RD_FAIL(RD_E_INVALID, "rd_set_refine: threshold %g out of range [0, 1]", (double)thresh);
+    m->refine_thresh = thresh;
+    return RD_OK;
+}
+
+static int rd_refine_launch(rd_model *m, const ReadBatch &rb, float *logits, uint8_t *labels, const float *mate_logits, float thresh,
+                            hipStream_t st) {
+    const int64_t nb = (rb.n + REFINE_SLICE - 1) / REFINE_SLICE;
+    hipLaunchKernelGGL(rd_refine_kernel, dim3((unsigned)nb), dim3(1024), 0, st, m->d, rb, (const float2 *)mate_logits, thresh, logits, labels);
+    RD_HIP(hipGetLastError());
+    return RD_OK;
+}
+
+int rd_refine(const rd_model *cm, const uint8_t *arena, const int64_t *seq_off, const int32_t *seq_len, int64_t n, int32_t max_len,
+              float *logits, uint8_t *labels, const float *mate_logits, void *stream) {
+    rd_model *m = const_cast<rd_model *>(cm);
+    if (!m || !logits) RD_FAIL(RD_E_INVALID, "rd_refine: null model or logits");
+    if (n < 0 || n > 0x7fffffffLL) RD_FAIL(RD_E_INVALID, "rd_refine: n=%lld out of range", (long long)n);
+    if (max_len < 1 || max_len > MAX_LEN_LIMIT) RD_FAIL(RD_E_INVALID, "rd_refine: max_len=%d out of range [1,%d]", max_len, MAX_LEN_LIMIT);
+    if (n == 0 || m->refine_thresh <= 0.0f) return RD_OK;
+    if (!arena || !seq_off || !seq_len) RD_FAIL(RD_E_INVALID, "rd_refine: null input pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (m->semantics == RD_SEM_PADDED && m->rev_tab_len != max_len) {
+        hipLaunchKernelGGL(rd_revtab_kernel, dim3(1), dim3(512), 0, st, m->d, max_len);
+        m->rev_tab_len = max_len;
+    }
+    ReadBatch rb{arena, seq_off, seq_len, nullptr, nullptr, n, max_len, m->semantics, m->d.rev_tab};
+    return rd_refine_launch(m, rb, logits, labels, mate_logits, m->refine_thresh, st);
 }
 
 size_t rd_classify_workspace_bytes(int64_t n, int32_t max_len) {
@@ -195,7 +230,7 @@ int rd_classify(const rd_model *cm, const uint8_t *arena, const int64_t *seq_off
         const int64_t nwg = (n + BT - 1) / BT;
         const dim3 grid((unsigned)nwg), blk(256);
         switch (m->variant) {
-        case RD_VARIANT_MFMA_F16X3_T32: hipLaunchKernelGGL(rd_lstm_mfma_f16x3_t32_kernel<6>, grid, blk, 0, st, m->d, rb, logits, labels); break;
+        case RD_VARIANT_MFMA_F16X3_T32: hipLaunchKernelGGL((rd_lstm_mfma_f16x3_t32_kernel<6, T32_PRODUCT>), grid, blk, 0, st, m->d, rb, logits, labels); break;
         case RD_VARIANT_MFMA_F32: hipLaunchKernelGGL((rd_lstm_mfma_f32_kernel<1, 0>), grid, blk, 0, st, m->d, rb, logits, labels); break;
 #ifdef RD_DIAG
         case 10: hipLaunchKernelGGL((rd_lstm_mfma_f32_kernel<0, 0>), grid, blk, 0, st, m->d, rb, logits, labels); break;
@@ -209,12 +244,23 @@ int rd_classify(const rd_model *cm, const uint8_t *arena, const int64_t *seq_off
         case 40: hipLaunchKernelGGL(rd_lstm_mfma_f16x3_t32_kernel<0>, grid, blk, 0, st, m->d, rb, logits, labels); break;
         case 41: hipLaunchKernelGGL(rd_lstm_mfma_f16x3_t32_kernel<-1>, grid, blk, 0, st, m->d, rb, logits, labels); break;
         case 42: hipLaunchKernelGGL(rd_lstm_mfma_f16x3_t32_kernel<7>, grid, blk, 0, st, m->d, rb, logits, labels); break;
+        // accuracy experiments (ACC bits, rd_lstm_t32.hpp): id = 50 + ACC
+        case 50: hipLaunchKernelGGL((rd_lstm_mfma_f16x3_t32_kernel<6, 0>), grid, blk, 0, st, m->d, rb, logits, labels); break;
+        case 51: hipLaunchKernelGGL((rd_lstm_mfma_f16x3_t32_kernel<6, 1>), grid, blk, 0, st, m->d, rb, logits, labels); break;
+        case 52: hipLaunchKernelGGL((rd_lstm_mfma_f16x3_t32_kernel<6, 2>), grid, blk, 0, st, m->d, rb, logits, labels); break;
+        case 54: hipLaunchKernelGGL((rd_lstm_mfma_f16x3_t32_kernel<6, 4>), grid, blk, 0, st, m->d, rb, logits, labels); break;
+        case 58: hipLaunchKernelGGL((rd_lstm_mfma_f16x3_t32_kernel<6, 8>), grid, blk, 0, st, m->d, rb, logits, labels); break;
+        case 65: hipLaunchKernelGGL((rd_lstm_mfma_f16x3_t32_kernel<6, 15>), grid, blk, 0, st, m->d, rb, logits, labels); break;
+        case 66: hipLaunchKernelGGL((rd_lstm_mfma_f16x3_t32_kernel<6, 16>), grid, blk, 0, st, m->d, rb, logits, labels); break;
+        case 82: hipLaunchKernelGGL((rd_lstm_mfma_f16x3_t32_kernel<6, 32>), grid, blk, 0, st, m->d, rb, logits, labels); break;
+        case 98: hipLaunchKernelGGL((rd_lstm_mfma_f16x3_t32_kernel<6, 48>), grid, blk, 0, st, m->d, rb, logits, labels); break;
 #endif
         default: RD_FAIL(RD_E_UNSUPPORTED, "rd_classify: variant %d not available in this build", m->variant);
         }
     }
     RD_HIP(hipGetLastError());
     if (ev) { RD_HIP(hipEventRecord(ev[1], st)); m->prof_count++; }
+    if (m->refine_thresh > 0.0f) return rd_refine_launch(m, rb, logits, labels, nullptr, m->refine_thresh, st);
     return RD_OK;
 }
 

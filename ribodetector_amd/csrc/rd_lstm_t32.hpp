@@ -76,6 +76,7 @@ struct EwRegs {
     float y[2], og[2], hs[2];
     f32x4 cs[2], hv[2]; // per row-tile, by row-tile parity
     f16x4 o1s[2], o2[2];
+    f32x4 call[4];      // ACC & 32: the tile's cell state, resident across phases
 };
 
 struct PhaseCtx {       // per-lane constants of a phase
@@ -83,46 +84,105 @@ struct PhaseCtx {       // per-lane constants of a phase
     bool last;
 };
 
-template <int TP, int U>
+// ACC: build options of the kernel. The product instantiates T32_PRODUCT (bits 16 + 32); the other bits are accuracy experiments
+// that exist only in diagnostic builds (-DRD_DIAG, tools/acc_experiment.py; results in DESIGN.md §4):
+//   1 = fourth product W2.H2 (the dropped lo x lo term)       2 = the small products first, W1.H1s last (H1s fragments read twice)
+//   4 = exp2 arguments formed from the fp32 pre-activation with a compensated product (table holds the raw in_lut rows)
+//   8 = one Newton step on every v_rcp_f32
+//   16 = gate math in 24 instead of 26 VALU ops per cell (scales folded into the reciprocals' arguments, see stage 4)
+//   32 = cell state kept in registers across phases instead of the LDS round trip
+constexpr int T32_PRODUCT = 16 | 32;
+__device__ __forceinline__ float rd_exp2c(float x, float khi, float klo) {   // 2^(x (khi + klo)), product error compensated
+    const float t = x * khi;
+    float e = __builtin_fmaf(x, khi, -t);
+    e = __builtin_fmaf(x, klo, e);
+    const float r = __builtin_amdgcn_exp2f(t);
+    return __builtin_fmaf(r, e * 0.693147182464599609375f, r);
+}
+__device__ __forceinline__ float rd_rcp_nr(float d) {
+    const float y = __builtin_amdgcn_rcpf(d);
+    return __builtin_fmaf(__builtin_fmaf(-d, y, 1.0f), y, y);
+}
+constexpr float KS_HI = -1.44269502162933349609375f, KS_LO = -1.925963033500011e-8f;   // -log2 e = KS_HI + KS_LO
+constexpr float KT_HI = 2.8853900432586669921875f, KT_LO = 3.851926067000022e-8f;      // 2 log2 e
+
+template <int TP, int U, int ACC = 0>
 __device__ __forceinline__ void rd_ew_unit(Lstm16bSmem &S, EwRegs &R, const f32x16 (&accP)[4], const PhaseCtx &c) {
     constexpr int cell = EW_CELL[U], stage = EW_STAGE[U];
     constexpr int a = cell >> 2, b = cell & 3, k = cell & 1, ap = a & 1;
     if constexpr (stage == 0) {   // table row of the NEXT cell (this cell's row was fetched one cell ago); cell state per row-tile
         constexpr int nc = cell + 1;
         if constexpr (nc < 16) R.kc[k ^ 1] = S.lut[c.wave][c.half][nc >> 2][nc & 3][c.codeEW];
-        if constexpr (b == 0) R.cs[ap] = S.cS[TP][a][c.tid];
+        if constexpr (b == 0 && !(ACC & 32)) R.cs[ap] = S.cS[TP][a][c.tid];
     } else if constexpr (stage == 1) {
         // exp2 arguments. Scalar FMAs on purpose: packed fp32 ops (v_pk_fma_f32 / v_pk_add_f32) cost ~10 cycles each beside
         // f16 MFMAs against ~1 for a scalar op (tools/ubench/mfma_fill.hip), so the build also passes -fno-slp-vectorize.
+        if constexpr (ACC & 4) {   // fp32 pre-activations (exact scaling, one rounding like the reference's bias add)
+            R.v[k][0][0] = __builtin_fmaf(accP[a][4 * b + 0], 1.0f / G_SCALE, R.kc[k][0]);
+            R.v[k][0][1] = __builtin_fmaf(accP[a][4 * b + 1], 1.0f / G_SCALE, R.kc[k][1]);
+            R.v[k][1][0] = __builtin_fmaf(accP[a][4 * b + 2], 1.0f / G_SCALE, R.kc[k][2]);
+            R.v[k][1][1] = __builtin_fmaf(accP[a][4 * b + 3], 1.0f / G_SCALE, R.kc[k][3]);
+        } else {
         R.v[k][0][0] = __builtin_fmaf(accP[a][4 * b + 0], KS / G_SCALE, R.kc[k][0]);
         R.v[k][0][1] = __builtin_fmaf(accP[a][4 * b + 1], KS / G_SCALE, R.kc[k][1]);
         R.v[k][1][0] = __builtin_fmaf(accP[a][4 * b + 2], KT / G_SCALE, R.kc[k][2]);
         R.v[k][1][1] = __builtin_fmaf(accP[a][4 * b + 3], KS / G_SCALE, R.kc[k][3]);
+        }
     } else if constexpr (stage == 2) {
+        if constexpr (ACC & 4) {
+            R.v[k][0][0] = rd_exp2c(R.v[k][0][0], KS_HI, KS_LO); R.v[k][0][1] = rd_exp2c(R.v[k][0][1], KS_HI, KS_LO);
+        } else {
         R.v[k][0][0] = __builtin_amdgcn_exp2f(R.v[k][0][0]); R.v[k][0][1] = __builtin_amdgcn_exp2f(R.v[k][0][1]);
+        }
     } else if constexpr (stage == 3) {
+        if constexpr (ACC & 4) {
+            R.v[k][1][0] = rd_exp2c(R.v[k][1][0], KT_HI, KT_LO); R.v[k][1][1] = rd_exp2c(R.v[k][1][1], KS_HI, KS_LO);
+        } else {
         R.v[k][1][0] = __builtin_amdgcn_exp2f(R.v[k][1][0]); R.v[k][1][1] = __builtin_amdgcn_exp2f(R.v[k][1][1]);
+        }
     } else if constexpr (stage == 4) {
+        if constexpr (ACC & 16) {
+            // the constants the gates are multiplied with later are folded into the reciprocals' arguments (an FMA instead of
+            // an add, nothing else): 1/((1+e)/KT) = KT sigmoid(i),  1/(-(1+e)/2) = -2/(1+e) = tanh(g) - 1,  1/((1+e) 2^-11) = 2^11 sigmoid(o)
+            R.v[k][0][0] = __builtin_fmaf(R.v[k][0][0], 1.0f / KT, 1.0f / KT); R.v[k][0][1] += 1.0f;
+            R.v[k][1][0] = __builtin_fmaf(R.v[k][1][0], -0.5f, -0.5f); R.v[k][1][1] = __builtin_fmaf(R.v[k][1][1], 1.0f / H_SCALE, 1.0f / H_SCALE);
+        } else {
         R.v[k][0][0] += 1.0f; R.v[k][0][1] += 1.0f;
         R.v[k][1][0] += 1.0f; R.v[k][1][1] += 1.0f;
+        }
     } else if constexpr (stage == 5) {
-        R.v[k][0][0] = __builtin_amdgcn_rcpf(R.v[k][0][0]); R.v[k][0][1] = __builtin_amdgcn_rcpf(R.v[k][0][1]);
+        if constexpr (ACC & 8) { R.v[k][0][0] = rd_rcp_nr(R.v[k][0][0]); R.v[k][0][1] = rd_rcp_nr(R.v[k][0][1]); }
+        else { R.v[k][0][0] = __builtin_amdgcn_rcpf(R.v[k][0][0]); R.v[k][0][1] = __builtin_amdgcn_rcpf(R.v[k][0][1]); }
     } else if constexpr (stage == 6) {
-        R.v[k][1][0] = __builtin_amdgcn_rcpf(R.v[k][1][0]); R.v[k][1][1] = __builtin_amdgcn_rcpf(R.v[k][1][1]);
+        if constexpr (ACC & 8) { R.v[k][1][0] = rd_rcp_nr(R.v[k][1][0]); R.v[k][1][1] = rd_rcp_nr(R.v[k][1][1]); }
+        else { R.v[k][1][0] = __builtin_amdgcn_rcpf(R.v[k][1][0]); R.v[k][1][1] = __builtin_amdgcn_rcpf(R.v[k][1][1]); }
     } else if constexpr (stage == 7) {
         // the cell state is kept pre-multiplied by KT (c' = KT c): c' = f c'_old + i (KT tanh g), and tanh(c) = 1 - 2/(1 + 2^c')
+        float cst;
+        if constexpr (ACC & 32) cst = R.call[a][b];
+        else cst = R.cs[ap][b];
+        float cn;
+        if constexpr (ACC & 16) {   // KT i tanh(g) = i' (1 + y') with i' = KT sigmoid(i), y' = tanh(g) - 1: one FMA
+            cn = __builtin_fmaf(R.v[k][0][1], cst, __builtin_fmaf(R.v[k][0][0], R.v[k][1][0], R.v[k][0][0]));
+        } else {
         const float gg = __builtin_fmaf(-2.0f * KT, R.v[k][1][0], KT);
-        const float cn = __builtin_fmaf(R.v[k][0][1], R.cs[ap][b], R.v[k][0][0] * gg);
-        R.cs[ap][b] = cn;
+        cn = __builtin_fmaf(R.v[k][0][1], cst, R.v[k][0][0] * gg);
+        }
+        if constexpr (ACC & 32) R.call[a][b] = cn;
+        else R.cs[ap][b] = cn;
         R.y[k] = cn;
         R.og[k] = R.v[k][1][1];
     } else if constexpr (stage == 8) {
         R.y[k] = __builtin_amdgcn_exp2f(R.y[k]);
     } else if constexpr (stage == 9) {
-        R.y[k] = 1.0f + R.y[k];
+        if constexpr (ACC & 16) R.y[k] = __builtin_fmaf(R.y[k], -0.5f, -0.5f);   // reciprocal = tanh(c) - 1
+        else R.y[k] = 1.0f + R.y[k];
     } else if constexpr (stage == 10) {
-        R.y[k] = __builtin_amdgcn_rcpf(R.y[k]);
+        if constexpr (ACC & 8) R.y[k] = rd_rcp_nr(R.y[k]);
+        else R.y[k] = __builtin_amdgcn_rcpf(R.y[k]);
     } else if constexpr (stage == 11) {
+        if constexpr (ACC & 16) R.hs[k] = __builtin_fmaf(R.og[k], R.y[k], R.og[k]);   // o' (1 + (tanh(c) - 1)), o' = 2^11 sigmoid(o)
+        else
         R.hs[k] = R.og[k] * __builtin_fmaf(-2.0f * H_SCALE, R.y[k], H_SCALE);   // 2^11 h = 2^11 o tanh(c)
         R.hv[ap][b] = R.hs[k];                                       // captured state is kept at scale 2^11 (epilogue divides)
     } else if constexpr (stage == 12) {
@@ -146,34 +206,57 @@ __device__ __forceinline__ void rd_ew_unit(Lstm16bSmem &S, EwRegs &R, const f32x
         const int wo = c.j * H16STR + 32 * c.wave + 16 * c.half + 4 * a;
         *reinterpret_cast<f16x4 *>(&S.H1s[TP][0][0] + wo) = R.o1s[ap];
         *reinterpret_cast<f16x4 *>(&S.H2[TP][0][0] + wo) = R.o2[ap];
-        S.cS[TP][a][c.tid] = R.cs[ap];
+        if constexpr (!(ACC & 32)) S.cS[TP][a][c.tid] = R.cs[ap];
         f32x4 *dst = c.last ? reinterpret_cast<f32x4 *>(&S.Hl[TP * 32 + c.j][32 * c.wave + 16 * c.half + 4 * a]) : &S.dummy[c.tid];
         *dst = R.hv[ap];
     }
 }
 
-template <int TP, int U0, int U1>
+template <int TP, int U0, int U1, int ACC = 0>
 __device__ __forceinline__ void rd_ew_units(Lstm16bSmem &S, EwRegs &R, const f32x16 (&accP)[4], const PhaseCtx &c) {
     if constexpr (U0 < U1) {
-        rd_ew_unit<TP, U0>(S, R, accP, c);
-        rd_ew_units<TP, U0 + 1, U1>(S, R, accP, c);
+        rd_ew_unit<TP, U0, ACC>(S, R, accP, c);
+        rd_ew_units<TP, U0 + 1, U1, ACC>(S, R, accP, c);
     }
 }
 
-// slot M = MFMA number M (k-step s = M/12, product (M%12)/4, row-tile M%4) followed by its share of gate-math units
-template <int TL, int FILL, int M>
+// slot M = MFMA number M followed by its share of gate-math units. Product build (ACC = 0): k-step s = M/12, product (M%12)/4,
+// row-tile M%4; products: 0 = W1.H1s, 1 = W2.H1s (W2 = unscaled residual of 16 w, so this pair also carries 2^15), 2 = W1.H2,
+// 3 (ACC & 1 only) = W2.H2.
+template <int ACC>
+struct SlotMap {
+    static constexpr int NPR = (ACC & 1) ? 4 : 3;     // products per k-step
+    static constexpr int NM = 32 * NPR;               // MFMAs per phase
+    static constexpr int NS = NPR - 1;                // small products (pass 1 of the small-first order)
+    static constexpr bool SF = (ACC & 2) != 0;
+    static constexpr int pass(int M) { return SF ? (M < 32 * NS ? 1 : 2) : 0; }
+    static constexpr int s(int M) { return !SF ? M / (4 * NPR) : (M < 32 * NS ? M / (4 * NS) : (M - 32 * NS) / 4); }
+    static constexpr int pr(int M) { return !SF ? (M % (4 * NPR)) / 4 : (M < 32 * NS ? 1 + (M % (4 * NS)) / 4 : 0); }
+    static constexpr bool first_of_step(int M) { return !SF ? M % (4 * NPR) == 0 : (M < 32 * NS ? M % (4 * NS) == 0 : (M - 32 * NS) % 4 == 0); }
+};
+
+template <int TL, int FILL, int M, int ACC = 0>
 __device__ __forceinline__ void rd_slots(Lstm16bSmem &S, const f16x8 (&W1)[4][8], const f16x8 (&W2)[4][8], f32x16 (&accC)[4],
                                          const f32x16 (&accP)[4], f16x8 (&Bf)[2][2], EwRegs &R, const PhaseCtx &c,
                                          const _Float16 *h1s, const _Float16 *h2) {
-    if constexpr (M < 96) {
-        constexpr int s = M / 12, pr = (M % 12) / 4, a = M % 4;
-        if constexpr (M % 12 == 0 && s < 7) {       // B fragments of the next k-step stream in behind this one's MFMAs
-            Bf[(s + 1) & 1][0] = *reinterpret_cast<const f16x8 *>(h1s + 16 * (s + 1));
-            Bf[(s + 1) & 1][1] = *reinterpret_cast<const f16x8 *>(h2 + 16 * (s + 1));
+    typedef SlotMap<ACC> SM;
+    if constexpr (M < SM::NM) {
+        constexpr int s = SM::s(M), pr = SM::pr(M), a = M % 4, pass = SM::pass(M);
+        if constexpr (SM::first_of_step(M)) {       // B fragments of the next k-step stream in behind this one's MFMAs
+            if constexpr (pass == 0 && s < 7) {
+                Bf[(s + 1) & 1][0] = *reinterpret_cast<const f16x8 *>(h1s + 16 * (s + 1));
+                Bf[(s + 1) & 1][1] = *reinterpret_cast<const f16x8 *>(h2 + 16 * (s + 1));
+            } else if constexpr (pass == 1 && s < 7) {
+                Bf[(s + 1) & 1][0] = *reinterpret_cast<const f16x8 *>(h1s + 16 * (s + 1));
+                Bf[(s + 1) & 1][1] = *reinterpret_cast<const f16x8 *>(h2 + 16 * (s + 1));
+            } else if constexpr (pass == 1 && s == 7) {
+                Bf[0][0] = *reinterpret_cast<const f16x8 *>(h1s);                       // pass 2 reads the H1s fragments again
+            } else if constexpr (pass == 2 && s < 7) {
+                Bf[(s + 1) & 1][0] = *reinterpret_cast<const f16x8 *>(h1s + 16 * (s + 1));
+            }
         }
-        // products: W1.H1s, W2.H1s (W2 = unscaled residual of 16 w, so this pair also carries 2^15), W1.H2
-        const f16x8 A = pr == 1 ? W2[a][s] : W1[a][s];
-        const f16x8 B = Bf[s & 1][pr == 2 ? 1 : 0];
+        const f16x8 A = (pr == 1 || pr == 3) ? W2[a][s] : W1[a][s];
+        const f16x8 B = Bf[s & 1][pr >= 2 ? 1 : 0];
         if constexpr (M < 4) {
             f32x16 z;
 #pragma unroll
@@ -183,10 +266,10 @@ __device__ __forceinline__ void rd_slots(Lstm16bSmem &S, const f16x8 (&W1)[4][8]
             accC[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, accC[a], 0, 0, 0);
         }
         if constexpr (FILL > 0) {
-            rd_ew_units<TL ^ 1, (M * EW_NU) / 96, ((M + 1) * EW_NU) / 96>(S, R, accP, c);
+            rd_ew_units<TL ^ 1, (M * EW_NU) / SM::NM, ((M + 1) * EW_NU) / SM::NM, ACC>(S, R, accP, c);
             __builtin_amdgcn_sched_barrier(0);
         }
-        rd_slots<TL, FILL, M + 1>(S, W1, W2, accC, accP, Bf, R, c, h1s, h2);
+        rd_slots<TL, FILL, M + 1, ACC>(S, W1, W2, accC, accP, Bf, R, c, h1s, h2);
     }
 }
 
@@ -198,9 +281,9 @@ __device__ __forceinline__ void rd_slots(Lstm16bSmem &S, const f16x8 (&W1)[4][8]
 // unit, table rows fetched one cell ahead) and the units are dealt out behind the 96 MFMAs, ~2.2 units (about 5 VALU
 // ops) per MFMA - what a 32x32x16 MFMA mostly hides (tools/ubench/mfma_fill.hip: 38.7 cycles bare, 48 with 2 exp + 3 fma).
 // A sched_barrier after every slot pins the order.
-template <int TL, int FILL>
+template <int TL, int FILL, int ACC = 0>
 __device__ __forceinline__ void rd_phase_t32(Lstm16bSmem &S, const f16x8 (&W1)[4][8], const f16x8 (&W2)[4][8], f32x16 (&accC)[4],
-                                             f32x16 (&accP)[4], int tEW, int codeEW, int wave, int half, int j, int tid) {
+                                             f32x16 (&accP)[4], EwRegs &R, int tEW, int codeEW, int wave, int half, int j, int tid) {
     constexpr int TP = TL ^ 1;
     const int boff = j * H16STR + 8 * half;     // this lane's B fragment: row j, k = 16s + 8half + e
     const _Float16 *h1s = &S.H1s[TL][0][0] + boff, *h2 = &S.H2[TL][0][0] + boff;
@@ -210,18 +293,17 @@ __device__ __forceinline__ void rd_phase_t32(Lstm16bSmem &S, const f16x8 (&W1)[4
     PhaseCtx c;
     c.codeEW = codeEW; c.wave = wave; c.half = half; c.j = j; c.tid = tid;
     c.last = (tEW == S.T[TP * 32 + j] - 1);
-    EwRegs R;
     R.kc[0] = S.lut[wave][half][0][0][codeEW];
     if (FILL > 0) __builtin_amdgcn_sched_barrier(0);
-    rd_slots<TL, (FILL > 0 ? FILL : 0), 0>(S, W1, W2, accC, accP, Bf, R, c, h1s, h2);
-    if constexpr (FILL == 0) rd_ew_units<TP, 0, EW_NU>(S, R, accP, c);
+    rd_slots<TL, (FILL > 0 ? FILL : 0), 0, ACC>(S, W1, W2, accC, accP, Bf, R, c, h1s, h2);
+    if constexpr (FILL == 0) rd_ew_units<TP, 0, EW_NU, ACC>(S, R, accP, c);
     if constexpr (FILL < 0) {   // bench diagnosis only (wrong results): no gate math, keep the accumulators live
         if (accC[0][0] + accC[1][5] + accC[2][9] + accC[3][15] == 123.456f) S.Hl[TP * 32 + j][tid & 127] = accC[0][1];
     }
     if constexpr (FILL != 7) __syncthreads();   // FILL 7: bench diagnosis only (racy, wrong results): what the barrier costs
 }
 
-template <int FILL>
+template <int FILL, int ACC = 0>
 __global__ __launch_bounds__(256, 1) void rd_lstm_mfma_f16x3_t32_kernel(DevModel d, ReadBatch rb, float *__restrict__ logits,
                                                                         uint8_t *__restrict__ labels) {
     __shared__ Lstm16bSmem S;
@@ -249,7 +331,7 @@ __global__ __launch_bounds__(256, 1) void rd_lstm_mfma_f16x3_t32_kernel(DevModel
         const int gate = i & 3, rest = i >> 2, code = rest % 6, cell = rest / 6;
         const int b = cell & 3, a = (cell >> 2) & 3, hf = (cell >> 4) & 1, w = cell >> 5;
         float v = 0.0f;
-        if (code < 5) v = (gate == 2 ? KT : KS) * d.in_lut[code * G4 + gate * HID + 32 * w + 16 * hf + 4 * a + b];
+        if (code < 5) v = ((ACC & 4) ? 1.0f : (gate == 2 ? KT : KS)) * d.in_lut[code * G4 + gate * HID + 32 * w + 16 * hf + 4 * a + b];
         (reinterpret_cast<float *>(&S.lut[0][0][0][0][0]))[i] = v;
     }
     S.wout[tid >> 7][tid & 127] = d.w_out[(tid >> 7) * 256 + (tid & 127)];
@@ -295,6 +377,9 @@ __global__ __launch_bounds__(256, 1) void rd_lstm_mfma_f16x3_t32_kernel(DevModel
 #pragma unroll
         for (int r = 0; r < 16; ++r) { X[a][r] = 0.0f; Y[a][r] = 0.0f; }
     int codeY = 5;   // code of (tile 1, step t-1): zero row before the first step
+    EwRegs R0, R1;   // gate-math registers of tile 0 / tile 1 (transient per phase, except call[] under ACC & 32)
+#pragma unroll
+    for (int a = 0; a < 4; ++a) { R0.call[a] = f32x4{0, 0, 0, 0}; R1.call[a] = f32x4{0, 0, 0, 0}; }
 
     for (int t = 0; t <= tmax; ++t) {
         const int tc = t < tmax ? t : 0;
@@ -302,7 +387,7 @@ __global__ __launch_bounds__(256, 1) void rd_lstm_mfma_f16x3_t32_kernel(DevModel
         const int codeX = crow[j];            // (tile 0, step t): consumed by phase B's gate math
         const int codeYn = crow[32 + j];      // (tile 1, step t): consumed by the next iteration's phase A
         // phase A: MFMAs of (tile 0, t) -> X ; gate math of (tile 1, t-1) <- Y
-        rd_phase_t32<0, FILL>(S, W1, W2, X, Y, t - 1, codeY, wave, half, j, tid);
+        rd_phase_t32<0, FILL, ACC>(S, W1, W2, X, Y, R1, t - 1, codeY, wave, half, j, tid);
         if (t < tmax) {
             // next code chunk: its buffer was last read by the gate math of phase A above (step t-1)
             if ((t % TC16) == 0) {
@@ -310,7 +395,7 @@ __global__ __launch_bounds__(256, 1) void rd_lstm_mfma_f16x3_t32_kernel(DevModel
                 if (chunk * TC16 < tmax + 1) rd_stage_codes16b(S, rb, chunk);
             }
             // phase B: MFMAs of (tile 1, t) -> Y ; gate math of (tile 0, t) <- X
-            rd_phase_t32<1, FILL>(S, W1, W2, Y, X, t, codeX, wave, half, j, tid);
+            rd_phase_t32<1, FILL, ACC>(S, W1, W2, Y, X, R0, t, codeX, wave, half, j, tid);
         }
         codeY = codeYn;
     }

@@ -193,13 +193,19 @@ class NativeReader:
 
     h = None
 
-    def __init__(self, path, est_record_bytes=320):
+    def __init__(self, path, est_record_bytes=320, byte_range=None):
+        """byte_range = (start, end): parse only those bytes of a plain file; both must be record boundaries (plan_ranges)."""
         import torch
         self._torch = torch
         self._pin = torch.cuda.is_available()
         fmt = get_seq_format(path)                  # raises ValueError like the reference for unknown extensions
         self.h = C.c_void_p()
-        N.host_check(N.host_lib().rd_reader_open(str(path).encode(), 1 if fmt.startswith("fa") else 0, C.byref(self.h)), "rd_reader_open")
+        f = 1 if fmt.startswith("fa") else 0
+        if byte_range is None:
+            N.host_check(N.host_lib().rd_reader_open(str(path).encode(), f, C.byref(self.h)), "rd_reader_open")
+        else:
+            N.host_check(N.host_lib().rd_reader_open_range(str(path).encode(), f, int(byte_range[0]), int(byte_range[1]), C.byref(self.h)),
+                         "rd_reader_open_range")
         self.est = est_record_bytes
         self.eof = False
 
@@ -254,9 +260,69 @@ class NativeReader:
                      (buf[:b_tot], so[:n_tot], sl[:n_tot]))
 
 
-def get_seq_chunks(seq_file, chunk_size=1048576):
-    """Chunks of at most `chunk_size` records (reference seq_encoder.py:75-87), as `Chunk` arrays, parsed by librd_host.so."""
-    r = NativeReader(seq_file)
+def _fmt_id(path):
+    return 1 if get_seq_format(path).startswith("fa") else 0
+
+
+def file_info(path):
+    """(size in bytes, starts with the gzip magic)"""
+    size, gz = C.c_int64(0), C.c_int32(0)
+    N.host_check(N.host_lib().rd_host_file_info(str(path).encode(), C.byref(size), C.byref(gz)), "rd_host_file_info")
+    return int(size.value), bool(gz.value)
+
+
+def find_record_start(path, pos):
+    out = C.c_int64(0)
+    N.host_check(N.host_lib().rd_host_find_record_start(str(path).encode(), _fmt_id(path), int(pos), C.byref(out)), "rd_host_find_record_start")
+    return int(out.value)
+
+
+def count_records(path, start, end):
+    out = C.c_int64(0)
+    N.host_check(N.host_lib().rd_host_count_records(str(path).encode(), _fmt_id(path), int(start), int(end), C.byref(out)), "rd_host_count_records")
+    return int(out.value)
+
+
+def skip_records(path, start, k):
+    out = C.c_int64(0)
+    N.host_check(N.host_lib().rd_host_skip_records(str(path).encode(), _fmt_id(path), int(start), int(k), C.byref(out)), "rd_host_skip_records")
+    return int(out.value)
+
+
+def plan_ranges(paths, rank, world, all_gather=None):
+    """Byte ranges [(start, end)] - one per input file - that rank `rank` of `world` parses, for plain (not gzip) inputs.
+
+    One file: the file is cut at the record boundaries next to size*r/world. Two mate files: record i of R1 and record i of R2 must
+    land on the same rank although their byte positions differ. Every rank counts the records of its own first-cut range of both
+    files (a newline count), the counts are exchanged (`all_gather(obj) -> list over ranks`, two tiny collectives), and the cut
+    before rank r moves forward, in each file, to record index K_r = max over the files of the records before its first cut:
+    only forward scans, each rank touches only its own bytes plus a few records past its end. The ranges concatenate to the
+    whole file and hold the same record indices in every file, so the ranks' outputs concatenate to the single-rank output."""
+    paths = list(paths)
+    sizes = [file_info(p)[0] for p in paths]
+    cuts = [[0] + [find_record_start(p, (sz * r) // world) for r in range(1, world)] + [sz] for p, sz in zip(paths, sizes)]
+    for c in cuts:
+        for r in range(1, world + 1):
+            c[r] = max(c[r], c[r - 1])
+    if len(paths) == 1 or world == 1:
+        return [(c[rank], c[rank + 1]) for c in cuts]
+    if all_gather is None:
+        raise ValueError("plan_ranges: several files need an all_gather callable")
+    mine = [count_records(p, c[rank], c[rank + 1]) for p, c in zip(paths, cuts)]
+    counts = all_gather(mine)                                   # [world][files]
+    before = [[sum(counts[q][f] for q in range(r)) for f in range(len(paths))] for r in range(world + 1)]
+    if len(set(before[world])) != 1:
+        raise ValueError("paired-end files have different numbers of records")
+    K = [max(before[r]) for r in range(world)]
+    start = [skip_records(p, c[rank], K[rank] - before[rank][f]) for f, (p, c) in enumerate(zip(paths, cuts))]
+    starts = all_gather(start)                                  # [world][files]
+    return [(starts[rank][f], starts[rank + 1][f] if rank + 1 < world else sizes[f]) for f in range(len(paths))]
+
+
+def get_seq_chunks(seq_file, chunk_size=1048576, byte_range=None):
+    """Chunks of at most `chunk_size` records (reference seq_encoder.py:75-87), as `Chunk` arrays, parsed by librd_host.so.
+    byte_range: parse only that part of a plain file (multi-rank CLI, plan_ranges)."""
+    r = NativeReader(seq_file, byte_range=byte_range)
     try:
         while True:
             c = r.read(chunk_size)
@@ -322,3 +388,22 @@ class NativeWriter:
 
 def open_for_write(read_file):
     return NativeWriter(read_file)
+
+
+def concatenate_parts(final_path, part_paths):
+    """final = part0 + part1 + ... (then the parts are removed). Plain text concatenates trivially; for .gz outputs every part is a
+    sequence of complete gzip members, and a concatenation of members is a valid gzip file (RFC 1952; the single-rank writer
+    produces several members per file as well). The copy runs inside the kernel (sendfile)."""
+    import os
+    with open(final_path, "wb") as out:
+        for p in part_paths:
+            with open(p, "rb") as src:
+                left = os.fstat(src.fileno()).st_size
+                off = 0
+                while left > 0:
+                    k = os.sendfile(out.fileno(), src.fileno(), off, min(left, 1 << 30))
+                    if k <= 0:
+                        raise OSError("sendfile stalled while joining %s" % p)
+                    off += k
+                    left -= k
+            os.remove(p)

@@ -8,8 +8,12 @@ Flow per chunk (reference run_with_chunks, detect.py:326-523):
     -> pinned host buffer -> H2D on a copy stream (double buffered: chunk k+1 is parsed/copied while chunk k computes)
     -> rd_classify (R1 [, R2]) -> rd_pair_fuse / argmax -> labels D2H (1 B/read)
     -> records written by label in input order.
-Under torchrun (WORLD_SIZE > 1) every rank classifies a contiguous shard of each chunk and rank 0 gathers the labels
-over RCCL and writes (ribodetector_amd/dist.py).
+Under torchrun (WORLD_SIZE > 1), one process per GPU:
+  * plain input files: every rank parses only its own byte range (record-aligned, mates cut at the same record index:
+    data_loader/fastx_parser.plan_ranges), classifies it, writes its own part of every output file; the counters are
+    all-reduced (RCCL) and rank 0 concatenates the parts - they are in rank order = input order;
+  * gzip input (one DEFLATE stream, not splittable): every rank parses the stream, classifies a contiguous shard of each
+    chunk, and rank 0 gathers the 1-byte labels over RCCL and writes (ribodetector_amd/dist.py).
 """
 import argparse
 import math
@@ -50,9 +54,11 @@ class Predictor:
     def __init__(self, config, args):
         self.config = config
         self.args = args
-        self.logger = config.get_logger('predict', 1, self.args.log)
+        # under torchrun only rank 0 owns the log file (the other ranks log to the console only)
+        self.logger = config.get_logger('predict', 1, self.args.log if int(os.environ.get('RANK', '0')) == 0 else None)
         self.chunk_size = self.args.chunk_size
         self.rank, self.world, self.local_rank = 0, 1, 0
+        self.sharded_parse = False               # several ranks, plain input: every rank parses its own byte range
 
     # ---- model -------------------------------------------------------------------------------------
     def get_state_dict(self):
@@ -94,6 +100,8 @@ class Predictor:
             raise RuntimeError("config.json kernel.variant must be one of auto, mfma_f16x3_t32, mfma_f32, simple; got %r" % (variant,))
         self.model.set_variant(variant)
         self.model.set_semantics(getattr(self.args, 'semantics', None) or kcfg.get('semantics', 'gpu'))
+        if 'refine' in kcfg:                     # margin band of the float64 re-evaluation (0 = off); default of the library: 5e-4
+            self.model.set_refine(float(kcfg['refine']))
         self.model.eval()
 
     # ---- classification of one chunk ------------------------------------------------------------------
@@ -115,7 +123,7 @@ class Predictor:
         collect_chunk()."""
         n = len(chunks[0].seq_len)
         bounds = None
-        if self.world > 1:                       # equal bases (= recurrence steps) per rank, not equal read counts
+        if self.world > 1 and not self.sharded_parse:   # equal bases (= recurrence steps) per rank, not equal read counts
             work = sum(np.minimum(np.asarray(c.seq_len, dtype=np.int64), self.len) for c in chunks)
             bounds = rdist.shard_bounds(n, self.world, work)
         lo, hi = (0, n) if bounds is None else (bounds[self.rank], bounds[self.rank + 1])
@@ -125,11 +133,15 @@ class Predictor:
         cur.wait_stream(cs)
         outs = [self.model.classify_bytes(a, o, l, self.len, want_labels=not self.is_paired) for a, o, l in dev_in]
         if self.is_paired:
+            if self.args.ensure == 'none':       # the pair label is argmax of the summed logits (reference detect.py:657): pairs
+                (a1, o1, l1), (a2, o2, l2) = dev_in   # whose SUMMED margin is inside the fp32 noise band are re-evaluated in float64
+                self.model.refine_pairs(a1, o1, l1, self.len, outs[0][0], outs[1][0])
+                self.model.refine_pairs(a2, o2, l2, self.len, outs[1][0], outs[0][0])
             labels = module_arch.pair_fuse(outs[0][0], outs[1][0], self.args.ensure)
         else:
             labels = outs[0][1].view(torch.int8)
         host = finish = None
-        if self.world == 1:
+        if self.world == 1 or self.sharded_parse:
             host = torch.empty(labels.shape, dtype=torch.int8, pin_memory=True)
             host.copy_(labels, non_blocking=True)
         else:                                    # label gather (1 B per read) queued behind the kernels, collected later
@@ -140,7 +152,7 @@ class Predictor:
 
     def collect_chunk(self, tk):
         """Labels of a submitted chunk: int8 numpy on rank 0 (whole chunk, input order), None elsewhere."""
-        if self.world > 1:
+        if self.world > 1 and not self.sharded_parse:
             labels = tk["finish"]()
             return None if self.rank != 0 else labels.cpu().numpy()
         tk["done"].synchronize()
@@ -160,12 +172,12 @@ class Predictor:
         th.start()
         return th
 
-    def _reader_queue(self, path, chunk_reads, depth=2):
+    def _reader_queue(self, path, chunk_reads, depth=2, byte_range=None):
         q = queue.Queue(maxsize=depth)
 
         def work():
             try:
-                for c in fx.get_seq_chunks(path, chunk_size=chunk_reads):
+                for c in fx.get_seq_chunks(path, chunk_size=chunk_reads, byte_range=byte_range):
                     q.put(c)
                 q.put(None)
             except BaseException as e:      # surface parser errors on the main thread
@@ -174,7 +186,8 @@ class Predictor:
         return q
 
     def _chunk_stream(self, chunk_reads):
-        qs = [self._reader_queue(p, chunk_reads) for p in self.input]
+        ranges = self._ranges if self.sharded_parse else [None] * len(self.input)
+        qs = [self._reader_queue(p, chunk_reads, byte_range=r) for p, r in zip(self.input, ranges)]
         while True:
             cs = []
             for q in qs:
@@ -194,24 +207,43 @@ class Predictor:
         """Classify the input in chunks and write the outputs (reference detect.py:326-523)."""
         if chunk_reads is None:
             chunk_reads = self.batch_size * self.chunk_size
-        writer = self.rank == 0
+        # plain inputs under several ranks: every rank parses, classifies and writes its own byte range (no label exchange)
+        self.sharded_parse = self.world > 1 and not any(fx.file_info(p)[1] for p in self.input)
+        self.bytes_parsed = None
+        if self.sharded_parse:
+            import torch.distributed as dist
+
+            def all_gather(obj):
+                out = [None] * self.world
+                dist.all_gather_object(out, obj)
+                return out
+            self._ranges = fx.plan_ranges(self.input, self.rank, self.world, all_gather)
+            self.bytes_parsed = [e - b for b, e in self._ranges]
+            for r, bp in enumerate(all_gather(self.bytes_parsed)):
+                if self.rank == 0:
+                    self.logger.info('Rank {} parses {} bytes of {}'.format(
+                        r, ", ".join(str(b) for b in bp), ", ".join(str(fx.file_info(p)[0]) for p in self.input)))
+        part = (lambda path: '%s.part%d' % (path, self.rank)) if self.sharded_parse else (lambda path: path)
+        writer = self.rank == 0 or self.sharded_parse
         ends = (0, 1) if self.is_paired else (0,)
         fhs = {}
         from . import _native
         _native.host_lib().rd_host_set_threads(int(self.args.threads))   # -t/--threads: gzip workers; read when a writer is opened
+        log = self.logger.info if self.rank == 0 else (lambda *a, **k: None)
+        finals = []                                # final output paths, in the order the handles are opened
         if writer:
             if self.rrna is not None:
-                self.logger.info('Writing output rRNA sequences into file: {}{}{}'.format(
-                    colors.OKBLUE, ", ".join(self.rrna), colors.ENDC))
-                fhs[1] = [fx.open_for_write(self.rrna[e]) for e in ends]
-            self.logger.info('Writing output non-rRNA sequences into file: {}{}{}'.format(
-                colors.OKBLUE, ", ".join(self.output), colors.ENDC))
-            fhs[0] = [fx.open_for_write(self.output[e]) for e in ends]
+                log('Writing output rRNA sequences into file: {}{}{}'.format(colors.OKBLUE, ", ".join(self.rrna), colors.ENDC))
+                fhs[1] = [fx.open_for_write(part(self.rrna[e])) for e in ends]
+                finals += [self.rrna[e] for e in ends]
+            log('Writing output non-rRNA sequences into file: {}{}{}'.format(colors.OKBLUE, ", ".join(self.output), colors.ENDC))
+            fhs[0] = [fx.open_for_write(part(self.output[e])) for e in ends]
+            finals += [self.output[e] for e in ends]
             if self.is_paired and self.args.ensure == 'both':
                 unclf = [self.output[e] + '.unclassified.gz' for e in ends]
-                fhs[-1] = [fx.open_for_write(u) for u in unclf]
-                self.logger.info('Writing unclassified sequences into file: {}{}{}'.format(
-                    colors.OKYELLOW, ", ".join(unclf), colors.ENDC))
+                fhs[-1] = [fx.open_for_write(part(u)) for u in unclf]
+                finals += unclf
+                log('Writing unclassified sequences into file: {}{}{}'.format(colors.OKYELLOW, ", ".join(unclf), colors.ENDC))
         num_read = num_nonrrna = num_rrna = num_unknown = 0
         self._stage_s = {"wait_reader": 0.0, "classify": 0.0, "wait_writer": 0.0}   # main-thread seconds per pipeline stage
         self._copy_stream = torch.cuda.Stream(self.device)
@@ -264,7 +296,7 @@ class Predictor:
                     for e in ends:
                         wq[e].put((chunks[e], labels))
                     self._stage_s["wait_writer"] += time.perf_counter() - t0
-                    self.logger.info('{}{}{} sequences finished!'.format(colors.OKGREEN, num_read, colors.ENDC))
+                    log('{}{}{} sequences finished!'.format(colors.OKGREEN, num_read, colors.ENDC))
         finally:
             for q in wq:
                 q.put(None)
@@ -273,16 +305,27 @@ class Predictor:
         if werr:
             raise werr[0]
         if writer:
+            self.writer_threads = sorted({fh.threads for handles in fhs.values() for fh in handles})
+            for handles in fhs.values():
+                for fh in handles:
+                    fh.close()
+        if self.sharded_parse:                     # totals over the ranks; rank 0 joins the parts (rank order = input order)
+            import torch.distributed as dist
+            tot = torch.tensor([num_read, num_nonrrna, num_rrna, num_unknown], dtype=torch.int64,
+                               device=self.device if dist.get_backend() == 'nccl' else 'cpu')
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM)          # also the barrier: every part file is closed before the merge
+            num_read, num_nonrrna, num_rrna, num_unknown = (int(x) for x in tot.cpu().tolist())
+            if self.rank == 0:
+                for path in finals:
+                    fx.concatenate_parts(path, ['%s.part%d' % (path, r) for r in range(self.world)])
+            dist.barrier()
+        if self.rank == 0:
             self.logger.info('Processed {}{}{}{} sequences in total'.format(colors.BOLD, colors.OKCYAN, num_read, colors.ENDC))
             self.logger.info('Detected {}{}{}{} non-rRNA sequences'.format(colors.BOLD, colors.OKCYAN, num_nonrrna, colors.ENDC))
             self.logger.info('Detected {}{}{}{} rRNA sequences'.format(colors.BOLD, colors.OKCYAN, num_rrna, colors.ENDC))
             if self.is_paired and self.args.ensure == 'both':
                 self.logger.info('Discarded {}{}{}{} unclassified sequences'.format(
                     colors.BOLD, colors.OKCYAN, num_unknown, colors.ENDC))
-            self.writer_threads = sorted({fh.threads for handles in fhs.values() for fh in handles})
-            for handles in fhs.values():
-                for fh in handles:
-                    fh.close()
         self.num_read, self.num_nonrrna, self.num_rrna, self.num_unknown = num_read, num_nonrrna, num_rrna, num_unknown
 
     def run(self):

@@ -5,8 +5,9 @@ Same constructor arguments (`config.json: arch.args`), same `load_state_dict` te
 The arithmetic runs in hand-written HIP kernels behind the C ABI (include/ribodetector_amd.h); there is no
 torch.nn.LSTM inside and no CPU fallback.
 
-Two entries:
+Entries:
   * `forward(x: PackedSequence)`  - API parity with the reference (the one-hot tensor is turned back into bases);
+  * `forward(x: Tensor[B,L,4])` when built with pack_seq=false - the reference's forward2 (padded input);
   * `classify_bytes(arena, offsets, lens, max_len)` - the native fast entry: raw ASCII reads resident in HBM,
     encoder + recurrence + FC + argmax fused on the device.
 """
@@ -32,9 +33,9 @@ class SeqModel:
             raise NotImplementedError("SeqModel: num_layers=%r is not covered by the HIP kernels (only 1)" % (num_layers,))
         if not bidirectional:
             raise NotImplementedError("SeqModel: bidirectional=False is not covered by the HIP kernels")
-        if not pack_seq:
-            raise NotImplementedError("SeqModel: pack_seq=False (reference forward2, padded input) is not covered; "
-                                      "config.json ships pack_seq=true")
+        if not pack_seq and not batch_first:
+            raise NotImplementedError("SeqModel: pack_seq=False needs batch_first=True (the reference's forward2 indexes the "
+                                      "batch on dim 0, model/model.py:67-72)")
         if input_size != 4 or hidden_size != 128 or num_classes != 2:
             raise NotImplementedError("SeqModel: kernels are built for input_size=4, hidden_size=128, num_classes=2")
         self.input_size, self.hidden_size, self.num_layers, self.num_classes = input_size, hidden_size, num_layers, num_classes
@@ -47,6 +48,7 @@ class SeqModel:
         self.device = None
         self._variant = "auto"
         self._semantics = "packed"
+        self._refine = None
         self._ws = None
         self.training = True
 
@@ -92,6 +94,8 @@ class SeqModel:
         self._handle = h
         self.set_variant(self._variant)
         self.set_semantics(self._semantics)
+        if self._refine is not None:
+            self.set_refine(self._refine)
 
     def to(self, device, non_blocking=False):
         device = torch.device(device)
@@ -127,6 +131,23 @@ class SeqModel:
         if self._handle is not None:
             N.check(N.lib().rd_set_semantics(self._handle, N.SEMANTICS[name]), "rd_set_semantics")
         return self
+
+    def set_refine(self, thresh):
+        """margin below which a read is re-evaluated in float64 (C ABI rd_set_refine; default 5e-4, 0 = off)"""
+        self._refine = float(thresh)
+        if self._handle is not None:
+            N.check(N.lib().rd_set_refine(self._handle, C.c_float(self._refine)), "rd_set_refine")
+        return self
+
+    def refine_pairs(self, arena, offsets, lens, max_len, logits, mate_logits, labels=None):
+        """float64 re-evaluation of the reads of one mate whose own margin or whose PAIR margin (logits + mate_logits, what
+        decides the pair label under --ensure none, reference detect.py:657) is inside the noise band; `logits` is updated
+        in place. Call once per mate, then pair_fuse()."""
+        n = int(lens.numel())
+        with torch.cuda.device(self.device):
+            N.check(N.lib().rd_refine(self._handle, N.ptr(arena), N.ptr(offsets), N.ptr(lens), n, int(max_len), N.ptr(logits),
+                                      N.ptr(labels), N.ptr(mate_logits), N.stream_ptr(self.device)), "rd_refine")
+        return logits
 
     def __del__(self):
         try:
@@ -167,11 +188,45 @@ class SeqModel:
         return logits, (labels if want_labels else None)
 
     # ---- reference-compatible call --------------------------------------------------------------------
+    def forward2(self, x):
+        """pack_seq=false entry of the reference (model/model.py:40-50 forward2 + last_pad_out_items :67-72): x is a padded
+        Tensor [B, L, 4] of one-hot / all-zero rows; the BiLSTM runs over all L rows and the output row is the last non-zero
+        one (row L-1 for an all-zero read). That is the 'padded' semantics of the kernels (the reference's CPU product uses the
+        same function), so the rows are turned back into bases and classified with RD_SEM_PADDED and max_len = L."""
+        if not torch.is_tensor(x) or x.dim() != 3 or x.shape[2] != 4:
+            raise TypeError("SeqModel.forward2 expects a padded Tensor [B, L, 4]; got %s" % (tuple(x.shape) if torch.is_tensor(x) else type(x).__name__))
+        if self._handle is None:
+            raise RuntimeError("SeqModel: call .to('cuda') before inference")
+        dev = self.device
+        data = x.to(dev, non_blocking=True)
+        B, L = int(data.shape[0]), int(data.shape[1])
+        if B == 0:
+            return torch.empty((0, 2), dtype=torch.float32, device=dev)
+        rs, mx = data.sum(2), data.max(2)
+        ok = ((rs == 1) & (mx.values == 1)) | ((rs == 0) & (data.abs().sum(2) == 0))
+        if not bool(ok.all()):
+            raise ValueError("SeqModel.forward2: input rows must be one-hot (A,C,G,T) or all-zero")
+        code = torch.where(rs == 1, mx.indices, torch.full_like(mx.indices, 4))
+        arena = torch.tensor(list(b"ACGTN"), dtype=torch.uint8, device=dev)[code].reshape(-1)
+        offsets = torch.arange(B, dtype=torch.int64, device=dev) * L
+        lens = torch.full((B,), L, dtype=torch.int32, device=dev)
+        prev = self._semantics
+        self.set_semantics("padded")
+        try:
+            logits, _ = self.classify_bytes(arena, offsets, lens, L, want_labels=False)
+        finally:
+            self.set_semantics(prev)
+        return logits
+
     def forward(self, x):
-        """x: PackedSequence of one-hot fp32 rows [sum T, 4] (what the reference collate builds, detect.py:681-685).
-        Returns logits fp32[B,2] in the original (unsorted) batch order, like forward1 + last_items(unsort=True)."""
+        """pack_seq=true (config.json): x is a PackedSequence of one-hot fp32 rows [sum T, 4] (what the reference collate
+        builds, detect.py:681-685); returns logits fp32[B,2] in the original (unsorted) batch order, like forward1 +
+        last_items(unsort=True). pack_seq=false: x is a padded Tensor -> forward2."""
+        if not self.pack_seq:
+            return self.forward2(x)
         if not isinstance(x, PackedSequence):
-            raise TypeError("SeqModel.forward expects a PackedSequence (config pack_seq=true); got %s" % type(x).__name__)
+            raise TypeError("SeqModel.forward expects a PackedSequence (config pack_seq=true; build the model with pack_seq=false "
+                            "for padded Tensor input, the reference's forward2); got %s" % type(x).__name__)
         if self._handle is None:
             raise RuntimeError("SeqModel: call .to('cuda') before inference")
         dev = self.device

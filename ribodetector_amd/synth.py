@@ -120,3 +120,42 @@ def reads_torch(n, length, seed, device, rrna_frac=0.10, sub_rate=0.05, n_rate=0
     offsets = torch.arange(n + 1, dtype=torch.int64, device=device) * L
     lens = torch.full((n,), L, dtype=torch.int32, device=device)
     return arena, offsets, lens
+
+
+def fastq_image_torch(arena, offsets, lens, mate=1, block=1 << 21):
+    """4-line FASTQ text of the reads as one uint8 tensor on the reads' device - 10^7-read files for the full-size tests are built
+    in HBM in a fraction of a second instead of a Python loop. Record i: '@s' + 9-digit index + '/' + mate + LF, bases, LF '+' LF,
+    'I' * len, LF (18 + 2 len bytes). offsets: int64[n+1] (or [n]); lens: int32[n]."""
+    import torch
+    dev = arena.device
+    n = int(lens.numel())
+    L = lens.to(torch.int64)
+    rec = 18 + 2 * L
+    start = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(rec, 0, out=start[1:])
+    out = torch.full((int(start[-1].item()),), ord("I"), dtype=torch.uint8, device=dev)
+    p10 = torch.tensor([10 ** k for k in range(8, -1, -1)], dtype=torch.int64, device=dev)
+    for s in range(0, n, block):
+        e = min(n, s + block)
+        idx = torch.arange(s, e, dtype=torch.int64, device=dev)
+        st, ln, of = start[s:e], L[s:e], offsets[s:e].to(torch.int64)
+        hdr = torch.empty((e - s, 14), dtype=torch.uint8, device=dev)
+        hdr[:, 0] = ord("@")
+        hdr[:, 1] = ord("s")
+        hdr[:, 2:11] = ((idx[:, None] // p10[None, :]) % 10 + 48).to(torch.uint8)
+        hdr[:, 11] = ord("/")
+        hdr[:, 12] = 48 + int(mate)
+        hdr[:, 13] = 10
+        out[(st[:, None] + torch.arange(14, device=dev)[None, :]).reshape(-1)] = hdr.reshape(-1)
+        tot = int(ln.sum().item())
+        if tot:
+            rid = torch.repeat_interleave(torch.arange(e - s, device=dev), ln, output_size=tot)
+            cum = torch.cumsum(ln, 0) - ln
+            k = torch.arange(tot, dtype=torch.int64, device=dev) - cum[rid]
+            out[st[rid] + 14 + k] = arena[of[rid] + k]
+        sep = st + 14 + ln
+        out[sep] = 10
+        out[sep + 1] = ord("+")
+        out[sep + 2] = 10
+        out[st + rec[s:e] - 1] = 10
+    return out

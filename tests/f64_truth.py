@@ -37,3 +37,35 @@ def f64_forward(sd, arena, off, lens, max_len):
     return np.concatenate([h, hr], 1) @ wout.T + bout
 
 
+
+
+def f64_forward_torch(sd, arena, L, dev, block=1 << 18):
+    """The same float64 evaluation for fixed-length reads on a torch device (the GPU's float64 units make 10^6-10^7 reads a matter
+    of seconds): arena uint8[n*L] on `dev` -> logits float64 [n, 2]."""
+    import torch
+    g = lambda k: torch.as_tensor(np.asarray(sd[k]), dtype=torch.float64, device=dev)   # noqa: E731
+    wih, whh, b = g("rnn.weight_ih_l0"), g("rnn.weight_hh_l0"), g("rnn.bias_ih_l0") + g("rnn.bias_hh_l0")
+    wihr, br = g("rnn.weight_ih_l0_reverse"), g("rnn.bias_ih_l0_reverse") + g("rnn.bias_hh_l0_reverse")
+    wout, bout = g("out.weight"), g("out.bias")
+    lut = torch.full((256,), 4, dtype=torch.int64, device=dev)
+    for ch, c in ((b"A", 0), (b"C", 1), (b"G", 2), (b"T", 3), (b"U", 3)):
+        lut[ch[0]] = c
+    inl = torch.cat([wih.T + b, b[None, :]], 0)
+    inr = torch.cat([wihr.T + br, br[None, :]], 0)
+    out = []
+    reads = arena.view(-1, L)
+    for s in range(0, reads.shape[0], block):
+        code = lut[reads[s:s + block].long()]
+        n = code.shape[0]
+        h = torch.zeros((n, 128), dtype=torch.float64, device=dev)
+        c = torch.zeros_like(h)
+        for t in range(L):
+            gates = inl[code[:, t]] + h @ whh.T
+            i, f, gg, o = torch.sigmoid(gates[:, :128]), torch.sigmoid(gates[:, 128:256]), torch.tanh(gates[:, 256:384]), torch.sigmoid(gates[:, 384:])
+            c = f * c + i * gg
+            h = o * torch.tanh(c)
+        gr = inr[code[:, L - 1]]
+        cr = torch.sigmoid(gr[:, :128]) * torch.tanh(gr[:, 256:384])
+        hr = torch.sigmoid(gr[:, 384:]) * torch.tanh(cr)
+        out.append(torch.cat([h, hr], 1) @ wout.T + bout)
+    return torch.cat(out, 0)

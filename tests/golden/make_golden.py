@@ -8,6 +8,7 @@ Only *data* is written: inputs (read bytes) and the reference's outputs for them
 Reference entry points used (the oracle definition of SURVEY.md §8c):
   ribodetector.parse_config.ConfigParser.from_json / init_obj   (parse_config.py:29-57)
   ribodetector.model.model.SeqModel  (forward1, model.py:32-37)  - GPU-path semantics
+  ribodetector.model.model.SeqModel(pack_seq=False)  (forward2 + last_pad_out_items, model.py:40-50,67-72) - padded Tensor input
   ribodetector.model.model_cpu.SeqModel (forward_last, model_cpu.py:29-37) - CPU-product semantics
   ribodetector.detect.unlabeled_read_collate_fn / unlabeled_paired_read_collate_fn (detect.py:666-726)
   ribodetector.detect.Predictor.separate_paired_reads (detect.py:616-663)
@@ -115,7 +116,32 @@ def pair_labels(r1_logits, r2_logits, ensure):
     return lab
 
 
+def make_forward2():
+    """F7: the reference's padded-Tensor entry (pack_seq=false -> forward2, model.py:40-50): input [B, L, 4] zero-padded one-hot,
+    BiLSTM over all L rows, gather at the last non-zero row (last_pad_out_items, model.py:67-72)."""
+    cfg = ConfigParser.from_json(os.path.join(REFPKG, "config.json"))
+    args = dict(cfg["arch"]["args"])
+    args["pack_seq"] = False
+    m2 = RM.SeqModel(**args)
+    m2.load_state_dict(torch.load(os.path.join(REFPKG, cfg["state_file"]["mcc"]), map_location="cpu")["state_dict"])
+    m2.eval()
+    e = np.load(os.path.join(HERE, "edge.npz"))
+    seqs = synth.as_strings(e["arena"], e["offsets"])
+    av, ov, lv = synth.reads_numpy(256, (1, 140), seed=71, rrna_frac=0.3, n_rate=0.02)
+    seqs += synth.as_strings(av, ov)
+    out = {}
+    for L in (100, 64):
+        x = np.array([RE.encode_variable_len_read(s, max_len=L) for s in seqs], dtype=np.float32)
+        with torch.no_grad():
+            out["logits_l%d" % L] = m2(torch.from_numpy(x)).numpy().astype(np.float32)
+    a, o, l = pack(seqs)
+    np.savez_compressed(os.path.join(HERE, "forward2.npz"), arena=a, offsets=o, lens=l, **out)
+    print("forward2:", len(seqs), "reads")
+
+
 def main():
+    if "--only-forward2" in sys.argv:
+        return make_forward2()
     m, mc = load_models()
     S = synth.RRNA_16S
     # ---- F1 known-answer table (SURVEY §8c) ---------------------------------------------
@@ -209,6 +235,7 @@ def main():
         json.dump({"fastq_text": fq, "fastq_records": [list(r) for r in seq_parser(io.StringIO(fq), "fastq")],
                    "fasta_text": fa, "fasta_records": [list(r) for r in seq_parser(io.StringIO(fa), "fasta")]},
                   fh, indent=1)
+    make_forward2()
     tot = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith((".npz", ".json")))
     print("golden fixtures written,", tot, "bytes total")
 

@@ -271,3 +271,105 @@ def test_writer_threads_follow_set_threads(tmp_path):
     w = fx.open_for_write(str(tmp_path / "auto.fq.gz"))
     assert 1 <= w.threads <= 32
     w.close()
+
+
+def _plan_all(paths, world):
+    """plan_ranges for every rank of `world`, with an in-process all_gather (threads + barrier)"""
+    import threading
+    bar = threading.Barrier(world)
+    slots = [None] * world
+    out = [None] * world
+    errs = []
+
+    def run(rank):
+        def all_gather(obj):
+            slots[rank] = obj
+            bar.wait()
+            got = list(slots)
+            bar.wait()
+            return got
+        try:
+            out[rank] = fx.plan_ranges(paths, rank, world, all_gather)
+        except BaseException as e:     # noqa: BLE001
+            errs.append(e)
+            bar.abort()
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    if errs:
+        raise errs[0]
+    return out
+
+
+def _range_records(path, byte_range=None):
+    recs = []
+    for c in fx.get_seq_chunks(path, chunk_size=997, byte_range=byte_range):
+        b = c.buf.tobytes()
+        recs += [b[c.rec_start[i]:c.rec_start[i + 1]] for i in range(len(c.seq_len))]
+    return recs
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 5, 8])
+def test_byte_range_sharding_of_mate_files(tmp_path, world):
+    """multi-rank ingest: the ranks' byte ranges tile each file, hold the same record indices in both mates (whose byte
+    positions differ: R2 has longer, varying headers) and parse to exactly the records of the whole file - also with quality
+    lines that start with '@' or '+', the classic FASTQ re-synchronisation trap"""
+    rng = np.random.default_rng(world)
+    n = 4000
+    r1, r2 = str(tmp_path / "m_1.fastq"), str(tmp_path / "m_2.fastq")
+    with open(r1, "w") as f1, open(r2, "w") as f2:
+        for i in range(n):
+            L1, L2 = int(rng.integers(30, 150)), int(rng.integers(30, 150))
+            s1 = "".join("ACGTN"[k] for k in rng.integers(0, 5, L1))
+            s2 = "".join("ACGTN"[k] for k in rng.integers(0, 5, L2))
+            q1 = "".join("@+I#F"[k] for k in rng.integers(0, 5, L1))          # qualities full of '@' and '+', also in column 0
+            q2 = "".join("@+I#F"[k] for k in rng.integers(0, 5, L2))
+            f1.write("@r%d/1\n%s\n+\n%s\n" % (i, s1, q1))
+            f2.write("@r%d/2 %s\n%s\n+r%d\n%s\n" % (i, "x" * int(rng.integers(0, 80)), s2, i, q2))
+    whole = [_range_records(r1), _range_records(r2)]
+    assert len(whole[0]) == n == len(whole[1])
+    plans = _plan_all([r1, r2], world)
+    for f, path in enumerate((r1, r2)):
+        assert plans[0][f][0] == 0 and plans[-1][f][1] == os.path.getsize(path)
+        for a, b in zip(plans[:-1], plans[1:]):
+            assert a[f][1] == b[f][0]                                          # the ranges tile the file
+        parts = [_range_records(path, byte_range=pl[f]) for pl in plans]
+        assert sum(parts, []) == whole[f]
+        if f == 1:
+            assert [len(p) for p in parts] == [len(_range_records(r1, byte_range=pl[0])) for pl in plans]   # same records per rank in both mates
+    if world > 1:
+        per = [len(_range_records(r1, byte_range=pl[0])) for pl in plans]
+        assert max(per) < 1.5 * n / world + 8
+    # single file, FASTA with multi-line sequences
+    fa = str(tmp_path / "s.fa")
+    with open(fa, "w") as fh:
+        for i in range(700):
+            s = "".join("ACGT"[k] for k in rng.integers(0, 4, int(rng.integers(1, 400))))
+            fh.write(">s%d\n" % i + "\n".join(s[k:k + 60] for k in range(0, len(s), 60)) + "\n")
+    plans = [fx.plan_ranges([fa], r, world) for r in range(world)]
+    assert sum([_range_records(fa, byte_range=pl[0]) for pl in plans], []) == _range_records(fa)
+
+
+def test_byte_range_sharding_edge_cases(tmp_path):
+    """fewer records than ranks, an empty file, mates of different record counts, gzip input refused"""
+    p1, p2 = str(tmp_path / "t_1.fq"), str(tmp_path / "t_2.fq")
+    open(p1, "w").write("@a\nAC\n+\nII\n@b\nGT\n+\nII\n")
+    open(p2, "w").write("@a\nACCC\n+\nIIII\n@b\nGTTTT\n+\n@@@@@\n")
+    plans = _plan_all([p1, p2], 5)
+    got1 = sum([_range_records(p1, byte_range=pl[0]) for pl in plans], [])
+    got2 = sum([_range_records(p2, byte_range=pl[1]) for pl in plans], [])
+    assert got1 == _range_records(p1) and got2 == _range_records(p2)
+    for pl in plans:
+        assert len(_range_records(p1, byte_range=pl[0])) == len(_range_records(p2, byte_range=pl[1]))
+    empty = str(tmp_path / "e.fq")
+    open(empty, "w").close()
+    assert fx.plan_ranges([empty], 1, 3) == [(0, 0)] and _range_records(empty, byte_range=(0, 0)) == []
+    open(p2, "a").write("@c\nA\n+\nI\n")
+    with pytest.raises(ValueError, match="different numbers of records"):
+        _plan_all([p1, p2], 2)
+    gz = str(tmp_path / "z.fq.gz")
+    with gzip.open(gz, "wt") as fh:
+        fh.write("@a\nAC\n+\nII\n")
+    assert fx.file_info(gz)[1] and not fx.file_info(p1)[1]
+    with pytest.raises(ValueError, match="gzip"):
+        fx.NativeReader(gz, byte_range=(0, 10))

@@ -101,9 +101,13 @@ def test_cli_fasta_and_cpu_semantics(tmp_path, oracle):
         assert _read(out) == want
 
 
-def test_cli_two_ranks_match_one(tmp_path):
-    """torchrun x2 (both ranks on this box's one GPU, labels exchanged over gloo) must write the same files as one process:
-    exercises the sharded path of the CLI - work-balanced bounds, sub-range H2D, label gather, rank-0-only output."""
+@pytest.mark.parametrize("suffix", ["", ".gz"])
+def test_cli_two_ranks_match_one(tmp_path, suffix):
+    """torchrun x2 (both ranks on this box's one GPU, exchange over gloo) must write the same files as one process.
+    Plain input: every rank parses only its own byte range (mates cut at the same record index), writes its own parts, rank 0
+    joins them - each rank reads about half of the bytes. gzip input: every rank parses the stream, classifies a work-balanced
+    shard of each chunk, rank 0 gathers the labels and writes."""
+    import re
     import socket
     import subprocess
     import sys
@@ -112,12 +116,12 @@ def test_cli_two_ranks_match_one(tmp_path):
     n = 5000
     a1, o1, _ = synth.reads_numpy(n, (40, 160), seed=51, rrna_frac=0.3)
     a2, o2, _ = synth.reads_numpy(n, (40, 160), seed=52, rrna_frac=0.3)
-    i1, i2 = str(tmp_path / "r_1.fq"), str(tmp_path / "r_2.fq")
+    i1, i2 = str(tmp_path / ("r_1.fq" + suffix)), str(tmp_path / ("r_2.fq" + suffix))
     synth.write_fastq(i1, a1, o1, 1)
-    synth.write_fastq(i2, a2, o2, 2)
-    one = [str(tmp_path / x) for x in ("a1.fq", "a2.fq", "ar1.fq", "ar2.fq")]
+    synth.write_fastq(i2, a2, o2, 2, prefix="the_second_mate_has_longer_headers")
+    one = [str(tmp_path / x) for x in ("a1.fq", "a2.fq.gz", "ar1.fq", "ar2.fq")]
     p = detect.main(["-l", "120", "-i", i1, i2, "-o", *one[:2], "-r", *one[2:], "-e", "both", "--chunk_size", "1", "-m", "3"])
-    two = [str(tmp_path / x) for x in ("b1.fq", "b2.fq", "br1.fq", "br2.fq")]
+    two = [str(tmp_path / x) for x in ("b1.fq", "b2.fq.gz", "br1.fq", "br2.fq")]
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -132,6 +136,17 @@ def test_cli_two_ranks_match_one(tmp_path):
     for a, b in zip(one, two):
         assert _read(a) == _read(b) and len(_read(a)) > 0
     assert _read(one[0] + ".unclassified.gz") == _read(two[0] + ".unclassified.gz")
+    assert not [f for f in os.listdir(tmp_path) if ".part" in f]                      # the parts were joined and removed
+    text = r.stdout + r.stderr                                                         # the logger writes to the console
+    assert "Processed" in text and str(n) in text
+    if not suffix:
+        rows = re.findall(r"Rank (\d) parses (\d+), (\d+) bytes of (\d+), (\d+)", text)
+        assert len(rows) == 2
+        for rk, b1, b2, t1, t2 in rows:
+            assert 0.4 < int(b1) / int(t1) < 0.6 and 0.4 < int(b2) / int(t2) < 0.6         # half of each file per rank
+        assert sum(int(x[1]) for x in rows) == os.path.getsize(i1) and sum(int(x[2]) for x in rows) == os.path.getsize(i2)
+    else:
+        assert "parses" not in text
 
 
 def test_cli_damaged_input_is_an_error(tmp_path):

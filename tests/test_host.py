@@ -43,7 +43,8 @@ def test_init_obj_and_arg_validation():
     assert m.hidden_size == 128 and m.pack_seq
     with pytest.raises(AssertionError):
         cfg.init_obj("arch", module_arch, hidden_size=64)          # overriding config kwargs is not allowed
-    for bad in (dict(num_layers=2), dict(bidirectional=False), dict(pack_seq=False), dict(hidden_size=64)):
+    assert not module_arch.SeqModel(**dict(cfg["arch"]["args"], pack_seq=False)).pack_seq      # forward2: padded Tensor input
+    for bad in (dict(num_layers=2), dict(bidirectional=False), dict(pack_seq=False, batch_first=False), dict(hidden_size=64)):
         args = dict(cfg["arch"]["args"])
         args.update(bad)
         with pytest.raises(NotImplementedError):

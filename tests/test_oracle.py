@@ -55,6 +55,15 @@ def test_cpu_product_semantics(oracle, golden):
     assert np.abs(lg - s["cpu_logits"]).max() < TOL
 
 
+def test_forward2_padded_tensor_semantics(oracle, golden):
+    """the reference's pack_seq=false entry (forward2 + last_pad_out_items, model/model.py:40-50,67-72) is the same function
+    as its CPU product: padded input, gather at the last non-zero row. Golden logits come from the reference's forward2."""
+    d = golden.npz("forward2")
+    for L in (100, 64):
+        lg = oracle.forward_padded(d["arena"], d["offsets"], d["lens"], L)
+        assert np.abs(lg - d["logits_l%d" % L]).max() < TOL, L
+
+
 def test_pair_fusion(oracle, golden):
     d = golden.npz("pe")
     for mode in ("none", "rrna", "norrna", "both"):
