@@ -4,8 +4,10 @@
 A "step" = one pass of the hot path over one batch of synthetic read pairs (timed region (ii)):
     read bytes in PINNED HOST memory -> H2D on a copy stream (double buffered: the bytes of step k+1 travel while step k
     computes) -> rd_classify(R1) + rd_classify(R2) (length bucketing, fused encoder, LSTM recurrence, FC, argmax)
+    -> rd_refine (float64 re-evaluation of the ~30 reads per million whose margin is inside the fp32 noise band)
     -> rd_pair_fuse(--ensure rrna) + counters -> D2H of the 1-byte pair labels into pinned host memory,
-    and for N>1 the RCCL gather of the labels to rank 0.
+    and for N>1 the RCCL gather of the labels to rank 0. The post-pass of a step (refine, fusion, D2H, gather) runs on a side
+    stream and overlaps the recurrences of the next step; everything is inside the timed region.
 Workload = BASELINE.json configs[2] ("10M paired-end 100 bp reads with --ensure rrna, 1 MI355X"): with the default
 --steps 10 x 1,048,576 pairs/step = 10.5 M pairs (21 M reads) are classified inside the timed region.
 For N>1 every rank gets its own shard of the same size (weak scaling), as the reads shard embarrassingly.
@@ -205,6 +207,9 @@ def main():
                     help="pe100 = BASELINE configs[2] (the metric's configuration, default); se100 = configs[1]; pe150 = the per-GPU "
                          "shard of configs[3]; var300 = the per-GPU shard of configs[4] (40-300 bp, -l 300)")
     ap.add_argument("--resident-only", action="store_true", help="time region (i) only: read bytes resident in HBM (diagnostics)")
+    ap.add_argument("--inline-refine", action="store_true",
+                    help="leave the float64 refine pass inside rd_classify (on the main stream) instead of overlapping it with the next "
+                         "step's recurrences on a side stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the short extra measurement of the exact-fp32 MFMA kernel")
     ap.add_argument("--no-encoder", action="store_true", help="skip the standalone encoder kernels")
@@ -253,24 +258,50 @@ def main():
     flops_per_launch = float((torch.clamp(lens, max=MAXLEN).to(torch.float64) * 131072 + 1024).sum().item())
     bytes_per_launch = float(lens.to(torch.float64).sum().item()) + P * (4 + 8 + 8 + 1)
     nm = 2 if paired else 1
-    lg = [torch.empty((P, 2), dtype=torch.float32, device=dev) for _ in range(nm)]
+    # two sets of result buffers: the post-pass of step i (side stream) runs while the recurrences of step i+1 (main stream) write
+    # the other set
+    lgs = [[torch.empty((P, 2), dtype=torch.float32, device=dev) for _ in range(nm)] for _ in range(2)]
+    lab8s = [torch.empty((P,), dtype=torch.uint8, device=dev) for _ in range(2)]
     counts = torch.zeros(3, dtype=torch.int64, device=dev)
     gathered = torch.empty(P * world, dtype=torch.int8, device=dev) if (world > 1 and rank == 0) else None
-    lab8 = torch.empty((P,), dtype=torch.uint8, device=dev)
     cur = torch.cuda.current_stream(dev)
+    side = torch.cuda.Stream(dev)
+    pipelined = not args.inline_refine
+    if pipelined:                                          # the float64 refine pass is issued by this script on the side stream
+        model.set_refine(0.0)
+    ev_post = [None, None]                                 # post-pass that last read result set k
 
-    def compute(a1, a2):
-        """kernels of one step on the current stream -> device labels int8[P]"""
+    def compute(i, a1, a2, after=None):
+        """one step: the recurrences of both mates on the main stream; on the side stream (overlapping the next step's recurrences)
+        the float64 re-evaluation of the reads inside the noise band, pair fusion / counters and `after(labels)` (label D2H,
+        RCCL gather). Returns the event that marks the end of the step's post-pass."""
+        k = i & 1
+        lg, lab8 = lgs[k], lab8s[k]
+        if ev_post[k] is not None:
+            cur.wait_event(ev_post[k])
+        model.classify_bytes(a1, offs, lens, MAXLEN, want_labels=not paired, logits=lg[0], labels=None if paired else lab8)
         if paired:
-            model.classify_bytes(a1, offs, lens, MAXLEN, want_labels=False, logits=lg[0])
             model.classify_bytes(a2, offs, lens, MAXLEN, want_labels=False, logits=lg[1])
-            if args.ensure == "none":
-                model.refine_pairs(a1, offs, lens, MAXLEN, lg[0], lg[1])
-                model.refine_pairs(a2, offs, lens, MAXLEN, lg[1], lg[0])
-            return module_arch.pair_fuse(lg[0], lg[1], args.ensure, counts)
-        model.classify_bytes(a1, offs, lens, MAXLEN, want_labels=True, logits=lg[0], labels=lab8)
-        module_arch.count_labels(lab8, counts)
-        return lab8.view(torch.int8)
+        ev_main = torch.cuda.Event()
+        ev_main.record(cur)
+        post = side if pipelined else cur
+        with torch.cuda.stream(post):
+            post.wait_event(ev_main)
+            if paired:
+                pair_none = args.ensure == "none"
+                if pipelined or pair_none:
+                    model.refine(a1, offs, lens, MAXLEN, lg[0], None, lg[1] if pair_none else None)
+                    model.refine(a2, offs, lens, MAXLEN, lg[1], None, lg[0] if pair_none else None)
+                lab = module_arch.pair_fuse(lg[0], lg[1], args.ensure, counts)
+            else:
+                if pipelined:
+                    model.refine(a1, offs, lens, MAXLEN, lg[0], lab8)
+                module_arch.count_labels(lab8, counts)
+                lab = lab8.view(torch.int8)
+            fin = after(lab) if after else None
+            ev_post[k] = torch.cuda.Event()
+            ev_post[k].record(post)
+        return ev_post[k], fin
 
     def exchange(lab):
         if world > 1:
@@ -288,7 +319,7 @@ def main():
         """region (i): inputs resident in HBM"""
         pend = []
         for i in range(nsteps):
-            f = exchange(compute(r1[i % nslices][0], r2[i % nslices][0] if paired else None))
+            _, f = compute(i, r1[i % nslices][0], r2[i % nslices][0] if paired else None, exchange)
             if f:
                 pend.append(f)
         for f in pend:
@@ -305,8 +336,7 @@ def main():
     dbuf = [[torch.empty_like(r1[0][0]) for _ in range(nm)] for _ in range(2)]
     host_lab = [torch.empty((P,), dtype=torch.int8).pin_memory() for _ in range(2)]
     ev_ready = [torch.cuda.Event() for _ in range(2)]      # H2D of the slot finished
-    ev_free = [None, None]                                 # kernels that read the slot finished
-    ev_lab = [None, None]                                  # labels of the slot are in host memory
+    ev_free = [None, None]                                 # every kernel that reads the slot's bytes finished (= the post-pass event)
 
     def h2d(i):
         s = i & 1
@@ -325,15 +355,13 @@ def main():
             if i + 1 < nsteps:
                 h2d(i + 1)
             cur.wait_event(ev_ready[s])
-            lab = compute(dbuf[s][0], dbuf[s][1] if paired else None)
-            ev_free[s] = torch.cuda.Event()
-            ev_free[s].record(cur)
-            if ev_lab[s] is not None:
-                ev_lab[s].synchronize()                    # the host consumed the labels of step i-2 (bounds the run-ahead)
-            host_lab[s].copy_(lab, non_blocking=True)
-            ev_lab[s] = torch.cuda.Event()
-            ev_lab[s].record(cur)
-            f = exchange(lab)
+            if ev_free[s] is not None:
+                ev_free[s].synchronize()                   # the host consumed the labels of step i-2 (bounds the run-ahead)
+
+            def after(lab, s=s):
+                host_lab[s].copy_(lab, non_blocking=True)  # 1 B per pair into pinned memory, behind the post-pass
+                return exchange(lab)
+            ev_free[s], f = compute(i, dbuf[s][0], dbuf[s][1] if paired else None, after)
             if f:
                 pend.append(f)
         for f in pend:
@@ -423,6 +451,9 @@ def main():
                                      if base == "mfma_f16x3_t32" else "fp32"),
                        "parallelism": "reads sharded x%d, label gather to rank 0" % world,
                        "rccl_ranks": world, "dist_backend": backend,
+                       "refine": {"band": module_arch.SeqModel.REFINE_DEFAULT, "what": "reads whose margin is inside the band are "
+                                  "re-evaluated in float64 (labels of the exact function); inside the timed region",
+                                  "placement": "side stream, overlapping the next step's recurrences" if pipelined else "inline in rd_classify"},
                        "label_counts": {"non_rrna": c[0], "rrna": c[1], "unclassified": c[2]},
                        "host_labels_nonzero_last_step": host_check},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
@@ -466,6 +497,7 @@ def main():
                 # ribodetector_cpu's padded input = the 'padded' switch of the HIP path)
                 import numpy as np
                 model.set_semantics("padded")
+                model.set_refine(module_arch.SeqModel.REFINE_DEFAULT)      # the library default: refine pass inside rd_classify
                 g_logits, g_labels = model.classify_bytes(r1[0][0], offs[:ns].contiguous(), lens[:ns].contiguous(), MAXLEN)
                 model.set_semantics("packed")
                 g_logits = g_logits.cpu().numpy()

@@ -90,14 +90,18 @@ int rd_set_semantics(rd_model *m, int semantics);
  * margin is below `thresh` (default RD_REFINE_DEFAULT, ~30 reads per million) in float64 - the same function, reference
  * model/model.py:32-37, with all products, sums and activations in double - and replaces its logits and label: labels are
  * those of the exact function, independent of kernel variant and batch split. thresh = 0 switches the pass off.
- * rd_refine is the same pass as a separate call, for callers that hold logits of BOTH mates: with `mate_logits` ([dev]
- * float[n*2], row i = the mate of read i) a read is also re-evaluated when the PAIR margin |(l1+m1) - (l0+m0)| is below
- * 2*thresh, which is what decides the pair label under --ensure none (detect.py:657); call it once per mate before
- * rd_pair_fuse. One launch: each workgroup scans 512 logit rows and re-evaluates the candidates among them itself. */
+ * rd_refine is the same pass as a separate call (thresh <= 0: the model's band):
+ *   - for callers that hold logits of BOTH mates: with `mate_logits` ([dev] float[n*2], row i = the mate of read i) a read is
+ *     also re-evaluated when the PAIR margin |(l1+m1) - (l0+m0)| is below 2*thresh, which is what decides the pair label under
+ *     --ensure none (detect.py:657); call it once per mate before rd_pair_fuse;
+ *   - for throughput: the pass has the latency of one read (~0.3 ms: 100 dependent float64 steps on one CU) with the rest of
+ *     the GPU idle. A pipelined caller switches the inline pass off (rd_set_refine(m, 0)) and issues rd_refine(..., thresh)
+ *     on a second stream, where it overlaps the next batch's recurrence (bench.py and the CLI do).
+ * One launch: each workgroup scans 512 logit rows and re-evaluates the candidates among them itself. */
 #define RD_REFINE_DEFAULT 5e-4f
 int rd_set_refine(rd_model *m, float thresh);
 int rd_refine(const rd_model *m, const uint8_t *arena, const int64_t *seq_off, const int32_t *seq_len, int64_t n,
-              int32_t max_len, float *logits, uint8_t *labels, const float *mate_logits, void *stream);
+              int32_t max_len, float *logits, uint8_t *labels, const float *mate_logits, float thresh, void *stream);
 
 /* Bytes of [dev] scratch rd_classify needs for n reads with truncation length max_len. */
 size_t rd_classify_workspace_bytes(int64_t n, int32_t max_len);

@@ -61,7 +61,7 @@ def lib():
     L.rd_variant_available.argtypes = [C.c_int]
     L.rd_set_semantics.argtypes = [vp, C.c_int]
     L.rd_set_refine.argtypes = [vp, C.c_float]
-    L.rd_refine.argtypes = [vp, vp, vp, vp, i64, i32, vp, vp, vp, vp]
+    L.rd_refine.argtypes = [vp, vp, vp, vp, i64, i32, vp, vp, vp, C.c_float, vp]
     L.rd_classify_workspace_bytes.argtypes = [i64, i32]
     L.rd_classify_workspace_bytes.restype = sz
     L.rd_classify.argtypes = [vp, vp, vp, vp, i64, i32, vp, vp, vp, sz, vp]

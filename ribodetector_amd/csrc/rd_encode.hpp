@@ -18,13 +18,23 @@ __device__ __forceinline__ f32x4 rd_onehot(int code) {
     return f32x4{code == 0 ? 1.f : 0.f, code == 1 ? 1.f : 0.f, code == 2 ? 1.f : 0.f, code == 3 ? 1.f : 0.f};
 }
 
-// codes[n][stride] u8 (4 = pad / not ACGTU): 4 output bytes per lane and iteration, one aligned dword store when VEC
+// codes[n][stride] u8 (4 = pad / not ACGTU). HBM-bound only if the byte mapping is cheap: the first version (compare chains per
+// byte, one division per 4 bytes) ran at 0.28 of the HBM peak, ALU-bound. Now: 16 output bytes per lane and iteration - one
+// division, one 16-byte load, one 16-byte store - and the mapping is a 256-entry table in LDS: 256 bytes = one dword per bank, so
+// two lanes that hit the same bank hit the same dword (broadcast): ds_read_u8 is conflict-free whatever the bases are.
+__device__ __forceinline__ uint32_t rd_map4(const uint8_t *lut, uint32_t raw) {
+    return (uint32_t)lut[raw & 0xff] | ((uint32_t)lut[(raw >> 8) & 0xff] << 8) | ((uint32_t)lut[(raw >> 16) & 0xff] << 16) |
+           ((uint32_t)lut[raw >> 24] << 24);
+}
+
 template <bool VEC>
 __global__ __launch_bounds__(256) void rd_encode_codes_kernel(const uint8_t *__restrict__ arena, const int64_t *__restrict__ off,
                                                               const int32_t *__restrict__ len, int64_t n, int max_len, int stride,
                                                               uint8_t *__restrict__ codes) {
     __shared__ int64_t s_off[ENC_R];
     __shared__ int s_T[ENC_R];
+    __shared__ __attribute__((aligned(256))) uint8_t s_lut[256];
+    s_lut[threadIdx.x] = (uint8_t)rd_code(threadIdx.x);
     for (int64_t r0 = (int64_t)blockIdx.x * ENC_R; r0 < n; r0 += (int64_t)gridDim.x * ENC_R) {
         const int R = (int)(n - r0 < ENC_R ? n - r0 : ENC_R);
         __syncthreads();
@@ -35,30 +45,35 @@ __global__ __launch_bounds__(256) void rd_encode_codes_kernel(const uint8_t *__r
         __syncthreads();
         const unsigned total = (unsigned)R * (unsigned)stride;
         uint8_t *dst = codes + (size_t)r0 * stride;
-        for (unsigned e = threadIdx.x * 4; e < total; e += 1024) {
+        for (unsigned e = threadIdx.x * 16; e < total; e += 4096) {
             unsigned i = e / (unsigned)stride, j = e - i * (unsigned)stride;
-            uint32_t w = 0;
-            if (j + 4 <= (unsigned)s_T[i]) {   // four bases of one read: one (unaligned) dword load
-                uint32_t raw;
-                __builtin_memcpy(&raw, arena + s_off[i] + j, 4);
+            u32x4 w;
+            if (j + 16 <= (unsigned)s_T[i]) {   // sixteen bases of one read: one (unaligned) 16-byte load
+                u32x4 raw;
+                __builtin_memcpy(&raw, arena + s_off[i] + j, 16);
 #pragma unroll
-                for (int b = 0; b < 4; ++b) w |= (unsigned)rd_code((raw >> (8 * b)) & 0xff) << (8 * b);
-            } else {
+                for (int q = 0; q < 4; ++q) w[q] = rd_map4(s_lut, raw[q]);
+            } else {                            // read end, padding or a row boundary inside the 16 bytes
 #pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    unsigned c = 4;
-                    if (e + b < total && j < (unsigned)s_T[i]) c = (unsigned)rd_code(arena[s_off[i] + j]);
-                    w |= c << (8 * b);
-                    if (++j == (unsigned)stride) {
-                        j = 0;
-                        ++i;
+                for (int q = 0; q < 4; ++q) {
+                    uint32_t x = 0;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        unsigned c = 4;
+                        if (e + 4 * q + b < total && j < (unsigned)s_T[i]) c = s_lut[arena[s_off[i] + j]];
+                        x |= c << (8 * b);
+                        if (++j == (unsigned)stride) {
+                            j = 0;
+                            ++i;
+                        }
                     }
+                    w[q] = x;
                 }
             }
-            if (VEC && e + 4 <= total) {
-                *(uint32_t *)(dst + e) = w;
+            if (VEC && e + 16 <= total) {
+                __builtin_nontemporal_store(w, (u32x4 *)(dst + e));
             } else {
-                for (int b = 0; b < 4 && e + b < total; ++b) dst[e + b] = (uint8_t)(w >> (8 * b));
+                for (int b = 0; b < 16 && e + b < total; ++b) dst[e + b] = (uint8_t)(w[b >> 2] >> (8 * (b & 3)));
             }
         }
     }

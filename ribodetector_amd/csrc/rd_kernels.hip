@@ -145,12 +145,14 @@ static int rd_refine_launch(rd_model *m, const ReadBatch &rb, float *logits, uin
 }
 
 int rd_refine(const rd_model *cm, const uint8_t *arena, const int64_t *seq_off, const int32_t *seq_len, int64_t n, int32_t max_len,
-              float *logits, uint8_t *labels, const float *mate_logits, void *stream) {
+              float *logits, uint8_t *labels, const float *mate_logits, float thresh, void *stream) {
     rd_model *m = const_cast<rd_model *>(cm);
     if (!m || !logits) RD_FAIL(RD_E_INVALID, "rd_refine: null model or logits");
     if (n < 0 || n > 0x7fffffffLL) RD_FAIL(RD_E_INVALID, "rd_refine: n=%lld out of range", (long long)n);
     if (max_len < 1 || max_len > MAX_LEN_LIMIT) RD_FAIL(RD_E_INVALID, "rd_refine: max_len=%d out of range [1,%d]", max_len, MAX_LEN_LIMIT);
-    if (n == 0 || m->refine_thresh <= 0.0f) return RD_OK;
+    if (!(thresh <= 1.0f)) RD_FAIL(RD_E_INVALID, "rd_refine: threshold %g out of range", (double)thresh);
+    if (thresh <= 0.0f) thresh = m->refine_thresh;   // the model's band
+    if (n == 0 || thresh <= 0.0f) return RD_OK;
     if (!arena || !seq_off || !seq_len) RD_FAIL(RD_E_INVALID, "rd_refine: null input pointer");
     hipStream_t st = (hipStream_t)stream;
     if (m->semantics == RD_SEM_PADDED && m->rev_tab_len != max_len) {
@@ -158,7 +160,7 @@ int rd_refine(const rd_model *cm, const uint8_t *arena, const int64_t *seq_off, 
         m->rev_tab_len = max_len;
     }
     ReadBatch rb{arena, seq_off, seq_len, nullptr, nullptr, n, max_len, m->semantics, m->d.rev_tab};
-    return rd_refine_launch(m, rb, logits, labels, mate_logits, m->refine_thresh, st);
+    return rd_refine_launch(m, rb, logits, labels, mate_logits, thresh, st);
 }
 
 size_t rd_classify_workspace_bytes(int64_t n, int32_t max_len) {
@@ -305,7 +307,7 @@ int rd_encode_codes(const uint8_t *arena, const int64_t *seq_off, const int32_t 
     if ((int64_t)ENC_R * stride > 0x7fffffffLL) RD_FAIL(RD_E_INVALID, "rd_encode_codes: stride too large");
     int64_t nb = (n + ENC_R - 1) / ENC_R;
     if (nb > 256 * 64) nb = 256 * 64;
-    if (((uintptr_t)codes & 3) == 0)   // a block's output starts at r0 * stride with r0 a multiple of 64
+    if (((uintptr_t)codes & 15) == 0)   // a block's output starts at r0 * stride with r0 a multiple of 64: 16-byte aligned stores
         hipLaunchKernelGGL(rd_encode_codes_kernel<true>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, arena, seq_off, seq_len,
                            n, max_len, stride, codes);
     else

@@ -48,6 +48,14 @@ class colors:
     BOLD = '\033[1m'
 
 
+def part_path(path, rank):
+    """name of rank `rank`'s part of an output file; keeps a trailing 'gz' because the writer compresses by name
+    (reference detect.py:738: read_file.endswith('gz'))"""
+    if path.endswith('gz'):
+        return '%s.part%d.gz' % (path[:-2].rstrip('.'), rank)
+    return '%s.part%d' % (path, rank)
+
+
 class Predictor:
     """Main class of predictor for rRNA, non-rRNA sequences (interface of reference detect.py:34-43)."""
 
@@ -100,8 +108,10 @@ class Predictor:
             raise RuntimeError("config.json kernel.variant must be one of auto, mfma_f16x3_t32, mfma_f32, simple; got %r" % (variant,))
         self.model.set_variant(variant)
         self.model.set_semantics(getattr(self.args, 'semantics', None) or kcfg.get('semantics', 'gpu'))
-        if 'refine' in kcfg:                     # margin band of the float64 re-evaluation (0 = off); default of the library: 5e-4
-            self.model.set_refine(float(kcfg['refine']))
+        # margin band of the float64 re-evaluation (config.json kernel.refine; 0 = off; default 5e-4). The CLI issues the pass
+        # itself on a side stream (submit_chunk), so the one inside rd_classify is switched off.
+        self.refine_band = float(kcfg.get('refine', module_arch.SeqModel.REFINE_DEFAULT))
+        self.model.set_refine(0.0)
         self.model.eval()
 
     # ---- classification of one chunk ------------------------------------------------------------------
@@ -132,22 +142,29 @@ class Predictor:
         cur = torch.cuda.current_stream(self.device)
         cur.wait_stream(cs)
         outs = [self.model.classify_bytes(a, o, l, self.len, want_labels=not self.is_paired) for a, o, l in dev_in]
-        if self.is_paired:
-            if self.args.ensure == 'none':       # the pair label is argmax of the summed logits (reference detect.py:657): pairs
-                (a1, o1, l1), (a2, o2, l2) = dev_in   # whose SUMMED margin is inside the fp32 noise band are re-evaluated in float64
-                self.model.refine_pairs(a1, o1, l1, self.len, outs[0][0], outs[1][0])
-                self.model.refine_pairs(a2, o2, l2, self.len, outs[1][0], outs[0][0])
-            labels = module_arch.pair_fuse(outs[0][0], outs[1][0], self.args.ensure)
-        else:
-            labels = outs[0][1].view(torch.int8)
-        host = finish = None
-        if self.world == 1 or self.sharded_parse:
-            host = torch.empty(labels.shape, dtype=torch.int8, pin_memory=True)
-            host.copy_(labels, non_blocking=True)
-        else:                                    # label gather (1 B per read) queued behind the kernels, collected later
-            _, finish = rdist.gather_labels(labels, n, dst=0, bounds=bounds, async_op=True)
-        done = torch.cuda.Event()
-        done.record(cur)
+        main_done = torch.cuda.Event()
+        main_done.record(cur)
+        # post-pass on its own stream: it overlaps the recurrences of the next chunk (the float64 refine pass has the latency of
+        # one read with most of the GPU idle)
+        post = self._post_stream
+        with torch.cuda.stream(post):
+            post.wait_event(main_done)
+            pair_none = self.is_paired and self.args.ensure == 'none'   # pair label = argmax of the SUMMED logits (detect.py:657)
+            for k, (a, o, l) in enumerate(dev_in):
+                mate = outs[1 - k][0] if pair_none else None
+                self.model.refine(a, o, l, self.len, outs[k][0], outs[k][1], mate, thresh=self.refine_band)
+            if self.is_paired:
+                labels = module_arch.pair_fuse(outs[0][0], outs[1][0], self.args.ensure)
+            else:
+                labels = outs[0][1].view(torch.int8)
+            host = finish = None
+            if self.world == 1 or self.sharded_parse:
+                host = torch.empty(labels.shape, dtype=torch.int8, pin_memory=True)
+                host.copy_(labels, non_blocking=True)
+            else:                                    # label gather (1 B per read) queued behind the kernels, collected later
+                _, finish = rdist.gather_labels(labels, n, dst=0, bounds=bounds, async_op=True)
+            done = torch.cuda.Event()
+            done.record(post)
         return {"n": n, "bounds": bounds, "labels": labels, "host": host, "finish": finish, "done": done, "keep": (dev_in, outs)}
 
     def collect_chunk(self, tk):
@@ -223,7 +240,7 @@ class Predictor:
                 if self.rank == 0:
                     self.logger.info('Rank {} parses {} bytes of {}'.format(
                         r, ", ".join(str(b) for b in bp), ", ".join(str(fx.file_info(p)[0]) for p in self.input)))
-        part = (lambda path: '%s.part%d' % (path, self.rank)) if self.sharded_parse else (lambda path: path)
+        part = (lambda path: part_path(path, self.rank)) if self.sharded_parse else (lambda path: path)
         writer = self.rank == 0 or self.sharded_parse
         ends = (0, 1) if self.is_paired else (0,)
         fhs = {}
@@ -247,6 +264,7 @@ class Predictor:
         num_read = num_nonrrna = num_rrna = num_unknown = 0
         self._stage_s = {"wait_reader": 0.0, "classify": 0.0, "wait_writer": 0.0}   # main-thread seconds per pipeline stage
         self._copy_stream = torch.cuda.Stream(self.device)
+        self._post_stream = torch.cuda.Stream(self.device)
 
         # writer threads (rank 0): one per mate, records of every label file in input order
         wq, werr, wth = [], [], []
@@ -317,7 +335,7 @@ class Predictor:
             num_read, num_nonrrna, num_rrna, num_unknown = (int(x) for x in tot.cpu().tolist())
             if self.rank == 0:
                 for path in finals:
-                    fx.concatenate_parts(path, ['%s.part%d' % (path, r) for r in range(self.world)])
+                    fx.concatenate_parts(path, [part_path(path, r) for r in range(self.world)])
             dist.barrier()
         if self.rank == 0:
             self.logger.info('Processed {}{}{}{} sequences in total'.format(colors.BOLD, colors.OKCYAN, num_read, colors.ENDC))

@@ -139,15 +139,24 @@ class SeqModel:
             N.check(N.lib().rd_set_refine(self._handle, C.c_float(self._refine)), "rd_set_refine")
         return self
 
-    def refine_pairs(self, arena, offsets, lens, max_len, logits, mate_logits, labels=None):
-        """float64 re-evaluation of the reads of one mate whose own margin or whose PAIR margin (logits + mate_logits, what
-        decides the pair label under --ensure none, reference detect.py:657) is inside the noise band; `logits` is updated
-        in place. Call once per mate, then pair_fuse()."""
+    REFINE_DEFAULT = 5e-4
+
+    def refine(self, arena, offsets, lens, max_len, logits, labels=None, mate_logits=None, thresh=None):
+        """float64 re-evaluation (C ABI rd_refine) of the reads whose own margin - or, with `mate_logits`, whose PAIR margin
+        (logits + mate_logits, what decides the pair label under --ensure none, reference detect.py:657) - is inside the noise
+        band; `logits` (and `labels`) are updated in place on the current stream. thresh None = the model's band (if that is
+        0 because the inline pass is switched off: the library default)."""
         n = int(lens.numel())
+        if thresh is None:
+            thresh = self._refine if self._refine else (0.0 if self._refine is None else self.REFINE_DEFAULT)
         with torch.cuda.device(self.device):
             N.check(N.lib().rd_refine(self._handle, N.ptr(arena), N.ptr(offsets), N.ptr(lens), n, int(max_len), N.ptr(logits),
-                                      N.ptr(labels), N.ptr(mate_logits), N.stream_ptr(self.device)), "rd_refine")
+                                      N.ptr(labels), N.ptr(mate_logits), C.c_float(float(thresh)), N.stream_ptr(self.device)), "rd_refine")
         return logits
+
+    def refine_pairs(self, arena, offsets, lens, max_len, logits, mate_logits, labels=None, thresh=None):
+        """one mate of a pair batch: call once per mate, then pair_fuse()"""
+        return self.refine(arena, offsets, lens, max_len, logits, labels, mate_logits, thresh)
 
     def __del__(self):
         try:

@@ -1,25 +1,44 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence for one round on the GPU box (run through gpurun from the repo root):
-#   tools/profile_round.sh r01
+#   tools/profile_round.sh r02
 # writes small text/CSV summaries to gpurun_out/prof_<tag>/ ; copy them into profiles/ afterwards.
+# Counter passes (--pmc) are their own runs, never combined with a trace domain.
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-B="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-alt"
 rm -rf /tmp/p_$TAG
-(rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_$TAG/stats -o bench -- $B) > $O/stats.log 2>&1
-find /tmp/p_$TAG/stats -name "*kernel_stats.csv" -exec cp {} $O/${TAG}_kernel_stats.csv \;
-for c in FETCH_SIZE WRITE_SIZE; do
-  (rocprofv3 --pmc $c --output-format csv -d /tmp/p_$TAG/pmc_$c -o bench -- $B) > $O/pmc_$c.log 2>&1
-done
-(rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU --output-format csv -d /tmp/p_$TAG/pmc_sq -o bench -- $B) > $O/pmc_sq.log 2>&1
-(rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_INSTS_SALU --output-format csv -d /tmp/p_$TAG/pmc_lds -o bench -- $B) > $O/pmc_lds.log 2>&1
-python $R/tools/prof_summarize.py /tmp/p_$TAG/stats /tmp/p_$TAG/pmc_FETCH_SIZE /tmp/p_$TAG/pmc_WRITE_SIZE /tmp/p_$TAG/pmc_sq /tmp/p_$TAG/pmc_lds | grep "^##\|rd_" > $O/${TAG}_summary.txt 2>&1
+BF="--steps 3 --warmup 1 --no-cpu-baseline --no-alt --no-encoder --traffic off"
+stats() {   # stats <name> <command...>: kernel trace + stats of a command
+  local name=$1; shift
+  (rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_$TAG/$name -o x -- "$@") > $O/$name.log 2>&1
+  find /tmp/p_$TAG/$name -name "*kernel_stats.csv" -exec cp {} $O/${TAG}_kernel_stats_$name.csv \;
+  grep -h "^{" $O/$name.log | head -1 > $O/${TAG}_line_$name.json
+}
+pmc() {     # pmc <name> <counters...> -- <command...>
+  local name=$1; shift
+  local ctrs=()
+  while [ "$1" != "--" ]; do ctrs+=("$1"); shift; done
+  shift
+  (rocprofv3 --pmc "${ctrs[@]}" --output-format csv -d /tmp/p_$TAG/$name -o x -- "$@") > $O/$name.log 2>&1
+}
+# 1. the metric's workload (pe100, default kernel) and the other BASELINE configs / the exact-fp32 kernel
+stats pe100 python $R/bench.py $BF
+for wl in se100 pe150 var300; do stats $wl python $R/bench.py $BF --workload $wl; done
+stats pe100_mfma_f32 python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alt --no-encoder --traffic off --variant mfma_f32
+# 2. HBM traffic and SQ counters of the recurrence kernel (resident inputs: the kernels are the same)
+for c in FETCH_SIZE WRITE_SIZE; do pmc pmc_$c $c -- python $R/bench.py $BF --resident-only; done
+pmc pmc_sq GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU -- python $R/bench.py $BF --resident-only
+pmc pmc_lds SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_INSTS_SALU -- python $R/bench.py $BF --resident-only
+# 3. the HBM-bound kernels: standalone encoders, pair fusion, counters
+stats encoders python $R/tools/encoder_bench.py
+for c in FETCH_SIZE WRITE_SIZE; do pmc enc_pmc_$c $c -- python $R/tools/encoder_bench.py; done
+python $R/tools/prof_summarize.py --tag $TAG --out $O /tmp/p_$TAG > $O/${TAG}_summary.txt 2>&1
 cd $R
-(timeout 900 python bench.py 2>&1 | grep "^{") > $O/${TAG}_bench.json
-grep -h "^{" $O/stats.log | head -1 > $O/${TAG}_bench_under_rocprof.json
+T0=$(date +%s)
+(timeout 900 python bench.py 2>/dev/null | grep "^{") > $O/${TAG}_bench.json
+echo "default bench.py wall seconds: $(( $(date +%s) - T0 ))" >> $O/${TAG}_summary.txt
 rm -f $O/*.log
 ls -la $O
