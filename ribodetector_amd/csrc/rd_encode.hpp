@@ -18,10 +18,15 @@ __device__ __forceinline__ f32x4 rd_onehot(int code) {
     return f32x4{code == 0 ? 1.f : 0.f, code == 1 ? 1.f : 0.f, code == 2 ? 1.f : 0.f, code == 3 ? 1.f : 0.f};
 }
 
-// codes[n][stride] u8 (4 = pad / not ACGTU). HBM-bound only if the byte mapping is cheap: the first version (compare chains per
-// byte, one division per 4 bytes) ran at 0.28 of the HBM peak, ALU-bound. Now: 16 output bytes per lane and iteration - one
-// division, one 16-byte load, one 16-byte store - and the mapping is a 256-entry table in LDS: 256 bytes = one dword per bank, so
-// two lanes that hit the same bank hit the same dword (broadcast): ds_read_u8 is conflict-free whatever the bases are.
+// codes[n][stride] u8 (4 = pad / not ACGTU). HBM-bound only if the byte mapping is cheap and no lane walks bytes: the first
+// version (compare chains per byte, a division per 4 bytes, a byte loop wherever 4 bytes crossed a row) ran at 0.28 of the HBM
+// peak. Now a lane takes one 16-byte PIECE OF ONE ROW (rows are cut into ceil(stride/16) pieces, so a piece never crosses a row):
+//   piece inside the read    one unaligned 16-byte load at its bytes
+//   piece holding the read's end (m < 16 valid bytes)   the 16 bytes that END at the read's end (still inside the read, never past
+//                            it), mapped, then shifted down by 16-m bytes with the padding code shifted in
+//   piece past the end       padding
+// and the mapping is a 256-entry table in LDS: 256 bytes = one dword per bank, so two lanes that hit the same bank hit the same
+// dword (broadcast) - ds_read_u8 is conflict-free whatever the bases are. Reads shorter than 16 bases take a byte loop.
 __device__ __forceinline__ uint32_t rd_map4(const uint8_t *lut, uint32_t raw) {
     return (uint32_t)lut[raw & 0xff] | ((uint32_t)lut[(raw >> 8) & 0xff] << 8) | ((uint32_t)lut[(raw >> 16) & 0xff] << 16) |
            ((uint32_t)lut[raw >> 24] << 24);
@@ -35,6 +40,7 @@ __global__ __launch_bounds__(256) void rd_encode_codes_kernel(const uint8_t *__r
     __shared__ int s_T[ENC_R];
     __shared__ __attribute__((aligned(256))) uint8_t s_lut[256];
     s_lut[threadIdx.x] = (uint8_t)rd_code(threadIdx.x);
+    const unsigned PP = ((unsigned)stride + 15u) / 16u;   // pieces per row
     for (int64_t r0 = (int64_t)blockIdx.x * ENC_R; r0 < n; r0 += (int64_t)gridDim.x * ENC_R) {
         const int R = (int)(n - r0 < ENC_R ? n - r0 : ENC_R);
         __syncthreads();
@@ -43,37 +49,50 @@ __global__ __launch_bounds__(256) void rd_encode_codes_kernel(const uint8_t *__r
             s_T[threadIdx.x] = rd_T(len, r0 + threadIdx.x, max_len);
         }
         __syncthreads();
-        const unsigned total = (unsigned)R * (unsigned)stride;
+        const unsigned pieces = (unsigned)R * PP;
         uint8_t *dst = codes + (size_t)r0 * stride;
-        for (unsigned e = threadIdx.x * 16; e < total; e += 4096) {
-            unsigned i = e / (unsigned)stride, j = e - i * (unsigned)stride;
-            u32x4 w;
-            if (j + 16 <= (unsigned)s_T[i]) {   // sixteen bases of one read: one (unaligned) 16-byte load
+        for (unsigned g = threadIdx.x; g < pieces; g += 256) {
+            const unsigned i = g / PP, j0 = (g - i * PP) * 16u;
+            const int T = s_T[i], m = T - (int)j0;             // valid input bytes from j0 on
+            const uint8_t *src = arena + s_off[i];
+            u32x4 w = {0x04040404u, 0x04040404u, 0x04040404u, 0x04040404u};
+            if (m >= 16) {
                 u32x4 raw;
-                __builtin_memcpy(&raw, arena + s_off[i] + j, 16);
+                __builtin_memcpy(&raw, src + j0, 16);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) w[q] = rd_map4(s_lut, raw[q]);
-            } else {                            // read end, padding or a row boundary inside the 16 bytes
+            } else if (m > 0 && T >= 16) {                      // the 16 bytes that end at the read's end, shifted down by 16-m bytes
+                u32x4 raw;
+                __builtin_memcpy(&raw, src + T - 16, 16);
+                uint32_t c[8];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { c[q] = rd_map4(s_lut, raw[q]); c[4 + q] = 0x04040404u; }
+                const unsigned sh = 16u - (unsigned)m, a = sh >> 2, bsh = (sh & 3u) * 8u;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    uint32_t x = 0;
+                    uint32_t lo = 0x04040404u, hi = 0x04040404u;   // c[q + a], c[q + a + 1] without dynamic register indexing
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) {
-                        unsigned c = 4;
-                        if (e + 4 * q + b < total && j < (unsigned)s_T[i]) c = s_lut[arena[s_off[i] + j]];
-                        x |= c << (8 * b);
-                        if (++j == (unsigned)stride) {
-                            j = 0;
-                            ++i;
-                        }
+                    for (int k = 0; k < 8; ++k) {
+                        lo = ((unsigned)k == q + a) ? c[k] : lo;
+                        hi = ((unsigned)k == q + a + 1) ? c[k] : hi;
                     }
-                    w[q] = x;
+                    w[q] = bsh ? ((lo >> bsh) | (hi << (32u - bsh))) : lo;
+                }
+            } else if (m > 0) {                                  // read shorter than 16 bases
+                for (int k = 0; k < m; ++k) {
+                    const uint32_t cd = s_lut[src[j0 + k]];
+                    w[k >> 2] = (w[k >> 2] & ~(0xffu << (8 * (k & 3)))) | (cd << (8 * (k & 3)));
                 }
             }
-            if (VEC && e + 16 <= total) {
-                __builtin_nontemporal_store(w, (u32x4 *)(dst + e));
+            uint8_t *o = dst + (size_t)i * stride + j0;
+            const unsigned ob = (unsigned)stride - j0 < 16u ? (unsigned)stride - j0 : 16u;   // output bytes of this piece
+            if (VEC && ob == 16) {
+                __builtin_nontemporal_store(w, (u32x4 *)o);       // 4-byte aligned at least (stride % 4 == 0 when VEC)
+            } else if (VEC) {
+                for (unsigned q = 0; q < ob / 4; ++q) *(uint32_t *)(o + 4 * q) = w[q];
+                for (unsigned k = ob & ~3u; k < ob; ++k) o[k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
             } else {
-                for (int b = 0; b < 16 && e + b < total; ++b) dst[e + b] = (uint8_t)(w[b >> 2] >> (8 * (b & 3)));
+                for (unsigned k = 0; k < ob; ++k) o[k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
             }
         }
     }

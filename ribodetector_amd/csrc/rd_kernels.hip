@@ -307,7 +307,7 @@ int rd_encode_codes(const uint8_t *arena, const int64_t *seq_off, const int32_t 
     if ((int64_t)ENC_R * stride > 0x7fffffffLL) RD_FAIL(RD_E_INVALID, "rd_encode_codes: stride too large");
     int64_t nb = (n + ENC_R - 1) / ENC_R;
     if (nb > 256 * 64) nb = 256 * 64;
-    if (((uintptr_t)codes & 15) == 0)   // a block's output starts at r0 * stride with r0 a multiple of 64: 16-byte aligned stores
+    if (((uintptr_t)codes & 3) == 0 && (stride & 3) == 0)   // every piece of every row starts on a dword boundary
         hipLaunchKernelGGL(rd_encode_codes_kernel<true>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, arena, seq_off, seq_len,
                            n, max_len, stride, codes);
     else

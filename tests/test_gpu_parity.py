@@ -153,12 +153,27 @@ def test_encoders_bit_exact(gpu_model, golden, oracle):
     # larger ragged batch against the oracle
     e = golden.npz("edge")
     b = E.batch_from_numpy(e["arena"], e["offsets"], e["lens"], "cuda")
-    codes = E.encode_codes(b, 100, stride=112).cpu().numpy()
-    for i in range(len(e["lens"])):
-        s = bytes(e["arena"][e["offsets"][i]:e["offsets"][i + 1]])[:100]
-        want = np.full(112, 4, dtype=np.uint8)
-        want[:len(s)] = oracle.encode_codes(s)
-        assert (codes[i] == want).all(), i
+    for max_len, stride in ((100, 112), (100, 100), (100, 101), (37, 40), (300, 304), (16, 16), (15, 18)):
+        codes = E.encode_codes(b, max_len, stride=stride).cpu().numpy()       # every piece path: inside / read end / padding / short reads
+        for i in range(len(e["lens"])):
+            s = bytes(e["arena"][e["offsets"][i]:e["offsets"][i + 1]])[:max_len]
+            want = np.full(stride, 4, dtype=np.uint8)
+            want[:len(s)] = oracle.encode_codes(s)
+            assert (codes[i] == want).all(), (max_len, stride, i)
+    from ribodetector_amd import synth
+    a3, o3, l3 = synth.reads_numpy(3000, (0, 140), seed=77, n_rate=0.05)       # ragged batch, odd block count, unaligned views
+    b3 = E.batch_from_numpy(a3, o3[:-1], l3, "cuda")
+    full = torch.empty((3000 * 100 + 1,), dtype=torch.uint8, device="cuda")
+    for view in (full[:-1], full[1:]):                                        # aligned / byte-shifted output
+        out = view.view(3000, 100)
+        from ribodetector_amd import _native as N
+        N.check(N.lib().rd_encode_codes(N.ptr(b3.arena), N.ptr(b3.offsets), N.ptr(b3.lens), 3000, 100, 100, N.ptr(out), N.stream_ptr("cuda")), "rd_encode_codes")
+        got = out.cpu().numpy()
+        for i in range(0, 3000, 7):
+            s = bytes(a3[o3[i]:o3[i + 1]])[:100]
+            want = np.full(100, 4, dtype=np.uint8)
+            want[:len(s)] = oracle.encode_codes(s)
+            assert (got[i] == want).all(), i
     data, bs, osi, oui = oracle.pack_sequence(e["arena"], e["offsets"], e["lens"], 100)
     p = E.pack_reads(b, 100)
     assert (p.batch_sizes.numpy() == bs).all()
