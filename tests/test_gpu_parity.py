@@ -375,7 +375,7 @@ def test_random_bytes_and_lengths_stress(gpu_model, oracle):
 
 def _check_tail(lg, lab, ref_logits, maxlen, what):
     """Like _check for reads of up to 100 steps. Beyond that the recurrence amplifies fp32 rounding noise so far that no two
-    fp32 implementations agree to 1e-4 on every read (tests/diag_error_tail.py: over 100,000 reads of <= 300 bp the oracle
+    fp32 implementations agree to 1e-4 on every read (tools/acc_experiment.py --len 300: over 10^5..10^6 reads of 300 bp the oracle
     itself is up to 2.6e-4 from a float64 evaluation, 3 reads beyond 1e-4): there the bar is 1e-4 for 99.9 % of the reads,
     5e-5 for 99 %, 1e-3 for all, and labels equal wherever the reference's own margin exceeds the observed error."""
     if maxlen <= 100:

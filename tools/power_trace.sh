@@ -4,6 +4,7 @@
 # Writes gpurun_out/power_trace.txt ; copy into profiles/ afterwards.
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
+export RD_HIP_LIB=$R/ribodetector_amd/csrc/librd_hip_diag.so    # the *_diag_* variants exist only in the diagnostic build
 O=$R/gpurun_out/power_trace.txt
 mkdir -p $R/gpurun_out
 VARS=${@:-auto mfma_f32 mfma_f16x3_t32_diag_mfmaonly}
@@ -11,7 +12,7 @@ VARS=${@:-auto mfma_f32 mfma_f16x3_t32_diag_mfmaonly}
 for v in $VARS; do
   steps=300; [ "$v" = "mfma_f32" ] && steps=80
   echo "## variant $v: python bench.py --variant $v --steps $steps --warmup 2 --no-cpu-baseline --no-alt" >> $O
-  python $R/bench.py --variant $v --steps $steps --warmup 2 --no-cpu-baseline --no-alt > /tmp/pt_$v.json 2>/dev/null &
+  python $R/bench.py --variant $v --steps $steps --warmup 2 --no-cpu-baseline --no-alt --no-encoder --traffic off --resident-only > /tmp/pt_$v.json 2>/dev/null &
   pid=$!
   t=0
   while kill -0 $pid 2>/dev/null; do
