@@ -266,7 +266,7 @@ def main():
     gathered = torch.empty(P * world, dtype=torch.int8, device=dev) if (world > 1 and rank == 0) else None
     cur = torch.cuda.current_stream(dev)
     side = torch.cuda.Stream(dev)
-    pipelined = not args.inline_refine
+    pipelined = not (args.inline_refine or args.pmc_child)   # counter passes: one stream, so that no other kernel runs beside the one counted
     if pipelined:                                          # the float64 refine pass is issued by this script on the side stream
         model.set_refine(0.0)
     ev_post = [None, None]                                 # post-pass that last read result set k

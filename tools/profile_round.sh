@@ -28,10 +28,10 @@ pmc() {     # pmc <name> <counters...> -- <command...>
 stats pe100 python $R/bench.py $BF
 for wl in se100 pe150 var300; do stats $wl python $R/bench.py $BF --workload $wl; done
 stats pe100_mfma_f32 python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alt --no-encoder --traffic off --variant mfma_f32
-# 2. HBM traffic and SQ counters of the recurrence kernel (resident inputs: the kernels are the same)
-for c in FETCH_SIZE WRITE_SIZE; do pmc pmc_$c $c -- python $R/bench.py $BF --resident-only; done
-pmc pmc_sq GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU -- python $R/bench.py $BF --resident-only
-pmc pmc_lds SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_INSTS_SALU -- python $R/bench.py $BF --resident-only
+# 2. HBM traffic and SQ counters of the recurrence kernel (resident inputs, everything on one stream: no kernel runs beside the one counted)
+for c in FETCH_SIZE WRITE_SIZE; do pmc pmc_$c $c -- python $R/bench.py $BF --resident-only --inline-refine; done
+pmc pmc_sq GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU -- python $R/bench.py $BF --resident-only --inline-refine
+pmc pmc_lds SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_INSTS_SALU -- python $R/bench.py $BF --resident-only --inline-refine
 # 3. the HBM-bound kernels: standalone encoders, pair fusion, counters
 stats encoders python $R/tools/encoder_bench.py
 for c in FETCH_SIZE WRITE_SIZE; do pmc enc_pmc_$c $c -- python $R/tools/encoder_bench.py; done
