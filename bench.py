@@ -4,7 +4,7 @@
 A "step" = one pass of the hot path over one batch of synthetic read pairs (timed region (ii)):
     read bytes in PINNED HOST memory -> H2D on a copy stream (double buffered: the bytes of step k+1 travel while step k
     computes) -> rd_classify(R1) + rd_classify(R2) (length bucketing, fused encoder, LSTM recurrence, FC, argmax)
-    -> rd_refine (float64 re-evaluation of the ~30 reads per million whose margin is inside the fp32 noise band)
+    -> rd_refine (float64 re-evaluation of the ~15 reads per million whose margin is inside the fp32 noise band)
     -> rd_pair_fuse(--ensure rrna) + counters -> D2H of the 1-byte pair labels into pinned host memory,
     and for N>1 the RCCL gather of the labels to rank 0. The post-pass of a step (refine, fusion, D2H, gather) runs on a side
     stream and overlaps the recurrences of the next step; everything is inside the timed region.

@@ -87,7 +87,7 @@ int rd_set_semantics(rd_model *m, int semantics);
 /* Label stability. The label is argmax(logits) (reference detect.py:288,481); every fp32 evaluation of the recurrence - the
  * reference's own included - carries up to ~1e-4 of rounding noise on the logits, so for the few reads per million whose margin
  * |logit1 - logit0| is smaller than that the label is decided by noise. rd_classify therefore re-evaluates every read whose
- * margin is below `thresh` (default RD_REFINE_DEFAULT, ~30 reads per million) in float64 - the same function, reference
+ * margin is below `thresh` (default RD_REFINE_DEFAULT, ~15 reads per million) in float64 - the same function, reference
  * model/model.py:32-37, with all products, sums and activations in double - and replaces its logits and label: labels are
  * those of the exact function, independent of kernel variant and batch split. thresh = 0 switches the pass off.
  * rd_refine is the same pass as a separate call (thresh <= 0: the model's band):
@@ -98,7 +98,7 @@ int rd_set_semantics(rd_model *m, int semantics);
  *     the GPU idle. A pipelined caller switches the inline pass off (rd_set_refine(m, 0)) and issues rd_refine(..., thresh)
  *     on a second stream, where it overlaps the next batch's recurrence (bench.py and the CLI do).
  * One launch: each workgroup scans 512 logit rows and re-evaluates the candidates among them itself. */
-#define RD_REFINE_DEFAULT 5e-4f
+#define RD_REFINE_DEFAULT 2.5e-4f
 int rd_set_refine(rd_model *m, float thresh);
 int rd_refine(const rd_model *m, const uint8_t *arena, const int64_t *seq_off, const int32_t *seq_len, int64_t n,
               int32_t max_len, float *logits, uint8_t *labels, const float *mate_logits, float thresh, void *stream);

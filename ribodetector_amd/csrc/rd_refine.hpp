@@ -5,7 +5,7 @@
 // Why: the label is argmax(logits) (detect.py:288,481). Any fp32 evaluation of the recurrence - the reference's torch/cuDNN
 // arithmetic, the CPU oracle, either MFMA kernel here - carries ~3e-6 rms / ~1e-4 worst-case rounding noise on the logits
 // (DESIGN.md §4), so for the ~6 reads per million whose margin |logit1 - logit0| is below that, the label is decided by rounding
-// noise and differs between implementations. Those reads (margin below the model's refine threshold, default 5e-4: ~30 per
+// noise and differs between implementations. Those reads (margin below the model's refine threshold, default 2.5e-4: ~15 per
 // million) are evaluated again in float64 - model.py:32-37 with every product, sum and activation in double - and their
 // logits and labels replaced. The result is the label of the exact function wherever its margin exceeds ~1e-7, whatever the
 // batch size or kernel variant.

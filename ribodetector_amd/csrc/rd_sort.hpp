@@ -32,50 +32,43 @@ __global__ void rd_len_hist_kernel(const int32_t *__restrict__ len, int64_t n, i
 
 // single block: exclusive scan of hist in the order (T descending, blk ascending); also per-length totals:
 // len_start[T] = first sorted position of length T; batch_sizes[t] = #reads with T > t; total_steps.
-__global__ void rd_len_scan_kernel(uint32_t *__restrict__ hist, int max_len, int nblk, int64_t *__restrict__ len_start,
-                                   int64_t *__restrict__ batch_sizes, int64_t *__restrict__ total_steps) {
-    __shared__ unsigned long long carry;
+// Each thread sums a contiguous run of the (max_len+1) x nblk counts, one 256-wide scan of the run sums, then each thread
+// rewrites its run (the first version walked the array 256 elements at a time: 202 dependent block scans, 186 us per 2^20 reads).
+__global__ __launch_bounds__(SORT_BLOCK) void rd_len_scan_kernel(uint32_t *__restrict__ hist, int max_len, int nblk,
+                                                                 int64_t *__restrict__ len_start, int64_t *__restrict__ batch_sizes,
+                                                                 int64_t *__restrict__ total_steps) {
+    __shared__ unsigned long long part[SORT_BLOCK];
     __shared__ unsigned long long wsum[SORT_BLOCK / 64];
     const int tid = threadIdx.x;
-    if (tid == 0) carry = 0;
-    __syncthreads();
     const int64_t total = (int64_t)(max_len + 1) * nblk;
-    unsigned long long steps = 0;
-    for (int64_t base = 0; base < total; base += SORT_BLOCK) {
-        int64_t e = base + tid;               // element in scan order
-        unsigned v = 0;
-        int T = 0;
-        if (e < total) {
-            T = max_len - (int)(e / nblk);
-            v = hist[(size_t)T * nblk + (e % nblk)];
-        }
-        // inclusive scan within the block
-        unsigned long long x = v;
-        for (int o = 1; o < 64; o <<= 1) {
-            unsigned long long y = __shfl_up(x, o);
-            if ((tid & 63) >= o) x += y;
-        }
-        if ((tid & 63) == 63) wsum[tid >> 6] = x;
+    const int64_t per = (total + SORT_BLOCK - 1) / SORT_BLOCK;
+    const int64_t e0 = (int64_t)tid * per, e1 = e0 + per < total ? e0 + per : total;
+    auto at = [&](int64_t e) -> size_t { return (size_t)(max_len - (int)(e / nblk)) * nblk + (size_t)(e % nblk); };   // scan position -> hist index
+    unsigned long long s = 0;
+    for (int64_t e = e0; e < e1; ++e) s += hist[at(e)];
+    part[tid] = s;
+    __syncthreads();
+    for (int d = 1; d < SORT_BLOCK; d <<= 1) {
+        const unsigned long long v = tid >= d ? part[tid - d] : 0;
         __syncthreads();
-        unsigned long long pre = carry;
-        for (int w = 0; w < (tid >> 6); ++w) pre += wsum[w];
-        unsigned long long excl = pre + x - v;
-        if (e < total) {
-            hist[(size_t)T * nblk + (e % nblk)] = (uint32_t)excl;   // n < 2^31
-            if ((e % nblk) == 0 && len_start) len_start[T] = (int64_t)excl;
-        }
-        __syncthreads();
-        if (tid == SORT_BLOCK - 1) carry = pre + x;
+        part[tid] += v;
         __syncthreads();
     }
-    (void)steps;
+    unsigned long long run = part[tid] - s;
+    for (int64_t e = e0; e < e1; ++e) {
+        const size_t i = at(e);
+        const uint32_t v = hist[i];
+        hist[i] = (uint32_t)run;   // n < 2^31
+        if ((e % nblk) == 0 && len_start) len_start[max_len - (int)(e / nblk)] = (int64_t)run;
+        run += v;
+    }
     if (batch_sizes || total_steps) {
-        // batch_sizes[t] = #reads with T >= t+1 = len_start[t] (start of the first length <= t) ... computed from len_start:
-        // reads with T > t occupy sorted positions [0, len_start[t]) because lengths are descending.
+        // reads with T > t occupy sorted positions [0, len_start[t]) because lengths are descending: batch_sizes[t] = len_start[t]
+        __threadfence_block();
         __syncthreads();
         unsigned long long acc = 0;
         for (int t = tid; t < max_len; t += SORT_BLOCK) {
-            int64_t bs = len_start[t];
+            const int64_t bs = len_start[t];
             if (batch_sizes) batch_sizes[t] = bs;
             acc += (unsigned long long)bs;
         }
@@ -83,9 +76,9 @@ __global__ void rd_len_scan_kernel(uint32_t *__restrict__ hist, int max_len, int
         if ((tid & 63) == 0) wsum[tid >> 6] = acc;
         __syncthreads();
         if (tid == 0 && total_steps) {
-            unsigned long long s = 0;
-            for (int w = 0; w < SORT_BLOCK / 64; ++w) s += wsum[w];
-            *total_steps = (int64_t)s;
+            unsigned long long t = 0;
+            for (int w = 0; w < SORT_BLOCK / 64; ++w) t += wsum[w];
+            *total_steps = (int64_t)t;
         }
     }
 }

@@ -108,7 +108,7 @@ class Predictor:
             raise RuntimeError("config.json kernel.variant must be one of auto, mfma_f16x3_t32, mfma_f32, simple; got %r" % (variant,))
         self.model.set_variant(variant)
         self.model.set_semantics(getattr(self.args, 'semantics', None) or kcfg.get('semantics', 'gpu'))
-        # margin band of the float64 re-evaluation (config.json kernel.refine; 0 = off; default 5e-4). The CLI issues the pass
+        # margin band of the float64 re-evaluation (config.json kernel.refine; 0 = off; default 2.5e-4). The CLI issues the pass
         # itself on a side stream (submit_chunk), so the one inside rd_classify is switched off.
         self.refine_band = float(kcfg.get('refine', module_arch.SeqModel.REFINE_DEFAULT))
         self.model.set_refine(0.0)

@@ -133,13 +133,13 @@ class SeqModel:
         return self
 
     def set_refine(self, thresh):
-        """margin below which a read is re-evaluated in float64 (C ABI rd_set_refine; default 5e-4, 0 = off)"""
+        """margin below which a read is re-evaluated in float64 (C ABI rd_set_refine; default 2.5e-4, 0 = off)"""
         self._refine = float(thresh)
         if self._handle is not None:
             N.check(N.lib().rd_set_refine(self._handle, C.c_float(self._refine)), "rd_set_refine")
         return self
 
-    REFINE_DEFAULT = 5e-4
+    REFINE_DEFAULT = 2.5e-4
 
     def refine(self, arena, offsets, lens, max_len, logits, labels=None, mate_logits=None, thresh=None):
         """float64 re-evaluation (C ABI rd_refine) of the reads whose own margin - or, with `mate_logits`, whose PAIR margin

@@ -31,11 +31,11 @@ out = {}
 res = {}
 for v in ("auto", "mfma_f32", "simple"):
     model.set_variant(v)
-    for r in (0.0, 5e-4):
+    for r in (0.0, 2.5e-4):
         model.set_refine(r)
         lg, lab = model.classify_bytes(arena, offs, lens, L)
         res["%s/refine=%g" % (v, r)] = lg.clone()
-e = (res["auto/refine=0.0005"].double() - truth).abs().max(dim=1).values
+e = (res["auto/refine=0.00025"].double() - truth).abs().max(dim=1).values
 top = torch.topk(e, 5).indices.tolist()
 ora = O.load_default()
 for i in top:
