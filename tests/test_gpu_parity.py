@@ -622,3 +622,31 @@ def test_logit_tail_against_the_oracle_at_one_million_reads(gpu_model, oracle, r
                                    "label_mismatches": int(len(bad)), "largest_oracle_margin_among_mismatches": float(margin[bad].max()) if len(bad) else None}
     assert np.quantile(e, 0.9999) < 5e-5 and int((e > 1e-4).sum()) <= 3 and e.max() < 1e-3
     assert (margin[bad] < 2e-4).all()
+
+
+def test_classify_is_capturable_in_a_hip_graph(gpu_model):
+    """every launch of rd_classify (memset, steps, bucketing, recurrence, refine) is asynchronous on the caller's stream and nothing
+    synchronises, so a caller with small batches (the reference's 16,384-read batch) can capture the call in a hipGraph; the replay
+    gives bit-identical results on new bytes in the same buffers"""
+    from ribodetector_amd import synth
+    n, L = 16384, 100
+    a1, off, lens = synth.reads_torch(n, L, seed=5, device="cuda")
+    a2, _, _ = synth.reads_torch(n, L, seed=6, device="cuda")
+    offs = off[:-1].contiguous()
+    want1, wl1 = gpu_model.classify_bytes(a1, offs, lens, L)
+    want2, wl2 = gpu_model.classify_bytes(a2, offs, lens, L)
+    buf = a1.clone()
+    lg = torch.empty((n, 2), dtype=torch.float32, device="cuda")
+    lab = torch.empty((n,), dtype=torch.uint8, device="cuda")
+    gpu_model.classify_bytes(buf, offs, lens, L, logits=lg, labels=lab)       # workspace allocated before the capture
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        gpu_model.classify_bytes(buf, offs, lens, L, logits=lg, labels=lab)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(lg, want1) and torch.equal(lab, wl1)
+    buf.copy_(a2)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(lg, want2) and torch.equal(lab, wl2)

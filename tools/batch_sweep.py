@@ -42,6 +42,26 @@ def main():
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t) / reps
         out[n] = {"us_per_call": dt * 1e6, "reads_per_s": n / dt, "read_steps_per_s": n * L / dt}
+        # the same call captured in a hipGraph (every launch of rd_classify is asynchronous on the caller's stream, so it can be
+        # captured as is): what the seven launches per call cost at small batches
+        for refine in (True, False):
+            model.set_refine(M.SeqModel.REFINE_DEFAULT if refine else 0.0)
+            model.classify_bytes(arena, offs, lens, L, logits=logits, labels=labels)      # workspace allocated outside the capture
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                model.classify_bytes(arena, offs, lens, L, logits=logits, labels=labels)
+            for _ in range(3):
+                g.replay()
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(reps):
+                g.replay()
+            torch.cuda.synchronize()
+            dg = (time.perf_counter() - t) / reps
+            out[n]["graph_us_per_call" + ("" if refine else "_no_refine")] = dg * 1e6
+            out[n]["graph_reads_per_s" + ("" if refine else "_no_refine")] = n / dg
+        model.set_refine(M.SeqModel.REFINE_DEFAULT)
     print(json.dumps(out))
 
 
