@@ -303,6 +303,18 @@ __device__ __forceinline__ void rd_phase_t32(Lstm16bSmem &S, const f16x8 (&W1)[4
     if constexpr (FILL != 7) __syncthreads();   // FILL 7: bench diagnosis only (racy, wrong results): what the barrier costs
 }
 
+// The gate math of the last step of tile TP, after the loop: no tile is left whose MFMAs it could hide behind.
+template <int TP, int ACC>
+__device__ __forceinline__ void rd_phase_ewonly(Lstm16bSmem &S, f32x16 (&accP)[4], EwRegs &R, int tEW, int codeEW, int wave, int half,
+                                                int j, int tid) {
+    PhaseCtx c;
+    c.codeEW = codeEW; c.wave = wave; c.half = half; c.j = j; c.tid = tid;
+    c.last = (tEW == S.T[TP * 32 + j] - 1);
+    R.kc[0] = S.lut[wave][half][0][0][codeEW];
+    rd_ew_units<TP, 0, EW_NU, ACC>(S, R, accP, c);
+    __syncthreads();
+}
+
 template <int FILL, int ACC = 0>
 __global__ __launch_bounds__(256, 1) void rd_lstm_mfma_f16x3_t32_kernel(DevModel d, ReadBatch rb, float *__restrict__ logits,
                                                                         uint8_t *__restrict__ labels) {
@@ -381,24 +393,23 @@ __global__ __launch_bounds__(256, 1) void rd_lstm_mfma_f16x3_t32_kernel(DevModel
 #pragma unroll
     for (int a = 0; a < 4; ++a) { R0.call[a] = f32x4{0, 0, 0, 0}; R1.call[a] = f32x4{0, 0, 0, 0}; }
 
-    for (int t = 0; t <= tmax; ++t) {
-        const int tc = t < tmax ? t : 0;
-        const uint8_t *crow = &S.codes[(tc / TC16) & 1][tc % TC16][0];
+    for (int t = 0; t < tmax; ++t) {
+        const uint8_t *crow = &S.codes[(t / TC16) & 1][t % TC16][0];
         const int codeX = crow[j];            // (tile 0, step t): consumed by phase B's gate math
         const int codeYn = crow[32 + j];      // (tile 1, step t): consumed by the next iteration's phase A
         // phase A: MFMAs of (tile 0, t) -> X ; gate math of (tile 1, t-1) <- Y
         rd_phase_t32<0, FILL, ACC>(S, W1, W2, X, Y, R1, t - 1, codeY, wave, half, j, tid);
-        if (t < tmax) {
-            // next code chunk: its buffer was last read by the gate math of phase A above (step t-1)
-            if ((t % TC16) == 0) {
-                const int chunk = t / TC16 + 1;
-                if (chunk * TC16 < tmax + 1) rd_stage_codes16b(S, rb, chunk);
-            }
-            // phase B: MFMAs of (tile 1, t) -> Y ; gate math of (tile 0, t) <- X
-            rd_phase_t32<1, FILL, ACC>(S, W1, W2, Y, X, R0, t, codeX, wave, half, j, tid);
+        // next code chunk: its buffer was last read by the gate math of phase A above (step t-1)
+        if ((t % TC16) == 0) {
+            const int chunk = t / TC16 + 1;
+            if (chunk * TC16 < tmax + 1) rd_stage_codes16b(S, rb, chunk);
         }
+        // phase B: MFMAs of (tile 1, t) -> Y ; gate math of (tile 0, t) <- X
+        rd_phase_t32<1, FILL, ACC>(S, W1, W2, Y, X, R0, t, codeX, wave, half, j, tid);
         codeY = codeYn;
     }
+    // the gate math of (tile 1, tmax-1): gate math only (the loop used to run one more phase A whose 96 MFMAs computed nothing)
+    if constexpr (FILL >= 0) rd_phase_ewonly<1, ACC>(S, Y, R1, tmax - 1, codeY, wave, half, j, tid);
 
     rd_fc_epilogue(
         64, [&](int row, int u) { return S.Hl[row][u] * (1.0f / H_SCALE); }, S.T, S.Lr, S.off, S.orig, &S.wout[0][0], d, rb, logits,
