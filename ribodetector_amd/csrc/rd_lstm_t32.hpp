@@ -82,16 +82,18 @@ struct EwRegs {
 struct PhaseCtx {       // per-lane constants of a phase
     int codeEW, wave, half, j, tid;
     bool last;
+    bool any_last;      // wave-uniform: some read of this wave's tile finishes in this phase
 };
 
-// ACC: build options of the kernel. The product instantiates T32_PRODUCT (bits 16 + 32); the other bits are accuracy experiments
+// ACC: build options of the kernel. The product instantiates T32_PRODUCT (bits 16 + 32 + 64); the other bits are accuracy experiments
 // that exist only in diagnostic builds (-DRD_DIAG, tools/acc_experiment.py; results in DESIGN.md §4):
 //   1 = fourth product W2.H2 (the dropped lo x lo term)       2 = the small products first, W1.H1s last (H1s fragments read twice)
 //   4 = exp2 arguments formed from the fp32 pre-activation with a compensated product (table holds the raw in_lut rows)
 //   8 = one Newton step on every v_rcp_f32
 //   16 = gate math in 24 instead of 26 VALU ops per cell (scales folded into the reciprocals' arguments, see stage 4)
 //   32 = cell state kept in registers across phases instead of the LDS round trip
-constexpr int T32_PRODUCT = 16 | 32;
+//   64 = captured-h stores only in phases where a read of the wave finishes (wave-uniform branch; -0.26 %)
+constexpr int T32_PRODUCT = 16 | 32 | 64;
 __device__ __forceinline__ float rd_exp2c(float x, float khi, float klo) {   // 2^(x (khi + klo)), product error compensated
     const float t = x * khi;
     float e = __builtin_fmaf(x, khi, -t);
@@ -112,7 +114,10 @@ __device__ __forceinline__ void rd_ew_unit(Lstm16bSmem &S, EwRegs &R, const f32x
     constexpr int a = cell >> 2, b = cell & 3, k = cell & 1, ap = a & 1;
     if constexpr (stage == 0) {   // table row of the NEXT cell (this cell's row was fetched one cell ago); cell state per row-tile
         constexpr int nc = cell + 1;
-        if constexpr (nc < 16) R.kc[k ^ 1] = S.lut[c.wave][c.half][nc >> 2][nc & 3][c.codeEW];
+        if constexpr (nc < 16) {
+            if constexpr (ACC & 128) R.kc[k ^ 1] = R.kc[k];   // timing diagnosis only (WRONG results): what the 16 table-row reads cost
+            else R.kc[k ^ 1] = S.lut[c.wave][c.half][nc >> 2][nc & 3][c.codeEW];
+        }
         if constexpr (b == 0 && !(ACC & 32)) R.cs[ap] = S.cS[TP][a][c.tid];
     } else if constexpr (stage == 1) {
         // exp2 arguments. Scalar FMAs on purpose: packed fp32 ops (v_pk_fma_f32 / v_pk_add_f32) cost ~10 cycles each beside
@@ -207,8 +212,15 @@ __device__ __forceinline__ void rd_ew_unit(Lstm16bSmem &S, EwRegs &R, const f32x
         *reinterpret_cast<f16x4 *>(&S.H1s[TP][0][0] + wo) = R.o1s[ap];
         *reinterpret_cast<f16x4 *>(&S.H2[TP][0][0] + wo) = R.o2[ap];
         if constexpr (!(ACC & 32)) S.cS[TP][a][c.tid] = R.cs[ap];
+        if constexpr (ACC & 64) {   // experiment: skip the captured-h store unless a read of this wave finishes in this phase
+            if (c.any_last) {
+                f32x4 *dst = c.last ? reinterpret_cast<f32x4 *>(&S.Hl[TP * 32 + c.j][32 * c.wave + 16 * c.half + 4 * a]) : &S.dummy[c.tid];
+                *dst = R.hv[ap];
+            }
+        } else {
         f32x4 *dst = c.last ? reinterpret_cast<f32x4 *>(&S.Hl[TP * 32 + c.j][32 * c.wave + 16 * c.half + 4 * a]) : &S.dummy[c.tid];
         *dst = R.hv[ap];
+        }
     }
 }
 
@@ -293,6 +305,7 @@ __device__ __forceinline__ void rd_phase_t32(Lstm16bSmem &S, const f16x8 (&W1)[4
     PhaseCtx c;
     c.codeEW = codeEW; c.wave = wave; c.half = half; c.j = j; c.tid = tid;
     c.last = (tEW == S.T[TP * 32 + j] - 1);
+    c.any_last = __builtin_amdgcn_ballot_w64(c.last) != 0;
     R.kc[0] = S.lut[wave][half][0][0][codeEW];
     if (FILL > 0) __builtin_amdgcn_sched_barrier(0);
     rd_slots<TL, (FILL > 0 ? FILL : 0), 0, ACC>(S, W1, W2, accC, accP, Bf, R, c, h1s, h2);
@@ -310,6 +323,7 @@ __device__ __forceinline__ void rd_phase_ewonly(Lstm16bSmem &S, f32x16 (&accP)[4
     PhaseCtx c;
     c.codeEW = codeEW; c.wave = wave; c.half = half; c.j = j; c.tid = tid;
     c.last = (tEW == S.T[TP * 32 + j] - 1);
+    c.any_last = __builtin_amdgcn_ballot_w64(c.last) != 0;
     R.kc[0] = S.lut[wave][half][0][0][codeEW];
     rd_ew_units<TP, 0, EW_NU, ACC>(S, R, accP, c);
     __syncthreads();
