@@ -477,6 +477,14 @@ int rd_host_count_records(const char *path, int format, int64_t start, int64_t e
     RangeFile f;
     if (!f.open_path(path)) RDH_FAIL("cannot open %s", path);
     if (end > f.size) end = f.size;
+    if (end == f.size) {   // trailing blank lines at the end of the file are not records (the reader tolerates them too)
+        while (end > start) {
+            const int c = f.byte_at(end - 1);
+            if (c < 0) RDH_FAIL("read error in %s", path);
+            if (!is_ws((unsigned char)c)) break;
+            --end;
+        }
+    }
     int64_t lines = 0, headers = 0, at = start;
     bool line_start = true;
     while (at < end) {

@@ -373,3 +373,26 @@ def test_byte_range_sharding_edge_cases(tmp_path):
     assert fx.file_info(gz)[1] and not fx.file_info(p1)[1]
     with pytest.raises(ValueError, match="gzip"):
         fx.NativeReader(gz, byte_range=(0, 10))
+
+
+def test_byte_range_sharding_crlf_and_trailing_blank_lines(tmp_path):
+    """CRLF line ends, a last line without terminator in one mate and blank lines at the end of the other: the ranks'
+    ranges still hold the same record indices and parse to the whole file's records"""
+    rng = np.random.default_rng(9)
+    p1, p2 = str(tmp_path / "c_1.fq"), str(tmp_path / "c_2.fq")
+    r1, r2 = [], []
+    for i in range(300):
+        L = int(rng.integers(1, 90))
+        s = "".join("ACGT"[k] for k in rng.integers(0, 4, L))
+        r1.append("@a%d\r\n%s\r\n+\r\n%s" % (i, s, "I" * L))
+        r2.append("@b%d xx\n%s\n+\n%s" % (i, s[::-1], "@" * L))
+    open(p1, "w", newline="").write("\r\n".join(r1))                 # no terminator after the last line
+    open(p2, "w", newline="").write("\n".join(r2) + "\n\n\n\n")     # three blank lines at the end (what the reader tolerates)
+    whole1, whole2 = _range_records(p1), _range_records(p2)
+    assert len(whole1) == 300 == len(whole2)
+    for world in (2, 3, 7):
+        plans = _plan_all([p1, p2], world)
+        got1 = [_range_records(p1, byte_range=pl[0]) for pl in plans]
+        got2 = [_range_records(p2, byte_range=pl[1]) for pl in plans]
+        assert sum(got1, []) == whole1 and sum(got2, []) == whole2
+        assert [len(g) for g in got1] == [len(g) for g in got2]
