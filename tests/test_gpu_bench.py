@@ -58,6 +58,22 @@ def test_bench_self_launches_two_ranks_one_gpu():
     assert abs(j["value"] - 2 * 2 * 65536 * 3 / (j["ms_per_step"] * 3e-3)) < 1e-6 * j["value"]     # whole-job aggregate
 
 
+def test_bench_self_launches_eight_ranks_one_gpu():
+    """the driver's largest point (--gpus 8) as far as a 1-GPU box can take it: eight ranks share the GPU, labels over gloo"""
+    env = dict(os.environ, RD_DIST_BACKEND="gloo", RD_LOCAL_DEVICE="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, "bench.py", "--gpus", "8", "--steps", "2", "--warmup", "1", "--pairs-per-step", "16384", "--no-alt",
+           "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    j = _line(r.stdout)
+    assert j["n_gpus"] == 8 and j["config"]["rccl_ranks"] == 8
+    assert abs(j["value"] - 2 * 8 * 16384 * 2 / (j["ms_per_step"] * 2e-3)) < 1e-6 * j["value"]
+    c = j["config"]["label_counts"]
+    assert c["non_rrna"] + c["rrna"] + c["unclassified"] == 8 * 16384 * 2
+
+
 def test_bench_under_torchrun_two_ranks_one_gpu():
     """the driver's own launch form: python -m torch.distributed.run ... bench.py --gpus 2"""
     s = socket.socket()

@@ -101,8 +101,8 @@ def test_cli_fasta_and_cpu_semantics(tmp_path, oracle):
         assert _read(out) == want
 
 
-@pytest.mark.parametrize("suffix", ["", ".gz"])
-def test_cli_two_ranks_match_one(tmp_path, suffix):
+@pytest.mark.parametrize("suffix,world", [("", 2), (".gz", 2), ("", 3)])
+def test_cli_two_ranks_match_one(tmp_path, suffix, world):
     """torchrun x2 (both ranks on this box's one GPU, exchange over gloo) must write the same files as one process.
     Plain input: every rank parses only its own byte range (mates cut at the same record index), writes its own parts, rank 0
     joins them - each rank reads about half of the bytes. gzip input: every rank parses the stream, classifies a work-balanced
@@ -127,7 +127,7 @@ def test_cli_two_ranks_match_one(tmp_path, suffix):
     port = s.getsockname()[1]
     s.close()
     env = dict(os.environ, RD_DIST_BACKEND="gloo", RD_LOCAL_DEVICE="0", PYTHONPATH=root)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(port), "-m", "ribodetector_amd.detect", "-l", "120", "-i", i1, i2, "-o", *two[:2], "-r", *two[2:],
            "-e", "both", "--chunk_size", "1", "-m", "3"]
     r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
@@ -141,9 +141,9 @@ def test_cli_two_ranks_match_one(tmp_path, suffix):
     assert "Processed" in text and str(n) in text
     if not suffix:
         rows = re.findall(r"Rank (\d) parses (\d+), (\d+) bytes of (\d+), (\d+)", text)
-        assert len(rows) == 2
+        assert len(rows) == world
         for rk, b1, b2, t1, t2 in rows:
-            assert 0.4 < int(b1) / int(t1) < 0.6 and 0.4 < int(b2) / int(t2) < 0.6         # half of each file per rank
+            assert 0.8 / world < int(b1) / int(t1) < 1.2 / world and 0.8 / world < int(b2) / int(t2) < 1.2 / world   # 1/W of each file per rank
         assert sum(int(x[1]) for x in rows) == os.path.getsize(i1) and sum(int(x[2]) for x in rows) == os.path.getsize(i2)
     else:
         assert "parses" not in text
