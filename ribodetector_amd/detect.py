@@ -432,8 +432,20 @@ def main(argv=None):
     config_file = os.path.join(cd, 'config.json') if args.config is None else args.config
     config = ConfigParser.from_json(config_file)
     seq_pred = Predictor(config, args)
-    seq_pred.load_model()
-    seq_pred.detect()
+    try:
+        seq_pred.load_model()
+        seq_pred.detect()
+    except BaseException:
+        if seq_pred.world > 1:
+            # a rank that fails must not leave the others waiting in a collective (and must not wait in one itself while the
+            # interpreter shuts down): report and leave at once - torch.distributed.run then tears the other ranks down
+            import sys
+            import traceback
+            traceback.print_exc()
+            sys.stdout.flush()
+            sys.stderr.flush()
+            os._exit(1)
+        raise
     return seq_pred
 
 

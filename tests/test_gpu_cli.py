@@ -149,6 +149,35 @@ def test_cli_two_ranks_match_one(tmp_path, suffix, world):
         assert "parses" not in text
 
 
+def test_cli_failing_rank_ends_the_job(tmp_path):
+    """two ranks, plain FASTQ cut inside its last record: only rank 1's byte range holds the damage. Rank 1 reports it and leaves;
+    rank 0 must not wait forever in the closing all-reduce - the launcher ends the job with a non-zero status"""
+    import socket
+    import subprocess
+    import sys
+    import time
+    from ribodetector_amd import synth
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    arena, off, _ = synth.reads_numpy(20000, 100, seed=71)
+    good = str(tmp_path / "g.fq")
+    synth.write_fastq(good, arena, off, 1)
+    blob = open(good, "rb").read()
+    cut = str(tmp_path / "cut.fq")
+    open(cut, "wb").write(blob[: len(blob) - 150])
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, RD_DIST_BACKEND="gloo", RD_LOCAL_DEVICE="0", PYTHONPATH=root)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "-m", "ribodetector_amd.detect", "-l", "100", "-i", cut, "-o", str(tmp_path / "o.fq"),
+           "--chunk_size", "1", "-m", "3"]
+    t0 = time.time()
+    r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and time.time() - t0 < 200
+    assert "truncated FASTQ record" in r.stderr + r.stdout
+
+
 def test_cli_damaged_input_is_an_error(tmp_path):
     """a truncated .gz (or a FASTQ cut inside a record) stops the run with an error instead of writing a short output"""
     from ribodetector_amd import detect, synth
