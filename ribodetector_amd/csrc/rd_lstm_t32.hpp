@@ -77,6 +77,7 @@ struct EwRegs {
     f32x4 cs[2], hv[2]; // per row-tile, by row-tile parity
     f16x4 o1s[2], o2[2];
     f32x4 call[4];      // ACC & 32: the tile's cell state, resident across phases
+    float nm[2];        // ACC & 128: numerators K (e_g - 1) resp. (e_c - 1) of the shared-reciprocal form
 };
 
 struct PhaseCtx {       // per-lane constants of a phase
@@ -85,7 +86,7 @@ struct PhaseCtx {       // per-lane constants of a phase
     bool any_last;      // wave-uniform: some read of this wave's tile finishes in this phase
 };
 
-// ACC: build options of the kernel. The product instantiates T32_PRODUCT (bits 16 + 32 + 64); the other bits are accuracy experiments
+// ACC: build options of the kernel. The product instantiates T32_PRODUCT (bits 16 + 32 + 64 + 128); the other bits are accuracy experiments
 // that exist only in diagnostic builds (-DRD_DIAG, tools/acc_experiment.py; results in DESIGN.md §4):
 //   1 = fourth product W2.H2 (the dropped lo x lo term)       2 = the small products first, W1.H1s last (H1s fragments read twice)
 //   4 = exp2 arguments formed from the fp32 pre-activation with a compensated product (table holds the raw in_lut rows)
@@ -93,7 +94,12 @@ struct PhaseCtx {       // per-lane constants of a phase
 //   16 = gate math in 24 instead of 26 VALU ops per cell (scales folded into the reciprocals' arguments, see stage 4)
 //   32 = cell state kept in registers across phases instead of the LDS round trip
 //   64 = captured-h stores only in phases where a read of the wave finishes (wave-uniform branch; -0.26 %)
-constexpr int T32_PRODUCT = 16 | 32 | 64;
+//   128 = shared reciprocals: sigmoid(i) tanh(g) = (e_g - 1) / ((1 + e_i)(1 + e_g)) and sigmoid(o) tanh(c) likewise: 8 instead of 10
+//         transcendentals per cell for 4 more plain VALU ops; the only clamp needed is on the exp2 argument of g and c (<= 64)
+//   256 = timing diagnosis (wrong results): table rows not fetched
+//   512 = (with 128) ONE reciprocal for the whole cell update: c' = (c' (1+e_i)(1+e_g) + K (e_g - 1)(1+e_f)) / ((1+e_f)(1+e_i)(1+e_g)),
+//         exp2 arguments of i, f, g clamped to <= 40 so that the triple product stays below 2^128: 7 transcendentals per cell
+constexpr int T32_PRODUCT = 16 | 32 | 64 | 128;
 __device__ __forceinline__ float rd_exp2c(float x, float khi, float klo) {   // 2^(x (khi + klo)), product error compensated
     const float t = x * khi;
     float e = __builtin_fmaf(x, khi, -t);
@@ -115,7 +121,7 @@ __device__ __forceinline__ void rd_ew_unit(Lstm16bSmem &S, EwRegs &R, const f32x
     if constexpr (stage == 0) {   // table row of the NEXT cell (this cell's row was fetched one cell ago); cell state per row-tile
         constexpr int nc = cell + 1;
         if constexpr (nc < 16) {
-            if constexpr (ACC & 128) R.kc[k ^ 1] = R.kc[k];   // timing diagnosis only (WRONG results): what the 16 table-row reads cost
+            if constexpr (ACC & 256) R.kc[k ^ 1] = R.kc[k];   // timing diagnosis only (WRONG results): what the 16 table-row reads cost
             else R.kc[k ^ 1] = S.lut[c.wave][c.half][nc >> 2][nc & 3][c.codeEW];
         }
         if constexpr (b == 0 && !(ACC & 32)) R.cs[ap] = S.cS[TP][a][c.tid];
@@ -137,16 +143,23 @@ __device__ __forceinline__ void rd_ew_unit(Lstm16bSmem &S, EwRegs &R, const f32x
         if constexpr (ACC & 4) {
             R.v[k][0][0] = rd_exp2c(R.v[k][0][0], KS_HI, KS_LO); R.v[k][0][1] = rd_exp2c(R.v[k][0][1], KS_HI, KS_LO);
         } else {
-        R.v[k][0][0] = __builtin_amdgcn_exp2f(R.v[k][0][0]); R.v[k][0][1] = __builtin_amdgcn_exp2f(R.v[k][0][1]);
+        if constexpr (ACC & 512) { R.v[k][0][0] = __builtin_amdgcn_exp2f(fminf(R.v[k][0][0], 40.0f)); R.v[k][0][1] = __builtin_amdgcn_exp2f(fminf(R.v[k][0][1], 40.0f)); }
+        else { R.v[k][0][0] = __builtin_amdgcn_exp2f(R.v[k][0][0]); R.v[k][0][1] = __builtin_amdgcn_exp2f(R.v[k][0][1]); }
         }
     } else if constexpr (stage == 3) {
         if constexpr (ACC & 4) {
             R.v[k][1][0] = rd_exp2c(R.v[k][1][0], KT_HI, KT_LO); R.v[k][1][1] = rd_exp2c(R.v[k][1][1], KS_HI, KS_LO);
         } else {
-        R.v[k][1][0] = __builtin_amdgcn_exp2f(R.v[k][1][0]); R.v[k][1][1] = __builtin_amdgcn_exp2f(R.v[k][1][1]);
+        if constexpr (ACC & 128) R.v[k][1][0] = __builtin_amdgcn_exp2f(fminf(R.v[k][1][0], (ACC & 512) ? 40.0f : 64.0f));   // e_g stays finite: (e_g - 1) * rcp(inf) must not be inf * 0
+        else R.v[k][1][0] = __builtin_amdgcn_exp2f(R.v[k][1][0]);
+        R.v[k][1][1] = __builtin_amdgcn_exp2f(R.v[k][1][1]);
         }
     } else if constexpr (stage == 4) {
-        if constexpr (ACC & 16) {
+        if constexpr (ACC & 128) {
+            R.nm[k] = __builtin_fmaf(R.v[k][1][0], KT, -KT);                                        // KT (e_g - 1)
+            R.v[k][0][0] += 1.0f; R.v[k][0][1] += 1.0f; R.v[k][1][0] += 1.0f;                      // 1 + e_i, 1 + e_f, 1 + e_g
+            R.v[k][1][1] = __builtin_fmaf(R.v[k][1][1], 1.0f / H_SCALE, 1.0f / H_SCALE);            // (1 + e_o) 2^-11
+        } else if constexpr (ACC & 16) {
             // the constants the gates are multiplied with later are folded into the reciprocals' arguments (an FMA instead of
             // an add, nothing else): 1/((1+e)/KT) = KT sigmoid(i),  1/(-(1+e)/2) = -2/(1+e) = tanh(g) - 1,  1/((1+e) 2^-11) = 2^11 sigmoid(o)
             R.v[k][0][0] = __builtin_fmaf(R.v[k][0][0], 1.0f / KT, 1.0f / KT); R.v[k][0][1] += 1.0f;
@@ -156,9 +169,15 @@ __device__ __forceinline__ void rd_ew_unit(Lstm16bSmem &S, EwRegs &R, const f32x
         R.v[k][1][0] += 1.0f; R.v[k][1][1] += 1.0f;
         }
     } else if constexpr (stage == 5) {
+        if constexpr (ACC & 512) { R.v[k][0][0] *= R.v[k][1][0]; R.v[k][1][0] = R.v[k][0][1] * R.v[k][0][0]; }   // AB = (1+e_i)(1+e_g); F AB
+        else if constexpr (ACC & 128) { R.v[k][0][1] = (ACC & 8) ? rd_rcp_nr(R.v[k][0][1]) : __builtin_amdgcn_rcpf(R.v[k][0][1]); R.v[k][0][0] *= R.v[k][1][0]; }   // f; (1+e_i)(1+e_g)
+        else
         if constexpr (ACC & 8) { R.v[k][0][0] = rd_rcp_nr(R.v[k][0][0]); R.v[k][0][1] = rd_rcp_nr(R.v[k][0][1]); }
         else { R.v[k][0][0] = __builtin_amdgcn_rcpf(R.v[k][0][0]); R.v[k][0][1] = __builtin_amdgcn_rcpf(R.v[k][0][1]); }
     } else if constexpr (stage == 6) {
+        if constexpr (ACC & 512) R.v[k][1][0] = __builtin_amdgcn_rcpf(R.v[k][1][0]);   // 1 / (F AB)
+        else if constexpr (ACC & 128) R.v[k][0][0] = (ACC & 8) ? rd_rcp_nr(R.v[k][0][0]) : __builtin_amdgcn_rcpf(R.v[k][0][0]);
+        else
         if constexpr (ACC & 8) { R.v[k][1][0] = rd_rcp_nr(R.v[k][1][0]); R.v[k][1][1] = rd_rcp_nr(R.v[k][1][1]); }
         else { R.v[k][1][0] = __builtin_amdgcn_rcpf(R.v[k][1][0]); R.v[k][1][1] = __builtin_amdgcn_rcpf(R.v[k][1][1]); }
     } else if constexpr (stage == 7) {
@@ -167,7 +186,11 @@ __device__ __forceinline__ void rd_ew_unit(Lstm16bSmem &S, EwRegs &R, const f32x
         if constexpr (ACC & 32) cst = R.call[a][b];
         else cst = R.cs[ap][b];
         float cn;
-        if constexpr (ACC & 16) {   // KT i tanh(g) = i' (1 + y') with i' = KT sigmoid(i), y' = tanh(g) - 1: one FMA
+        if constexpr (ACC & 512) {   // (c' AB + KT (e_g - 1) F) / (F AB)
+            cn = __builtin_fmaf(R.nm[k], R.v[k][0][1], cst * R.v[k][0][0]) * R.v[k][1][0];
+        } else if constexpr (ACC & 128) {   // KT sigmoid(i) tanh(g) = KT (e_g - 1) / ((1 + e_i)(1 + e_g))
+            cn = __builtin_fmaf(R.v[k][0][1], cst, R.nm[k] * R.v[k][0][0]);
+        } else if constexpr (ACC & 16) {   // KT i tanh(g) = i' (1 + y') with i' = KT sigmoid(i), y' = tanh(g) - 1: one FMA
             cn = __builtin_fmaf(R.v[k][0][1], cst, __builtin_fmaf(R.v[k][0][0], R.v[k][1][0], R.v[k][0][0]));
         } else {
         const float gg = __builtin_fmaf(-2.0f * KT, R.v[k][1][0], KT);
@@ -178,14 +201,21 @@ __device__ __forceinline__ void rd_ew_unit(Lstm16bSmem &S, EwRegs &R, const f32x
         R.y[k] = cn;
         R.og[k] = R.v[k][1][1];
     } else if constexpr (stage == 8) {
-        R.y[k] = __builtin_amdgcn_exp2f(R.y[k]);
+        if constexpr (ACC & 128) R.y[k] = __builtin_amdgcn_exp2f(fminf(R.y[k], 64.0f));
+        else R.y[k] = __builtin_amdgcn_exp2f(R.y[k]);
     } else if constexpr (stage == 9) {
+        if constexpr (ACC & 128) {   // 2^11 sigmoid(o) tanh(c) = (e_c - 1) / ((1 + e_o) 2^-11 (1 + e_c))
+            R.nm[k] = R.y[k] - 1.0f;
+            R.y[k] = R.og[k] * (R.y[k] + 1.0f);
+        } else
         if constexpr (ACC & 16) R.y[k] = __builtin_fmaf(R.y[k], -0.5f, -0.5f);   // reciprocal = tanh(c) - 1
         else R.y[k] = 1.0f + R.y[k];
     } else if constexpr (stage == 10) {
         if constexpr (ACC & 8) R.y[k] = rd_rcp_nr(R.y[k]);
         else R.y[k] = __builtin_amdgcn_rcpf(R.y[k]);
     } else if constexpr (stage == 11) {
+        if constexpr (ACC & 128) R.hs[k] = R.nm[k] * R.y[k];
+        else
         if constexpr (ACC & 16) R.hs[k] = __builtin_fmaf(R.og[k], R.y[k], R.og[k]);   // o' (1 + (tanh(c) - 1)), o' = 2^11 sigmoid(o)
         else
         R.hs[k] = R.og[k] * __builtin_fmaf(-2.0f * H_SCALE, R.y[k], H_SCALE);   // 2^11 h = 2^11 o tanh(c)
