@@ -233,7 +233,7 @@ int rd_classify(const rd_model *cm, const uint8_t *arena, const int64_t *seq_off
         const dim3 grid((unsigned)nwg), blk(256);
         switch (m->variant) {
         case RD_VARIANT_MFMA_F16X3_T32: hipLaunchKernelGGL((rd_lstm_mfma_f16x3_t32_kernel<6, T32_PRODUCT>), grid, blk, 0, st, m->d, rb, logits, labels); break;
-        case RD_VARIANT_MFMA_F32: hipLaunchKernelGGL((rd_lstm_mfma_f32_kernel<1, 0>), grid, blk, 0, st, m->d, rb, logits, labels); break;
+        case RD_VARIANT_MFMA_F32: hipLaunchKernelGGL((rd_lstm_mfma_f32_kernel<2, 0>), grid, blk, 0, st, m->d, rb, logits, labels); break;
 #ifdef RD_DIAG
         case 10: hipLaunchKernelGGL((rd_lstm_mfma_f32_kernel<0, 0>), grid, blk, 0, st, m->d, rb, logits, labels); break;
         case 11: hipLaunchKernelGGL((rd_lstm_mfma_f32_kernel<1, 0>), grid, blk, 0, st, m->d, rb, logits, labels); break;

@@ -60,7 +60,7 @@ __device__ __forceinline__ float act_tanh(float x) {
     return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * 2.88539008177792681f)), 1.0f);
 }
 
-// ACT: 0 = compensated exp, 1 = plain v_exp_f32 forms.  SCHED: 0 = compiler's own order, 1 = LDS reads of the gate math
+// ACT: 0 = compensated exp, 1 = plain v_exp_f32 forms (round 1), 2 = shared reciprocals (the product).  SCHED: 0 = compiler's own order, 1 = LDS reads of the gate math
 // pinned to the top of the phase + explicit MFMA/VALU interleave (sched_group_barrier).
 template <int ACT, int SCHED, int DIAG = 0>   // DIAG (bench diagnosis only, wrong results): 1 = no gate math, 2 = no MFMA
 __global__ __launch_bounds__(256, 1) void rd_lstm_mfma_f32_kernel(DevModel d, ReadBatch rb, float *__restrict__ logits,
@@ -201,9 +201,23 @@ __global__ __launch_bounds__(256, 1) void rd_lstm_mfma_f32_kernel(DevModel d, Re
                     const float gf = accP[2 + s][r] + lv[r][0][2 + s];
                     const float gg = accP[4 + s][r] + lv[r][1][0 + s];
                     const float go = accP[6 + s][r] + lv[r][1][2 + s];
-                    float cn = __builtin_fmaf(act_sigmoid<ACT>(gf), cs[s][r], act_sigmoid<ACT>(gi) * act_tanh<ACT>(gg));
-                    cn *= live;
-                    const float h = act_sigmoid<ACT>(go) * act_tanh<ACT>(cn) * live;
+                    float cn, h;
+                    if constexpr (ACT == 2) {
+                        // shared reciprocals (as in the default kernel, rd_lstm_t32.hpp): sigmoid(i) tanh(g) = (e_g - 1) / ((1 + e_i)(1 + e_g)),
+                        // sigmoid(o) tanh(c) likewise - 8 instead of 10 transcendentals per cell and less rounding noise; the exp2
+                        // arguments of g and c are capped so that e stays finite (a saturated neighbour then gives finite * 0)
+                        const float ei = __builtin_amdgcn_exp2f(gi * -1.44269504088896341f), ef = __builtin_amdgcn_exp2f(gf * -1.44269504088896341f);
+                        const float eg = __builtin_amdgcn_exp2f(fminf(gg * 2.88539008177792681f, 64.0f));
+                        const float eo = __builtin_amdgcn_exp2f(go * -1.44269504088896341f);
+                        const float u = (eg - 1.0f) * __builtin_amdgcn_rcpf((1.0f + ei) * (1.0f + eg));
+                        cn = __builtin_fmaf(__builtin_amdgcn_rcpf(1.0f + ef), cs[s][r], u) * live;
+                        const float ec = __builtin_amdgcn_exp2f(fminf(cn * 2.88539008177792681f, 64.0f));
+                        h = (ec - 1.0f) * __builtin_amdgcn_rcpf((1.0f + eo) * (1.0f + ec)) * live;
+                    } else {
+                        cn = __builtin_fmaf(act_sigmoid<ACT>(gf), cs[s][r], act_sigmoid<ACT>(gi) * act_tanh<ACT>(gg));
+                        cn *= live;
+                        h = act_sigmoid<ACT>(go) * act_tanh<ACT>(cn) * live;
+                    }
                     cs[s][r] = cn;
                     const int row = 4 * q + r, u = 32 * wave + 16 * s + l15;
                     S.Hs[ptile][row][u] = h;
