@@ -81,3 +81,28 @@ def test_gate_math_schedule_is_reproducible():
     root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "gen_ew_schedule.py"), "--check"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_part_files_of_the_sharded_cli(tmp_path):
+    """every rank writes '<output>.part<r>' (gzip outputs keep a name that ends in 'gz': the writer compresses by name) and rank 0
+    joins the parts in rank order; a concatenation of gzip members is a valid gzip file"""
+    import gzip
+    from ribodetector_amd.detect import part_path
+    from ribodetector_amd.data_loader import fastx_parser as fx
+    assert part_path("out/n.fq", 3) == "out/n.fq.part3"
+    assert part_path("out/n.fq.gz", 0) == "out/n.fq.part0.gz" and part_path("o.fq.unclassified.gz", 7).endswith(".part7.gz")
+    final = str(tmp_path / "joined.fq.gz")
+    parts = [part_path(final, r) for r in range(3)]
+    blobs = [b"@a\nAC\n+\nII\n" * 1000, b"", b"@b\nGT\n+\nII\n" * 7]
+    for p, b in zip(parts, blobs):
+        with gzip.open(p, "wb") as fh:
+            fh.write(b)
+    fx.concatenate_parts(final, parts)
+    assert gzip.open(final, "rb").read() == b"".join(blobs)
+    assert not any(os.path.exists(p) for p in parts)
+    plain = str(tmp_path / "joined.fq")
+    pp = [part_path(plain, r) for r in range(2)]
+    open(pp[0], "wb").write(b"x" * 5)
+    open(pp[1], "wb").write(b"y" * 3)
+    fx.concatenate_parts(plain, pp)
+    assert open(plain, "rb").read() == b"xxxxxyyy"
