@@ -407,3 +407,30 @@ def concatenate_parts(final_path, part_paths):
                     off += k
                     left -= k
             os.remove(p)
+
+
+def place_part(final_path, part_path, offset):
+    """copy a part file into `final_path` at byte `offset` (the file exists at its full size already) and remove the part: the
+    multi-rank CLI's ranks join their parts concurrently, each at the offset that the sizes of the lower ranks' parts give.
+    copy_file_range keeps the bytes inside the kernel; a plain pread/pwrite loop is the fallback where it is not supported."""
+    import os
+    src = os.open(part_path, os.O_RDONLY)
+    dst = os.open(final_path, os.O_WRONLY)
+    try:
+        left = os.fstat(src).st_size
+        so, do = 0, int(offset)
+        while left > 0:
+            try:
+                k = os.copy_file_range(src, dst, min(left, 1 << 30), so, do)
+            except (OSError, AttributeError):
+                buf = os.pread(src, min(left, 8 << 20), so)
+                k = os.pwrite(dst, buf, do)
+            if k <= 0:
+                raise OSError("copy stalled while placing %s" % part_path)
+            so += k
+            do += k
+            left -= k
+    finally:
+        os.close(src)
+        os.close(dst)
+    os.remove(part_path)

@@ -333,9 +333,18 @@ class Predictor:
                                device=self.device if dist.get_backend() == 'nccl' else 'cpu')
             dist.all_reduce(tot, op=dist.ReduceOp.SUM)          # also the barrier: every part file is closed before the merge
             num_read, num_nonrrna, num_rrna, num_unknown = (int(x) for x in tot.cpu().tolist())
+            # join the parts (rank order = input order) concurrently: every rank copies its own part to the offset that the sizes
+            # of the lower ranks' parts give; gzip parts are complete members, whose concatenation is a valid gzip file
+            mine = [os.path.getsize(part_path(path, self.rank)) for path in finals]
+            sizes = [None] * self.world
+            dist.all_gather_object(sizes, mine)
             if self.rank == 0:
-                for path in finals:
-                    fx.concatenate_parts(path, [part_path(path, r) for r in range(self.world)])
+                for f, path in enumerate(finals):
+                    with open(path, 'wb') as fh:
+                        fh.truncate(sum(sz[f] for sz in sizes))
+            dist.barrier()
+            for f, path in enumerate(finals):
+                fx.place_part(path, part_path(path, self.rank), sum(sizes[r][f] for r in range(self.rank)))
             dist.barrier()
         if self.rank == 0:
             self.logger.info('Processed {}{}{}{} sequences in total'.format(colors.BOLD, colors.OKCYAN, num_read, colors.ENDC))

@@ -100,6 +100,19 @@ def test_part_files_of_the_sharded_cli(tmp_path):
     fx.concatenate_parts(final, parts)
     assert gzip.open(final, "rb").read() == b"".join(blobs)
     assert not any(os.path.exists(p) for p in parts)
+    # the concurrent form: the final file is created at its full size, every part is placed at its offset (any order)
+    final2 = str(tmp_path / "placed.fq.gz")
+    parts2 = [part_path(final2, r) for r in range(3)]
+    comp = []
+    for p, b in zip(parts2, blobs):
+        with gzip.open(p, "wb") as fh:
+            fh.write(b)
+        comp.append(os.path.getsize(p))
+    with open(final2, "wb") as fh:
+        fh.truncate(sum(comp))
+    for r in (2, 0, 1):
+        fx.place_part(final2, parts2[r], sum(comp[:r]))
+    assert gzip.open(final2, "rb").read() == b"".join(blobs) and not any(os.path.exists(p) for p in parts2)
     plain = str(tmp_path / "joined.fq")
     pp = [part_path(plain, r) for r in range(2)]
     open(pp[0], "wb").write(b"x" * 5)
