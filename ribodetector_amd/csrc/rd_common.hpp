@@ -79,6 +79,7 @@ struct DevModel {
     float *w_out;     // [2][256]
     float *b_out;     // [2]
     uint32_t *wpack16b; // f16x3 32x32x16 A operand
+    float *lut_t32;     // in_lut in the LDS layout of the default kernel: [wave][half][a][b][code 0..5][gate], exp2-argument scale folded in
     float *rev_tab;     // padded (ribodetector_cpu) semantics: [max_len][5][2] reverse-direction logit terms, see rd_revtab_kernel
 };
 

@@ -65,6 +65,7 @@ int rd_model_create(const rd_weights *w, int device, rd_model **out) {
     A((void **)&m->d.wt_hh, sizeof(float) * HID * G4);
     A((void **)&m->d.wpack16b, sizeof(uint16_t) * 4 * 2 * 4 * 8 * 64 * 8);
     A((void **)&m->d.in_lut, sizeof(float) * 5 * G4);
+    A((void **)&m->d.lut_t32, sizeof(float) * 4 * 2 * 4 * 4 * 6 * 4);
     A((void **)&m->d.rev_lut, sizeof(float) * 10);
     A((void **)&m->d.rev_tab, sizeof(float) * (size_t)MAX_LEN_LIMIT * 10);
     A((void **)&m->d.w_out, sizeof(float) * 512);
@@ -91,6 +92,7 @@ void rd_model_destroy(rd_model *m) {
     hipFree(m->d.raw); hipFree(m->d.wpack32); hipFree(m->d.wt_hh); hipFree(m->d.in_lut);
     hipFree(m->d.rev_lut); hipFree(m->d.rev_tab); hipFree(m->d.w_out); hipFree(m->d.b_out);
     if (m->d.wpack16b) hipFree(m->d.wpack16b);
+    if (m->d.lut_t32) hipFree(m->d.lut_t32);
     for (int i = 0; i < 2 * 512; ++i)
         if (m->prof_ev[i]) hipEventDestroy(m->prof_ev[i]);
     delete m;

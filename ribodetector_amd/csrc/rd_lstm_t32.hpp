@@ -33,6 +33,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+constexpr int CSTR = TC16 + 4;
 struct __attribute__((aligned(16))) Lstm16bSmem {
     // hot arrays first: everything the phase loop touches per cell sits below 64 KiB, so its LDS addresses are one base
     // register + a 16-bit immediate offset (no per-access address arithmetic)
@@ -43,7 +44,7 @@ struct __attribute__((aligned(16))) Lstm16bSmem {
     float Hl[64][HSTR];            // h captured at t == T-1
     f32x4 dummy[256];              // sink of predicated-off Hl stores
     float wout[2][HID];
-    uint8_t codes[2][TC16][64];
+    uint8_t codes[2][64][CSTR];    // [buffer][row][t % TC16], rows padded to 17 words: the lanes' byte reads hit 32 banks
     int T[64];
     int Lr[64];       // readable bytes of the read = min(len, max_len)
     long long off[64];
@@ -51,15 +52,47 @@ struct __attribute__((aligned(16))) Lstm16bSmem {
     int tmax;
 };
 
-__device__ __forceinline__ void rd_stage_codes16b(Lstm16bSmem &S, const ReadBatch &rb, int chunk) {
-    const int t0 = chunk * TC16;
-    uint8_t(*dst)[64] = S.codes[chunk & 1];
-    for (int idx = threadIdx.x; idx < 64 * TC16; idx += 256) {
-        const int row = idx / TC16, tt = idx % TC16, t = t0 + tt;
-        int code = 4;
-        if (t < S.Lr[row]) code = rd_code(rb.arena[S.off[row] + t]);
-        dst[tt][row] = (uint8_t)code;
+// Code chunks: thread (row = tid >> 2, piece = tid & 3) moves the 16 bases t0 + 16 piece .. + 15 of read `row` with ONE unaligned 16-byte
+// load (the first version walked bytes, one dependent global load per loop trip: 16 serialized round trips per chunk and workgroup,
+// ~10 us of the ~18 us a workgroup spent outside its phase loop). The piece that holds the read's end loads the 16 bytes that END at
+// the read's end (never past it: the arena's size is not known here) and shifts them down; bytes past the end are 0 = code 4.
+// (Issuing the load some steps before its use - and a persistent-workgroup form that fetches the next tile's metadata and bases
+// inside the phase loop - was built and measured in round 2: equal to this form on a full chip)
+__device__ __forceinline__ u32x4 rd_codes_load(const Lstm16bSmem &S, const ReadBatch &rb, int chunk) {
+    const int row = threadIdx.x >> 2, j0 = chunk * TC16 + 16 * (threadIdx.x & 3);
+    const int lr = S.Lr[row], m = lr - j0;                    // valid bytes from j0 on
+    const uint8_t *src = rb.arena + S.off[row];
+    u32x4 raw = {0u, 0u, 0u, 0u};
+    if (m >= 16) {
+        __builtin_memcpy(&raw, src + j0, 16);
+    } else if (m > 0 && lr >= 16) {
+        __builtin_memcpy(&raw, src + lr - 16, 16);
+    } else if (m > 0) {                                        // read shorter than 16 bases: bytes, already in place
+        for (int k = 0; k < m; ++k) raw[k >> 2] |= (uint32_t)src[j0 + k] << (8 * (k & 3));
     }
+    return raw;
+}
+__device__ __forceinline__ void rd_codes_store(Lstm16bSmem &S, int chunk, int buf, u32x4 raw) {
+    const int row = threadIdx.x >> 2, piece = threadIdx.x & 3, j0 = chunk * TC16 + 16 * piece;
+    const int lr = S.Lr[row], m = lr - j0;
+    if (m > 0 && m < 16 && lr >= 16) {                         // window that ends at the read's end: shift down by 16 - m bytes
+        const unsigned sh = 16u - (unsigned)m, b = sh & 3u;
+        if (sh & 8u) raw = u32x4{raw[2], raw[3], 0u, 0u};
+        if (sh & 4u) raw = u32x4{raw[1], raw[2], raw[3], 0u};
+        raw = u32x4{__builtin_amdgcn_alignbyte(raw[1], raw[0], b), __builtin_amdgcn_alignbyte(raw[2], raw[1], b),
+                    __builtin_amdgcn_alignbyte(raw[3], raw[2], b), __builtin_amdgcn_alignbyte(0u, raw[3], b)};
+    }
+    u32x4 w;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        uint32_t o = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o |= (uint32_t)rd_code((raw[q] >> (8 * k)) & 0xffu) << (8 * k);
+        w[q] = o;
+    }
+    uint32_t *dst = reinterpret_cast<uint32_t *>(&S.codes[buf][row][16 * piece]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dst[q] = w[q];
 }
 
 // One phase: MFMAs of (tile TL, current step) into accC; gate math of (tile TL^1, step tEW) from accP.
@@ -388,17 +421,22 @@ __global__ __launch_bounds__(256, 1) void rd_lstm_mfma_f16x3_t32_kernel(DevModel
     for (int i = tid; i < 2 * 32 * H16STR / 2; i += 256) { (reinterpret_cast<uint32_t *>(&S.H1s[0][0][0]))[i] = 0u; (reinterpret_cast<uint32_t *>(&S.H2[0][0][0]))[i] = 0u; }
     for (int i = tid; i < 64 * HSTR; i += 256) (&S.Hl[0][0])[i] = 0.0f;
     for (int i = tid; i < 2 * 4 * 256; i += 256) (&S.cS[0][0][0])[i] = f32x4{0, 0, 0, 0};
-    for (int i = tid; i < 4 * 2 * 4 * 4 * 6 * 4; i += 256) {   // i = ((((w*2 + hf)*4 + a)*4 + b)*6 + code)*4 + gate
-        const int gate = i & 3, rest = i >> 2, code = rest % 6, cell = rest / 6;
-        const int b = cell & 3, a = (cell >> 2) & 3, hf = (cell >> 4) & 1, w = cell >> 5;
-        float v = 0.0f;
-        if (code < 5) v = ((ACC & 4) ? 1.0f : (gate == 2 ? KT : KS)) * d.in_lut[code * G4 + gate * HID + 32 * w + 16 * hf + 4 * a + b];
-        (reinterpret_cast<float *>(&S.lut[0][0][0][0][0]))[i] = v;
+    if constexpr (ACC & 4) {
+        for (int i = tid; i < 4 * 2 * 4 * 4 * 6 * 4; i += 256) {   // i = ((((w*2 + hf)*4 + a)*4 + b)*6 + code)*4 + gate
+            const int gate = i & 3, rest = i >> 2, code = rest % 6, cell = rest / 6;
+            const int b = cell & 3, a = (cell >> 2) & 3, hf = (cell >> 4) & 1, w = cell >> 5;
+            (reinterpret_cast<float *>(&S.lut[0][0][0][0][0]))[i] = code < 5 ? d.in_lut[code * G4 + gate * HID + 32 * w + 16 * hf + 4 * a + b] : 0.0f;
+        }
+    } else {   // the table in this kernel's layout, rows pre-multiplied by -log2 e resp. 2 log2 e (rd_prep_kernel): a straight copy
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(d.lut_t32);
+        f32x4 *dst = &S.lut[0][0][0][0][0];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dst[tid + 256 * k] = src[tid + 256 * k];
     }
     S.wout[tid >> 7][tid & 127] = d.w_out[(tid >> 7) * 256 + (tid & 127)];
     __syncthreads();
     if (tid < 64) atomicMax(&S.tmax, S.T[tid]);
-    rd_stage_codes16b(S, rb, 0);
+    rd_codes_store(S, 0, 0, rd_codes_load(S, rb, 0));
     if (FILL < 0) {   // diagnosis: realistic (pseudo-random) B operands that are never updated
         for (int i = tid; i < 2 * 32 * H16STR / 2; i += 256) {
             uint32_t x = (uint32_t)i * 2654435761u + blockIdx.x * 40503u;
@@ -411,23 +449,30 @@ __global__ __launch_bounds__(256, 1) void rd_lstm_mfma_f16x3_t32_kernel(DevModel
     // ---- resident weights: 4 row-tiles x 8 k-steps x (W1, W2) x 4 registers = 256 registers, all pinned in AGPRs ----
     f16x8 W1[4][8], W2[4][8];
     {
+        // 16 loads in flight, then their 64 v_accvgpr_write (the asm statements are scheduling barriers: with one load per
+        // statement group every load waited for its own round trip, 64 in a row)
         const uint4 *wp = reinterpret_cast<const uint4 *>(d.wpack16b) + (size_t)wave * (2 * 4 * 8 * 64) + lane;
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < 4; ++a) {
+            uint4 x[2][8];
+#pragma unroll
+            for (int hl = 0; hl < 2; ++hl)
+#pragma unroll
+                for (int s = 0; s < 8; ++s) x[hl][s] = wp[((hl * 4 + a) * 8 + s) * 64];
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
 #pragma unroll
                 for (int hl = 0; hl < 2; ++hl) {
-                    const uint4 x = wp[((hl * 4 + a) * 8 + s) * 64];
                     uint4 y;
-                    asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(y.x) : "v"(x.x));
-                    asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(y.y) : "v"(x.y));
-                    asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(y.z) : "v"(x.z));
-                    asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(y.w) : "v"(x.w));
+                    asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(y.x) : "v"(x[hl][s].x));
+                    asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(y.y) : "v"(x[hl][s].y));
+                    asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(y.z) : "v"(x[hl][s].z));
+                    asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(y.w) : "v"(x[hl][s].w));
                     if (hl == 0) W1[a][s] = __builtin_bit_cast(f16x8, y);
                     else W2[a][s] = __builtin_bit_cast(f16x8, y);
                 }
             }
+        }
     }
     __syncthreads();
     const int tmax = S.tmax;
@@ -443,15 +488,15 @@ __global__ __launch_bounds__(256, 1) void rd_lstm_mfma_f16x3_t32_kernel(DevModel
     for (int a = 0; a < 4; ++a) { R0.call[a] = f32x4{0, 0, 0, 0}; R1.call[a] = f32x4{0, 0, 0, 0}; }
 
     for (int t = 0; t < tmax; ++t) {
-        const uint8_t *crow = &S.codes[(t / TC16) & 1][t % TC16][0];
-        const int codeX = crow[j];            // (tile 0, step t): consumed by phase B's gate math
-        const int codeYn = crow[32 + j];      // (tile 1, step t): consumed by the next iteration's phase A
+        const uint8_t *ccol = &S.codes[(t / TC16) & 1][0][t % TC16];
+        const int codeX = ccol[j * CSTR];            // (tile 0, step t): consumed by phase B's gate math
+        const int codeYn = ccol[(32 + j) * CSTR];    // (tile 1, step t): consumed by the next iteration's phase A
         // phase A: MFMAs of (tile 0, t) -> X ; gate math of (tile 1, t-1) <- Y
         rd_phase_t32<0, FILL, ACC>(S, W1, W2, X, Y, R1, t - 1, codeY, wave, half, j, tid);
         // next code chunk: its buffer was last read by the gate math of phase A above (step t-1)
         if ((t % TC16) == 0) {
             const int chunk = t / TC16 + 1;
-            if (chunk * TC16 < tmax + 1) rd_stage_codes16b(S, rb, chunk);
+            if (chunk * TC16 < tmax + 1) rd_codes_store(S, chunk, chunk & 1, rd_codes_load(S, rb, chunk));
         }
         // phase B: MFMAs of (tile 1, t) -> Y ; gate math of (tile 0, t) <- X
         rd_phase_t32<1, FILL, ACC>(S, W1, W2, Y, X, R0, t, codeX, wave, half, j, tid);

@@ -47,6 +47,19 @@ __global__ void rd_prep_kernel(DevModel d) {
         base[((((size_t)(w * 2 + 0) * 4 + a) * 8 + s) * 64 + lane) * 8 + e] = hi;
         base[((((size_t)(w * 2 + 1) * 4 + a) * 8 + s) * 64 + lane) * 8 + e] = lo;
     }
+    // the input table of the default kernel, in its LDS layout: i = ((((w*2 + hf)*4 + a)*4 + b)*6 + code)*4 + gate; the rows are the
+    // exp2 arguments' additive constants (gate g: 2 log2 e, the others: -log2 e); code 5 = the all-zero row of the dummy first pass
+    for (int i = tid; i < 4 * 2 * 4 * 4 * 6 * 4; i += nth) {
+        const int gate = i & 3, rest = i >> 2, code = rest % 6, cell = rest / 6;
+        const int b = cell & 3, a = (cell >> 2) & 3, hf = (cell >> 4) & 1, w = cell >> 5;
+        float v = 0.0f;
+        if (code < 5) {
+            const int col = gate * HID + 32 * w + 16 * hf + 4 * a + b;
+            const float bb = raw[OFF_BIH + col] + raw[OFF_BHH + col];
+            v = (gate == 2 ? 2.88539008177792681f : -1.44269504088896341f) * (code < 4 ? bb + raw[OFF_WIH + col * 4 + code] : bb);
+        }
+        d.lut_t32[i] = v;
+    }
     for (int i = tid; i < 512; i += nth) d.w_out[i] = raw[OFF_WOUT + i];
     if (tid < 2) d.b_out[tid] = raw[OFF_BOUT + tid];
     // reverse direction: one cell step from (h,c) = 0 on base `code` (W_hh_r . 0 vanishes), then the FC's reverse half.

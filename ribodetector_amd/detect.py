@@ -11,7 +11,7 @@ Flow per chunk (reference run_with_chunks, detect.py:326-523):
 Under torchrun (WORLD_SIZE > 1), one process per GPU:
   * plain input files: every rank parses only its own byte range (record-aligned, mates cut at the same record index:
     data_loader/fastx_parser.plan_ranges), classifies it, writes its own part of every output file; the counters are
-    all-reduced (RCCL) and rank 0 concatenates the parts - they are in rank order = input order;
+    all-reduced (RCCL) and every rank copies its part to its offset in the final file (rank order = input order);
   * gzip input (one DEFLATE stream, not splittable): every rank parses the stream, classifies a contiguous shard of each
     chunk, and rank 0 gathers the 1-byte labels over RCCL and writes (ribodetector_amd/dist.py).
 """
@@ -327,7 +327,7 @@ class Predictor:
             for handles in fhs.values():
                 for fh in handles:
                     fh.close()
-        if self.sharded_parse:                     # totals over the ranks; rank 0 joins the parts (rank order = input order)
+        if self.sharded_parse:                     # totals over the ranks; the parts are joined in rank order = input order
             import torch.distributed as dist
             tot = torch.tensor([num_read, num_nonrrna, num_rrna, num_unknown], dtype=torch.int64,
                                device=self.device if dist.get_backend() == 'nccl' else 'cpu')
