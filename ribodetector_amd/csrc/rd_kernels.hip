@@ -106,7 +106,7 @@ static bool rd_variant_known(int v) {
 #ifdef RD_DIAG
     switch (v) {
     case 10: case 11: case 12: case 13: case 20: case 21: case 22: case 23: case 40: case 41: case 42:
-    case 50: case 51: case 52: case 54: case 58: case 65: case 66: case 82: case 98: case 162: case 290: case 418: case 802: case 298: return true;
+    case 50: case 51: case 52: case 54: case 58: case 65: case 66: case 82: case 98: case 162: case 290: case 418: case 802: case 298: case 1314: return true;
     default: break;
     }
 #endif
@@ -262,6 +262,7 @@ int rd_classify(const rd_model *cm, const uint8_t *arena, const int64_t *seq_off
         case 290: hipLaunchKernelGGL((rd_lstm_mfma_f16x3_t32_kernel<6, 48 + 64 + 128>), grid, blk, 0, st, m->d, rb, logits, labels); break;
         case 802: hipLaunchKernelGGL((rd_lstm_mfma_f16x3_t32_kernel<6, 48 + 64 + 128 + 512>), grid, blk, 0, st, m->d, rb, logits, labels); break;
         case 298: hipLaunchKernelGGL((rd_lstm_mfma_f16x3_t32_kernel<6, 48 + 64 + 128 + 8>), grid, blk, 0, st, m->d, rb, logits, labels); break;
+        case 1314: hipLaunchKernelGGL((rd_lstm_mfma_f16x3_t32_kernel<6, 48 + 64 + 128 + 1024>), grid, blk, 0, st, m->d, rb, logits, labels); break;   // wrong by design
         case 418: hipLaunchKernelGGL((rd_lstm_mfma_f16x3_t32_kernel<6, 48 + 64 + 256>), grid, blk, 0, st, m->d, rb, logits, labels); break;   // wrong by design
 #endif
         default: RD_FAIL(RD_E_UNSUPPORTED, "rd_classify: variant %d not available in this build", m->variant);

@@ -135,6 +135,7 @@ struct PhaseCtx {       // per-lane constants of a phase
 //   128 = shared reciprocals: sigmoid(i) tanh(g) = (e_g - 1) / ((1 + e_i)(1 + e_g)) and sigmoid(o) tanh(c) likewise: 8 instead of 10
 //         transcendentals per cell for 4 more plain VALU ops; the only clamp needed is on the exp2 argument of g and c (<= 64)
 //   256 = timing diagnosis (wrong results): table rows not fetched
+//   1024 = timing diagnosis (wrong results): every 32x32x16 MFMA issued as two 16x16x32 (rd_slots)
 //   512 = (with 128) ONE reciprocal for the whole cell update: c' = (c' (1+e_i)(1+e_g) + K (e_g - 1)(1+e_f)) / ((1+e_f)(1+e_i)(1+e_g)),
 //         exp2 arguments of i, f, g clamped to <= 40 so that the triple product stays below 2^128: 7 transcendentals per cell
 constexpr int T32_PRODUCT = 16 | 32 | 64 | 128;
@@ -337,6 +338,31 @@ __device__ __forceinline__ void rd_slots(Lstm16bSmem &S, const f16x8 (&W1)[4][8]
         }
         const f16x8 A = (pr == 1 || pr == 3) ? W2[a][s] : W1[a][s];
         const f16x8 B = Bf[s & 1][pr >= 2 ? 1 : 0];
+        if constexpr (ACC & 1024) {
+            // timing diagnosis (WRONG results, same magnitudes): the slot's 16,384 MACs as two v_mfma_f32_16x16x32_f16 on two 4-register
+            // slices of the accumulator, half of the slot's gate-math units behind each - what a 16x16x32 form of this kernel would
+            // cost in time and energy, before writing it (8 of the 192 MFMAs per phase are merged away by the compiler: identical operands)
+            constexpr int sa = 2 * ((M / 4) & 1);
+            constexpr int U0 = (M * EW_NU) / SM::NM, U1 = ((M + 1) * EW_NU) / SM::NM, UM = (U0 + U1 + 1) / 2;
+            f32x4 c0 = {accC[a][4 * sa], accC[a][4 * sa + 1], accC[a][4 * sa + 2], accC[a][4 * sa + 3]};
+            f32x4 c1 = {accC[a][4 * sa + 4], accC[a][4 * sa + 5], accC[a][4 * sa + 6], accC[a][4 * sa + 7]};
+            if constexpr (M < 8) { c0 = f32x4{0, 0, 0, 0}; c1 = f32x4{0, 0, 0, 0}; }
+            c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, B, c0, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) accC[a][4 * sa + r] = c0[r];
+            if constexpr (FILL > 0) {
+                rd_ew_units<TL ^ 1, U0, UM, ACC>(S, R, accP, c);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const f16x8 A2 = (pr == 1 || pr == 3) ? W1[a][s] : W2[a][s];   // (not the same product again: the compiler would merge the two)
+            c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(A2, B, c1, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) accC[a][4 * sa + 4 + r] = c1[r];
+            if constexpr (FILL > 0) {
+                rd_ew_units<TL ^ 1, UM, U1, ACC>(S, R, accP, c);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
         if constexpr (M < 4) {
             f32x16 z;
 #pragma unroll
@@ -348,6 +374,7 @@ __device__ __forceinline__ void rd_slots(Lstm16bSmem &S, const f16x8 (&W1)[4][8]
         if constexpr (FILL > 0) {
             rd_ew_units<TL ^ 1, (M * EW_NU) / SM::NM, ((M + 1) * EW_NU) / SM::NM, ACC>(S, R, accP, c);
             __builtin_amdgcn_sched_barrier(0);
+        }
         }
         rd_slots<TL, FILL, M + 1, ACC>(S, W1, W2, accC, accP, Bf, R, c, h1s, h2);
     }
