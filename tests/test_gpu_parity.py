@@ -78,6 +78,22 @@ def test_vs_oracle_ragged_and_empty(gpu_model, oracle):
         _check(lg, lab, ref, "oracle n=%d" % n)
 
 
+def test_every_length_through_the_code_staging(gpu_model, oracle):
+    """the default kernel stages the bases in 16-byte pieces of 64-step chunks; the piece that holds a read's end is loaded as the 16
+    bytes that END there and shifted (reads shorter than 16 bases take a byte path): every length 0..210, three reads each, at -l
+    values on, below and above the chunk size, the last reads of the arena flush with its end"""
+    rng = np.random.default_rng(7)
+    lens = np.repeat(np.arange(0, 211, dtype=np.int32), 3)
+    rng.shuffle(lens)
+    off = np.zeros(len(lens) + 1, dtype=np.int64)
+    np.cumsum(lens, out=off[1:])
+    arena = np.frombuffer(b"ACGTUNacgt", dtype=np.uint8)[rng.choice(10, int(off[-1]), p=[.22, .22, .22, .2, .04, .04, .015, .015, .015, .015])]
+    for L in (15, 16, 17, 63, 64, 65, 100, 150, 200):
+        ref = oracle.forward_packed(arena, off, lens, L)
+        lg, lab = _run(gpu_model, arena, off, lens, L)
+        _check_tail(lg, lab, ref, L, "all lengths, -l %d" % L)
+
+
 def test_long_reads_chunked_codes(gpu_model, oracle):
     """max_len beyond one staged code chunk (TC=128) exercises the double-buffered code staging"""
     from ribodetector_amd import synth
