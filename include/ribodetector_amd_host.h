@@ -64,10 +64,21 @@ int rd_reader_next(rd_reader *r, int64_t max_records, uint8_t *buf, int64_t buf_
  * CRC / length mismatch, bad magic -> -1 + message. Used by the tests and for small side files. */
 int rd_host_gunzip(const char *path, uint8_t *out, int64_t cap, int64_t *n);
 
+/* The same through the parallel decoder (csrc/rd_pgzip.h: sections of `section_bytes` compressed bytes decoded by `threads`
+ * threads with an unknown window, markers resolved in order; 0 = defaults). The reader uses it for large .gz inputs; anything it
+ * cannot handle (binary payload, damaged data, further members) is finished by the sequential decoder, so results and error
+ * messages are those of rd_host_gunzip. stats[0..3] (may be null) = sections used, sections dropped (a block start that was not
+ * one), batches, 1 if the sequential decoder took over inside the first member. */
+int rd_host_gunzip_parallel(const char *path, uint8_t *out, int64_t cap, int64_t *n, int threads, int64_t section_bytes, int64_t *stats);
+
 /* Worker threads for gzip output (independent level-5 members compressed in parallel, by libdeflate.so.0 when the system
  * has it - bound at run time - else zlib; RD_HOST_ZLIB=1 forces zlib); 0 = auto (usable cores, <= 32).
  * Mirrors the reference's -t/--threads flag (detect.py:787). */
 int rd_host_set_threads(int threads);
+
+/* Decoder threads per .gz input opened from now on (csrc/rd_pgzip.h; files >= 16 MB): 0 = the sequential decoder, < 0 = auto.
+ * The CLI divides its -t value among its input files. */
+int rd_host_set_gz_threads(int threads);
 
 int rd_writer_open(const char *path, rd_writer **out);
 /* compressor threads this writer was opened with (= the rd_host_set_threads value in force at rd_writer_open) */

@@ -101,7 +101,7 @@ def ptr(t):
 HOST_LIB_PATH = os.path.join(_HERE, "csrc", "librd_host.so")
 HOST_SYMBOLS = ["rd_reader_open", "rd_reader_close", "rd_reader_next", "rd_host_file_info", "rd_host_find_record_start",
                 "rd_host_count_records", "rd_host_skip_records", "rd_reader_open_range", "rd_writer_open", "rd_writer_write_selected",
-                "rd_writer_close", "rd_writer_threads", "rd_host_last_error", "rd_host_set_threads", "rd_host_gunzip"]
+                "rd_writer_close", "rd_writer_threads", "rd_host_last_error", "rd_host_set_threads", "rd_host_set_gz_threads", "rd_host_gunzip", "rd_host_gunzip_parallel"]
 _host = None
 
 
@@ -128,7 +128,9 @@ def host_lib():
     L.rd_writer_close.argtypes = [vp]
     L.rd_writer_threads.argtypes = [vp]
     L.rd_host_set_threads.argtypes = [C.c_int]
+    L.rd_host_set_gz_threads.argtypes = [C.c_int]
     L.rd_host_gunzip.argtypes = [C.c_char_p, vp, i64, C.POINTER(i64)]
+    L.rd_host_gunzip_parallel.argtypes = [C.c_char_p, vp, i64, C.POINTER(i64), C.c_int, i64, vp]
     L.rd_host_last_error.restype = C.c_char_p
     _host = L
     return L

@@ -23,6 +23,7 @@
 
 #include "../../include/ribodetector_amd_host.h"
 #include "rd_inflate.h"
+#include "rd_pgzip.h"
 
 namespace {
 
@@ -113,6 +114,7 @@ struct rd_prefetch {
 struct rd_reader {
     FILE *fp = nullptr;
     rdz::GzipStream *gz = nullptr;   // set when the file starts with the gzip magic; plain bytes otherwise
+    rdz::ParallelGzip *pgz = nullptr;   // ... and is large: sections of the DEFLATE stream decoded in parallel (rd_pgzip.h)
     rd_prefetch *pf = nullptr;
     std::vector<uint8_t> blk;        // block being copied into the window, from blk_off
     size_t blk_off = 0;
@@ -236,6 +238,7 @@ bool pwrite_all(int fd, const uint8_t *p, size_t len, int64_t off) {
 }
 
 int g_threads = 0;                  // 0 = auto
+int g_gz_threads = -1;              // decoder threads per .gz input: -1 = auto, 0 = sequential decoder
 
 int usable_threads() {
     if (g_threads > 0) return g_threads;
@@ -358,8 +361,23 @@ int rd_reader_open(const char *path, int format, rd_reader **out) {
     uint8_t magic[2];
     const size_t got = fread(magic, 1, 2, fp);
     if (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
-        rdz::GzipStream *gz = r->gz = new rdz::GzipStream(fp, magic, 2);
-        r->pf = new rd_prefetch([gz](uint8_t *dst, size_t cap) { return gz->read(dst, cap); }, [gz]() { return gz->err; });
+        // large files: the parallel decoder (falls back to the sequential one by itself for anything it is not made for).
+        // Threads per file: rd_host_set_gz_threads (the CLI divides -t among its input files), else half of the usable cores - 1,
+        // <= 8 (paired input decodes two files at once); RD_GZ_THREADS overrides both, 0 = the sequential decoder.
+        int pt = g_gz_threads >= 0 ? g_gz_threads : std::min(8, std::max(2, usable_threads() / 2 - 1));
+        if (const char *e = getenv("RD_GZ_THREADS")) pt = atoi(e);
+        struct stat st;
+        long long min_size = 16ll << 20, section = 2ll << 20;   // (RD_GZ_PARALLEL_MIN / RD_GZ_SECTION: knobs of the tests)
+        if (const char *e = getenv("RD_GZ_PARALLEL_MIN")) min_size = atoll(e);
+        if (const char *e = getenv("RD_GZ_SECTION")) section = atoll(e);
+        const bool large = fstat(fileno(fp), &st) == 0 && (long long)st.st_size >= min_size;
+        if (pt >= 2 && large && (usable_threads() >= 4 || getenv("RD_GZ_THREADS"))) {
+            rdz::ParallelGzip *pg = r->pgz = new rdz::ParallelGzip(fp, pt, (size_t)std::max(4096ll, section));
+            r->pf = new rd_prefetch([pg](uint8_t *dst, size_t cap) { return pg->read(dst, cap); }, [pg]() { return pg->err; });
+        } else {
+            rdz::GzipStream *gz = r->gz = new rdz::GzipStream(fp, magic, 2);
+            r->pf = new rd_prefetch([gz](uint8_t *dst, size_t cap) { return gz->read(dst, cap); }, [gz]() { return gz->err; });
+        }
     } else {
         memcpy(r->in.data(), magic, got);
         r->end = got;
@@ -574,6 +592,7 @@ void rd_reader_close(rd_reader *r) {
     if (!r) return;
     delete r->pf;   // joins the decompression thread first
     delete r->gz;
+    delete r->pgz;
     fclose(r->fp);
     delete r;
 }
@@ -713,10 +732,52 @@ int rd_host_gunzip(const char *path, uint8_t *out, int64_t cap, int64_t *n_out) 
     return rc;
 }
 
+int rd_host_gunzip_parallel(const char *path, uint8_t *out, int64_t cap, int64_t *n_out, int threads, int64_t section_bytes, int64_t *stats) {
+    if (!path || !out || !n_out) RDH_FAIL("rd_host_gunzip_parallel: null argument");
+    FILE *fp = fopen(path, "rb");
+    if (!fp) RDH_FAIL("cannot open %s", path);
+    setvbuf(fp, nullptr, _IONBF, 0);
+    int64_t n = 0;
+    int rc = 0;
+    {
+        rdz::ParallelGzip gz(fp, threads > 0 ? threads : std::max(2, usable_threads() - 2), section_bytes > 0 ? (size_t)section_bytes : (4u << 20));
+        for (;;) {
+            uint8_t extra;
+            const long got = n < cap ? gz.read(out + n, (size_t)(cap - n)) : gz.read(&extra, 1);
+            if (got < 0) {
+                snprintf(g_err, sizeof(g_err), "%s", gz.err.c_str());
+                rc = -1;
+                break;
+            }
+            if (got == 0) break;
+            if (n >= cap) {
+                snprintf(g_err, sizeof(g_err), "rd_host_gunzip: output exceeds the buffer (%lld bytes)", (long long)cap);
+                rc = -1;
+                break;
+            }
+            n += got;
+        }
+        if (stats) {
+            stats[0] = (int64_t)gz.sections_used;
+            stats[1] = (int64_t)gz.sections_dropped;
+            stats[2] = (int64_t)gz.batches;
+            stats[3] = gz.fell_back ? 1 : 0;
+        }
+    }
+    fclose(fp);
+    *n_out = n;
+    return rc;
+}
+
 int rd_writer_threads(const rd_writer *w) { return w ? w->threads : -1; }
 
 int rd_host_set_threads(int threads) {
     g_threads = threads > 0 ? threads : 0;
+    return 0;
+}
+
+int rd_host_set_gz_threads(int threads) {
+    g_gz_threads = threads < 0 ? -1 : threads;
     return 0;
 }
 

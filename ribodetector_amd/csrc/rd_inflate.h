@@ -204,6 +204,36 @@ class GzipStream {
         return (long)done;
     }
 
+    // Continue a member in its middle (rd_pgzip.h hands over here): the next block header is `bit_off` bits into byte `byte_off`
+    // of the file; `window` = the last <= 32 KiB produced so far; crc / produced = CRC-32 and size of everything produced so far.
+    bool resume(uint64_t byte_off, unsigned bit_off, const uint8_t *window, size_t wlen, uint32_t crc, uint64_t produced) {
+        if (!seek_input(byte_off)) return false;
+        if (iend_ == 0) return fail("Compressed file ended before the end-of-stream marker was reached");
+        bitbuf_ = (uint64_t)(ib_[0] >> bit_off);
+        bitcnt_ = 8 - bit_off;
+        ip_ = 1;
+        const size_t keep = std::min(wlen, WIN);
+        if (keep) memcpy(ob_.data() + WIN - keep, window + (wlen - keep), keep);
+        hist0_ = WIN - keep;
+        op_ = rp_ = crc_from_ = WIN;
+        crc_ = crc;
+        base_abs_ = produced;
+        member_abs_ = 0;
+        state_ = ST_BLOCK;
+        final_block_ = finished_ = failed_ = false;
+        return true;
+    }
+    // Start over at a member header at byte `byte_off` of the file.
+    bool restart_at(uint64_t byte_off) {
+        if (!seek_input(byte_off)) return false;
+        bitbuf_ = 0;
+        bitcnt_ = 0;
+        op_ = rp_ = hist0_ = crc_from_ = WIN;
+        state_ = ST_MEMBER;
+        final_block_ = finished_ = failed_ = false;
+        return true;
+    }
+
   private:
     enum State { ST_MEMBER, ST_BLOCK, ST_STORED, ST_HUFF, ST_TRAILER };
 
@@ -231,6 +261,13 @@ class GzipStream {
         return false;
     }
 
+    bool seek_input(uint64_t byte_off) {
+        if (fseeko(fp_, (off_t)byte_off, SEEK_SET) != 0) return fail("seek failed");
+        ip_ = iend_ = 0;
+        in_eof_ = false;
+        refill_input();
+        return true;
+    }
     void refill_input() {
         if (in_eof_) return;
         if (ip_ > 0) {

@@ -191,3 +191,112 @@ def test_match_must_not_reach_into_previous_member(tmp_path):
     p.write_bytes(bad)
     rc, _, err = gunzip(p, 1 << 16)
     assert rc != 0 and "distance" in err.lower(), err
+
+
+# ---- the parallel decoder (csrc/rd_pgzip.h): same bytes and same errors as the sequential one -----------------------------------
+def pgunzip(path, cap, threads=4, section=65536):
+    L = N.host_lib()
+    out = np.empty(max(cap, 1), dtype=np.uint8)
+    n = C.c_int64(0)
+    st = (C.c_int64 * 4)()
+    rc = L.rd_host_gunzip_parallel(str(path).encode(), out.ctypes.data, cap, C.byref(n), threads, section, st)
+    return rc, out[: n.value].tobytes(), L.rd_host_last_error().decode(), {"used": st[0], "dropped": st[1], "batches": st[2], "fell_back": st[3]}
+
+
+@pytest.mark.parametrize("level", [1, 5, 6, 9])
+@pytest.mark.parametrize("threads,section", [(2, 16384), (4, 65536), (3, 300000), (8, 1 << 20)])
+def test_parallel_decoder_matches_zlib_on_fastq(tmp_path, level, threads, section):
+    data = PAYLOADS["fastq"]
+    p = tmp_path / "x.gz"
+    p.write_bytes(member(data, level))
+    rc, got, err, st = pgunzip(p, len(data) + 16, threads, section)
+    assert rc == 0, err
+    assert got == data
+    if section in (65536, 300000):   # several sections were really decoded with an unknown window and stitched; nothing fell back
+        assert st["used"] >= 4 and st["fell_back"] == 0, st
+    # (16 KiB sections are shorter than a deflate block: no block start within a batch, the sequential decoder takes over - same bytes)
+
+
+@pytest.mark.parametrize("name", list(PAYLOADS))
+def test_parallel_decoder_on_every_payload(tmp_path, name):
+    """binary payloads have no block start the search accepts (it wants text): the sequential decoder finishes them - same bytes"""
+    data = PAYLOADS[name]
+    p = tmp_path / "x.gz"
+    for level, strategy in ((1, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_FIXED), (0, zlib.Z_DEFAULT_STRATEGY)):
+        p.write_bytes(member(data, level, strategy))
+        rc, got, err, st = pgunzip(p, len(data) + 16, 4, 32768)
+        assert rc == 0, (name, level, err)
+        assert got == data, (name, level, st)
+
+
+def test_parallel_decoder_framing_and_windows(tmp_path):
+    a, b, c = PAYLOADS["fastq"][:3000000], b"second member\n" * 1000, PAYLOADS["random"][:70000]
+    blob = member(a, 5, flags=4 | 8 | 16 | 2) + member(b"", 6) + member(b, 9, flags=8) + bytes(37) + member(c, 1) + bytes(512)
+    p = tmp_path / "multi.gz"
+    p.write_bytes(blob)
+    rc, got, err, st = pgunzip(p, len(a + b + c) + 1, 4, 65536)
+    assert rc == 0, err
+    assert got == a + b + c and st["used"] >= 4          # first member in parallel, the others by the sequential decoder
+    # a text that refers back across every section boundary (long repeats: the window really is needed), small windows, tiny files
+    rep = (PAYLOADS["fastq"][:20000] * 150)
+    for data, kw in ((rep, {}), (PAYLOADS["fastq"], {"mem": 1, "wbits": 9}), (b"", {}), (b"A", {}), (b"@r\nACGT\n+\nIIII\n", {})):
+        p.write_bytes(member(data, 6, **kw))
+        rc, got, err, st = pgunzip(p, len(data) + 16, 4, 40000)
+        assert rc == 0 and got == data, (err, st)
+
+
+def test_parallel_decoder_reports_damage_like_the_sequential_one(tmp_path):
+    data = PAYLOADS["fastq"][:2000000]
+    good = member(data, 5)
+    p = tmp_path / "bad.gz"
+    cases = [good[:cut] for cut in (5, 11, 200, len(good) // 2, len(good) - 9, len(good) - 8, len(good) - 1)]
+    x = bytearray(good); x[-6] ^= 0x10; cases.append(bytes(x))               # CRC
+    x = bytearray(good); x[-2] ^= 0x01; cases.append(bytes(x))               # ISIZE
+    cases.append(good + b"trailing garbage")
+    rng = np.random.default_rng(6)
+    for _ in range(30):
+        x = bytearray(good)
+        x[int(rng.integers(10, len(good) - 8))] ^= 1 << int(rng.integers(0, 8))
+        cases.append(bytes(x))
+    for blob in cases:
+        p.write_bytes(blob)
+        rc0, got0, err0 = gunzip(p, len(data) + 1024)
+        rc1, got1, err1, st = pgunzip(p, len(data) + 1024, 4, 65536)
+        assert rc1 == rc0 and err1 == err0, (len(blob), err0, err1, st)
+        if rc0 == 0:
+            assert got1 == got0
+        else:   # what precedes the error is handed out too; how far that is depends on the decoder's buffering, the bytes do not
+            assert got0.startswith(got1) or got1.startswith(got0)
+
+
+def test_parallel_decoder_fuzz_never_crashes(tmp_path):
+    rng = np.random.default_rng(10)
+    p = tmp_path / "fuzz.gz"
+    good = member(PAYLOADS["fastq"][:400000], 6)
+    for i in range(150):
+        x = bytearray(good)
+        for _ in range(int(rng.integers(1, 4))):
+            x[int(rng.integers(10, len(x)))] = int(rng.integers(0, 256))
+        p.write_bytes(bytes(x))
+        rc, got, err, st = pgunzip(p, 1 << 21, 3, 20000)
+        rc0, got0, err0 = gunzip(p, 1 << 21)
+        assert rc == rc0 and (rc0 != 0 or got == got0), (i, err, err0)
+
+
+def test_reader_uses_the_parallel_decoder_for_large_files(tmp_path, monkeypatch):
+    """records through the reader with the parallel decoder forced on a small file (thresholds are test knobs)"""
+    arena, off, _ = synth.reads_numpy(60000, 100, seed=8)
+    fq = tmp_path / "r.fq.gz"
+    synth.write_fastq(str(fq), arena, off, 1)
+    monkeypatch.setenv("RD_GZ_THREADS", "0")
+    seq = [(c.buf[: c.rec_start[-1]].tobytes(), c.seq_len.copy()) for c in fx.get_seq_chunks(str(fq), 8192)]
+    monkeypatch.setenv("RD_GZ_THREADS", "3")
+    monkeypatch.setenv("RD_GZ_PARALLEL_MIN", "0")
+    monkeypatch.setenv("RD_GZ_SECTION", "50000")
+    par = [(c.buf[: c.rec_start[-1]].tobytes(), c.seq_len.copy()) for c in fx.get_seq_chunks(str(fq), 8192)]
+    assert len(seq) == len(par) and all(a[0] == b[0] and (a[1] == b[1]).all() for a, b in zip(seq, par))
+    cut = tmp_path / "cut.fq.gz"
+    cut.write_bytes(fq.read_bytes()[: fq.stat().st_size * 2 // 3])
+    with pytest.raises(ValueError, match="ended before the end-of-stream marker"):
+        for _ in fx.get_seq_chunks(str(cut), 8192):
+            pass

@@ -44,7 +44,23 @@ def main():
         return lambda: sum(len(c.seq_len) for c in fx.get_seq_chunks(path, 1 << 18))
 
     out["reader_plain_reads_per_s"] = rate(a.reads, consume(plain))
-    out["reader_gz_reads_per_s"] = rate(a.reads, consume(gz))
+    out["reader_gz_reads_per_s"] = rate(a.reads, consume(gz))            # parallel decoder for files >= 16 MB (csrc/rd_pgzip.h)
+    os.environ["RD_GZ_THREADS"] = "0"
+    out["reader_gz_sequential_reads_per_s"] = rate(a.reads, consume(gz))
+    del os.environ["RD_GZ_THREADS"]
+    # the decoders alone: decompressed MB/s, sequential vs parallel by thread count
+    import ctypes as C
+    from ribodetector_amd import _native as N
+    L = N.host_lib()
+    raw_n = os.path.getsize(plain)
+    buf = np.empty(raw_n + 16, dtype=np.uint8)
+    n = C.c_int64(0)
+    out["inflate_sequential_MB_per_s"] = rate(raw_n / 1e6, lambda: L.rd_host_gunzip(gz.encode(), buf.ctypes.data, raw_n + 16, C.byref(n)))
+    for th in (2, 4, 7, 8, 12):
+        st = (C.c_int64 * 4)()
+        out["inflate_parallel_%d_MB_per_s" % th] = rate(
+            raw_n / 1e6, lambda: L.rd_host_gunzip_parallel(gz.encode(), buf.ctypes.data, raw_n + 16, C.byref(n), th, 4 << 20, st))
+        out["inflate_parallel_%d_stats" % th] = list(st)
     out["python_gzip_read_reads_per_s"] = rate(a.reads, lambda: gzip.open(gz, "rb").read(), reps=1)
     chunk = next(fx.get_seq_chunks(plain, a.reads))
     labels = (np.arange(a.reads) % 10 == 0).astype(np.int8)
