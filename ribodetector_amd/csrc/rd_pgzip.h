@@ -609,7 +609,7 @@ class ParallelGzip {
             s.ok = false;
             s.bytes.n = 0;
         }
-        const size_t max_out = std::max<size_t>(64u << 20, sec_ * 80);
+        const size_t max_out = std::max<size_t>(16u << 20, sec_ * 32);   // symbols per section; beyond that (a 32:1 text) the sequential decoder takes over
         parallel_for(ns, [&](int j) {
             if (S[(size_t)j] == PG_NONE) return;
             if (j == last && !to_eof) return;
@@ -726,7 +726,7 @@ class ParallelGzip {
             uint64_t outb = 0;
             for (size_t c = 0; c < nc; ++c) outb += sec[(size_t)chain[c]].n;
             const uint64_t inb = (sec[(size_t)chain[nc - 1]].end - S[0]) / 8 + 1;
-            ratio_hint_ = std::min(40.0, std::max(ratio_hint_, 1.15 * (double)outb / (double)inb));
+            ratio_hint_ = std::min(24.0, std::max(ratio_hint_, 1.15 * (double)outb / (double)inb));
         }
         window_ = win[nc];
         const PgSection &tail = sec[(size_t)chain[nc - 1]];

@@ -245,6 +245,17 @@ def test_parallel_decoder_framing_and_windows(tmp_path):
         assert rc == 0 and got == data, (err, st)
 
 
+def test_parallel_decoder_bounds_its_buffers_on_extremely_compressible_text(tmp_path):
+    """a 250:1 text: a section would decode to more symbols than the decoder allows itself - the sequential decoder takes over"""
+    data = b"@read\nACGTACGTACGTACGTACGTACGTACGTACGTACGTACGTACGTACGT\n+\nIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIII\n" * 1100000
+    p = tmp_path / "rep.gz"
+    p.write_bytes(member(data, 6))
+    assert p.stat().st_size * 150 < len(data)
+    rc, got, err, st = pgunzip(p, len(data) + 16, 4, 131072)
+    assert rc == 0 and got == data, (err, st)
+    assert st["fell_back"] == 1
+
+
 def test_parallel_decoder_reports_damage_like_the_sequential_one(tmp_path):
     data = PAYLOADS["fastq"][:2000000]
     good = member(data, 5)
