@@ -207,7 +207,8 @@ class Predictor:
         # -t/--threads also bounds the decoder threads of .gz inputs (parallel DEFLATE decoding, csrc/rd_pgzip.h): what is left after
         # the parser threads and this one, divided among the input files
         from . import _native
-        _native.host_lib().rd_host_set_gz_threads(max(2, min(12, (int(self.args.threads) - 2) // max(1, len(self.input)))))
+        # (under torchrun every rank decodes the stream itself, on the same host: the budget is shared among the ranks too)
+        _native.host_lib().rd_host_set_gz_threads(max(2, min(12, (int(self.args.threads) - 2) // max(1, len(self.input) * self.world))))
         qs = [self._reader_queue(p, chunk_reads, byte_range=r) for p, r in zip(self.input, ranges)]
         while True:
             cs = []
