@@ -206,6 +206,8 @@ struct LibDeflate {
     void (*release)(void *) = nullptr;
     size_t (*gzip_compress)(void *, const void *, size_t, void *, size_t) = nullptr;
     size_t (*gzip_bound)(void *, size_t) = nullptr;
+    size_t (*deflate_compress)(void *, const void *, size_t, void *, size_t) = nullptr;
+    size_t (*deflate_bound)(void *, size_t) = nullptr;
     bool ok = false;
 };
 
@@ -220,7 +222,9 @@ const LibDeflate &libdeflate() {
         l.release = (void (*)(void *))dlsym(h, "libdeflate_free_compressor");
         l.gzip_compress = (size_t(*)(void *, const void *, size_t, void *, size_t))dlsym(h, "libdeflate_gzip_compress");
         l.gzip_bound = (size_t(*)(void *, size_t))dlsym(h, "libdeflate_gzip_compress_bound");
-        l.ok = l.alloc && l.release && l.gzip_compress && l.gzip_bound;
+        l.deflate_compress = (size_t(*)(void *, const void *, size_t, void *, size_t))dlsym(h, "libdeflate_deflate_compress");
+        l.deflate_bound = (size_t(*)(void *, size_t))dlsym(h, "libdeflate_deflate_compress_bound");
+        l.ok = l.alloc && l.release && l.gzip_compress && l.gzip_bound && l.deflate_compress && l.deflate_bound;
         return l;
     }();
     return L;
@@ -260,29 +264,39 @@ int usable_threads() {
 
 constexpr size_t GZ_BLOCK = 4u << 20;   // uncompressed bytes per gzip member
 
+// One gzip member: header with an extra field that holds the member's own size ('R','D', 4 bytes: size - 1, the 32-bit analogue of
+// BGZF's 'B','C' subfield - readers that do not know it skip it, RFC 1952 2.3.1.1), raw deflate at level 5, CRC-32 + ISIZE. With the
+// sizes in the headers a reader can walk the members without decoding them and decode them in parallel (rd_pgzip.h, indexed mode).
+constexpr size_t GZ_HDR = 20;
 bool gz_member(const uint8_t *src, size_t len, std::vector<uint8_t> &out, void *comp) {
+    size_t body = 0;
     if (comp) {
         const LibDeflate &L = libdeflate();
-        out.resize(L.gzip_bound(comp, len));
-        const size_t n = L.gzip_compress(comp, src, len, out.data(), out.size());
-        if (n) {
-            out.resize(n);
-            return true;
-        }
+        out.resize(GZ_HDR + L.deflate_bound(comp, len) + 8);
+        body = L.deflate_compress(comp, src, len, out.data() + GZ_HDR, out.size() - GZ_HDR - 8);
     }
-    z_stream zs;
-    memset(&zs, 0, sizeof(zs));
-    if (deflateInit2(&zs, 5, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
-    out.resize(deflateBound(&zs, (uLong)len) + 64);
-    zs.next_in = const_cast<Bytef *>(src);
-    zs.avail_in = (uInt)len;
-    zs.next_out = out.data();
-    zs.avail_out = (uInt)out.size();
-    const int rc = deflate(&zs, Z_FINISH);
-    const size_t produced = out.size() - zs.avail_out;
-    deflateEnd(&zs);
-    if (rc != Z_STREAM_END) return false;
-    out.resize(produced);
+    if (!body) {
+        z_stream zs;
+        memset(&zs, 0, sizeof(zs));
+        if (deflateInit2(&zs, 5, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+        out.resize(GZ_HDR + deflateBound(&zs, (uLong)len) + 64 + 8);
+        zs.next_in = const_cast<Bytef *>(src);
+        zs.avail_in = (uInt)len;
+        zs.next_out = out.data() + GZ_HDR;
+        zs.avail_out = (uInt)(out.size() - GZ_HDR - 8);
+        const int rc = deflate(&zs, Z_FINISH);
+        body = (out.size() - GZ_HDR - 8) - zs.avail_out;
+        deflateEnd(&zs);
+        if (rc != Z_STREAM_END) return false;
+    }
+    const size_t total = GZ_HDR + body + 8;
+    out.resize(total);
+    static const uint8_t hdr[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 8, 0, 'R', 'D', 4, 0};
+    memcpy(out.data(), hdr, 16);
+    const uint32_t sz = (uint32_t)(total - 1), crc = rdz::crc32_update(0, src, len), isize = (uint32_t)len;
+    memcpy(out.data() + 16, &sz, 4);                    // little-endian host
+    memcpy(out.data() + GZ_HDR + body, &crc, 4);
+    memcpy(out.data() + GZ_HDR + body + 4, &isize, 4);
     return true;
 }
 

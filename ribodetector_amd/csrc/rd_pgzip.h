@@ -513,7 +513,120 @@ class ParallelGzip {
         return true;
     }
 
+    // RFC 1952 header at `off`: its length, and the member's total size when an extra subfield gives it (BGZF 'B','C': 16 bits; this
+    // build's writer 'R','D': 32 bits), else 0
+    bool parse_header(uint64_t off, size_t &hlen, uint64_t &msize) {
+        uint8_t h[1 << 12];
+        if (off + 18 > fsize_) return false;
+        const size_t n = (size_t)std::min<uint64_t>(sizeof(h), fsize_ - off);
+        if (!pread_all(h, n, off) || h[0] != 0x1f || h[1] != 0x8b || h[2] != 8) return false;
+        const unsigned flg = h[3];
+        size_t p = 10;
+        msize = 0;
+        if (flg & 4) {
+            if (p + 2 > n) return false;
+            const size_t xlen = h[p] | ((size_t)h[p + 1] << 8);
+            p += 2;
+            if (p + xlen > n) return false;
+            for (size_t q = p; q + 4 <= p + xlen;) {
+                const size_t sl = h[q + 2] | ((size_t)h[q + 3] << 8);
+                if (q + 4 + sl > p + xlen) break;
+                if (h[q] == 'B' && h[q + 1] == 'C' && sl == 2) msize = (uint64_t)(h[q + 4] | (h[q + 5] << 8)) + 1;
+                if (h[q] == 'R' && h[q + 1] == 'D' && sl == 4)
+                    msize = (uint64_t)(h[q + 4] | (h[q + 5] << 8) | (h[q + 6] << 16) | ((uint64_t)h[q + 7] << 24)) + 1;
+                q += 4 + sl;
+            }
+            p += xlen;
+        }
+        for (unsigned bit = 8; bit <= 16; bit <<= 1) {
+            if (!(flg & bit)) continue;
+            while (p < n && h[p]) ++p;
+            ++p;
+        }
+        if (flg & 2) p += 2;
+        if (p + 8 > n) return false;
+        hlen = p;
+        return true;
+    }
+
+    // ---- indexed mode: every member says how long it is, so the members are walked without decoding and decoded in parallel ----
+    bool indexed_ = false;
+    uint64_t member_off_ = 0;
+    struct Member { uint64_t off; size_t hlen; uint64_t size; };
+    void run_batch_indexed() {
+        ++batches;
+        std::vector<Member> ms;
+        uint64_t bytes = 0;
+        const uint64_t budget = (uint64_t)T_ * sec_;
+        uint64_t off = member_off_;
+        Then after = TH_BATCH;
+        while (bytes < budget && ms.size() < 16384) {
+            while (off < fsize_) {   // zero padding between members
+                uint8_t z;
+                if (!pread_all(&z, 1, off) || z != 0) break;
+                ++off;
+            }
+            if (off >= fsize_) {
+                after = TH_DONE;
+                break;
+            }
+            Member m{off, 0, 0};
+            if (!parse_header(off, m.hlen, m.size) || m.size == 0 || m.size < m.hlen + 8 || off + m.size > fsize_) {
+                after = TH_MEMBER;   // a member without its size, damage, garbage: the sequential decoder from here on
+                next_member_ = off;
+                break;
+            }
+            ms.push_back(m);
+            bytes += m.size;
+            off += m.size;
+        }
+        std::vector<PgBytes> outs(ms.size());
+        std::vector<char> ok(ms.size(), 0);
+        parallel_for((int)ms.size(), [&](int i) {
+            const Member &m = ms[(size_t)i];
+            std::vector<uint8_t> z((size_t)m.size);
+            if (!pread_all(z.data(), z.size(), m.off)) return;
+            const uint8_t *t = z.data() + m.size - 8;
+            const uint32_t want_crc = t[0] | (t[1] << 8) | (t[2] << 16) | ((uint32_t)t[3] << 24);
+            const uint32_t isize = t[4] | (t[5] << 8) | (t[6] << 16) | ((uint32_t)t[7] << 24);
+            if ((uint64_t)isize > 1032ull * m.size + 64 || !outs[(size_t)i].resize(isize)) return;   // deflate cannot expand more than 1032:1
+            z_stream zs;
+            memset(&zs, 0, sizeof(zs));
+            if (inflateInit2(&zs, -15) != Z_OK) return;
+            zs.next_in = z.data() + m.hlen;
+            zs.avail_in = (uInt)(m.size - m.hlen - 8);
+            uint8_t dummy;
+            zs.next_out = isize ? outs[(size_t)i].data() : &dummy;
+            zs.avail_out = isize;
+            const int rc = inflate(&zs, Z_FINISH);
+            const bool fine = rc == Z_STREAM_END && zs.avail_in == 0 && zs.total_out == isize;
+            inflateEnd(&zs);
+            if (fine && crc32_update(0, outs[(size_t)i].data(), isize) == want_crc) ok[(size_t)i] = 1;
+        });
+        for (size_t i = 0; i < ms.size(); ++i) {
+            if (!ok[i]) {   // the sequential decoder finds the words for what is wrong with this member
+                after = TH_MEMBER;
+                next_member_ = ms[i].off;
+                off = ms[i].off;
+                break;
+            }
+            staged_.push_back(std::move(outs[i]));
+            ++sections_used;
+        }
+        member_off_ = off;
+        then_ = after;
+    }
+
     bool member_header() {   // RFC 1952 header at offset 0 -> next_bit_
+        {
+            size_t hl;
+            uint64_t ms;
+            if (parse_header(0, hl, ms) && ms) {
+                indexed_ = true;
+                member_off_ = 0;
+                return true;
+            }
+        }
         uint8_t h[1 << 16];
         const size_t n = (size_t)std::min<uint64_t>(sizeof(h), fsize_);
         if (n < 18 || !pread_all(h, n, 0) || h[0] != 0x1f || h[1] != 0x8b || h[2] != 8) {
@@ -561,6 +674,7 @@ class ParallelGzip {
         return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
     }
     void run_batch() {
+        if (indexed_) return run_batch_indexed();
         ++batches;
         double t0 = now();
         const uint64_t b0 = next_bit_ >> 3;                       // first byte of the batch

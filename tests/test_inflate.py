@@ -311,3 +311,58 @@ def test_reader_uses_the_parallel_decoder_for_large_files(tmp_path, monkeypatch)
     with pytest.raises(ValueError, match="ended before the end-of-stream marker"):
         for _ in fx.get_seq_chunks(str(cut), 8192):
             pass
+
+
+def bgzf(data, block=60000):
+    """BGZF (SAM/BAM spec 4.1): members of <= 64 KiB with their size in a 'BC' extra subfield, closed by the empty EOF member"""
+    out = []
+    for i in list(range(0, len(data), block)) + [None]:
+        piece = b"" if i is None else data[i:i + block]
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        body = co.compress(piece) + co.flush()
+        size = 18 + len(body) + 8
+        out.append(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff" + struct.pack("<HccHH", 6, b"B", b"C", 2, size - 1) + body +
+                   struct.pack("<II", zlib.crc32(piece) & 0xffffffff, len(piece)))
+    return b"".join(out)
+
+
+def test_members_that_carry_their_size_are_decoded_in_parallel(tmp_path):
+    """BGZF files and this build's own .gz outputs ('R','D' subfield, 32-bit size): the members are walked without decoding"""
+    data = PAYLOADS["fastq"]
+    p = tmp_path / "x.gz"
+    blob = bgzf(data)
+    assert gzip.decompress(blob) == data
+    p.write_bytes(blob)
+    rc, got, err, st = pgunzip(p, len(data) + 16, 4, 65536)
+    assert rc == 0 and got == data, err
+    assert st["used"] == len(data) // 60000 + 2 and st["fell_back"] == 0, st      # every member, incl. the empty EOF member
+    rc, got, err = gunzip(p, len(data) + 16)                                      # and the sequential decoder reads the same
+    assert rc == 0 and got == data
+    # this build's writer
+    arena, off, _ = synth.reads_numpy(30000, 100, seed=4)
+    src = tmp_path / "in.fq"
+    synth.write_fastq(str(src), arena, off, 1)
+    chunk = next(fx.get_seq_chunks(str(src), 30000))
+    w = fx.open_for_write(str(tmp_path / "out.fq.gz"))
+    for _ in range(3):                                                            # > 4 MiB of records: several members
+        w.write_selected(chunk, np.zeros(30000, dtype=np.int8), 0)
+    w.close()
+    out = (tmp_path / "out.fq.gz").read_bytes()
+    want = src.read_bytes() * 3
+    assert gzip.decompress(out) == want                                           # any gzip reader skips the extra field
+    assert out[3] == 4 and out[12:16] == b"RD\x04\x00"
+    rc, got, err, st = pgunzip(tmp_path / "out.fq.gz", len(want) + 16, 4, 1 << 20)
+    assert rc == 0 and got == want and st["used"] >= 3 and st["fell_back"] == 0, (err, st)
+    # a member without the subfield after sized ones, and zero padding between members: the sequential decoder continues
+    tail = b"plain member\n" * 5000
+    p.write_bytes(blob + bytes(100) + member(tail, 6))
+    rc, got, err, st = pgunzip(p, len(data) + len(tail) + 16, 4, 65536)
+    assert rc == 0 and got == data + tail, err
+    # damage inside a sized member, a size that lies, a truncated file: the same error as the sequential decoder
+    for mutate in (lambda b: b[:40000] + bytes([b[40000] ^ 0x55]) + b[40001:], lambda b: b[:16] + b"\xff\xff" + b[18:], lambda b: b[: len(b) // 2],
+                   lambda b: b[:-20]):
+        p.write_bytes(mutate(blob))
+        rc0, got0, err0 = gunzip(p, len(data) + 16)
+        rc1, got1, err1, st = pgunzip(p, len(data) + 16, 4, 65536)
+        assert rc1 == rc0 and err1 == err0, (err0, err1, st)
+        assert got0.startswith(got1) or got1.startswith(got0)

@@ -70,6 +70,10 @@ def main():
             w.write_selected(chunk, labels, 0)
             w.close()
         out["writer_%s_reads_per_s" % ("gz" if name.endswith("gz") else "plain")] = rate(int((labels == 0).sum()), write, reps=2)
+    # this build's own .gz output read back: its members carry their size, the reader decodes them in parallel (indexed mode)
+    own = os.path.join(d, "o.fq.gz")
+    n_own = int((labels == 0).sum())
+    out["reader_own_gz_output_reads_per_s"] = rate(n_own, consume(own))
     print(json.dumps(out))
 
 
