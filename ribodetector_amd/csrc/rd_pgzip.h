@@ -431,9 +431,10 @@ class ParallelGzip {
             if (mode_ == M_DONE) break;
             if (mode_ == M_FAIL) return done ? (long)done : -1;
             if (ri_ == ready_.size()) {
-                {
+                if (!indexed_) {   // recycle the section buffers of the batch just handed out (a bounded pool; the rest is freed)
                     std::lock_guard<std::mutex> lk(spare_m_);
-                    for (auto &b : ready_) spare_.push_back(std::move(b));
+                    for (auto &b : ready_)
+                        if (spare_.size() < 2 * ((size_t)T_ + 1)) spare_.push_back(std::move(b));
                 }
                 ready_.clear();
                 ri_ = roff_ = 0;
