@@ -26,6 +26,7 @@ __device__ __forceinline__ f16x8 rnd8(unsigned &s, float scale) {
 #define TR(x) asm volatile("v_exp_f32 %0, %0" : "+v"(x))
 #define FM(x) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x) : "v"(fb), "v"(fa))
 #define LD(x) asm volatile("ds_read_b128 %0, %1" : "=v"(x) : "v"(addr))
+// bit 6 / 7: the A operand changes only every 2nd / 4th MFMA; bit 8: B changes every MFMA
 // MODE bit 0: chain (one accumulator) instead of rotating over 4; bit 1: A operands in AGPRs; bit 2: 16x16x32; bit 3: 8 distinct
 // B fragments cycling (instead of 1); bit 4: small-magnitude B (like the residual arrays: |x| < 2^-11)
 template <int MODE>
@@ -81,8 +82,9 @@ __global__ __launch_bounds__(256, 1) void kern(float *out, int iters) {
             for (int m = 0; m < 32; ++m) {
                 const int c = (MODE & 1) ? ((m >> 3) & 3) : (m & 3);
                 const int b = (MODE & 8) ? ((m >> 2) & 7) : 0;
-                if constexpr (MODE & 2) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[c]) : "a"(A[m & 7]), "v"(B[b]));
-                else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[c]) : "v"(A[m & 7]), "v"(B[b]));
+                const int ai = (MODE & 64) ? ((m >> 1) & 7) : (MODE & 128) ? ((m >> 2) & 7) : (m & 7);
+                if constexpr (MODE & 2) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[c]) : "a"(A[ai]), "v"(B[(MODE & 256) ? (m & 7) : b]));
+                else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[c]) : "v"(A[ai]), "v"(B[(MODE & 256) ? (m & 7) : b]));
                 if constexpr (MODE & 32) {
                     const int q = m % 3;
                     TR(v[(m + 1) & 7]);
@@ -132,6 +134,11 @@ int main(int argc, char **argv) {
     run<2>("32x32x16 rotate, A agpr, 1 B", out, seconds);
     run<3>("32x32x16 chain, A agpr, 1 B", out, seconds);
     run<8>("32x32x16 rotate, A vgpr, 8 B cycling every 4", out, seconds);
+    run<2 + 8>("32x32x16 rotate, A agpr changing every MFMA, B every 4", out, seconds);
+    run<2 + 8 + 64>("32x32x16 rotate, A agpr changing every 2nd MFMA, B every 4", out, seconds);
+    run<2 + 8 + 128>("32x32x16 rotate, A agpr changing every 4th MFMA, B every 4", out, seconds);
+    run<2 + 256>("32x32x16 rotate, A agpr and B changing every MFMA", out, seconds);
+    run<2 + 256 + 128>("32x32x16 rotate, A agpr every 4th, B every MFMA", out, seconds);
     run<9>("32x32x16 chain, A vgpr, 8 B cycling every 4", out, seconds);
     run<8 + 16>("32x32x16 rotate, A vgpr, 8 small B", out, seconds);
     run<4>("16x16x32 rotate 4 acc, A vgpr, 1 B", out, seconds);
