@@ -366,3 +366,21 @@ def test_members_that_carry_their_size_are_decoded_in_parallel(tmp_path):
         rc1, got1, err1, st = pgunzip(p, len(data) + 16, 4, 65536)
         assert rc1 == rc0 and err1 == err0, (err0, err1, st)
         assert got0.startswith(got1) or got1.startswith(got0)
+
+
+def test_parallel_decoder_on_flushed_streams_like_pigz(tmp_path):
+    """pigz compresses 128 KiB pieces and joins them with empty stored blocks (sync flush), -i with full flushes; a member can also
+    hold many tiny blocks: all one DEFLATE stream"""
+    data = PAYLOADS["fastq"]
+    p = tmp_path / "x.gz"
+    for mode, step in ((zlib.Z_SYNC_FLUSH, 131072), (zlib.Z_FULL_FLUSH, 131072), (zlib.Z_SYNC_FLUSH, 3000)):
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        body = b"".join(co.compress(data[i:i + step]) + co.flush(mode) for i in range(0, len(data), step)) + co.flush()
+        blob = b"\x1f\x8b\x08\0\0\0\0\0\0\xff" + body + struct.pack("<II", zlib.crc32(data) & 0xffffffff, len(data))
+        assert gzip.decompress(blob) == data
+        p.write_bytes(blob)
+        for threads, section in ((4, 65536), (3, 200000)):
+            rc, got, err, st = pgunzip(p, len(data) + 16, threads, section)
+            assert rc == 0 and got == data, (mode, step, err, st)
+            if step > 3000:
+                assert st["used"] >= 4 and st["fell_back"] == 0, st
