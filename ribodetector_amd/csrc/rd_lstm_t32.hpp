@@ -50,6 +50,7 @@ struct __attribute__((aligned(16))) Lstm16bSmem {
     long long off[64];
     int orig[64];
     int tmax;
+    int wmax[4];      // per wave: the largest step count of its 16 reads
 };
 
 // Code chunks: thread (row = tid >> 2, piece = tid & 3) moves the 16 bases t0 + 16 piece .. + 15 of read `row` with ONE unaligned 16-byte
@@ -58,10 +59,9 @@ struct __attribute__((aligned(16))) Lstm16bSmem {
 // the read's end (never past it: the arena's size is not known here) and shifts them down; bytes past the end are 0 = code 4.
 // (Issuing the load some steps before its use - and a persistent-workgroup form that fetches the next tile's metadata and bases
 // inside the phase loop - was built and measured in round 2: equal to this form on a full chip)
-__device__ __forceinline__ u32x4 rd_codes_load(const Lstm16bSmem &S, const ReadBatch &rb, int chunk) {
-    const int row = threadIdx.x >> 2, j0 = chunk * TC16 + 16 * (threadIdx.x & 3);
-    const int lr = S.Lr[row], m = lr - j0;                    // valid bytes from j0 on
-    const uint8_t *src = rb.arena + S.off[row];
+__device__ __forceinline__ u32x4 rd_codes_load(int lr, const uint8_t *src, int chunk) {   // lr, src: readable bytes and first byte of read tid >> 2
+    const int j0 = chunk * TC16 + 16 * (threadIdx.x & 3);
+    const int m = lr - j0;                                     // valid bytes from j0 on
     u32x4 raw = {0u, 0u, 0u, 0u};
     if (m >= 16) {
         __builtin_memcpy(&raw, src + j0, 16);
@@ -72,9 +72,9 @@ __device__ __forceinline__ u32x4 rd_codes_load(const Lstm16bSmem &S, const ReadB
     }
     return raw;
 }
-__device__ __forceinline__ void rd_codes_store(Lstm16bSmem &S, int chunk, int buf, u32x4 raw) {
+__device__ __forceinline__ void rd_codes_store(Lstm16bSmem &S, int lr, int chunk, int buf, u32x4 raw) {
     const int row = threadIdx.x >> 2, piece = threadIdx.x & 3, j0 = chunk * TC16 + 16 * piece;
-    const int lr = S.Lr[row], m = lr - j0;
+    const int m = lr - j0;
     if (m > 0 && m < 16 && lr >= 16) {                         // window that ends at the read's end: shift down by 16 - m bytes
         const unsigned sh = 16u - (unsigned)m, b = sh & 3u;
         if (sh & 8u) raw = u32x4{raw[2], raw[3], 0u, 0u};
@@ -87,7 +87,11 @@ __device__ __forceinline__ void rd_codes_store(Lstm16bSmem &S, int chunk, int bu
     for (int q = 0; q < 4; ++q) {
         uint32_t o = 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) o |= (uint32_t)rd_code((raw[q] >> (8 * k)) & 0xffu) << (8 * k);
+        for (int k = 0; k < 4; ++k) {   // rd_code without branches (its ternary chain compiles to sixteen divergent branch ladders here)
+            const uint32_t ch = (raw[q] >> (8 * k)) & 0xffu;
+            const uint32_t c = 4u - 4u * (ch == 'A') - 3u * (ch == 'C') - 2u * (ch == 'G') - (uint32_t)(ch == 'T') - (uint32_t)(ch == 'U');
+            o |= c << (8 * k);
+        }
         w[q] = o;
     }
     uint32_t *dst = reinterpret_cast<uint32_t *>(&S.codes[buf][row][16 * piece]);
@@ -432,19 +436,67 @@ __global__ __launch_bounds__(256, 1) void rd_lstm_mfma_f16x3_t32_kernel(DevModel
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, j = lane & 31;
 
-    if (tid < 64) {
-        const int64_t g = (int64_t)blockIdx.x * 64 + tid;
-        int T = 0, lr = 0, orig = -1;
-        long long off = 0;
-        if (g < rb.n) {
-            orig = rb.order ? rb.order[g] : (int)g;
-            T = rd_T(rb.steps, orig, rb.max_len);
-            lr = rd_T(rb.len, orig, rb.max_len);
-            off = rb.off[orig];
-        }
-        S.T[tid] = T; S.Lr[tid] = lr; S.off[tid] = off; S.orig[tid] = orig;
+    // Everything a workgroup fetches before its first phase is three dependent round trips (order entry -> steps, length, offset ->
+    // the first 64 bases) plus 64 KiB of weights per wave and the input table. Every thread fetches the metadata of read tid >> 2
+    // itself (four threads share a read and its addresses), so no barrier separates the trips, and the weight loads - whose
+    // v_accvgpr_write statements are scheduling barriers - are issued between them and cover their latency.
+    const int row = tid >> 2;
+    const int64_t g = (int64_t)blockIdx.x * 64 + row;
+    const bool valid = g < rb.n;
+    int orig = -1;
+    if (valid) orig = rb.order ? rb.order[g] : (int)g;                                            // round trip 1
+    f32x4 lut_v[3];
+    if constexpr (!(ACC & 4)) {   // the table in this kernel's layout, rows pre-multiplied by -log2 e resp. 2 log2 e (rd_prep_kernel): a straight copy
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(d.lut_t32);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) lut_v[k] = src[tid + 256 * k];
     }
-    if (tid == 0) S.tmax = 0;
+    const float wout_v = d.w_out[(tid >> 7) * 256 + (tid & 127)];
+    // resident weights: 4 row-tiles x 8 k-steps x (W1, W2) x 4 registers = 256 registers, all pinned in AGPRs
+    f16x8 W1[4][8], W2[4][8];
+    const uint4 *wp = reinterpret_cast<const uint4 *>(d.wpack16b) + (size_t)wave * (2 * 4 * 8 * 64) + lane;
+    auto load_row_tile = [&](auto a_c) {   // 16 loads in flight, then their 64 v_accvgpr_write
+        constexpr int a = decltype(a_c)::value;
+        uint4 x[2][8];
+#pragma unroll
+        for (int hl = 0; hl < 2; ++hl)
+#pragma unroll
+            for (int s = 0; s < 8; ++s) x[hl][s] = wp[((hl * 4 + a) * 8 + s) * 64];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+#pragma unroll
+            for (int hl = 0; hl < 2; ++hl) {
+                uint4 y;
+                asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(y.x) : "v"(x[hl][s].x));
+                asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(y.y) : "v"(x[hl][s].y));
+                asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(y.z) : "v"(x[hl][s].z));
+                asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(y.w) : "v"(x[hl][s].w));
+                if (hl == 0) W1[a][s] = __builtin_bit_cast(f16x8, y);
+                else W2[a][s] = __builtin_bit_cast(f16x8, y);
+            }
+        }
+    };
+    load_row_tile(std::integral_constant<int, 0>());
+    int T = 0, lr = 0;
+    long long off = 0;
+    if (valid) {                                                                                   // round trip 2
+        T = rd_T(rb.steps, orig, rb.max_len);
+        lr = rd_T(rb.len, orig, rb.max_len);
+        off = rb.off[orig];
+    }
+    load_row_tile(std::integral_constant<int, 1>());
+    const uint8_t *src0 = rb.arena + off;
+    const u32x4 raw0 = rd_codes_load(lr, src0, 0);                                                 // round trip 3
+    load_row_tile(std::integral_constant<int, 2>());
+    load_row_tile(std::integral_constant<int, 3>());
+    // LDS: state, tables, this tile's metadata and first code chunk
+    if ((tid & 3) == 0) { S.T[row] = T; S.Lr[row] = lr; S.off[row] = off; S.orig[row] = orig; }
+    {
+        int m = T;   // wave maximum of T (16 reads per wave)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
+        if (lane == 0) S.wmax[wave] = m;
+    }
     for (int i = tid; i < 2 * 32 * H16STR / 2; i += 256) { (reinterpret_cast<uint32_t *>(&S.H1s[0][0][0]))[i] = 0u; (reinterpret_cast<uint32_t *>(&S.H2[0][0][0]))[i] = 0u; }
     for (int i = tid; i < 64 * HSTR; i += 256) (&S.Hl[0][0])[i] = 0.0f;
     for (int i = tid; i < 2 * 4 * 256; i += 256) (&S.cS[0][0][0])[i] = f32x4{0, 0, 0, 0};
@@ -454,16 +506,13 @@ __global__ __launch_bounds__(256, 1) void rd_lstm_mfma_f16x3_t32_kernel(DevModel
             const int b = cell & 3, a = (cell >> 2) & 3, hf = (cell >> 4) & 1, w = cell >> 5;
             (reinterpret_cast<float *>(&S.lut[0][0][0][0][0]))[i] = code < 5 ? d.in_lut[code * G4 + gate * HID + 32 * w + 16 * hf + 4 * a + b] : 0.0f;
         }
-    } else {   // the table in this kernel's layout, rows pre-multiplied by -log2 e resp. 2 log2 e (rd_prep_kernel): a straight copy
-        const f32x4 *src = reinterpret_cast<const f32x4 *>(d.lut_t32);
+    } else {
         f32x4 *dst = &S.lut[0][0][0][0][0];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) dst[tid + 256 * k] = src[tid + 256 * k];
+        for (int k = 0; k < 3; ++k) dst[tid + 256 * k] = lut_v[k];
     }
-    S.wout[tid >> 7][tid & 127] = d.w_out[(tid >> 7) * 256 + (tid & 127)];
-    __syncthreads();
-    if (tid < 64) atomicMax(&S.tmax, S.T[tid]);
-    rd_codes_store(S, 0, 0, rd_codes_load(S, rb, 0));
+    S.wout[tid >> 7][tid & 127] = wout_v;
+    rd_codes_store(S, lr, 0, 0, raw0);
     if (FILL < 0) {   // diagnosis: realistic (pseudo-random) B operands that are never updated
         for (int i = tid; i < 2 * 32 * H16STR / 2; i += 256) {
             uint32_t x = (uint32_t)i * 2654435761u + blockIdx.x * 40503u;
@@ -472,37 +521,8 @@ __global__ __launch_bounds__(256, 1) void rd_lstm_mfma_f16x3_t32_kernel(DevModel
             (reinterpret_cast<uint32_t *>(&S.H2[0][0][0]))[i] = ((x * 31u) & 0x83ff83ffu) | 0x34003400u;
         }
     }
-
-    // ---- resident weights: 4 row-tiles x 8 k-steps x (W1, W2) x 4 registers = 256 registers, all pinned in AGPRs ----
-    f16x8 W1[4][8], W2[4][8];
-    {
-        // 16 loads in flight, then their 64 v_accvgpr_write (the asm statements are scheduling barriers: with one load per
-        // statement group every load waited for its own round trip, 64 in a row)
-        const uint4 *wp = reinterpret_cast<const uint4 *>(d.wpack16b) + (size_t)wave * (2 * 4 * 8 * 64) + lane;
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            uint4 x[2][8];
-#pragma unroll
-            for (int hl = 0; hl < 2; ++hl)
-#pragma unroll
-                for (int s = 0; s < 8; ++s) x[hl][s] = wp[((hl * 4 + a) * 8 + s) * 64];
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-#pragma unroll
-                for (int hl = 0; hl < 2; ++hl) {
-                    uint4 y;
-                    asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(y.x) : "v"(x[hl][s].x));
-                    asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(y.y) : "v"(x[hl][s].y));
-                    asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(y.z) : "v"(x[hl][s].z));
-                    asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(y.w) : "v"(x[hl][s].w));
-                    if (hl == 0) W1[a][s] = __builtin_bit_cast(f16x8, y);
-                    else W2[a][s] = __builtin_bit_cast(f16x8, y);
-                }
-            }
-        }
-    }
     __syncthreads();
-    const int tmax = S.tmax;
+    const int tmax = max(max(S.wmax[0], S.wmax[1]), max(S.wmax[2], S.wmax[3]));
 
     f32x16 X[4], Y[4];
 #pragma unroll
@@ -523,7 +543,7 @@ __global__ __launch_bounds__(256, 1) void rd_lstm_mfma_f16x3_t32_kernel(DevModel
         // next code chunk: its buffer was last read by the gate math of phase A above (step t-1)
         if ((t % TC16) == 0) {
             const int chunk = t / TC16 + 1;
-            if (chunk * TC16 < tmax + 1) rd_codes_store(S, chunk, chunk & 1, rd_codes_load(S, rb, chunk));
+            if (chunk * TC16 < tmax + 1) rd_codes_store(S, lr, chunk, chunk & 1, rd_codes_load(lr, src0, chunk));
         }
         // phase B: MFMAs of (tile 1, t) -> Y ; gate math of (tile 0, t) <- X
         rd_phase_t32<1, FILL, ACC>(S, W1, W2, Y, X, R0, t, codeX, wave, half, j, tid);
