@@ -487,6 +487,8 @@ __global__ __launch_bounds__(256, 1) void rd_lstm_mfma_f16x3_t32_kernel(DevModel
     load_row_tile(std::integral_constant<int, 1>());
     const uint8_t *src0 = rb.arena + off;
     const u32x4 raw0 = rd_codes_load(lr, src0, 0);                                                 // round trip 3
+    u32x4 raw1 = {0u, 0u, 0u, 0u};   // both code buffers are free now: reads of up to 128 steps never stage inside the phase loop
+    if (lr > TC16) raw1 = rd_codes_load(lr, src0, 1);
     load_row_tile(std::integral_constant<int, 2>());
     load_row_tile(std::integral_constant<int, 3>());
     // LDS: state, tables, this tile's metadata and first code chunk
@@ -513,6 +515,7 @@ __global__ __launch_bounds__(256, 1) void rd_lstm_mfma_f16x3_t32_kernel(DevModel
     }
     S.wout[tid >> 7][tid & 127] = wout_v;
     rd_codes_store(S, lr, 0, 0, raw0);
+    rd_codes_store(S, lr, 1, 1, raw1);
     if (FILL < 0) {   // diagnosis: realistic (pseudo-random) B operands that are never updated
         for (int i = tid; i < 2 * 32 * H16STR / 2; i += 256) {
             uint32_t x = (uint32_t)i * 2654435761u + blockIdx.x * 40503u;
@@ -540,8 +543,8 @@ __global__ __launch_bounds__(256, 1) void rd_lstm_mfma_f16x3_t32_kernel(DevModel
         const int codeYn = ccol[(32 + j) * CSTR];    // (tile 1, step t): consumed by the next iteration's phase A
         // phase A: MFMAs of (tile 0, t) -> X ; gate math of (tile 1, t-1) <- Y
         rd_phase_t32<0, FILL, ACC>(S, W1, W2, X, Y, R1, t - 1, codeY, wave, half, j, tid);
-        // next code chunk: its buffer was last read by the gate math of phase A above (step t-1)
-        if ((t % TC16) == 0) {
+        // next code chunk (chunks 0 and 1 were staged before the loop): its buffer was last read by the gate math of phase A above (step t-1)
+        if ((t % TC16) == 0 && t > 0) {
             const int chunk = t / TC16 + 1;
             if (chunk * TC16 < tmax + 1) rd_codes_store(S, lr, chunk, chunk & 1, rd_codes_load(lr, src0, chunk));
         }
