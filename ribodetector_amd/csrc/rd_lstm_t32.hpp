@@ -113,13 +113,15 @@ constexpr unsigned char EW_STAGE[EW_NU] = {0,1,2,3,4,5,6,0,7,1,8,2,9,3,10,4,11,5
 // (schedule above, generated by tools/gen_ew_schedule.py: 16 cells x 13 stages, cell c starts at step floor(6.5 c) so that two cells are in flight and never in
 //  the same stage; stage 13 = stores of a finished row-tile; generated offline, units are dealt out in this order)
 struct EwRegs {
-    f32x4 kc[2];        // table rows of the cells in flight, by cell parity
-    f32x2 v[2][2];      // gate pipeline values by cell parity: {i,f} and {g,o} as register pairs (packed fp32 math)
-    float y[2], og[2], hs[2];
+    // slots of the cells in flight: cell % 2 in the phases (two cells in flight), cell % 4 in the gate-math-only tail (a row-tile's
+    // four cells side by side)
+    f32x4 kc[4];        // table rows
+    f32x2 v[4][2];      // gate pipeline values: {i,f} and {g,o} as register pairs
+    float y[4], og[4], hs[4];
     f32x4 cs[2], hv[2]; // per row-tile, by row-tile parity
     f16x4 o1s[2], o2[2];
     f32x4 call[4];      // ACC & 32: the tile's cell state, resident across phases
-    float nm[2];        // ACC & 128: numerators K (e_g - 1) resp. (e_c - 1) of the shared-reciprocal form
+    float nm[4];        // ACC & 128: numerators K (e_g - 1) resp. (e_c - 1) of the shared-reciprocal form
 };
 
 struct PhaseCtx {       // per-lane constants of a phase
@@ -157,11 +159,15 @@ __device__ __forceinline__ float rd_rcp_nr(float d) {
 constexpr float KS_HI = -1.44269502162933349609375f, KS_LO = -1.925963033500011e-8f;   // -log2 e = KS_HI + KS_LO
 constexpr float KT_HI = 2.8853900432586669921875f, KT_LO = 3.851926067000022e-8f;      // 2 log2 e
 
-template <int TP, int U, int ACC = 0>
-__device__ __forceinline__ void rd_ew_unit(Lstm16bSmem &S, EwRegs &R, const f32x16 (&accP)[4], const PhaseCtx &c) {
-    constexpr int cell = EW_CELL[U], stage = EW_STAGE[U];
-    constexpr int a = cell >> 2, b = cell & 3, k = cell & 1, ap = a & 1;
-    if constexpr (stage == 0) {   // table row of the NEXT cell (this cell's row was fetched one cell ago); cell state per row-tile
+// One stage of one cell. NS = register slots of the cells in flight (slot = cell % NS); OWNROW: stage 0 fetches the cell's own
+// table row (the tail) instead of the next cell's (the phases, whose first row is fetched before the first unit).
+template <int TP, int cell, int stage, int ACC, int NS, bool OWNROW>
+__device__ __forceinline__ void rd_ew_cs(Lstm16bSmem &S, EwRegs &R, const f32x16 (&accP)[4], const PhaseCtx &c) {
+    constexpr int a = cell >> 2, b = cell & 3, k = cell % NS, ap = a & 1;
+    if constexpr (stage == 0 && OWNROW) {
+        R.kc[k] = S.lut[c.wave][c.half][a][b][c.codeEW];
+        if constexpr (b == 0 && !(ACC & 32)) R.cs[ap] = S.cS[TP][a][c.tid];
+    } else if constexpr (stage == 0) {   // table row of the NEXT cell (this cell's row was fetched one cell ago); cell state per row-tile
         constexpr int nc = cell + 1;
         if constexpr (nc < 16) {
             if constexpr (ACC & 256) R.kc[k ^ 1] = R.kc[k];   // timing diagnosis only (WRONG results): what the 16 table-row reads cost
@@ -269,13 +275,13 @@ __device__ __forceinline__ void rd_ew_unit(Lstm16bSmem &S, EwRegs &R, const f32x
         //   r  = hs - fp32(P.half)  (exact, in fp32)    one v_fma_mix_f32 each (fp32 result: the fp16-output form
         //                                               v_fma_mixlo_f16 measurably loses accuracy)
         //   O2 = {fp16(r0), fp16(r1)}                   one v_cvt_pk_f16_f32
-        if constexpr (k == 1) {
+        if constexpr (cell & 1) {
             typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-            const f16x2 P = {(_Float16)R.hs[0], (_Float16)R.hs[1]};
+            const f16x2 P = {(_Float16)R.hs[k - 1], (_Float16)R.hs[k]};
             unsigned pbits = __builtin_bit_cast(unsigned, P);
             float r0, r1;
-            asm volatile("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(R.hs[0]), "v"(pbits));
-            asm volatile("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(R.hs[1]), "v"(pbits));
+            asm volatile("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(R.hs[k - 1]), "v"(pbits));
+            asm volatile("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(R.hs[k]), "v"(pbits));
             const f16x2 O = {(_Float16)r0, (_Float16)r1};
             R.o1s[ap][b - 1] = P[0]; R.o1s[ap][b] = P[1];
             R.o2[ap][b - 1] = O[0]; R.o2[ap][b] = O[1];
@@ -295,6 +301,11 @@ __device__ __forceinline__ void rd_ew_unit(Lstm16bSmem &S, EwRegs &R, const f32x
         *dst = R.hv[ap];
         }
     }
+}
+
+template <int TP, int U, int ACC = 0>
+__device__ __forceinline__ void rd_ew_unit(Lstm16bSmem &S, EwRegs &R, const f32x16 (&accP)[4], const PhaseCtx &c) {
+    rd_ew_cs<TP, EW_CELL[U], EW_STAGE[U], ACC, 2, false>(S, R, accP, c);
 }
 
 template <int TP, int U0, int U1, int ACC = 0>
@@ -415,6 +426,28 @@ __device__ __forceinline__ void rd_phase_t32(Lstm16bSmem &S, const f16x8 (&W1)[4
     if constexpr (FILL != 7) __syncthreads();   // FILL 7: bench diagnosis only (racy, wrong results): what the barrier costs
 }
 
+template <int TP, int ACC, int A, int STAGE, int B>
+__device__ __forceinline__ void rd_tail_cells(Lstm16bSmem &S, EwRegs &R, const f32x16 (&accP)[4], const PhaseCtx &c) {
+    if constexpr (B < 4) {
+        if constexpr (STAGE < 13 || B == 3) rd_ew_cs<TP, 4 * A + B, STAGE, ACC, 4, true>(S, R, accP, c);   // stage 13 = the row-tile's stores
+        rd_tail_cells<TP, ACC, A, STAGE, B + 1>(S, R, accP, c);
+    }
+}
+template <int TP, int ACC, int A, int STAGE>
+__device__ __forceinline__ void rd_tail_stages(Lstm16bSmem &S, EwRegs &R, const f32x16 (&accP)[4], const PhaseCtx &c) {
+    if constexpr (STAGE < 14) {
+        rd_tail_cells<TP, ACC, A, STAGE, 0>(S, R, accP, c);
+        rd_tail_stages<TP, ACC, A, STAGE + 1>(S, R, accP, c);
+    }
+}
+template <int TP, int ACC, int A>
+__device__ __forceinline__ void rd_tail_rowtiles(Lstm16bSmem &S, EwRegs &R, const f32x16 (&accP)[4], const PhaseCtx &c) {
+    if constexpr (A < 4) {
+        rd_tail_stages<TP, ACC, A, 0>(S, R, accP, c);
+        rd_tail_rowtiles<TP, ACC, A + 1>(S, R, accP, c);
+    }
+}
+
 // The gate math of the last step of tile TP, after the loop: no tile is left whose MFMAs it could hide behind.
 template <int TP, int ACC>
 __device__ __forceinline__ void rd_phase_ewonly(Lstm16bSmem &S, f32x16 (&accP)[4], EwRegs &R, int tEW, int codeEW, int wave, int half,
@@ -423,8 +456,10 @@ __device__ __forceinline__ void rd_phase_ewonly(Lstm16bSmem &S, f32x16 (&accP)[4
     c.codeEW = codeEW; c.wave = wave; c.half = half; c.j = j; c.tid = tid;
     c.last = (tEW == S.T[TP * 32 + j] - 1);
     c.any_last = __builtin_amdgcn_ballot_w64(c.last) != 0;
-    R.kc[0] = S.lut[wave][half][0][0][codeEW];
-    rd_ew_units<TP, 0, EW_NU, ACC>(S, R, accP, c);
+    // No MFMAs to hide behind, so no pipeline of two cells either: the four cells of a row-tile go through every stage side by side
+    // (the same operations on the same values as in a phase - the results are bit-identical - but 4 independent chains per lane
+    // instead of 2: -0.3 % on one CU, -0.13 % on the full chip).
+    rd_tail_rowtiles<TP, ACC, 0>(S, R, accP, c);
     __syncthreads();
 }
 
@@ -541,7 +576,8 @@ __global__ __launch_bounds__(256, 1) void rd_lstm_mfma_f16x3_t32_kernel(DevModel
         const uint8_t *ccol = &S.codes[(t / TC16) & 1][0][t % TC16];
         const int codeX = ccol[j * CSTR];            // (tile 0, step t): consumed by phase B's gate math
         const int codeYn = ccol[(32 + j) * CSTR];    // (tile 1, step t): consumed by the next iteration's phase A
-        // phase A: MFMAs of (tile 0, t) -> X ; gate math of (tile 1, t-1) <- Y
+        // phase A: MFMAs of (tile 0, t) -> X ; gate math of (tile 1, t-1) <- Y. (At t = 0 the phase changes nothing - h = 0, zero
+        // accumulators, the all-zero table row - but skipping it behind a branch made the loop 1.2 % slower: measured, left in.)
         rd_phase_t32<0, FILL, ACC>(S, W1, W2, X, Y, R1, t - 1, codeY, wave, half, j, tid);
         // next code chunk (chunks 0 and 1 were staged before the loop): its buffer was last read by the gate math of phase A above (step t-1)
         if ((t % TC16) == 0 && t > 0) {
