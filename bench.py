@@ -135,6 +135,8 @@ def pmc_traffic(args, kernel_substr, timeout_s=240):
                "--pmc-child", "--workload", args.workload, "--variant", args.variant, "--pairs-per-step", str(args.pairs_per_step),
                "--ensure", args.ensure]
         env = dict(os.environ, TMPDIR="/tmp")
+        for k in ("RD_FORCE_DIST", "MASTER_PORT"):         # the counter child is a plain one-process run
+            env.pop(k, None)
         try:
             r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout_s)
         except subprocess.TimeoutExpired:
@@ -234,7 +236,8 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     dev = torch.device("cuda", int(os.environ.get("RD_LOCAL_DEVICE", local)))   # override: several ranks on one GPU (tests only)
     torch.cuda.set_device(dev)
-    backend = dist.get_backend() if world > 1 else None
+    multi = rdist.active()                                 # several ranks - or ONE rank under RD_FORCE_DIST=1 (a one-rank RCCL
+    backend = dist.get_backend() if multi else None        # communicator: the collectives of the N>1 run, executed on a 1-GPU box)
 
     cfg = ConfigParser.from_json(os.path.join(ROOT, "ribodetector_amd", "config.json"))
     model = cfg.init_obj("arch", module_arch)
@@ -263,7 +266,7 @@ def main():
     lgs = [[torch.empty((P, 2), dtype=torch.float32, device=dev) for _ in range(nm)] for _ in range(2)]
     lab8s = [torch.empty((P,), dtype=torch.uint8, device=dev) for _ in range(2)]
     counts = torch.zeros(3, dtype=torch.int64, device=dev)
-    gathered = torch.empty(P * world, dtype=torch.int8, device=dev) if (world > 1 and rank == 0) else None
+    gathered = torch.empty(P * world, dtype=torch.int8, device=dev) if (multi and rank == 0) else None
     cur = torch.cuda.current_stream(dev)
     side = torch.cuda.Stream(dev)
     pipelined = not (args.inline_refine or args.pmc_child)   # counter passes: one stream, so that no other kernel runs beside the one counted
@@ -304,14 +307,14 @@ def main():
         return ev_post[k], fin
 
     def exchange(lab):
-        if world > 1:
+        if multi:
             _, fin = rdist.gather_labels(lab, P * world, dst=0, async_op=True, out=gathered)
             return fin
         return None
 
     def sync():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if multi:
             dist.barrier()
             torch.cuda.synchronize(dev)
 
@@ -367,7 +370,7 @@ def main():
         for f in pend:
             f()
 
-    if world > 1:                                           # create the communicators (incl. the point-to-point ones the gather
+    if multi:                                               # create the communicators (incl. the point-to-point ones the gather
         f = exchange(torch.zeros((P,), dtype=torch.int8, device=dev))   # uses) outside the timed region, whatever --warmup is
         if f:
             f()
@@ -385,9 +388,9 @@ def main():
     launches, kms = model.profile_read()
     model.profile_enable(False)
     rdist.reduce_counts(counts)
-    on_dev = world == 1 or backend == "nccl"
+    on_dev = not multi or backend == "nccl"
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev if on_dev else "cpu")
-    if world > 1:
+    if multi:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     total_pairs = P * args.steps * world
@@ -404,7 +407,7 @@ def main():
         sync()
         dt_res = time.perf_counter() - t1
         tr = torch.tensor([dt_res], dtype=torch.float64, device=dev if on_dev else "cpu")
-        if world > 1:
+        if multi:
             dist.all_reduce(tr, op=dist.ReduceOp.MAX)
         dt_res = float(tr.item())
 
@@ -455,7 +458,7 @@ def main():
                                      "parity_sample below is this run's check against the fp32 CPU port"
                                      if base == "mfma_f16x3_t32" else "fp32"),
                        "parallelism": "reads sharded x%d, label gather to rank 0" % world,
-                       "rccl_ranks": world, "dist_backend": backend,
+                       "rccl_ranks": world, "dist_backend": backend, "forced_dist": bool(multi and world == 1),
                        "refine": {"band": module_arch.SeqModel.REFINE_DEFAULT, "what": "reads whose margin is inside the band are "
                                   "re-evaluated in float64 (labels of the exact function); inside the timed region",
                                   "placement": "side stream, overlapping the next step's recurrences" if pipelined else "inline in rd_classify"},
@@ -517,7 +520,7 @@ def main():
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out))
         sys.stdout.flush()
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -66,6 +66,8 @@ class Predictor:
         self.logger = config.get_logger('predict', 1, self.args.log if int(os.environ.get('RANK', '0')) == 0 else None)
         self.chunk_size = self.args.chunk_size
         self.rank, self.world, self.local_rank = 0, 1, 0
+        self.multi = False                       # collectives in use: several ranks (or one rank under RD_FORCE_DIST=1, dist.py)
+        self._part_files = []                    # this rank's part files of a sharded-parse run (removed if the run fails)
         self.sharded_parse = False               # several ranks, plain input: every rank parses its own byte range
 
     # ---- model -------------------------------------------------------------------------------------
@@ -86,13 +88,14 @@ class Predictor:
             os.environ["HIP_VISIBLE_DEVICES"] = self.args.deviceid
             os.environ["CUDA_VISIBLE_DEVICES"] = self.args.deviceid
         self.rank, self.world, self.local_rank = rdist.init_from_env()
+        self.multi = rdist.active()
         self.get_state_dict()
         model = self.config.init_obj('arch', module_arch)
         if not torch.cuda.is_available():
             self.logger.error('{}No visible GPU devices!{} This build runs the HIP kernels only; the CPU product of the '
                               'reference is ribodetector_cpu'.format(colors.FAIL, colors.ENDC))
             raise RuntimeError("Set HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES or use CPU inference.")
-        if self.world > 1:                       # one process per GPU; RD_LOCAL_DEVICE pins a rank elsewhere (ranks sharing a GPU)
+        if self.multi:                           # one process per GPU; RD_LOCAL_DEVICE pins a rank elsewhere (ranks sharing a GPU)
             self.device = torch.device('cuda', int(os.environ.get('RD_LOCAL_DEVICE', self.local_rank)))
             torch.cuda.set_device(self.device)
         else:
@@ -133,7 +136,7 @@ class Predictor:
         collect_chunk()."""
         n = len(chunks[0].seq_len)
         bounds = None
-        if self.world > 1 and not self.sharded_parse:   # equal bases (= recurrence steps) per rank, not equal read counts
+        if self.multi and not self.sharded_parse:   # equal bases (= recurrence steps) per rank, not equal read counts
             work = sum(np.minimum(np.asarray(c.seq_len, dtype=np.int64), self.len) for c in chunks)
             bounds = rdist.shard_bounds(n, self.world, work)
         lo, hi = (0, n) if bounds is None else (bounds[self.rank], bounds[self.rank + 1])
@@ -158,7 +161,7 @@ class Predictor:
             else:
                 labels = outs[0][1].view(torch.int8)
             host = finish = None
-            if self.world == 1 or self.sharded_parse:
+            if not self.multi or self.sharded_parse:
                 host = torch.empty(labels.shape, dtype=torch.int8, pin_memory=True)
                 host.copy_(labels, non_blocking=True)
             else:                                    # label gather (1 B per read) queued behind the kernels, collected later
@@ -169,7 +172,7 @@ class Predictor:
 
     def collect_chunk(self, tk):
         """Labels of a submitted chunk: int8 numpy on rank 0 (whole chunk, input order), None elsewhere."""
-        if self.world > 1 and not self.sharded_parse:
+        if self.multi and not self.sharded_parse:
             labels = tk["finish"]()
             return None if self.rank != 0 else labels.cpu().numpy()
         tk["done"].synchronize()
@@ -230,7 +233,7 @@ class Predictor:
         if chunk_reads is None:
             chunk_reads = self.batch_size * self.chunk_size
         # plain inputs under several ranks: every rank parses, classifies and writes its own byte range (no label exchange)
-        self.sharded_parse = self.world > 1 and not any(fx.file_info(p)[1] for p in self.input)
+        self.sharded_parse = self.multi and not any(fx.file_info(p)[1] for p in self.input)
         self.bytes_parsed = None
         if self.sharded_parse:
             import torch.distributed as dist
@@ -245,7 +248,11 @@ class Predictor:
                 if self.rank == 0:
                     self.logger.info('Rank {} parses {} bytes of {}'.format(
                         r, ", ".join(str(b) for b in bp), ", ".join(str(fx.file_info(p)[0]) for p in self.input)))
-        part = (lambda path: part_path(path, self.rank)) if self.sharded_parse else (lambda path: path)
+        def part(path):
+            if not self.sharded_parse:
+                return path
+            self._part_files.append(part_path(path, self.rank))
+            return self._part_files[-1]
         writer = self.rank == 0 or self.sharded_parse
         ends = (0, 1) if self.is_paired else (0,)
         fhs = {}
@@ -343,13 +350,22 @@ class Predictor:
             mine = [os.path.getsize(part_path(path, self.rank)) for path in finals]
             sizes = [None] * self.world
             dist.all_gather_object(sizes, mine)
+            # the join goes into '<final>.joining' and is renamed after the last barrier: a run that dies while the parts are
+            # being placed never leaves a full-size, partly zero-filled file under the final name
+            tmps = [path + '.joining' for path in finals]
+            self._part_files += tmps if self.rank == 0 else []
             if self.rank == 0:
-                for f, path in enumerate(finals):
-                    with open(path, 'wb') as fh:
+                for f, tmp in enumerate(tmps):
+                    with open(tmp, 'wb') as fh:
                         fh.truncate(sum(sz[f] for sz in sizes))
             dist.barrier()
             for f, path in enumerate(finals):
-                fx.place_part(path, part_path(path, self.rank), sum(sizes[r][f] for r in range(self.rank)))
+                fx.place_part(tmps[f], part_path(path, self.rank), sum(sizes[r][f] for r in range(self.rank)))
+            dist.barrier()
+            if self.rank == 0:
+                for tmp, path in zip(tmps, finals):
+                    os.replace(tmp, path)
+            self._part_files = []
             dist.barrier()
         if self.rank == 0:
             self.logger.info('Processed {}{}{}{} sequences in total'.format(colors.BOLD, colors.OKCYAN, num_read, colors.ENDC))
@@ -450,7 +466,12 @@ def main(argv=None):
         seq_pred.load_model()
         seq_pred.detect()
     except BaseException:
-        if seq_pred.world > 1:
+        for f in seq_pred._part_files:           # a failed sharded run leaves no '<out>.partN' / '<out>.joining' files behind
+            try:
+                os.remove(f)
+            except OSError:
+                pass
+        if seq_pred.multi:
             # a rank that fails must not leave the others waiting in a collective (and must not wait in one itself while the
             # interpreter shuts down): report and leave at once - torch.distributed.run then tears the other ranks down
             import sys

@@ -13,19 +13,37 @@ import torch
 import torch.distributed as dist
 
 
+def forced():
+    """RD_FORCE_DIST=1: take the collective branches even with ONE rank (a one-rank RCCL communicator), so that the code a
+    multi-GPU node runs - init_process_group("nccl"), the label gather and the counter all-reduce on device tensors - also
+    executes on a 1-GPU box (tests/test_gpu_dist.py, `RD_FORCE_DIST=1 python bench.py`)."""
+    return os.environ.get("RD_FORCE_DIST", "") == "1"
+
+
+def active(group=None):
+    """True when the collectives below really run: several ranks, or one rank under RD_FORCE_DIST=1"""
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or forced())
+
+
 def init_from_env(backend=None):
     """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun). Returns (rank, world, local_rank)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or forced()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1 and "MASTER_PORT" not in os.environ:   # a forced one-rank group outside torchrun: any free port
+            import socket
+            with socket.socket() as s:
+                s.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(s.getsockname()[1])
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:                      # RD_DIST_BACKEND=gloo: label exchange over host memory (e.g. several ranks
             backend = os.environ.get("RD_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")   # sharing one GPU)
         if backend == "nccl":
-            torch.cuda.set_device(local)
-            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+            dev = int(os.environ.get("RD_LOCAL_DEVICE", local))
+            torch.cuda.set_device(dev)
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", dev))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, world, local
@@ -62,7 +80,7 @@ def gather_labels(local_labels, n_total, dst=0, group=None, async_op=False, out=
     Every rank passes its shard's labels (length shard_range(n_total, rank, world), or bounds[rank+1]-bounds[rank] when the
     shard_bounds() of a weighted split are given). Returns the [n_total] tensor on `dst` (None elsewhere); with
     async_op=True returns (tensor_or_None, finish) where finish() waits and trims."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not active(group):
         return (local_labels, (lambda: local_labels)) if async_op else local_labels
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     if local_labels.is_cuda and dist.get_backend(group) == "gloo":
@@ -95,7 +113,7 @@ def gather_labels(local_labels, n_total, dst=0, group=None, async_op=False, out=
 
 def reduce_counts(counts, group=None):
     """all-reduce(SUM) of the int64[3] counters; every rank gets the totals."""
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    if active(group):
         if counts.is_cuda and dist.get_backend(group) == "gloo":
             host = counts.cpu()
             dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)

@@ -1,0 +1,96 @@
+"""The RCCL branch of ribodetector_amd/dist.py on the hardware a 1-GPU box has: a ONE-rank `nccl` process group
+(RD_FORCE_DIST=1 bypasses the world == 1 shortcuts). What a multi-GPU node runs - init_process_group("nccl", device_id=...),
+dist.gather of device label tensors issued asynchronously, the int64[3] all-reduce, the async finish() inside bench.py's
+timed region, the gz-input label-gather mode of the CLI - executes here with W = 1; W >= 2 over RCCL stays
+tests/test_gpu_bench.py::test_two_gpu_rccl_when_available. The reference has nothing to mirror (its DataParallel wrap is
+dead code, reference detect.py:95-96)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+_WORKER = r"""
+import os, sys
+sys.path.insert(0, %(root)r)
+import torch, torch.distributed as dist
+from ribodetector_amd import dist as rdist
+rank, world, local = rdist.init_from_env()
+assert (rank, world) == (0, 1) and dist.is_initialized() and dist.get_backend() == "nccl" and rdist.active()
+dev = torch.device("cuda", 0)
+g = torch.Generator(device=dev); g.manual_seed(11)
+for n in (1, 63, 4096, 1 << 20):
+    lab = torch.randint(-1, 2, (n,), generator=g, device=dev, dtype=torch.int8)
+    full = rdist.gather_labels(lab, n, dst=0)                       # blocking form
+    assert full.is_cuda and full.data_ptr() != lab.data_ptr() and torch.equal(full, lab)
+    out = torch.empty(n, dtype=torch.int8, device=dev)
+    side = torch.cuda.Stream(dev)
+    with torch.cuda.stream(side):                                    # the form bench.py / detect.py use: async, on a side stream
+        buf, fin = rdist.gather_labels(lab, n, dst=0, async_op=True, out=out)
+    got = fin()
+    torch.cuda.synchronize()
+    assert got.data_ptr() == out.data_ptr() and torch.equal(got, lab)
+    got = rdist.gather_labels(lab.view(torch.uint8), n, dst=0, bounds=[0, n])   # weighted-split form
+    assert torch.equal(got.view(torch.int8), lab)
+counts = torch.tensor([5, 7, 11], dtype=torch.int64, device=dev)
+assert rdist.reduce_counts(counts) is counts and counts.tolist() == [5, 7, 11]
+dist.barrier()
+dist.destroy_process_group()
+print("RCCL_ONE_RANK_OK")
+"""
+
+
+def _env(**kw):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "RD_LOCAL_DEVICE", "RD_DIST_BACKEND", "MASTER_PORT")}
+    env.update(RD_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0", **kw)
+    return env
+
+
+def test_one_rank_rccl_gather_and_allreduce():
+    r = subprocess.run([sys.executable, "-c", _WORKER % {"root": ROOT}], cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL_ONE_RANK_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_bench_forced_dist_one_rank_rccl(report):
+    """`RD_FORCE_DIST=1 python bench.py --gpus 1`: the label gather over a one-rank RCCL communicator inside the timed region;
+    the rate must be the normal line's (the exchange hides behind the next step's recurrences)."""
+    common = ["--steps", "6", "--warmup", "2", "--no-alt", "--no-cpu-baseline", "--no-encoder", "--traffic", "off"]
+    lines = {}
+    for name, env in (("forced", _env()), ("plain", {k: v for k, v in _env().items() if k != "RD_FORCE_DIST"})):
+        r = subprocess.run([sys.executable, "bench.py", "--gpus", "1"] + common, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        js = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(js) == 1
+        lines[name] = json.loads(js[0])
+    f, p = lines["forced"], lines["plain"]
+    assert f["config"]["dist_backend"] == "nccl" and f["config"]["rccl_ranks"] == 1 and f["config"]["forced_dist"] is True
+    assert p["config"]["dist_backend"] is None and p["config"]["forced_dist"] is False
+    assert f["config"]["label_counts"] == p["config"]["label_counts"]
+    report["bench_forced_dist"] = {"forced_reads_per_s": f["value"], "plain_reads_per_s": p["value"], "ratio": f["value"] / p["value"]}
+    assert f["value"] > 0.97 * p["value"], (f["value"], p["value"])
+
+
+@pytest.mark.parametrize("ext", [".fq.gz", ".fq"])
+def test_cli_modes_over_one_rank_rccl(tmp_path, ext):
+    """gz input under (forced) dist = the label-gather mode of the CLI: shard bounds by bases, dist.gather of the device labels
+    on the post stream; plain input = the sharded-parse mode: plan_ranges' all_gather_object, counter all-reduce, part files
+    joined through '<out>.joining' + rename. Output files must equal the plain single-process run's, nothing else left behind."""
+    from ribodetector_amd import synth
+    n = 20000
+    a, o, _ = synth.reads_numpy(n, (40, 130), seed=77, rrna_frac=0.3)
+    inp = str(tmp_path / ("in" + ext))
+    synth.write_fastq(inp, a, o, 1)
+    outs = {}
+    for name, env in (("forced", _env()), ("plain", {k: v for k, v in _env().items() if k != "RD_FORCE_DIST"})):
+        out, rr = str(tmp_path / (name + ".non.fq")), str(tmp_path / (name + ".rrna.fq"))
+        r = subprocess.run([sys.executable, "-m", "ribodetector_amd.detect", "-l", "100", "-i", inp, "-o", out, "-r", rr, "--chunk_size", "1", "-m", "3"],
+                           cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        outs[name] = (open(out, "rb").read(), open(rr, "rb").read())
+    assert outs["forced"] == outs["plain"] and len(outs["plain"][0]) > 0 and len(outs["plain"][1]) > 0
+    assert sorted(os.listdir(tmp_path)) == sorted(["in" + ext, "forced.non.fq", "forced.rrna.fq", "plain.non.fq", "plain.rrna.fq"])
