@@ -30,6 +30,9 @@
 #include "rd_sort.hpp"
 #include "rd_lstm_f32.hpp"
 #include "rd_lstm_t32.hpp"
+#ifdef RD_DIAG
+#include "rd_lstm_t32_diag.hpp"   // A/B and accuracy experiments: diagnostic builds only
+#endif
 #include "rd_refine.hpp"
 #include "rd_encode.hpp"
 
@@ -234,7 +237,7 @@ int rd_classify(const rd_model *cm, const uint8_t *arena, const int64_t *seq_off
         const int64_t nwg = (n + BT - 1) / BT;
         const dim3 grid((unsigned)nwg), blk(256);
         switch (m->variant) {
-        case RD_VARIANT_MFMA_F16X3_T32: hipLaunchKernelGGL((rd_lstm_mfma_f16x3_t32_kernel<6, T32_PRODUCT>), grid, blk, 0, st, m->d, rb, logits, labels); break;
+        case RD_VARIANT_MFMA_F16X3_T32: hipLaunchKernelGGL(rd_lstm_mfma_f16x3_t32_kernel, grid, blk, 0, st, m->d, rb, logits, labels); break;
         case RD_VARIANT_MFMA_F32: hipLaunchKernelGGL((rd_lstm_mfma_f32_kernel<2, 0>), grid, blk, 0, st, m->d, rb, logits, labels); break;
 #ifdef RD_DIAG
         case 10: hipLaunchKernelGGL((rd_lstm_mfma_f32_kernel<0, 0>), grid, blk, 0, st, m->d, rb, logits, labels); break;
@@ -245,25 +248,25 @@ int rd_classify(const rd_model *cm, const uint8_t *arena, const int64_t *seq_off
         case 21: hipLaunchKernelGGL((rd_lstm_mfma_f32_kernel<1, 0, 2>), grid, blk, 0, st, m->d, rb, logits, labels); break;
         case 22: hipLaunchKernelGGL((rd_lstm_mfma_f32_kernel<1, 0, 3>), grid, blk, 0, st, m->d, rb, logits, labels); break;
         case 23: hipLaunchKernelGGL((rd_lstm_mfma_f32_kernel<1, 0, 4>), grid, blk, 0, st, m->d, rb, logits, labels); break;
-        case 40: hipLaunchKernelGGL(rd_lstm_mfma_f16x3_t32_kernel<0>, grid, blk, 0, st, m->d, rb, logits, labels); break;
-        case 41: hipLaunchKernelGGL(rd_lstm_mfma_f16x3_t32_kernel<-1>, grid, blk, 0, st, m->d, rb, logits, labels); break;
-        case 42: hipLaunchKernelGGL(rd_lstm_mfma_f16x3_t32_kernel<7>, grid, blk, 0, st, m->d, rb, logits, labels); break;
+        case 40: hipLaunchKernelGGL(t32diag::rd_lstm_mfma_f16x3_t32_kernel<0>, grid, blk, 0, st, m->d, rb, logits, labels); break;
+        case 41: hipLaunchKernelGGL(t32diag::rd_lstm_mfma_f16x3_t32_kernel<-1>, grid, blk, 0, st, m->d, rb, logits, labels); break;
+        case 42: hipLaunchKernelGGL(t32diag::rd_lstm_mfma_f16x3_t32_kernel<7>, grid, blk, 0, st, m->d, rb, logits, labels); break;
         // accuracy experiments (ACC bits, rd_lstm_t32.hpp): id = 50 + ACC
-        case 50: hipLaunchKernelGGL((rd_lstm_mfma_f16x3_t32_kernel<6, 0>), grid, blk, 0, st, m->d, rb, logits, labels); break;
-        case 51: hipLaunchKernelGGL((rd_lstm_mfma_f16x3_t32_kernel<6, 1>), grid, blk, 0, st, m->d, rb, logits, labels); break;
-        case 52: hipLaunchKernelGGL((rd_lstm_mfma_f16x3_t32_kernel<6, 2>), grid, blk, 0, st, m->d, rb, logits, labels); break;
-        case 54: hipLaunchKernelGGL((rd_lstm_mfma_f16x3_t32_kernel<6, 4>), grid, blk, 0, st, m->d, rb, logits, labels); break;
-        case 58: hipLaunchKernelGGL((rd_lstm_mfma_f16x3_t32_kernel<6, 8>), grid, blk, 0, st, m->d, rb, logits, labels); break;
-        case 65: hipLaunchKernelGGL((rd_lstm_mfma_f16x3_t32_kernel<6, 15>), grid, blk, 0, st, m->d, rb, logits, labels); break;
-        case 66: hipLaunchKernelGGL((rd_lstm_mfma_f16x3_t32_kernel<6, 16>), grid, blk, 0, st, m->d, rb, logits, labels); break;
-        case 82: hipLaunchKernelGGL((rd_lstm_mfma_f16x3_t32_kernel<6, 32>), grid, blk, 0, st, m->d, rb, logits, labels); break;
-        case 98: hipLaunchKernelGGL((rd_lstm_mfma_f16x3_t32_kernel<6, 48>), grid, blk, 0, st, m->d, rb, logits, labels); break;
-        case 162: hipLaunchKernelGGL((rd_lstm_mfma_f16x3_t32_kernel<6, 48 + 64>), grid, blk, 0, st, m->d, rb, logits, labels); break;   // = the product
-        case 290: hipLaunchKernelGGL((rd_lstm_mfma_f16x3_t32_kernel<6, 48 + 64 + 128>), grid, blk, 0, st, m->d, rb, logits, labels); break;
-        case 802: hipLaunchKernelGGL((rd_lstm_mfma_f16x3_t32_kernel<6, 48 + 64 + 128 + 512>), grid, blk, 0, st, m->d, rb, logits, labels); break;
-        case 298: hipLaunchKernelGGL((rd_lstm_mfma_f16x3_t32_kernel<6, 48 + 64 + 128 + 8>), grid, blk, 0, st, m->d, rb, logits, labels); break;
-        case 1314: hipLaunchKernelGGL((rd_lstm_mfma_f16x3_t32_kernel<6, 48 + 64 + 128 + 1024>), grid, blk, 0, st, m->d, rb, logits, labels); break;   // wrong by design
-        case 418: hipLaunchKernelGGL((rd_lstm_mfma_f16x3_t32_kernel<6, 48 + 64 + 256>), grid, blk, 0, st, m->d, rb, logits, labels); break;   // wrong by design
+        case 50: hipLaunchKernelGGL((t32diag::rd_lstm_mfma_f16x3_t32_kernel<6, 0>), grid, blk, 0, st, m->d, rb, logits, labels); break;
+        case 51: hipLaunchKernelGGL((t32diag::rd_lstm_mfma_f16x3_t32_kernel<6, 1>), grid, blk, 0, st, m->d, rb, logits, labels); break;
+        case 52: hipLaunchKernelGGL((t32diag::rd_lstm_mfma_f16x3_t32_kernel<6, 2>), grid, blk, 0, st, m->d, rb, logits, labels); break;
+        case 54: hipLaunchKernelGGL((t32diag::rd_lstm_mfma_f16x3_t32_kernel<6, 4>), grid, blk, 0, st, m->d, rb, logits, labels); break;
+        case 58: hipLaunchKernelGGL((t32diag::rd_lstm_mfma_f16x3_t32_kernel<6, 8>), grid, blk, 0, st, m->d, rb, logits, labels); break;
+        case 65: hipLaunchKernelGGL((t32diag::rd_lstm_mfma_f16x3_t32_kernel<6, 15>), grid, blk, 0, st, m->d, rb, logits, labels); break;
+        case 66: hipLaunchKernelGGL((t32diag::rd_lstm_mfma_f16x3_t32_kernel<6, 16>), grid, blk, 0, st, m->d, rb, logits, labels); break;
+        case 82: hipLaunchKernelGGL((t32diag::rd_lstm_mfma_f16x3_t32_kernel<6, 32>), grid, blk, 0, st, m->d, rb, logits, labels); break;
+        case 98: hipLaunchKernelGGL((t32diag::rd_lstm_mfma_f16x3_t32_kernel<6, 48>), grid, blk, 0, st, m->d, rb, logits, labels); break;
+        case 162: hipLaunchKernelGGL((t32diag::rd_lstm_mfma_f16x3_t32_kernel<6, 48 + 64>), grid, blk, 0, st, m->d, rb, logits, labels); break;   // = the product
+        case 290: hipLaunchKernelGGL((t32diag::rd_lstm_mfma_f16x3_t32_kernel<6, 48 + 64 + 128>), grid, blk, 0, st, m->d, rb, logits, labels); break;
+        case 802: hipLaunchKernelGGL((t32diag::rd_lstm_mfma_f16x3_t32_kernel<6, 48 + 64 + 128 + 512>), grid, blk, 0, st, m->d, rb, logits, labels); break;
+        case 298: hipLaunchKernelGGL((t32diag::rd_lstm_mfma_f16x3_t32_kernel<6, 48 + 64 + 128 + 8>), grid, blk, 0, st, m->d, rb, logits, labels); break;
+        case 1314: hipLaunchKernelGGL((t32diag::rd_lstm_mfma_f16x3_t32_kernel<6, 48 + 64 + 128 + 1024>), grid, blk, 0, st, m->d, rb, logits, labels); break;   // wrong by design
+        case 418: hipLaunchKernelGGL((t32diag::rd_lstm_mfma_f16x3_t32_kernel<6, 48 + 64 + 256>), grid, blk, 0, st, m->d, rb, logits, labels); break;   // wrong by design
 #endif
         default: RD_FAIL(RD_E_UNSUPPORTED, "rd_classify: variant %d not available in this build", m->variant);
         }

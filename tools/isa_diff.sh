@@ -24,7 +24,7 @@ for line in open(path):
         if re.match(r"^_Z\w*%s\w*:" % re.escape(kern), line):
             on = True
         continue
-    if line.startswith("\t.end_amdhsa_kernel") or re.match(r"^\.Lfunc_end", line):
+    if line.startswith("\t.amdhsa_kernel") or re.match(r"^\.Lfunc_end", line):   # the kernel descriptor carries the (mangled) name
         break
     line = line.split(";")[0].rstrip()
     if not line.strip() or line.lstrip().startswith((".p2align", ".section", ".type", ".size", ".globl", ".protected")):
