@@ -103,6 +103,24 @@ int rd_set_refine(rd_model *m, float thresh);
 int rd_refine(const rd_model *m, const uint8_t *arena, const int64_t *seq_off, const int32_t *seq_len, int64_t n,
               int32_t max_len, float *logits, uint8_t *labels, const float *mate_logits, float thresh, void *stream);
 
+/* Prefix-state table of the default kernel (an extension; nothing in the reference to replace - its cuDNN call steps over every
+ * base, reference model/model.py:33). The forward recurrence is a pure function of the bases read so far, and there are only 4^k
+ * sequences of k bases: row p of the table is the recurrence state (h as the kernel's two fp16 arrays, the cell state in fp32;
+ * 1 KiB) after the k bases whose base-4 number is p, computed by the classifying kernel itself, so that a read whose first k bases
+ * are A/C/G/T(U) starts from its row and runs min(len,max_len) - k steps with bit-identical results (reads with another letter in
+ * the prefix, or no step left after it, run all their steps from the zero state as before). This is the reverse-direction table
+ * (one step, 5 rows) carried k steps forward: k = 12 takes 16 GiB of the 288 GB of HBM and removes 12 % of the steps of a 100 bp read.
+ *   rd_prefix_table_bytes(k): bytes of [dev] memory for k in [RD_PREFIX_K_MIN, RD_PREFIX_K_MAX] ((4^k + 1) KiB); 0 otherwise.
+ *   rd_set_prefix_table: builds the table for the model's weights into caller-owned `table` (256-byte aligned, >= that many
+ *     bytes; it must stay allocated until the model is destroyed or another / no table is set) and attaches it. k = 0 (table may
+ *     be NULL) detaches. Synchronous on `stream`. Only RD_VARIANT_MFMA_F16X3_T32 uses the table; the other kernels ignore it.
+ *   rd_prefix_k: k of the attached table, 0 if none. */
+#define RD_PREFIX_K_MIN 4
+#define RD_PREFIX_K_MAX 13
+size_t rd_prefix_table_bytes(int32_t k);
+int rd_set_prefix_table(rd_model *m, int32_t k, void *table, size_t table_bytes, void *stream);
+int rd_prefix_k(const rd_model *m);
+
 /* Bytes of [dev] scratch rd_classify needs for n reads with truncation length max_len. */
 size_t rd_classify_workspace_bytes(int64_t n, int32_t max_len);
 

@@ -10,6 +10,7 @@ LIB_PATH = os.environ.get("RD_HIP_LIB") or os.path.join(_HERE, "csrc", "librd_hi
 
 ENSURE_MODES = {"none": 0, "rrna": 1, "norrna": 2, "both": 3}
 SEMANTICS = {"packed": 0, "gpu": 0, "padded": 1, "cpu": 1}
+PREFIX_K_MIN, PREFIX_K_MAX, PREFIX_K_AUTO = 4, 13, 12     # include/ribodetector_amd.h RD_PREFIX_K_*; AUTO: 16 GiB, -12 % steps at 100 bp
 VARIANTS = {"auto": 0, "mfma_f32": 1, "simple": 2, "mfma_f16x3_t32": 4}      # what librd_hip.so (the product build) accepts
 # A/B and diagnostic instantiations: only in librd_hip_diag.so (built with -DRD_DIAG by __graft_entry__.build_diag(), selected
 # with RD_HIP_LIB=.../librd_hip_diag.so by the scripts under tools/). Several compute wrong results by design.
@@ -25,7 +26,7 @@ if os.path.basename(LIB_PATH).startswith("librd_hip_diag"):
 
 # every symbol include/ribodetector_amd.h declares (tests/test_abi.py checks the .so exports all of them)
 SYMBOLS = [
-    "rd_model_create", "rd_model_destroy", "rd_set_variant", "rd_variant_available", "rd_set_semantics", "rd_set_refine", "rd_refine", "rd_classify_workspace_bytes", "rd_classify",
+    "rd_model_create", "rd_model_destroy", "rd_set_variant", "rd_variant_available", "rd_set_semantics", "rd_set_refine", "rd_refine", "rd_prefix_table_bytes", "rd_set_prefix_table", "rd_prefix_k", "rd_classify_workspace_bytes", "rd_classify",
     "rd_pair_fuse", "rd_count_labels", "rd_encode_codes", "rd_encode_onehot_padded", "rd_pack_plan",
     "rd_pack_onehot", "rd_profile_enable", "rd_profile_read", "rd_last_error", "rd_version",
 ]
@@ -63,6 +64,10 @@ def lib():
     L.rd_set_semantics.argtypes = [vp, C.c_int]
     L.rd_set_refine.argtypes = [vp, C.c_float]
     L.rd_refine.argtypes = [vp, vp, vp, vp, i64, i32, vp, vp, vp, C.c_float, vp]
+    L.rd_prefix_table_bytes.argtypes = [i32]
+    L.rd_prefix_table_bytes.restype = sz
+    L.rd_set_prefix_table.argtypes = [vp, i32, vp, sz, vp]
+    L.rd_prefix_k.argtypes = [vp]
     L.rd_classify_workspace_bytes.argtypes = [i64, i32]
     L.rd_classify_workspace_bytes.restype = sz
     L.rd_classify.argtypes = [vp, vp, vp, vp, i64, i32, vp, vp, vp, sz, vp]

@@ -81,6 +81,7 @@ struct DevModel {
     uint32_t *wpack16b; // f16x3 32x32x16 A operand
     float *lut_t32;     // in_lut in the LDS layout of the default kernel: [wave][half][a][b][code 0..5][gate], exp2-argument scale folded in
     float *rev_tab;     // padded (ribodetector_cpu) semantics: [max_len][5][2] reverse-direction logit terms, see rd_revtab_kernel
+    uint8_t *zero_row;  // one all-zero prefix-table row (1 KiB): where every read starts while no prefix-state table is attached
 };
 
 }  // namespace
@@ -91,6 +92,8 @@ struct rd_model {
     int semantics;      // RD_SEM_PACKED / RD_SEM_PADDED
     int rev_tab_len;    // max_len the padded-semantics table was built for (0 = none)
     float refine_thresh;  // margin below which a read is re-evaluated in float64 (rd_refine.hpp); 0 = off
+    int prefix_k;         // bases covered by a row of the attached prefix-state table (0 = none attached)
+    const uint8_t *ptab;  // the table (caller-owned memory, rd_set_prefix_table), (4^prefix_k + 1) rows of 1 KiB
     DevModel d;
     // profiling of the recurrence kernel (bench.py roofline)
     int prof_enabled;

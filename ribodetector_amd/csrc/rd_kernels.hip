@@ -59,6 +59,7 @@ int rd_model_create(const rd_weights *w, int device, rd_model **out) {
     m->device = device;
     m->variant = RD_VARIANT_MFMA_F16X3_T32;
     m->refine_thresh = RD_REFINE_DEFAULT;
+    m->prefix_k = 0;
     float *host = new float[RAW_FLOATS];
     for (int i = 0; i < 10; ++i) memcpy(host + offs[i], src[i], sizeof(float) * (size_t)(offs[i + 1] - offs[i]));
     hipError_t e = hipSuccess;
@@ -73,6 +74,8 @@ int rd_model_create(const rd_weights *w, int device, rd_model **out) {
     A((void **)&m->d.rev_tab, sizeof(float) * (size_t)MAX_LEN_LIMIT * 10);
     A((void **)&m->d.w_out, sizeof(float) * 512);
     A((void **)&m->d.b_out, sizeof(float) * 2);
+    A((void **)&m->d.zero_row, PFX_ROW);
+    if (e == hipSuccess) e = hipMemset(m->d.zero_row, 0, PFX_ROW);
     if (e == hipSuccess) e = hipMemcpy(m->d.raw, host, sizeof(float) * RAW_FLOATS, hipMemcpyHostToDevice);
     delete[] host;
     if (e == hipSuccess) {
@@ -85,6 +88,7 @@ int rd_model_create(const rd_weights *w, int device, rd_model **out) {
         rd_model_destroy(m);
         return RD_E_HIP;
     }
+    m->ptab = m->d.zero_row;
     *out = m;
     return RD_OK;
 }
@@ -96,6 +100,7 @@ void rd_model_destroy(rd_model *m) {
     hipFree(m->d.rev_lut); hipFree(m->d.rev_tab); hipFree(m->d.w_out); hipFree(m->d.b_out);
     if (m->d.wpack16b) hipFree(m->d.wpack16b);
     if (m->d.lut_t32) hipFree(m->d.lut_t32);
+    if (m->d.zero_row) hipFree(m->d.zero_row);
     for (int i = 0; i < 2 * 512; ++i)
         if (m->prof_ev[i]) hipEventDestroy(m->prof_ev[i]);
     delete m;
@@ -164,8 +169,39 @@ int rd_refine(const rd_model *cm, const uint8_t *arena, const int64_t *seq_off, 
         hipLaunchKernelGGL(rd_revtab_kernel, dim3(1), dim3(512), 0, st, m->d, max_len);
         m->rev_tab_len = max_len;
     }
-    ReadBatch rb{arena, seq_off, seq_len, nullptr, nullptr, n, max_len, m->semantics, m->d.rev_tab};
+    ReadBatch rb{arena, seq_off, seq_len, nullptr, nullptr, n, max_len, m->semantics, m->d.rev_tab, nullptr, nullptr, 0};
     return rd_refine_launch(m, rb, logits, labels, mate_logits, thresh, st);
+}
+
+size_t rd_prefix_table_bytes(int32_t k) {
+    if (k < RD_PREFIX_K_MIN || k > RD_PREFIX_K_MAX) return 0;
+    return (((size_t)1 << (2 * k)) + 1) * PFX_ROW;
+}
+
+int rd_prefix_k(const rd_model *m) { return m ? m->prefix_k : 0; }
+
+int rd_set_prefix_table(rd_model *m, int32_t k, void *table, size_t table_bytes, void *stream) {
+    if (!m) RD_FAIL(RD_E_INVALID, "rd_set_prefix_table: null model");
+    if (k == 0) {
+        m->prefix_k = 0;
+        m->ptab = m->d.zero_row;
+        return RD_OK;
+    }
+    const size_t need = rd_prefix_table_bytes(k);
+    if (!need) RD_FAIL(RD_E_INVALID, "rd_set_prefix_table: k=%d out of range [%d,%d] (or 0 = none)", k, RD_PREFIX_K_MIN, RD_PREFIX_K_MAX);
+    if (!table || ((uintptr_t)table & 255)) RD_FAIL(RD_E_INVALID, "rd_set_prefix_table: table must be a 256-byte aligned device pointer");
+    if (table_bytes < need) RD_FAIL(RD_E_WORKSPACE, "rd_set_prefix_table: table too small for k=%d: %zu < %zu", k, table_bytes, need);
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t rows = (int64_t)1 << (2 * k);
+    uint8_t *tab = (uint8_t *)table;
+    RD_HIP(hipMemsetAsync(tab + (size_t)rows * PFX_ROW, 0, PFX_ROW, st));        // the zero row: where the prefixes themselves start
+    ReadBatch rb{nullptr, nullptr, nullptr, nullptr, nullptr, rows, k, RD_SEM_PACKED, nullptr, tab, nullptr, k};
+    hipLaunchKernelGGL(rd_lstm_mfma_f16x3_t32_kernel<true>, dim3((unsigned)(rows / 64)), dim3(256), 0, st, m->d, rb, (float *)tab, (uint8_t *)nullptr);
+    RD_HIP(hipGetLastError());
+    RD_HIP(hipStreamSynchronize(st));
+    m->prefix_k = k;
+    m->ptab = tab;
+    return RD_OK;
 }
 
 size_t rd_classify_workspace_bytes(int64_t n, int32_t max_len) {
@@ -218,10 +254,11 @@ int rd_classify(const rd_model *cm, const uint8_t *arena, const int64_t *seq_off
         hipLaunchKernelGGL(rd_revtab_kernel, dim3(1), dim3(512), 0, st, m->d, max_len);
         m->rev_tab_len = max_len;
     }
-    int32_t *steps = nullptr, *order = nullptr;
-    int rc = run_steps_and_buckets(arena, seq_off, seq_len, n, max_len, m->semantics, workspace, workspace_bytes, steps, order, st);
+    int32_t *steps = nullptr, *order = nullptr, *pfx = nullptr;
+    const int pk = m->variant == RD_VARIANT_MFMA_F16X3_T32 ? m->prefix_k : 0;      // the table holds THAT kernel's state
+    int rc = run_steps_and_buckets(arena, seq_off, seq_len, n, max_len, m->semantics, workspace, workspace_bytes, steps, order, pk, pfx, st);
     if (rc) return rc;
-    ReadBatch rb{arena, seq_off, seq_len, steps, order, n, max_len, m->semantics, m->d.rev_tab};
+    ReadBatch rb{arena, seq_off, seq_len, steps, order, n, max_len, m->semantics, m->d.rev_tab, pk > 0 ? m->ptab : m->d.zero_row, pfx, pk};
     hipEvent_t *ev = nullptr;
     if (m->prof_enabled) {
         if (m->prof_count == 512) { rc = rd_profile_drain(m); if (rc) return rc; }
@@ -237,7 +274,7 @@ int rd_classify(const rd_model *cm, const uint8_t *arena, const int64_t *seq_off
         const int64_t nwg = (n + BT - 1) / BT;
         const dim3 grid((unsigned)nwg), blk(256);
         switch (m->variant) {
-        case RD_VARIANT_MFMA_F16X3_T32: hipLaunchKernelGGL(rd_lstm_mfma_f16x3_t32_kernel, grid, blk, 0, st, m->d, rb, logits, labels); break;
+        case RD_VARIANT_MFMA_F16X3_T32: hipLaunchKernelGGL(rd_lstm_mfma_f16x3_t32_kernel<false>, grid, blk, 0, st, m->d, rb, logits, labels); break;
         case RD_VARIANT_MFMA_F32: hipLaunchKernelGGL((rd_lstm_mfma_f32_kernel<2, 0>), grid, blk, 0, st, m->d, rb, logits, labels); break;
 #ifdef RD_DIAG
         case 10: hipLaunchKernelGGL((rd_lstm_mfma_f32_kernel<0, 0>), grid, blk, 0, st, m->d, rb, logits, labels); break;

@@ -40,7 +40,6 @@ struct __attribute__((aligned(16))) Lstm16bSmem {
     f32x4 lut[4][2][4][4][6];      // [wave][half][a][b][code] -> exp2-argument constants of (i,f,g,o); code 5 = zeros
     _Float16 H1s[2][32][H16STR];   // 2^11 h_hi   (B operand of the W1 and of the unscaled-W2 products)
     _Float16 H2[2][32][H16STR];    // 2^11 h - H1s
-    f32x4 cS[2][4][256];           // cell state [tile][row-tile a][tid] -> units b = 0..3
     float Hl[64][HSTR];            // h captured at t == T-1
     f32x4 dummy[256];              // sink of predicated-off Hl stores
     float wout[2][HID];
@@ -49,6 +48,10 @@ struct __attribute__((aligned(16))) Lstm16bSmem {
     int Lr[64];       // readable bytes of the read = min(len, max_len)
     long long off[64];
     int orig[64];
+    int k0[64];       // bases of the read covered by its prefix-table row (0 or pk)
+    // tile 1's start state waits here until phase A of t = 0 has run (see the kernel): h rows of threads 128..255, cell state per lane
+    u32x4 st_h[128][8];
+    f32x4 st_c[4][256];
     int tmax;
     int wmax[4];      // per wave: the largest step count of its 16 reads
 };
@@ -119,8 +122,6 @@ struct EwRegs {
     f32x4 kc[4];        // table rows
     f32x2 v[4][2];      // gate pipeline values: {i,f} and {g,o} as register pairs
     float y[4], og[4], hs[4];
-    f32x4 cs[2];        // unused since the cell state lives in call[] (kept in this commit: the struct layout steers register allocation, and
-                        // this commit is the instruction-identical refactor - tools/isa_diff.sh)
     f32x4 hv[2];        // per row-tile, by row-tile parity
     f16x4 o1s[2], o2[2];
     f32x4 call[4];      // the tile's cell state (pre-multiplied by KT), resident in registers across phases
@@ -306,6 +307,13 @@ __device__ __forceinline__ void rd_phase_ewonly(Lstm16bSmem &S, f32x16 (&accP)[4
     __syncthreads();
 }
 
+// BUILD = false: classification (the product path). Every read starts from a row of the prefix-state table: the recurrence state after
+// its first pk bases (rd_steps_kernel chose the row and took pk off the step count), or the all-zero row.
+// BUILD = true: the same code builds that table (rd_set_prefix_table): "read" g is the pk-base prefix whose base-4 number is g, it
+// runs its pk steps from the zero row, and instead of the FC epilogue the workgroup writes the state - the two fp16 arrays of h
+// as they stand in LDS and the cell state as it stands in the registers - into row g (through `logits`, which then points to the
+// table). Building with the classifying code is what makes a table start bit-identical to stepping over the bases.
+template <bool BUILD>
 __global__ __launch_bounds__(256, 1) void rd_lstm_mfma_f16x3_t32_kernel(DevModel d, ReadBatch rb, float *__restrict__ logits,
                                                                         uint8_t *__restrict__ labels) {
     __shared__ Lstm16bSmem S;
@@ -313,15 +321,23 @@ __global__ __launch_bounds__(256, 1) void rd_lstm_mfma_f16x3_t32_kernel(DevModel
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, j = lane & 31;
 
-    // Everything a workgroup fetches before its first phase is three dependent round trips (order entry -> steps, length, offset ->
-    // the first 64 bases) plus 64 KiB of weights per wave and the input table. Every thread fetches the metadata of read tid >> 2
-    // itself (four threads share a read and its addresses), so no barrier separates the trips, and the weight loads - whose
-    // v_accvgpr_write statements are scheduling barriers - are issued between them and cover their latency.
-    const int row = tid >> 2;
+    // Everything a workgroup fetches before its first phase is three dependent round trips (order entry -> steps, length, offset,
+    // table row -> the first 64 bases and the 1 KiB of start state) plus 64 KiB of weights per wave and the input table. Every thread
+    // fetches the metadata of read tid >> 2 itself (four threads share a read and its addresses) and of the two reads whose cell
+    // state its lane holds (j and 32 + j), so no barrier separates the trips, and the weight loads - whose v_accvgpr_write
+    // statements are scheduling barriers - are issued between them and cover their latency.
+    const int row = tid >> 2, piece = tid & 3;
     const int64_t g = (int64_t)blockIdx.x * 64 + row;
     const bool valid = g < rb.n;
-    int orig = -1;
-    if (valid) orig = rb.order ? rb.order[g] : (int)g;                                            // round trip 1
+    const int nz = rb.pk > 0 ? 1 << (2 * rb.pk) : 0;                                               // the zero row
+    const int64_t gc0 = (int64_t)blockIdx.x * 64 + j, gc1 = gc0 + 32;
+    const bool use_pfx = !BUILD && rb.pfx != nullptr;
+    int orig = -1, oc0 = -1, oc1 = -1;
+    if (valid) orig = (!BUILD && rb.order) ? rb.order[g] : (int)g;                                 // round trip 1
+    if (use_pfx) {
+        if (gc0 < rb.n) oc0 = rb.order ? rb.order[gc0] : (int)gc0;
+        if (gc1 < rb.n) oc1 = rb.order ? rb.order[gc1] : (int)gc1;
+    }
     f32x4 lut_v[3];
     {   // the table in this kernel's layout, rows pre-multiplied by -log2 e resp. 2 log2 e (rd_prep_kernel): a straight copy
         const f32x4 *src = reinterpret_cast<const f32x4 *>(d.lut_t32);
@@ -354,31 +370,69 @@ __global__ __launch_bounds__(256, 1) void rd_lstm_mfma_f16x3_t32_kernel(DevModel
         }
     };
     load_row_tile(std::integral_constant<int, 0>());
-    int T = 0, lr = 0;
+    int T = 0, lr = 0, k0 = 0, prow = nz, pc0 = nz, pc1 = nz;
     long long off = 0;
-    if (valid) {                                                                                   // round trip 2
+    if (BUILD) {
+        if (valid) { T = rb.pk; lr = rb.pk; }
+    } else if (valid) {                                                                            // round trip 2
         T = rd_T(rb.steps, orig, rb.max_len);
         lr = rd_T(rb.len, orig, rb.max_len);
         off = rb.off[orig];
+        if (use_pfx) prow = rb.pfx[orig];
     }
+    if (use_pfx) {
+        if (oc0 >= 0) pc0 = rb.pfx[oc0];
+        if (oc1 >= 0) pc1 = rb.pfx[oc1];
+    }
+    if (prow != nz) { k0 = rb.pk; lr -= k0; off += k0; }      // the row covers the first pk bases: the kernel steps over the rest
     load_row_tile(std::integral_constant<int, 1>());
     const uint8_t *src0 = rb.arena + off;
-    const u32x4 raw0 = rd_codes_load(lr, src0, 0);                                                 // round trip 3
-    u32x4 raw1 = {0u, 0u, 0u, 0u};   // both code buffers are free now: reads of up to 128 steps never stage inside the phase loop
-    if (lr > TC16) raw1 = rd_codes_load(lr, src0, 1);
+    u32x4 raw0, raw1 = {0u, 0u, 0u, 0u};   // both code buffers are free now: reads of up to 128 steps never stage inside the phase loop
+    if (BUILD) {   // the bases of prefix g, first base = most significant digit (rd_steps_kernel numbers prefixes the same way)
+        raw0 = u32x4{0u, 0u, 0u, 0u};
+        if (valid && piece == 0)
+            for (int t = 0; t < rb.pk; ++t) raw0[t >> 2] |= (uint32_t)"ACGT"[(g >> (2 * (rb.pk - 1 - t))) & 3] << (8 * (t & 3));
+    } else {
+        raw0 = rd_codes_load(lr, src0, 0);                                                         // round trip 3
+        if (lr > TC16) raw1 = rd_codes_load(lr, src0, 1);
+    }
+    // start state: thread (row, piece) moves 64 B of each fp16 array of h of its read into LDS; lane (j, half) of wave w takes the
+    // cell state of units [32w + 16half, +16) of reads j (tile 0) and 32 + j (tile 1) into its registers
+    u32x4 hrow[2][4];
+    f32x4 c0[4], c1[4];
+    {
+        const u32x4 *tr = reinterpret_cast<const u32x4 *>(rb.ptab + (size_t)prow * PFX_ROW);
+        const f32x4 *t0 = reinterpret_cast<const f32x4 *>(rb.ptab + (size_t)pc0 * PFX_ROW + 512) + 8 * wave + 4 * half;
+        const f32x4 *t1 = reinterpret_cast<const f32x4 *>(rb.ptab + (size_t)pc1 * PFX_ROW + 512) + 8 * wave + 4 * half;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { hrow[0][q] = tr[4 * piece + q]; hrow[1][q] = tr[16 + 4 * piece + q]; c0[q] = t0[q]; c1[q] = t1[q]; }
+    }
     load_row_tile(std::integral_constant<int, 2>());
     load_row_tile(std::integral_constant<int, 3>());
     // LDS: state, tables, this tile's metadata and first code chunk
-    if ((tid & 3) == 0) { S.T[row] = T; S.Lr[row] = lr; S.off[row] = off; S.orig[row] = orig; }
+    if (piece == 0) { S.T[row] = T; S.Lr[row] = lr; S.off[row] = off; S.orig[row] = orig; S.k0[row] = k0; }
     {
         int m = T;   // wave maximum of T (16 reads per wave)
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
         if (lane == 0) S.wmax[wave] = m;
     }
-    for (int i = tid; i < 2 * 32 * H16STR / 2; i += 256) { (reinterpret_cast<uint32_t *>(&S.H1s[0][0][0]))[i] = 0u; (reinterpret_cast<uint32_t *>(&S.H2[0][0][0]))[i] = 0u; }
+    // tile 0 (rows 0-31 = waves 0, 1) starts from its table rows now. Tile 1 must wait: phase A of t = 0 runs tile 1's gate math on
+    // zero accumulators with the all-zero table row, which leaves a ZERO state unchanged (and writes h = 0 into tile 1's LDS rows)
+    // but would halve a loaded cell state - its rows and registers are filled between the two phases of t = 0, from an LDS staging
+    // area (held in registers until then they would be live across the whole loop: spills).
+    u32x4 *const h1row = reinterpret_cast<u32x4 *>(&S.H1s[row >> 5][row & 31][32 * piece]);
+    u32x4 *const h2row = reinterpret_cast<u32x4 *>(&S.H2[row >> 5][row & 31][32 * piece]);
+    if (wave < 2) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { h1row[q] = hrow[0][q]; h2row[q] = hrow[1][q]; }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { S.st_h[tid - 128][q] = hrow[0][q]; S.st_h[tid - 128][4 + q] = hrow[1][q]; }
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) S.st_c[a][tid] = c1[a];
     for (int i = tid; i < 64 * HSTR; i += 256) (&S.Hl[0][0])[i] = 0.0f;
-    for (int i = tid; i < 2 * 4 * 256; i += 256) (&S.cS[0][0][0])[i] = f32x4{0, 0, 0, 0};
     {
         f32x4 *dst = &S.lut[0][0][0][0][0];
 #pragma unroll
@@ -398,15 +452,24 @@ __global__ __launch_bounds__(256, 1) void rd_lstm_mfma_f16x3_t32_kernel(DevModel
     int codeY = 5;   // code of (tile 1, step t-1): zero row before the first step
     EwRegs R0, R1;   // gate-math registers of tile 0 / tile 1 (transient per phase, except the cell state call[])
 #pragma unroll
-    for (int a = 0; a < 4; ++a) { R0.call[a] = f32x4{0, 0, 0, 0}; R1.call[a] = f32x4{0, 0, 0, 0}; }
+    for (int a = 0; a < 4; ++a) { R0.call[a] = c0[a]; R1.call[a] = f32x4{0, 0, 0, 0}; }
 
     for (int t = 0; t < tmax; ++t) {
         const uint8_t *ccol = &S.codes[(t / TC16) & 1][0][t % TC16];
         const int codeX = ccol[j * CSTR];            // (tile 0, step t): consumed by phase B's gate math
         const int codeYn = ccol[(32 + j) * CSTR];    // (tile 1, step t): consumed by the next iteration's phase A
-        // phase A: MFMAs of (tile 0, t) -> X ; gate math of (tile 1, t-1) <- Y. (At t = 0 the phase changes nothing - h = 0, zero
-        // accumulators, the all-zero table row - but skipping it behind a branch made the loop 1.2 % slower: measured, left in.)
+        // phase A: MFMAs of (tile 0, t) -> X ; gate math of (tile 1, t-1) <- Y. (At t = 0 the gate math changes nothing - zero state,
+        // zero accumulators, the all-zero table row - but skipping it behind a branch made the loop 1.2 % slower: measured, left in.)
         rd_phase_t32<0>(S, W1, W2, X, Y, R1, t - 1, codeY, wave, half, j, tid);
+        if (t == 0) {   // tile 1's start state (see above); phase B's MFMAs read the rows
+            if (wave >= 2) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { h1row[q] = S.st_h[tid - 128][q]; h2row[q] = S.st_h[tid - 128][4 + q]; }
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a) R1.call[a] = S.st_c[a][tid];
+            __syncthreads();
+        }
         // next code chunk (chunks 0 and 1 were staged before the loop): its buffer was last read by the gate math of phase A above (step t-1)
         if ((t % TC16) == 0 && t > 0) {
             const int chunk = t / TC16 + 1;
@@ -419,9 +482,27 @@ __global__ __launch_bounds__(256, 1) void rd_lstm_mfma_f16x3_t32_kernel(DevModel
     // the gate math of (tile 1, tmax-1): gate math only (the loop used to run one more phase A whose 96 MFMAs computed nothing)
     rd_phase_ewonly<1>(S, Y, R1, tmax - 1, codeY, wave, half, j, tid);
 
-    rd_fc_epilogue(
-        64, [&](int row, int u) { return S.Hl[row][u] * (1.0f / H_SCALE); }, S.T, S.Lr, S.off, S.orig, &S.wout[0][0], d, rb, logits,
-        labels);
+    if constexpr (BUILD) {
+        uint8_t *tab = reinterpret_cast<uint8_t *>(logits);
+        if (valid) {
+            u32x4 *tr = reinterpret_cast<u32x4 *>(tab + (size_t)g * PFX_ROW);
+            const u32x4 *h1 = reinterpret_cast<const u32x4 *>(&S.H1s[row >> 5][row & 31][32 * piece]);
+            const u32x4 *h2 = reinterpret_cast<const u32x4 *>(&S.H2[row >> 5][row & 31][32 * piece]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { tr[4 * piece + q] = h1[q]; tr[16 + 4 * piece + q] = h2[q]; }
+        }
+        f32x4 *t0 = reinterpret_cast<f32x4 *>(tab + (size_t)gc0 * PFX_ROW + 512) + 8 * wave + 4 * half;
+        f32x4 *t1 = reinterpret_cast<f32x4 *>(tab + (size_t)gc1 * PFX_ROW + 512) + 8 * wave + 4 * half;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            if (gc0 < rb.n) t0[a] = R0.call[a];
+            if (gc1 < rb.n) t1[a] = R1.call[a];
+        }
+    } else {
+        rd_fc_epilogue(
+            64, [&](int row, int u) { return S.Hl[row][u] * (1.0f / H_SCALE); }, S.T, S.Lr, S.off, S.orig, &S.wout[0][0], d, rb, logits,
+            labels, S.k0);
+    }
 }
 
 }  // namespace

@@ -19,14 +19,22 @@ struct ReadBatch {
     int max_len;
     int sem;                // RD_SEM_PACKED: gather at step len-1 (reference GPU path); RD_SEM_PADDED: ribodetector_cpu
     const float *rev_tab;   // padded semantics only
+    // prefix-state table of the default kernel (rd_lstm_t32.hpp): row p = the recurrence state after the pk bases
+    // whose base-4 number is p; row 4^pk = zeros. pfx[i] = the row read i starts from (4^pk: from the zero state, all its steps);
+    // pfx == nullptr: every read starts from row 0 of ptab (a zero row), steps[] are the full step counts.
+    const uint8_t *ptab;
+    const int32_t *pfx;
+    int pk;
 };
+constexpr int PFX_ROW = 1024;   // bytes per table row: 2^11 h_hi fp16[128] | residual fp16[128] | KT c fp32[128]
 
-// FC + argmax epilogue for one workgroup's reads. hl(row,u) = captured last forward hidden state.
+// FC + argmax epilogue for one workgroup's reads. hl(row,u) = captured last forward hidden state. Trow / Lrow / offrow count from
+// the first base the kernel stepped over; k0row (default kernel only) = the bases before it that a prefix-table row covered.
 // logits = b_out + W_out[:, :128] . h_fwd + rev_lut[last base]   (model.py:36; reverse half folded, see header)
 template <typename HL>
 __device__ __forceinline__ void rd_fc_epilogue(int nrows, HL hl, const int *Trow, const int *Lrow, const long long *offrow,
                                                const int *origrow, const float *s_wout, const DevModel &d, const ReadBatch &rb,
-                                               float *logits, uint8_t *labels) {
+                                               float *logits, uint8_t *labels, const int *k0row = nullptr) {
     const int tid = threadIdx.x;
     if (tid < 2 * nrows) {
         const int row = tid >> 1, k = tid & 1;
@@ -37,7 +45,7 @@ __device__ __forceinline__ void rd_fc_epilogue(int nrows, HL hl, const int *Trow
             // reverse half of output row pos = T-1: the reverse LSTM has walked max_len-1-pos zero rows, then x[pos]
             const int pos = T - 1;
             const int code = pos < Lrow[row] ? rd_code(rb.arena[offrow[row] + pos]) : 4;
-            s += rb.rev_tab[((rb.max_len - 1 - pos) * 5 + code) * 2 + k];
+            s += rb.rev_tab[((rb.max_len - 1 - pos - (k0row ? k0row[row] : 0)) * 5 + code) * 2 + k];
         } else if (rb.sem != RD_SEM_PADDED && T > 0) {
             s += d.rev_lut[rd_code(rb.arena[offrow[row] + T - 1]) * 2 + k];
         }

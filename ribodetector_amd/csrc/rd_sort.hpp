@@ -137,9 +137,13 @@ __device__ __forceinline__ uint32_t rd_bin_add(uint32_t *bins, int T, bool valid
     return valid ? atomicAdd(&bins[T], 1u) : 0;
 }
 
+// With a prefix-state table of pk bases (default kernel): a read whose first pk bases are all A/C/G/T(U) and that
+// has at least one more step to run starts from the table row numbered by those bases (first base = most significant base-4 digit):
+// pfx[i] = that row and steps[i] = the steps that remain. Every other read gets pfx[i] = 4^pk (the zero row) and all its steps.
 __global__ __launch_bounds__(256) void rd_steps_kernel(const uint8_t *__restrict__ arena, const int64_t *__restrict__ off,
                                                        const int32_t *__restrict__ len, int64_t n, int max_len, int sem,
-                                                       int32_t *__restrict__ steps, uint32_t *__restrict__ ghist) {
+                                                       int32_t *__restrict__ steps, uint32_t *__restrict__ ghist, int pk,
+                                                       int32_t *__restrict__ pfx) {
     extern __shared__ uint32_t sh_bins[];   // max_len+1
     for (int i = threadIdx.x; i <= max_len; i += 256) sh_bins[i] = 0;
     __syncthreads();
@@ -155,6 +159,21 @@ __global__ __launch_bounds__(256) void rd_steps_kernel(const uint8_t *__restrict
                 int pos = lr - 1;
                 while (pos >= 0 && rd_code(p[pos]) == 4) --pos;
                 T = pos >= 0 ? pos + 1 : max_len;
+            }
+            if (pk > 0) {
+                int prow = 1 << (2 * pk);
+                if (T > pk && lr >= pk) {
+                    const uint8_t *p = arena + off[i];
+                    uint32_t idx = 0;
+                    bool ok = true;
+                    for (int t = 0; t < pk; ++t) {
+                        const int c = rd_code(p[t]);
+                        ok = ok && c < 4;
+                        idx = idx * 4u + (uint32_t)(c & 3);
+                    }
+                    if (ok) { prow = (int)idx; T -= pk; }
+                }
+                pfx[i] = prow;
             }
             steps[i] = T;
         }
@@ -233,7 +252,7 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 struct SortPlan {
     int nblk;
-    size_t hist_bytes, order_bytes, lenstart_bytes, steps_bytes, total;
+    size_t hist_bytes, order_bytes, lenstart_bytes, steps_bytes, pfx_bytes, total;
 };
 inline SortPlan sort_plan(int64_t n, int max_len) {
     SortPlan p;
@@ -243,7 +262,8 @@ inline SortPlan sort_plan(int64_t n, int max_len) {
     p.order_bytes = align_up((size_t)(n > 0 ? n : 1) * sizeof(int32_t), 256);
     p.lenstart_bytes = align_up((size_t)(max_len + 1) * sizeof(int64_t) * 2, 256);   // len_start + cum scratch
     p.steps_bytes = align_up((size_t)(n > 0 ? n : 1) * sizeof(int32_t), 256);
-    p.total = p.hist_bytes + p.order_bytes + p.lenstart_bytes + p.steps_bytes;
+    p.pfx_bytes = p.steps_bytes;                                                      // table row per read (rd_steps_kernel)
+    p.total = p.hist_bytes + p.order_bytes + p.lenstart_bytes + p.steps_bytes + p.pfx_bytes;
     return p;
 }
 
@@ -270,21 +290,22 @@ int run_sort(const int32_t *seq_len, int64_t n, int max_len, void *workspace, si
 
 // steps[] + order[] for rd_classify: steps kernel (with histogram) -> bucket starts -> scatter
 int run_steps_and_buckets(const uint8_t *arena, const int64_t *seq_off, const int32_t *seq_len, int64_t n, int max_len, int sem,
-                          void *workspace, size_t wbytes, int32_t *&steps, int32_t *&order, hipStream_t st) {
+                          void *workspace, size_t wbytes, int32_t *&steps, int32_t *&order, int pk, int32_t *&pfx, hipStream_t st) {
     SortPlan p = sort_plan(n, max_len);
     if (wbytes < p.total) RD_FAIL(RD_E_WORKSPACE, "workspace too small: %zu < %zu", wbytes, p.total);
     char *w = (char *)workspace;
     uint32_t *ghist = (uint32_t *)w;                                          // (max_len+1) u32 fit in hist_bytes
     order = (int32_t *)(w + p.hist_bytes);
     uint32_t *cursor = (uint32_t *)(w + p.hist_bytes + p.order_bytes);        // (max_len+1) u32 fit in lenstart_bytes
-    steps = (int32_t *)(w + p.total - p.steps_bytes);
+    steps = (int32_t *)(w + p.total - p.pfx_bytes - p.steps_bytes);
+    pfx = pk > 0 ? (int32_t *)(w + p.total - p.pfx_bytes) : nullptr;
     const size_t sh = (size_t)(max_len + 1) * sizeof(uint32_t);
     RD_HIP(hipMemsetAsync(ghist, 0, sh, st));
     // one workgroup per CU at most: every workgroup ends with one global atomic per non-empty bin, and with fixed-length
     // reads they all hit the same bin
     int64_t nb = (n + 255) / 256;
     if (nb > 256) nb = 256;
-    hipLaunchKernelGGL(rd_steps_kernel, dim3((unsigned)nb), dim3(256), sh, st, arena, seq_off, seq_len, n, max_len, sem, steps, ghist);
+    hipLaunchKernelGGL(rd_steps_kernel, dim3((unsigned)nb), dim3(256), sh, st, arena, seq_off, seq_len, n, max_len, sem, steps, ghist, pk, pfx);
     hipLaunchKernelGGL(rd_bucket_scan_kernel, dim3(1), dim3(256), 0, st, ghist, max_len, cursor);
     int64_t nbs = (n + BK_ITEMS - 1) / BK_ITEMS;
     if (nbs > 256) nbs = 256;

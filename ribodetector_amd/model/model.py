@@ -12,6 +12,7 @@ Entries:
     encoder + recurrence + FC + argmax fused on the device.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -49,6 +50,8 @@ class SeqModel:
         self._variant = "auto"
         self._semantics = "packed"
         self._refine = None
+        self._prefix = os.environ.get("RD_PREFIX_K", "auto")   # prefix-state table: "auto" | 0 (none) | 4..13 (set_prefix_table)
+        self._ptab = None
         self._ws = None
         self.training = True
 
@@ -81,6 +84,7 @@ class SeqModel:
         if self._handle is not None:
             N.lib().rd_model_destroy(self._handle)
             self._handle = None
+        self._ptab = None
 
     def _create(self):
         self._destroy()
@@ -96,6 +100,7 @@ class SeqModel:
         self.set_semantics(self._semantics)
         if self._refine is not None:
             self.set_refine(self._refine)
+        self.set_prefix_table(self._prefix)
 
     def to(self, device, non_blocking=False):
         device = torch.device(device)
@@ -140,6 +145,41 @@ class SeqModel:
         return self
 
     REFINE_DEFAULT = 2.5e-4
+
+    def set_prefix_table(self, k="auto"):
+        """Prefix-state table of the default kernel (C ABI rd_set_prefix_table): the recurrence state after every
+        possible sequence of k bases, (4^k + 1) KiB of HBM, built by the kernel itself in milliseconds; a read then starts k steps
+        in, with bit-identical logits. k = 0: none; 4..13: exactly that; "auto" (default; environment RD_PREFIX_K overrides): 12
+        (16 GiB) when that is at most a quarter of the free device memory, else the largest k that is, else none."""
+        if isinstance(k, str) and k != "auto":
+            k = int(k)
+        self._prefix = k
+        if self._handle is None:
+            return self
+        lib = N.lib()
+        with torch.cuda.device(self.device):
+            if k == "auto":
+                free, _ = torch.cuda.mem_get_info(self.device)
+                free += torch.cuda.memory_reserved(self.device) - torch.cuda.memory_allocated(self.device)   # cached blocks are reusable
+                k = N.PREFIX_K_AUTO
+                while k >= N.PREFIX_K_MIN and int(lib.rd_prefix_table_bytes(k)) > free // 4:
+                    k -= 1
+                if k < N.PREFIX_K_MIN:
+                    k = 0
+            k = int(k)
+            if k != 0 and not (N.PREFIX_K_MIN <= k <= N.PREFIX_K_MAX):
+                raise RuntimeError("SeqModel.set_prefix_table: k must be 0, 'auto' or in [%d, %d]; got %r" % (N.PREFIX_K_MIN, N.PREFIX_K_MAX, k))
+            if k == int(lib.rd_prefix_k(self._handle)) and (k == 0 or self._ptab is not None):
+                return self
+            tab = torch.empty(int(lib.rd_prefix_table_bytes(k)), dtype=torch.uint8, device=self.device) if k else None
+            N.check(lib.rd_set_prefix_table(self._handle, k, N.ptr(tab), 0 if tab is None else tab.numel(), N.stream_ptr(self.device)),
+                    "rd_set_prefix_table")
+            self._ptab = tab
+        return self
+
+    @property
+    def prefix_k(self):
+        return 0 if self._handle is None else int(N.lib().rd_prefix_k(self._handle))
 
     def refine(self, arena, offsets, lens, max_len, logits, labels=None, mate_logits=None, thresh=None):
         """float64 re-evaluation (C ABI rd_refine) of the reads whose own margin - or, with `mate_logits`, whose PAIR margin
