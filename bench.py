@@ -158,6 +158,41 @@ def pmc_traffic(args, kernel_substr, timeout_s=240):
     return out, None
 
 
+def e2e_record(torch, synth, arenas, offsets, lens, L, ensure):
+    """Timed region (iii) of SURVEY §8d: the whole `ribodetector` CLI - detect.main(): model load (incl. building the prefix-state
+    table), native FASTQ parse, H2D, kernels, label D2H, output write - on a FASTQ file (pair) built from the rank-0 stream of this
+    run in tmpfs, plain -> plain (the reference flow: detect.py:464-499). Two calls; the second one is reported (the first pays
+    one-off costs of the process: first pinned allocations, page cache)."""
+    import shutil
+    import tempfile
+    from ribodetector_amd import detect
+    d = tempfile.mkdtemp(prefix="rd_e2e_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        n = int(lens.numel())
+        ins = []
+        for m, a in enumerate(arenas):
+            p = os.path.join(d, "r_%d.fq" % (m + 1))
+            synth.fastq_image_torch(a, offsets, lens, mate=m + 1).cpu().numpy().tofile(p)
+            ins.append(p)
+        outs = [os.path.join(d, "non_%d.fq" % (m + 1)) for m in range(len(ins))]
+        rrs = [os.path.join(d, "rrna_%d.fq" % (m + 1)) for m in range(len(ins))]
+        argv = ["-l", str(L), "-i", *ins, "-o", *outs, "-r", *rrs] + (["-e", ensure] if len(ins) == 2 else [])
+        rec = {}
+        for call in ("first_call", "second_call"):
+            t0 = time.perf_counter()
+            pr = detect.main(argv)
+            dt = time.perf_counter() - t0
+            rec[call] = {"seconds": dt, "reads_per_s": len(ins) * n / dt, "main_thread_s": {k: round(v, 4) for k, v in pr._stage_s.items()}}
+            del pr
+        out_bytes = sum(os.path.getsize(p) for p in outs + rrs)
+        return {"reads_per_s": rec["second_call"]["reads_per_s"], "seconds": rec["second_call"]["seconds"], "files": len(ins),
+                "records_per_file": n, "input_bytes": sum(os.path.getsize(p) for p in ins), "output_bytes": out_bytes,
+                "what": "whole detect.main() call on FASTQ in tmpfs, plain -> plain, default -t 10: model load + prefix table build + "
+                        "parse + H2D + kernels + D2H + write; second of two calls", "calls": rec}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def encoder_record(torch, N, dev, arena, offs, lens, n, L):
     """standalone encoder kernels on the first n reads: algorithmic bytes / kernel time (events on the launch stream)"""
     lib, st = N.lib(), N.stream_ptr(dev)
@@ -215,6 +250,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the short extra measurement of the exact-fp32 MFMA kernel")
     ap.add_argument("--no-encoder", action="store_true", help="skip the standalone encoder kernels")
+    ap.add_argument("--no-e2e", action="store_true", help="skip timed region (iii): the whole CLI on a FASTQ file built from the rank-0 stream")
     ap.add_argument("--traffic", default="live", choices=["live", "off"],
                     help="live: collect FETCH_SIZE/WRITE_SIZE with rocprofv3 --pmc over a child run of this command (adds ~40 s)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
@@ -260,6 +296,18 @@ def main():
         lens = torch.randint(40, 301, (P,), generator=g, device=dev, dtype=torch.int32)
     flops_per_launch = float((torch.clamp(lens, max=MAXLEN).to(torch.float64) * 131072 + 1024).sum().item())
     bytes_per_launch = float(lens.to(torch.float64).sum().item()) + P * (4 + 8 + 8 + 1)
+    # prefix-state table: a read whose first k bases are A/C/G/T(U) starts from its table row, k steps in. The
+    # algorithmic FLOPs above stay those of SURVEY §8d (every step of every read); what the MFMAs execute is counted separately.
+    PK = model.prefix_k if variant == "mfma_f16x3_t32" else 0
+    steps_full = torch.clamp(lens, max=MAXLEN).to(torch.int64)
+    steps_exec = steps_full
+    if PK:
+        isb = torch.zeros(256, dtype=torch.bool, device=dev)
+        isb[[65, 67, 71, 84, 85]] = True
+        first = isb[r1[0][0].view(P, RL)[:, :PK].long()].all(1) & (steps_full > PK)
+        steps_exec = steps_full - PK * first.to(torch.int64)
+        bytes_per_launch += P * 1024.0                        # one table row per read
+    exec_steps_frac = float(steps_exec.sum().item()) / float(steps_full.sum().item())
     nm = 2 if paired else 1
     # two sets of result buffers: the post-pass of step i (side stream) runs while the recurrences of step i+1 (main stream) write
     # the other set
@@ -448,6 +496,8 @@ def main():
             "config": {"workload": wl_text + ", %d %s/step/GPU x %d steps (%.1f M total); %s"
                                    % (P, "pairs" if paired else "reads", args.steps, total_pairs / 1e6, region),
                        "timed_region": "i" if args.resident_only else "ii",
+                       "timed_regions": "value = (ii) pinned host bytes -> host labels; kernel_only_reads_per_s = (i) bytes resident in HBM; "
+                                        "e2e_cli_reads_per_s = (iii) the whole CLI on a FASTQ file in tmpfs (SURVEY 8d)",
                        "kernel_only_reads_per_s": (mult * total_pairs / dt_res) if dt_res else None,
                        "device_path_over_kernel_only": (dt_res / dt) if dt_res else None,
                        "pairs_per_s": (total_pairs / dt) if paired else None, "per_step_per_gpu": P,
@@ -459,6 +509,10 @@ def main():
                                      if base == "mfma_f16x3_t32" else "fp32"),
                        "parallelism": "reads sharded x%d, label gather to rank 0" % world,
                        "rccl_ranks": world, "dist_backend": backend, "forced_dist": bool(multi and world == 1),
+                       "prefix_table": {"k": PK, "bytes": (4 ** PK + 1) * 1024 if PK else 0,
+                                        "what": "recurrence state after every sequence of k bases, built by the kernel itself at model load; "
+                                                "a read whose first k bases are A/C/G/T starts from its row (bit-identical logits, "
+                                                "tests/test_gpu_prefix.py); alt_no_prefix_table = the same steps with k = 0"},
                        "refine": {"band": module_arch.SeqModel.REFINE_DEFAULT, "what": "reads whose margin is inside the band are "
                                   "re-evaluated in float64 (labels of the exact function); inside the timed region",
                                   "placement": "side stream, overlapping the next step's recurrences" if pipelined else "inline in rd_classify"},
@@ -469,8 +523,9 @@ def main():
                          "kernel": kname, "launches": launches, "avg_launch_ms": avg_ms,
                          "algorithmic_flops_per_launch": flops_per_launch,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "mfma_flops_executed_per_algorithmic_flop": MFMA_FLOPS_PER_ALGO_FLOP[base],
-                         "mfma_pipe_frac": (achieved * MFMA_FLOPS_PER_ALGO_FLOP[base] / peak) if achieved else None},
+                         "mfma_flops_executed_per_algorithmic_flop": MFMA_FLOPS_PER_ALGO_FLOP[base] * exec_steps_frac,
+                         "mfma_pipe_frac": (achieved * MFMA_FLOPS_PER_ALGO_FLOP[base] * exec_steps_frac / peak) if achieved else None,
+                         "steps_executed_over_steps": exec_steps_frac},
         }
         if world == 1 and not args.no_alt and base != "mfma_f32":
             # the same step on the exact-fp32 MFMA kernel (v_mfma_f32_16x16x4_f32), for the fp32-MFMA roofline of SURVEY §8d
@@ -489,11 +544,36 @@ def main():
                                       "timed_region": "i",
                                       "roofline": {"bound": "mfma", "achieved": a2, "peak": PEAKS["mfma_f32"], "unit": "TFLOP/s",
                                                    "frac": a2 / PEAKS["mfma_f32"], "avg_launch_ms": k2 / max(l2, 1)}}
+        if world == 1 and not args.no_alt and PK:
+            # the same steps without the prefix-state table (every read steps over all its bases)
+            model.set_prefix_table(0)
+            model.profile_enable(True)
+            sync()
+            t1 = time.perf_counter()
+            run_resident(4)
+            sync()
+            d1 = time.perf_counter() - t1
+            l2, k2 = model.profile_read()
+            model.profile_enable(False)
+            model.set_prefix_table(PK)
+            a2 = flops_per_launch / (k2 / max(l2, 1) * 1e-3) / 1e12
+            out["alt_no_prefix_table"] = {"kernel": kname, "value": mult * P * 4 / d1, "unit": "reads/s", "steps": 4, "timed_region": "i",
+                                          "roofline": {"bound": "mfma", "achieved": a2, "peak": peak, "unit": "TFLOP/s", "frac": a2 / peak,
+                                                       "avg_launch_ms": k2 / max(l2, 1)}}
         if world == 1 and not args.no_encoder:
             try:
                 out["encoder"] = encoder_record(torch, N, dev, r1[0][0], offs, lens, P, MAXLEN)
             except Exception as e:
                 out["encoder"] = {"error": repr(e)}
+        if world == 1 and not args.no_e2e and not multi:
+            try:
+                ne = min(P, 1 << 20)
+                e2e = e2e_record(torch, synth, [r1[0][0][: ne * RL]] + ([r2[0][0][: ne * RL]] if paired else []),
+                                 r1[0][1][: ne + 1], lens[:ne].contiguous(), MAXLEN, args.ensure)
+                out["config"]["e2e_cli_reads_per_s"] = e2e["reads_per_s"]
+                out["e2e_cli"] = e2e
+            except Exception as e:
+                out["e2e_cli"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1 and args.workload in ("pe100", "se100"):
             try:
                 nb = min(P, 400000)

@@ -104,6 +104,10 @@ int main(int argc, char **argv) {
         int64_t n = 0, nbytes = 0;
         const int rc = rd_reader_next(reader, CHUNK, buf.data(), CAP, rec_start.data(), seq_off.data(), seq_len.data(), &n, &nbytes);
         if (rc < 0) { fprintf(stderr, "%s\n", rd_host_last_error()); return 1; }
+        if (n == 0 && rc == 0) {   // the next record alone needs `nbytes` bytes and the buffer is smaller: this example gives up
+            fprintf(stderr, "a record of %lld bytes does not fit into the %lld-byte chunk buffer\n", (long long)nbytes, (long long)CAP);
+            return 1;              // (ribodetector_amd/data_loader/fastx_parser.py grows its buffer and calls again)
+        }
         if (n > 0) {
             HIP_OK(hipMemcpy(d_arena, buf.data(), (size_t)nbytes, hipMemcpyHostToDevice));
             HIP_OK(hipMemcpy(d_off, seq_off.data(), n * sizeof(int64_t), hipMemcpyHostToDevice));

@@ -55,7 +55,8 @@ int rd_reader_open_range(const char *path, int format, int64_t start, int64_t en
  * *n = number of records delivered. Returns 1 when the end of the file was reached (no record follows those delivered),
  * 0 when more may follow, <0 on error. *n == 0 with return 0 means: the next record does not fit into the remaining buffer;
  * *nbytes then holds the bytes that record needs, so that the caller can grow the buffer (the reference parser has no
- * record-size limit, fastx_parser.py:15-55). */
+ * record-size limit, fastx_parser.py:15-55). EVERY caller must handle that case - grow and call again, or stop: calling again
+ * with the same buffer returns the same answer forever (examples/classify_fastq.cpp stops, fastx_parser.py grows). */
 int rd_reader_next(rd_reader *r, int64_t max_records, uint8_t *buf, int64_t buf_cap, int64_t *rec_start, int64_t *seq_off,
                    int32_t *seq_len, int64_t *n, int64_t *nbytes);
 

@@ -165,10 +165,12 @@ int rd_refine(const rd_model *cm, const uint8_t *arena, const int64_t *seq_off, 
     if (n == 0 || thresh <= 0.0f) return RD_OK;
     if (!arena || !seq_off || !seq_len) RD_FAIL(RD_E_INVALID, "rd_refine: null input pointer");
     hipStream_t st = (hipStream_t)stream;
-    if (m->semantics == RD_SEM_PADDED && m->rev_tab_len != max_len) {
-        hipLaunchKernelGGL(rd_revtab_kernel, dim3(1), dim3(512), 0, st, m->d, max_len);
-        m->rev_tab_len = max_len;
-    }
+    // padded semantics: the reverse-half table is built by rd_classify for ITS max_len, on ITS stream. Rebuilding it here - typically
+    // on a side stream, while a recurrence kernel of the main stream reads it - would be a data race (advisor finding, round 2), so
+    // the pass refuses a max_len the table was not built for: it re-evaluates reads of an earlier rd_classify call by definition.
+    if (m->semantics == RD_SEM_PADDED && m->rev_tab_len != max_len)
+        RD_FAIL(RD_E_INVALID, "rd_refine: padded semantics needs a preceding rd_classify with the same max_len (table built for %d, got %d)",
+                m->rev_tab_len, max_len);
     ReadBatch rb{arena, seq_off, seq_len, nullptr, nullptr, n, max_len, m->semantics, m->d.rev_tab, nullptr, nullptr, 0};
     return rd_refine_launch(m, rb, logits, labels, mate_logits, thresh, st);
 }

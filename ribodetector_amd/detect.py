@@ -82,8 +82,26 @@ class Predictor:
         self.logger.info('Using high {} model'.format(model_file_ext.upper()))
         self.logger.info('Log file: {}'.format(self.args.log))
 
+    def kernel_config(self):
+        """the `kernel` block of config.json (specific to this build), validated before anything touches the GPU"""
+        kcfg = dict(self.config.config.get('kernel', {}))
+        variant = kcfg.get('variant', 'auto')
+        if variant not in ('auto', 'mfma_f32', 'simple', 'mfma_f16x3_t32'):
+            raise RuntimeError("config.json kernel.variant must be one of auto, mfma_f16x3_t32, mfma_f32, simple; got %r" % (variant,))
+        sem = getattr(self.args, 'semantics', None) or kcfg.get('semantics', 'gpu')
+        if sem not in ('gpu', 'cpu', 'packed', 'padded'):
+            raise RuntimeError("config.json kernel.semantics must be gpu or cpu; got %r" % (sem,))
+        refine = float(kcfg.get('refine', module_arch.SeqModel.REFINE_DEFAULT))
+        if not 0.0 <= refine <= 1.0:
+            raise RuntimeError("config.json kernel.refine must be in [0, 1]; got %r" % (refine,))
+        pk = kcfg.get('prefix_k', None)           # prefix-state table: absent = the model's default (RD_PREFIX_K or "auto")
+        if pk is not None and pk != 'auto' and not (isinstance(pk, int) and (pk == 0 or 4 <= pk <= 13)):
+            raise RuntimeError("config.json kernel.prefix_k must be \"auto\", 0 or an integer in [4, 13]; got %r" % (pk,))
+        return {"variant": variant, "semantics": sem, "refine": refine, "prefix_k": pk}
+
     def load_model(self):
         """Load the model onto the GPU (reference detect.py:84-119). Raises RuntimeError without a visible device."""
+        kcfg = self.kernel_config()
         if self.args.deviceid is not None:
             os.environ["HIP_VISIBLE_DEVICES"] = self.args.deviceid
             os.environ["CUDA_VISIBLE_DEVICES"] = self.args.deviceid
@@ -104,16 +122,14 @@ class Predictor:
         model.load_state_dict(self.config.load_state_dict(self.state_key))
         self.logger.info('Model using {} for read length {}{}{}{} loaded'.format(
             self.device, colors.BOLD, colors.OKCYAN, self.len, colors.ENDC))
+        if kcfg["prefix_k"] is not None:
+            model.set_prefix_table(kcfg["prefix_k"])     # recorded now, built by .to()
         self.model = model.to(self.device)
-        kcfg = dict(self.config.config.get('kernel', {}))
-        variant = kcfg.get('variant', 'auto')
-        if variant not in ('auto', 'mfma_f32', 'simple', 'mfma_f16x3_t32'):
-            raise RuntimeError("config.json kernel.variant must be one of auto, mfma_f16x3_t32, mfma_f32, simple; got %r" % (variant,))
-        self.model.set_variant(variant)
-        self.model.set_semantics(getattr(self.args, 'semantics', None) or kcfg.get('semantics', 'gpu'))
+        self.model.set_variant(kcfg["variant"])
+        self.model.set_semantics(kcfg["semantics"])
         # margin band of the float64 re-evaluation (config.json kernel.refine; 0 = off; default 2.5e-4). The CLI issues the pass
         # itself on a side stream (submit_chunk), so the one inside rd_classify is switched off.
-        self.refine_band = float(kcfg.get('refine', module_arch.SeqModel.REFINE_DEFAULT))
+        self.refine_band = kcfg["refine"]
         self.model.set_refine(0.0)
         self.model.eval()
 

@@ -73,10 +73,28 @@ def test_product_build_has_no_diagnostic_variants():
             m.set_variant(name)
 
 
-def test_config_rejects_unknown_kernel_variant(tmp_path):
-    """detect.load_model refuses a config.json kernel.variant outside the product set before touching the GPU model"""
+def test_config_rejects_bad_kernel_block(tmp_path):
+    """Predictor.load_model refuses a config.json `kernel` block outside the product set - run, not read: the check comes before
+    anything touches a device, so it raises the same way on a box without a GPU"""
+    import argparse
     import json
-    import inspect
     from ribodetector_amd import detect
-    src = inspect.getsource(detect.Predictor.load_model)
-    assert "kernel.variant must be one of" in src
+    from ribodetector_amd.parse_config import ConfigParser
+    base = json.load(open(os.path.join(ROOT, "ribodetector_amd", "config.json")))
+    base["state_file"] = {k: os.path.join(ROOT, "ribodetector_amd", v) for k, v in base["state_file"].items()}
+    args = argparse.Namespace(log=None, chunk_size=None, len=100, ensure="none", deviceid=None, semantics=None)
+    for block, msg in (({"variant": "mfma_f16x3_t32_diag_mfmaonly"}, "kernel.variant must be one of"),
+                       ({"variant": "typo"}, "kernel.variant must be one of"),
+                       ({"semantics": "tpu"}, "kernel.semantics"),
+                       ({"refine": 7}, "kernel.refine"),
+                       ({"prefix_k": 3}, "kernel.prefix_k"),
+                       ({"prefix_k": "big"}, "kernel.prefix_k")):
+        cfg = dict(base, kernel=dict(base["kernel"], **block))
+        path = tmp_path / "config.json"
+        path.write_text(json.dumps(cfg))
+        p = detect.Predictor(ConfigParser.from_json(str(path)), args)
+        with pytest.raises(RuntimeError, match=msg):
+            p.load_model()
+    # the shipped block passes the check (and then fails later only for want of a GPU)
+    p = detect.Predictor(ConfigParser.from_json(os.path.join(ROOT, "ribodetector_amd", "config.json")), args)
+    assert p.kernel_config() == {"variant": "auto", "semantics": "gpu", "refine": 2.5e-4, "prefix_k": None}

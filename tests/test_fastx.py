@@ -396,3 +396,54 @@ def test_byte_range_sharding_crlf_and_trailing_blank_lines(tmp_path):
         got2 = [_range_records(p2, byte_range=pl[1]) for pl in plans]
         assert sum(got1, []) == whole1 and sum(got2, []) == whole2
         assert [len(g) for g in got1] == [len(g) for g in got2]
+
+
+def test_byte_range_fasta_empty_sequence_at_a_cut(tmp_path):
+    """the FASTA end-of-file quirk - a last record with an empty sequence is dropped (reference
+    fastx_parser.py:39-55 yields at end of file only `if seq`) - applies at the TRUE end of the file only. A range that ends
+    before the file does is followed by the next rank's header, where the reference yields the record whatever its sequence is.
+    CRLF FASTA with empty-sequence records sprinkled in, so that cuts land right behind some of them."""
+    rng = np.random.default_rng(15)
+    for trial in range(6):
+        recs = []
+        for i in range(64):
+            if rng.random() < 0.35 and i != 63:
+                recs.append(">r%d\r\n\r\n" % i)                                  # header, blank line: empty sequence
+            else:
+                s = "".join("ACGTn"[k] for k in rng.integers(0, 5, int(rng.integers(1, 50))))
+                recs.append(">r%d\r\n%s\r\n" % (i, s))
+        if trial % 2:
+            recs.append(">last\r\n\r\n")                                         # dropped by the whole-file parse AND by the last range
+        p1, p2 = str(tmp_path / ("e%d_1.fa" % trial)), str(tmp_path / ("e%d_2.fa" % trial))
+        open(p1, "w", newline="").write("".join(recs))
+        open(p2, "w", newline="").write("".join(r.replace(">r", ">mate") for r in recs))
+        whole = _range_records(p1)
+        assert len(whole) == 64                                                  # the trailing '>last' never counts
+        for world in (2, 3, 8):
+            plans = [fx.plan_ranges([p1], r, world) for r in range(world)]
+            assert sum([_range_records(p1, byte_range=pl[0]) for pl in plans], []) == whole, (trial, world)
+            plans = _plan_all([p1, p2], world)
+            per1 = [len(_range_records(p1, byte_range=pl[0])) for pl in plans]
+            per2 = [len(_range_records(p2, byte_range=pl[1])) for pl in plans]
+            assert per1 == per2 and sum(per1) == 64, (trial, world, per1, per2)
+
+
+def test_count_records_counts_an_empty_last_fastq_record(tmp_path):
+    """'@b\\n\\n+\\n\\n' at the end of a FASTQ file is a record for the reader, so the record count that aligns
+    the mates' cuts must count it too (trimmed data: one mate may end with an empty read)"""
+    from ribodetector_amd import _native as N
+    import ctypes as C
+    p1, p2 = str(tmp_path / "t_1.fq"), str(tmp_path / "t_2.fq")
+    open(p1, "w").write("@a\nACGT\n+\nIIII\n@b\n\n+\n\n")
+    open(p2, "w").write("@a\nAC\n+\nII\n@b\nG\n+\nI\n")
+    assert len(_range_records(p1)) == 2
+    n = C.c_int64(-1)
+    for path, want in ((p1, 2), (p2, 2)):
+        N.host_check(N.host_lib().rd_host_count_records(path.encode(), -1, 0, os.path.getsize(path), C.byref(n)), "count")
+        assert n.value == want
+    open(p1, "a").write("\n\n")                                                   # blank remainder of fewer than four lines: tolerated
+    N.host_check(N.host_lib().rd_host_count_records(p1.encode(), -1, 0, os.path.getsize(p1), C.byref(n)), "count")
+    assert n.value == 2 and len(_range_records(p1)) == 2
+    for world in (2, 3):
+        plans = _plan_all([p1, p2], world)                                       # round 2: 'paired-end files have different numbers of records'
+        assert [len(_range_records(p1, byte_range=pl[0])) for pl in plans] == [len(_range_records(p2, byte_range=pl[1])) for pl in plans]
