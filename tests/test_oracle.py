@@ -119,3 +119,74 @@ def test_empty_read_defined(oracle):
     w = load_file(os.path.join(os.path.dirname(__file__), "..", "ribodetector_amd", "data",
                                "ribodetector_600k_variable_len70_101_epoch47.safetensors"))
     assert np.allclose(lg[0], w["out.bias"], atol=1e-7)
+
+
+# ---- the reference AT SCALE (tests/golden/scale_*.npz, make_golden_scale.py) --------------------------------------------------
+# What these fixtures pin - and what every relaxed bar of the parity tests cites:
+#   * the reference's own fp32 arithmetic is 2.4e-6 rms / 1.0e-5 at p99.9 / 1.6e-5 at p99.99 from the exact (float64) value of
+#     model/model.py:32-37 on 100 bp reads, and its worst read of the set is 1.5e-4 off: the "1e-4" of the north star is a bar
+#     the reference does not hold against the function it implements;
+#   * on read 1,169,376 of synth.reads_torch(2^21, 100, seed=2026) the reference called with a batch of 2,048 reads and the
+#     reference called with that read alone differ by 3.7e-4: it does not hold the bar against ITSELF either.
+def _scale(name):
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from scale_sets import ScaleSet, err_stats
+    return ScaleSet(name), err_stats
+
+
+def test_reference_tail_is_a_property_of_fp32_not_of_this_build():
+    """the sentence of DESIGN.md §4 'the reference itself is > 1e-4 off on that read' as an assertion on reference-made data"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from f64_truth import f64_forward
+    from ribodetector_amd.parse_config import ConfigParser
+    s, _ = _scale("scale_se100")
+    st = s.stats
+    # (1) the recorded float64 values are what tests/f64_truth.py computes from the shipped weights (the fixture is not taken on trust)
+    sd = ConfigParser.from_json(os.path.join(os.path.dirname(__file__), "..", "ribodetector_amd", "config.json")).load_state_dict("mcc")
+    rows = st["worst"]["index"]
+    a, o, l = s.subset(rows)
+    truth = f64_forward(sd, a, o, l, s.max_len)
+    assert np.abs(truth - np.array(st["worst"]["f64"])).max() < 1e-9
+    err = np.abs(s.ref[rows].astype(np.float64) - truth).max(axis=1)
+    assert np.abs(err - np.array(st["worst"]["err"])).max() < 1e-9
+    # (2) the reference against float64: the bulk is far inside 1e-4, the worst read is outside it
+    assert st["rms"] < 3e-6 and st["p999"] < 2e-5 and st["p9999"] < 3e-5
+    assert st["n_over_1e-4"] >= 1 and err.max() > 1e-4
+    # (3) the rounding-sensitive read: the reference in a batch, the reference alone and float64
+    ex = st["extra"]
+    k = ex["stream_index"].index(1169376)
+    ref_b, ref_1, f64 = np.array(ex["ref"][k]), np.array(ex["ref_alone"][k]), np.array(ex["f64"][k])
+    assert np.abs(ref_b - s.ref[ex["rows"][k]]).max() == 0
+    assert np.abs(ref_b - f64).max() > 1.4e-4 and np.abs(ref_1 - f64).max() > 2e-4      # both forms > 1e-4 from the exact value
+    assert np.abs(ref_b - ref_1).max() > 3.5e-4                                           # and 3.7e-4 from each other
+    assert (ref_b[1] > ref_b[0]) == (ref_1[1] > ref_1[0]) == (f64[1] > f64[0])            # the label is never in question (margin 12)
+    # (4) no label of the set is decided by that noise: the smallest float64 margin is above the reference's error
+    for name in ("scale_se100", "scale_pe150", "scale_var300"):
+        assert _scale(name)[0].stats["label_mismatches_vs_f64"] == 0
+
+
+def test_oracle_against_the_reference_at_scale(oracle):
+    """oracle (the checker the GPU tests use at 10^5-10^7 reads) vs the reference's own logits on reference-made fixtures:
+    30,000 of the 100 bp reads (+ the 5 rounding-sensitive ones), all 20,000 of 150 bp, all 20,000 of 40-300 bp.
+    Two fp32 evaluations of one function: their difference is the two noises added (3e-6 rms each)."""
+    worst_seeded = 0.0
+    for name, take in (("scale_se100", 30000), ("scale_pe150", 20000), ("scale_var300", 20000)):
+        s, err_stats = _scale(name)
+        rows = np.concatenate([np.arange(take), np.arange(s.n_seeded, s.n)])
+        a, o, l = s.subset(rows)
+        lg = oracle.forward_packed(a, o, l, s.max_len)
+        e = np.abs(lg.astype(np.float64) - s.ref[rows]).max(axis=1)
+        seeded = e[:take]
+        st = err_stats(seeded)
+        assert st["rms"] < 6e-6 and st["p999"] < 3e-5 and st["p9999"] < 5e-5, (name, st)
+        assert st["max"] < 1e-4, (name, st)                   # the north star's bar, held by the oracle on every seeded read
+        assert (oracle.argmax(lg) == (s.ref[rows][:, 1] > s.ref[rows][:, 0])).all(), name
+        worst_seeded = max(worst_seeded, st["max"])
+        if s.n > s.n_seeded:                                   # the rounding-sensitive reads: outside 1e-4, inside 1e-3
+            ex = e[take:]
+            assert ex.max() < 1e-3 and ex.max() > 1e-4, ex
+    assert worst_seeded > 2e-5                                 # (the bar is not vacuous: the tail is real)
