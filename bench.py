@@ -429,10 +429,10 @@ def main():
     counts.zero_()
     model.profile_enable(True)
     sync()
-    t0 = time.perf_counter()
+    t0, c0 = time.perf_counter(), time.process_time()
     timed_path(args.steps)
     sync()
-    dt = time.perf_counter() - t0
+    dt, cpu_s = time.perf_counter() - t0, time.process_time() - c0      # cpu_s: user + system time of ALL threads of this rank
     launches, kms = model.profile_read()
     model.profile_enable(False)
     rdist.reduce_counts(counts)
@@ -441,6 +441,10 @@ def main():
     if multi:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
+    cpu_ranks = [cpu_s]
+    if multi:
+        cpu_ranks = [None] * world
+        dist.all_gather_object(cpu_ranks, cpu_s)
     total_pairs = P * args.steps * world
     c = counts.cpu().tolist()
     assert c[0] + c[1] + c[2] == total_pairs, (c, total_pairs)
@@ -508,6 +512,8 @@ def main():
                                      "parity_sample below is this run's check against the fp32 CPU port"
                                      if base == "mfma_f16x3_t32" else "fp32"),
                        "parallelism": "reads sharded x%d, label gather to rank 0" % world,
+                       "host_cpu_seconds_per_rank_in_timed_region": [round(c, 4) for c in cpu_ranks],
+                       "host_cores_busy": sum(cpu_ranks) / dt, "host_cores_usable": usable_cores(),
                        "rccl_ranks": world, "dist_backend": backend, "forced_dist": bool(multi and world == 1),
                        "prefix_table": {"k": PK, "bytes": (4 ** PK + 1) * 1024 if PK else 0,
                                         "what": "recurrence state after every sequence of k bases, built by the kernel itself at model load; "

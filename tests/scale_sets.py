@@ -48,3 +48,19 @@ def err_stats(e):
     e = np.asarray(e, dtype=np.float64)
     return {"rms": float(np.sqrt((e ** 2).mean())), "p999": float(np.quantile(e, 0.999)), "p9999": float(np.quantile(e, 0.9999)),
             "max": float(e.max()), "n_over_5e-5": int((e > 5e-5).sum()), "n_over_1e-4": int((e > 1e-4).sum())}
+
+
+def reference_tail():
+    """What the relaxed bars of the large parity tests cite (reference-made data only, no reads regenerated):
+    worst distance of the reference from float64 per fixture, and the largest distance of the reference from ITSELF (batch of
+    2,048 vs batch of 1) on the rounding-sensitive reads of scale_se100."""
+    out = {}
+    for name in NAMES:
+        st = json.loads(np.load(os.path.join(GOLDEN, name + ".npz"))["stats"].tobytes().decode())
+        out[name] = {k: st[k] for k in ("rms", "p999", "p9999", "max", "n_over_1e-4", "reads")}
+        if "extra" in st:
+            ex = st["extra"]
+            out["self_gap"] = float(np.abs(np.array(ex["ref"]) - np.array(ex["ref_alone"])).max())
+            out["extra_max_vs_f64"] = float(max(np.abs(np.array(ex["ref"]) - np.array(ex["f64"])).max(),
+                                                np.abs(np.array(ex["ref_alone"]) - np.array(ex["f64"])).max()))
+    return out

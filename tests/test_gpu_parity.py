@@ -390,13 +390,28 @@ def test_random_bytes_and_lengths_stress(gpu_model, oracle):
         _check(lg.cpu().numpy(), lab.cpu().numpy(), ref, "stress %d" % trial)
 
 
+def _ref_tail():
+    """the reference's own tail, from reference-made fixtures (tests/golden/scale_*.npz via tests/scale_sets.py)"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from scale_sets import reference_tail
+    t = reference_tail()
+    # the citations below are live: if the fixtures stop saying this, the relaxed bars lose their justification and the tests fail
+    assert t["scale_se100"]["max"] > 1.4e-4 and t["self_gap"] > 3.5e-4 and t["extra_max_vs_f64"] > 2e-4
+    return t
+
+
 def _check_tail(lg, lab, ref_logits, maxlen, what):
-    """Like _check for reads of up to 100 steps. Beyond that the recurrence amplifies fp32 rounding noise so far that no two
-    fp32 implementations agree to 1e-4 on every read (tools/acc_experiment.py --len 300: over 10^5..10^6 reads of 300 bp the oracle
-    itself is up to 2.6e-4 from a float64 evaluation, 3 reads beyond 1e-4): there the bar is 1e-4 for 99.9 % of the reads,
-    5e-5 for 99 %, 1e-3 for all, and labels equal wherever the reference's own margin exceeds the observed error."""
+    """Like _check (1e-4 on every read) for reads of up to 100 steps on small sets. For longer reads and 10^5+ reads the bar is
+    1e-4 for 99.9 % of the reads, 5e-5 for 99 %, 1e-3 for all, labels equal wherever the checker's own margin exceeds the observed
+    error. Justification, from data the REFERENCE produced (tests/golden/scale_*.npz, asserted in _ref_tail): over 100,005 reads
+    of 100 bp the reference itself is up to 1.5e-4 from the float64 value of its own function, and on a rounding-sensitive read it
+    differs from ITSELF by 3.7e-4 when called with a batch of 2,048 instead of 1 - two faithful fp32 evaluations cannot be held to
+    1e-4 on every read of a large set; tests/test_gpu_scale.py holds the kernels to 1e-4 against the reference on 140,000 reads."""
     if maxlen <= 100:
         return _check(lg, lab, ref_logits, what)
+    _ref_tail()
     e = np.abs(lg - ref_logits).max(axis=1)
     assert np.quantile(e, 0.999) < TOL and np.quantile(e, 0.99) < 5e-5 and e.max() < 1e-3, \
         "%s: logit error max %.3g p99.9 %.3g p99 %.3g" % (what, e.max(), np.quantile(e, 0.999), np.quantile(e, 0.99))
@@ -582,9 +597,11 @@ def test_labels_equal_float64_labels_at_scale(gpu_model, report):
     """2^21 reads x 100 bp against a float64 evaluation of the same function: with the default refine band every label equals the
     float64 label (reads whose exact margin is below 1e-6 excepted - there the yardstick's own rounding decides). The logits carry
     fp32 rounding noise: 3e-6 rms, 99.99 % of the reads within 5e-5; a few reads per million are rounding-sensitive far beyond
-    that for EVERY fp32 evaluation - read 1,169,376 of this very set is 6.7e-4 from the exact value under the reference's own
-    arithmetic (the CPU oracle), 6.8e-4 under the default kernel, 1.8e-4 under the fp32 MFMA kernel - so the bound on
-    the tail is a count, not zero."""
+    that for EVERY fp32 evaluation - read 1,169,376 of this very set is 1.5e-4 (batch of 2,048) resp. 2.2e-4 (alone) from the exact
+    value under THE REFERENCE (tests/golden/scale_se100.npz, extra rows: reference-made, asserted in _ref_tail and in
+    tests/test_oracle.py), 6.7e-4 under the CPU oracle, 5.0e-4 under the default kernel - so the bound on the tail is a count, not
+    zero: <= 4 reads per 2^21 beyond 1e-4, the reference's own rate being 1 per 100,005 (same fixture)."""
+    _ref_tail()
     import os
     import sys
     from ribodetector_amd import synth
@@ -623,7 +640,9 @@ def test_logit_tail_against_the_oracle_at_one_million_reads(gpu_model, oracle, r
     """VERDICT r1 asked for tests/diag_error_tail.py as a test: 2^20 reads x 100 bp, default kernel against the fp32 CPU oracle
     (= the reference's arithmetic). Both sides carry ~3e-6 rms of independent rounding noise, so their difference has a tail: the
     bound is 1e-4 for all but at most 3 reads per million (observed 0-2), 5e-5 at the 99.99th percentile, labels equal wherever
-    the oracle's own margin exceeds 2e-4."""
+    the oracle's own margin exceeds 2e-4. The allowance of 3 per million is the reference's own rate: 1 of the 100,005 reads of
+    tests/golden/scale_se100.npz is beyond 1e-4 from float64 for the REFERENCE (asserted in _ref_tail)."""
+    _ref_tail()
     from ribodetector_amd import synth
     n, L = 1 << 20, 100
     arena, off, lens = synth.reads_torch(n, L, seed=4242, device="cuda", rrna_frac=0.3, n_rate=0.002)

@@ -1,0 +1,112 @@
+#!/usr/bin/env python
+"""Do W ranks fit the host of ONE box? (VERDICT r2 next #1c)
+
+The 8-GPU node of the scaling run gives every rank its own GPU but the same cgroup of host cores as the 1-GPU boxes have
+(bench.py usable_cores(): 16). This tool runs what can be run on a 1-GPU box - W ranks SHARING the one GPU, labels exchanged
+over gloo - and records the host side of it: CPU seconds per rank inside the timed region, cores busy, and the ratio device
+path / kernel-only, for bench.py at W = 1, 2, 4, 8 and for the CLI (plain and gz input) at W = 1 and 8. The GPU is shared, so
+reads/s do NOT scale here; what the numbers show is that W x (launch thread + reader + writers) stay below the core budget.
+Writes gpurun_out/r03_host_scaling.json.      python tools/host_scaling.py [--reads 4000000]"""
+import argparse
+import json
+import os
+import resource
+import socket
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, ROOT)
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def child_cpu():
+    r = resource.getrusage(resource.RUSAGE_CHILDREN)
+    return r.ru_utime + r.ru_stime
+
+
+def run_bench(world, pairs):
+    env = dict(os.environ, RD_DIST_BACKEND="gloo", RD_LOCAL_DEVICE="0", RD_PREFIX_K="12")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "6", "--warmup", "2", "--pairs-per-step", str(pairs),
+           "--no-alt", "--no-cpu-baseline", "--no-encoder", "--no-e2e", "--traffic", "off"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1800)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if r.returncode != 0 or len(lines) != 1:
+        return {"error": (r.stdout + r.stderr)[-1500:]}
+    j = json.loads(lines[0])
+    c = j["config"]
+    return {"ranks": world, "pairs_per_step_per_rank": pairs, "reads_per_s_all_ranks_one_gpu": j["value"], "ms_per_step": j["ms_per_step"],
+            "device_path_over_kernel_only": c["device_path_over_kernel_only"], "cpu_seconds_per_rank": c["host_cpu_seconds_per_rank_in_timed_region"],
+            "host_cores_busy": c["host_cores_busy"], "host_cores_usable": c["host_cores_usable"], "dist_backend": c["dist_backend"]}
+
+
+def run_cli(world, inputs, outdir, tag, threads):
+    outs = [os.path.join(outdir, "%s_w%d_%d.fq" % (tag, world, i)) for i in range(len(inputs))]
+    base = ["-l", "100", "-i", *inputs, "-o", *outs, "-t", str(threads)] + (["-e", "rrna"] if len(inputs) == 2 else [])
+    env = dict(os.environ, RD_PREFIX_K="12")
+    if world == 1:
+        cmd = [sys.executable, "-m", "ribodetector_amd.detect"] + base
+    else:
+        env.update(RD_DIST_BACKEND="gloo", RD_LOCAL_DEVICE="0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+               "--master-port", str(free_port()), "-m", "ribodetector_amd.detect"] + base
+    c0, t0 = child_cpu(), time.perf_counter()
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1800)
+    dt, cpu = time.perf_counter() - t0, child_cpu() - c0
+    if r.returncode != 0:
+        return {"error": (r.stdout + r.stderr)[-1500:]}
+    import hashlib
+    sha = [hashlib.sha1(open(o, "rb").read()).hexdigest() for o in outs]
+    for o in outs:
+        os.remove(o)
+    return {"ranks": world, "threads_flag": threads, "wall_s_whole_process": dt, "cpu_s_all_ranks": cpu, "cores_busy": cpu / dt, "output_sha1": sha}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reads", type=int, default=4000000)
+    a = ap.parse_args()
+    from bench import usable_cores
+    out = {"host_cores_usable": usable_cores(), "os_cpu_count": os.cpu_count(), "note": "all ranks share ONE GPU (RD_LOCAL_DEVICE=0, gloo): host-side evidence only"}
+    out["bench"] = [run_bench(w, 1 << 18) for w in (1, 2, 4, 8)]
+    import gzip
+    import shutil
+    from ribodetector_amd import synth
+    d = tempfile.mkdtemp(prefix="rd_hs_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        files = []
+        for mate, seed in ((1, 1), (2, 2)):
+            arena, off, _ = synth.reads_numpy(a.reads, 100, seed=seed)
+            p = os.path.join(d, "r_%d.fq" % mate)
+            synth.write_fastq_realistic(p, arena, off, mate, seed=seed)
+            with open(p, "rb") as fi, gzip.open(p + ".gz", "wb", compresslevel=4) as fo:
+                shutil.copyfileobj(fi, fo, 1 << 24)
+            files.append(p)
+        out["cli_reads_per_file"] = a.reads
+        out["cli"] = {}
+        for tag, ins in (("pe_plain", files), ("pe_gz", [f + ".gz" for f in files])):
+            rows = []
+            for w in (1, 8):
+                rows.append(run_cli(w, ins, d, tag, threads=10 if w == 1 else 2))
+            same = all("output_sha1" in r for r in rows) and rows[0]["output_sha1"] == rows[1]["output_sha1"]
+            out["cli"][tag] = {"runs": rows, "outputs_identical_w1_w8": same}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "r03_host_scaling.json"), "w"), indent=1)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
