@@ -97,9 +97,20 @@ int rd_set_semantics(rd_model *m, int semantics);
  *   - for throughput: the pass has the latency of one read (~0.3 ms: 100 dependent float64 steps on one CU) with the rest of
  *     the GPU idle. A pipelined caller switches the inline pass off (rd_set_refine(m, 0)) and issues rd_refine(..., thresh)
  *     on a second stream, where it overlaps the next batch's recurrence (bench.py and the CLI do).
- * One launch: each workgroup scans 512 logit rows and re-evaluates the candidates among them itself. */
+ * One launch: each workgroup scans 512 logit rows and re-evaluates the candidates among them itself.
+ * rd_set_refine_async(m, 1) moves the pass off the caller's critical path without a second stream on the caller's side (opt-in):
+ * rd_classify then issues it on a stream the model owns and returns with it pending; it is joined into the caller's stream
+ *   (a) by the NEXT rd_classify / rd_refine of this model - behind that call's recurrence launch, so that the pass overlaps it,
+ *   (b) by rd_sync_results(m, stream), (c) by rd_model_destroy.
+ * Contract of the mode: the logits / labels of a call are final, and its input buffers may be overwritten, only after one of
+ * (a)-(c) has been issued on the stream that consumes them - i.e. a streaming caller alternates two sets of buffers and reads
+ * the results of call i after issuing call i+1 (what the reference's loop cannot do: it synchronises on .tolist() every batch,
+ * reference detect.py:288,481). A next call that passes one of the pending call's pointers, or overlapping output ranges, is
+ * detected and joins first (correct results, no overlap). A call captured in a hipGraph keeps the pass inline. */
 #define RD_REFINE_DEFAULT 2.5e-4f
 int rd_set_refine(rd_model *m, float thresh);
+int rd_set_refine_async(rd_model *m, int enable);
+int rd_sync_results(rd_model *m, void *stream);
 int rd_refine(const rd_model *m, const uint8_t *arena, const int64_t *seq_off, const int32_t *seq_len, int64_t n,
               int32_t max_len, float *logits, uint8_t *labels, const float *mate_logits, float thresh, void *stream);
 
@@ -111,14 +122,17 @@ int rd_refine(const rd_model *m, const uint8_t *arena, const int64_t *seq_off, c
  * the prefix, or no step left after it, run all their steps from the zero state as before). This is the reverse-direction table
  * (one step, 5 rows) carried k steps forward: k = 12 takes 16 GiB of the 288 GB of HBM and removes 12 % of the steps of a 100 bp read.
  *   rd_prefix_table_bytes(k): bytes of [dev] memory for k in [RD_PREFIX_K_MIN, RD_PREFIX_K_MAX] ((4^k + 1) KiB); 0 otherwise.
+ *   rd_prefix_scratch_bytes(k): bytes of [dev] scratch the build needs (4^(k-1) KiB: the level below), free again afterwards.
  *   rd_set_prefix_table: builds the table for the model's weights into caller-owned `table` (256-byte aligned, >= that many
- *     bytes; it must stay allocated until the model is destroyed or another / no table is set) and attaches it. k = 0 (table may
- *     be NULL) detaches. Synchronous on `stream`. Only RD_VARIANT_MFMA_F16X3_T32 uses the table; the other kernels ignore it.
+ *     bytes; it must stay allocated until the model is destroyed or another / no table is set) and attaches it: k launches, level
+ *     j = the states after every j-base prefix from level j-1 by ONE step (4/3 4^k steps in all: 15 ms at k = 12). k = 0 (pointers
+ *     may be NULL) detaches. Synchronous on `stream`. Only RD_VARIANT_MFMA_F16X3_T32 uses the table; the other kernels ignore it.
  *   rd_prefix_k: k of the attached table, 0 if none. */
 #define RD_PREFIX_K_MIN 4
 #define RD_PREFIX_K_MAX 13
 size_t rd_prefix_table_bytes(int32_t k);
-int rd_set_prefix_table(rd_model *m, int32_t k, void *table, size_t table_bytes, void *stream);
+size_t rd_prefix_scratch_bytes(int32_t k);
+int rd_set_prefix_table(rd_model *m, int32_t k, void *table, size_t table_bytes, void *scratch, size_t scratch_bytes, void *stream);
 int rd_prefix_k(const rd_model *m);
 
 /* Bytes of [dev] scratch rd_classify needs for n reads with truncation length max_len. */

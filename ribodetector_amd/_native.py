@@ -26,7 +26,7 @@ if os.path.basename(LIB_PATH).startswith("librd_hip_diag"):
 
 # every symbol include/ribodetector_amd.h declares (tests/test_abi.py checks the .so exports all of them)
 SYMBOLS = [
-    "rd_model_create", "rd_model_destroy", "rd_set_variant", "rd_variant_available", "rd_set_semantics", "rd_set_refine", "rd_refine", "rd_prefix_table_bytes", "rd_set_prefix_table", "rd_prefix_k", "rd_classify_workspace_bytes", "rd_classify",
+    "rd_model_create", "rd_model_destroy", "rd_set_variant", "rd_variant_available", "rd_set_semantics", "rd_set_refine", "rd_set_refine_async", "rd_sync_results", "rd_refine", "rd_prefix_table_bytes", "rd_prefix_scratch_bytes", "rd_set_prefix_table", "rd_prefix_k", "rd_classify_workspace_bytes", "rd_classify",
     "rd_pair_fuse", "rd_count_labels", "rd_encode_codes", "rd_encode_onehot_padded", "rd_pack_plan",
     "rd_pack_onehot", "rd_profile_enable", "rd_profile_read", "rd_last_error", "rd_version",
 ]
@@ -63,10 +63,14 @@ def lib():
     L.rd_variant_available.argtypes = [C.c_int]
     L.rd_set_semantics.argtypes = [vp, C.c_int]
     L.rd_set_refine.argtypes = [vp, C.c_float]
+    L.rd_set_refine_async.argtypes = [vp, C.c_int]
+    L.rd_sync_results.argtypes = [vp, vp]
     L.rd_refine.argtypes = [vp, vp, vp, vp, i64, i32, vp, vp, vp, C.c_float, vp]
     L.rd_prefix_table_bytes.argtypes = [i32]
     L.rd_prefix_table_bytes.restype = sz
-    L.rd_set_prefix_table.argtypes = [vp, i32, vp, sz, vp]
+    L.rd_prefix_scratch_bytes.argtypes = [i32]
+    L.rd_prefix_scratch_bytes.restype = sz
+    L.rd_set_prefix_table.argtypes = [vp, i32, vp, sz, vp, sz, vp]
     L.rd_prefix_k.argtypes = [vp]
     L.rd_classify_workspace_bytes.argtypes = [i64, i32]
     L.rd_classify_workspace_bytes.restype = sz

@@ -95,6 +95,14 @@ struct rd_model {
     int prefix_k;         // bases covered by a row of the attached prefix-state table (0 = none attached)
     const uint8_t *ptab;  // the table (caller-owned memory, rd_set_prefix_table), (4^prefix_k + 1) rows of 1 KiB
     DevModel d;
+    // deferred float64 pass (rd_set_refine_async): issued on a stream the model owns, joined into the caller's stream by the NEXT
+    // rd_classify (behind that call's recurrence launch), by rd_sync_results or by rd_model_destroy
+    int refine_async;
+    int refine_pending;
+    hipStream_t side;
+    hipEvent_t ev_fork, ev_join;
+    const void *pend_ptr[5];   // arena, seq_off, seq_len, logits, labels of the pending call (reuse by the next call = join first)
+    int64_t pend_n;
     // profiling of the recurrence kernel (bench.py roofline)
     int prof_enabled;
     int prof_count;

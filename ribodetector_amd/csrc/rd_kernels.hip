@@ -96,6 +96,9 @@ int rd_model_create(const rd_weights *w, int device, rd_model **out) {
 void rd_model_destroy(rd_model *m) {
     if (!m) return;
     hipSetDevice(m->device);
+    if (m->side) { hipStreamSynchronize(m->side); hipStreamDestroy(m->side); }
+    if (m->ev_fork) hipEventDestroy(m->ev_fork);
+    if (m->ev_join) hipEventDestroy(m->ev_join);
     hipFree(m->d.raw); hipFree(m->d.wpack32); hipFree(m->d.wt_hh); hipFree(m->d.in_lut);
     hipFree(m->d.rev_lut); hipFree(m->d.rev_tab); hipFree(m->d.w_out); hipFree(m->d.b_out);
     if (m->d.wpack16b) hipFree(m->d.wpack16b);
@@ -146,6 +149,33 @@ int rd_set_refine(rd_model *m, float thresh) {
     return RD_OK;
 }
 
+int rd_set_refine_async(rd_model *m, int enable) {
+    if (!m) RD_FAIL(RD_E_INVALID, "rd_set_refine_async: null model");
+    if (enable && !m->side) {
+        RD_HIP(hipSetDevice(m->device));
+        // highest priority: when a CU becomes free its workgroups go first - a workgroup of the float64 pass needs a whole CU (1,024
+        // threads), and so does every workgroup of the recurrence kernel that the pass is meant to run beside
+        int lo = 0, hi = 0;
+        RD_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        RD_HIP(hipStreamCreateWithPriority(&m->side, hipStreamNonBlocking, hi));
+        RD_HIP(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
+        RD_HIP(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
+    }
+    if (!enable && m->refine_pending) RD_HIP(hipStreamSynchronize(m->side));   // leaving the mode: nothing stays in flight
+    if (!enable) m->refine_pending = 0;
+    m->refine_async = enable ? 1 : 0;
+    return RD_OK;
+}
+
+int rd_sync_results(rd_model *m, void *stream) {
+    if (!m) RD_FAIL(RD_E_INVALID, "rd_sync_results: null model");
+    if (m->refine_pending) {
+        RD_HIP(hipStreamWaitEvent((hipStream_t)stream, m->ev_join, 0));
+        m->refine_pending = 0;
+    }
+    return RD_OK;
+}
+
 static int rd_refine_launch(rd_model *m, const ReadBatch &rb, float *logits, uint8_t *labels, const float *mate_logits, float thresh,
                             hipStream_t st) {
     const int64_t nb = (rb.n + REFINE_SLICE - 1) / REFINE_SLICE;
@@ -165,6 +195,7 @@ int rd_refine(const rd_model *cm, const uint8_t *arena, const int64_t *seq_off, 
     if (n == 0 || thresh <= 0.0f) return RD_OK;
     if (!arena || !seq_off || !seq_len) RD_FAIL(RD_E_INVALID, "rd_refine: null input pointer");
     hipStream_t st = (hipStream_t)stream;
+    if (m->refine_pending) { RD_HIP(hipStreamWaitEvent(st, m->ev_join, 0)); m->refine_pending = 0; }
     // padded semantics: the reverse-half table is built by rd_classify for ITS max_len, on ITS stream. Rebuilding it here - typically
     // on a side stream, while a recurrence kernel of the main stream reads it - would be a data race (advisor finding, round 2), so
     // the pass refuses a max_len the table was not built for: it re-evaluates reads of an earlier rd_classify call by definition.
@@ -180,26 +211,40 @@ size_t rd_prefix_table_bytes(int32_t k) {
     return (((size_t)1 << (2 * k)) + 1) * PFX_ROW;
 }
 
+size_t rd_prefix_scratch_bytes(int32_t k) {
+    if (k < RD_PREFIX_K_MIN || k > RD_PREFIX_K_MAX) return 0;
+    return ((size_t)1 << (2 * (k - 1))) * PFX_ROW;
+}
+
 int rd_prefix_k(const rd_model *m) { return m ? m->prefix_k : 0; }
 
-int rd_set_prefix_table(rd_model *m, int32_t k, void *table, size_t table_bytes, void *stream) {
+int rd_set_prefix_table(rd_model *m, int32_t k, void *table, size_t table_bytes, void *scratch, size_t scratch_bytes, void *stream) {
     if (!m) RD_FAIL(RD_E_INVALID, "rd_set_prefix_table: null model");
     if (k == 0) {
         m->prefix_k = 0;
         m->ptab = m->d.zero_row;
         return RD_OK;
     }
-    const size_t need = rd_prefix_table_bytes(k);
+    const size_t need = rd_prefix_table_bytes(k), need_s = rd_prefix_scratch_bytes(k);
     if (!need) RD_FAIL(RD_E_INVALID, "rd_set_prefix_table: k=%d out of range [%d,%d] (or 0 = none)", k, RD_PREFIX_K_MIN, RD_PREFIX_K_MAX);
-    if (!table || ((uintptr_t)table & 255)) RD_FAIL(RD_E_INVALID, "rd_set_prefix_table: table must be a 256-byte aligned device pointer");
+    if (!table || ((uintptr_t)table & 255) || !scratch || ((uintptr_t)scratch & 255))
+        RD_FAIL(RD_E_INVALID, "rd_set_prefix_table: table and scratch must be 256-byte aligned device pointers");
     if (table_bytes < need) RD_FAIL(RD_E_WORKSPACE, "rd_set_prefix_table: table too small for k=%d: %zu < %zu", k, table_bytes, need);
+    if (scratch_bytes < need_s) RD_FAIL(RD_E_WORKSPACE, "rd_set_prefix_table: scratch too small for k=%d: %zu < %zu", k, scratch_bytes, need_s);
     hipStream_t st = (hipStream_t)stream;
-    const int64_t rows = (int64_t)1 << (2 * k);
-    uint8_t *tab = (uint8_t *)table;
-    RD_HIP(hipMemsetAsync(tab + (size_t)rows * PFX_ROW, 0, PFX_ROW, st));        // the zero row: where the prefixes themselves start
-    ReadBatch rb{nullptr, nullptr, nullptr, nullptr, nullptr, rows, k, RD_SEM_PACKED, nullptr, tab, nullptr, k};
-    hipLaunchKernelGGL(rd_lstm_mfma_f16x3_t32_kernel<true>, dim3((unsigned)(rows / 64)), dim3(256), 0, st, m->d, rb, (float *)tab, (uint8_t *)nullptr);
+    uint8_t *tab = (uint8_t *)table, *scr = (uint8_t *)scratch;
+    // level j (the states after every j-base prefix) from level j-1, one step per launch; the levels alternate between the table
+    // and the scratch so that level k lands in the table (level k-1, a quarter of its size, is the largest one in the scratch)
+    const uint8_t *prev = m->d.zero_row;
+    for (int j = 1; j <= k; ++j) {
+        uint8_t *dst = ((k - j) & 1) ? scr : tab;
+        const int64_t rows = (int64_t)1 << (2 * j);
+        ReadBatch rb{nullptr, nullptr, nullptr, nullptr, nullptr, rows, 1, RD_SEM_PACKED, nullptr, prev, nullptr, j};
+        hipLaunchKernelGGL(rd_lstm_mfma_f16x3_t32_kernel<true>, dim3((unsigned)((rows + 63) / 64)), dim3(256), 0, st, m->d, rb, (float *)dst, (uint8_t *)nullptr);
+        prev = dst;
+    }
     RD_HIP(hipGetLastError());
+    RD_HIP(hipMemsetAsync(tab + ((size_t)1 << (2 * k)) * PFX_ROW, 0, PFX_ROW, st));   // the zero row: reads that cannot use a prefix row
     RD_HIP(hipStreamSynchronize(st));
     m->prefix_k = k;
     m->ptab = tab;
@@ -255,6 +300,15 @@ int rd_classify(const rd_model *cm, const uint8_t *arena, const int64_t *seq_off
     if (m->semantics == RD_SEM_PADDED && m->rev_tab_len != max_len) {
         hipLaunchKernelGGL(rd_revtab_kernel, dim3(1), dim3(512), 0, st, m->d, max_len);
         m->rev_tab_len = max_len;
+    }
+    // deferred float64 pass of the previous call (rd_set_refine_async): normally joined BEHIND this call's recurrence so that the two
+    // overlap; if this call touches a buffer of that one, it is joined first (correct, no overlap)
+    if (m->refine_pending) {
+        const char *lo = (const char *)m->pend_ptr[3], *la = (const char *)m->pend_ptr[4];
+        const bool clash = arena == m->pend_ptr[0] || seq_off == m->pend_ptr[1] || seq_len == m->pend_ptr[2] ||
+                           ((const char *)logits < lo + 8 * m->pend_n && lo < (const char *)logits + 8 * n) ||
+                           (labels && la && (const char *)labels < la + m->pend_n && la < (const char *)labels + n);
+        if (clash) { RD_HIP(hipStreamWaitEvent(st, m->ev_join, 0)); m->refine_pending = 0; }
     }
     int32_t *steps = nullptr, *order = nullptr, *pfx = nullptr;
     const int pk = m->variant == RD_VARIANT_MFMA_F16X3_T32 ? m->prefix_k : 0;      // the table holds THAT kernel's state
@@ -312,7 +366,24 @@ int rd_classify(const rd_model *cm, const uint8_t *arena, const int64_t *seq_off
     }
     RD_HIP(hipGetLastError());
     if (ev) { RD_HIP(hipEventRecord(ev[1], st)); m->prof_count++; }
-    if (m->refine_thresh > 0.0f) return rd_refine_launch(m, rb, logits, labels, nullptr, m->refine_thresh, st);
+    if (m->refine_pending) {   // the previous call's float64 pass ran beside this call's recurrence; everything later on `st` sees its results
+        RD_HIP(hipStreamWaitEvent(st, m->ev_join, 0));
+        m->refine_pending = 0;
+    }
+    if (m->refine_thresh > 0.0f) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (m->refine_async) (void)hipStreamIsCapturing(st, &cap);
+        if (!m->refine_async || cap != hipStreamCaptureStatusNone)      // (a captured call stays self-contained: no open fork at EndCapture)
+            return rd_refine_launch(m, rb, logits, labels, nullptr, m->refine_thresh, st);
+        RD_HIP(hipEventRecord(m->ev_fork, st));
+        RD_HIP(hipStreamWaitEvent(m->side, m->ev_fork, 0));
+        rc = rd_refine_launch(m, rb, logits, labels, nullptr, m->refine_thresh, m->side);
+        if (rc) return rc;
+        RD_HIP(hipEventRecord(m->ev_join, m->side));
+        m->refine_pending = 1;
+        m->pend_ptr[0] = arena; m->pend_ptr[1] = seq_off; m->pend_ptr[2] = seq_len; m->pend_ptr[3] = logits; m->pend_ptr[4] = labels;
+        m->pend_n = n;
+    }
     return RD_OK;
 }
 

@@ -309,10 +309,12 @@ __device__ __forceinline__ void rd_phase_ewonly(Lstm16bSmem &S, f32x16 (&accP)[4
 
 // BUILD = false: classification (the product path). Every read starts from a row of the prefix-state table: the recurrence state after
 // its first pk bases (rd_steps_kernel chose the row and took pk off the step count), or the all-zero row.
-// BUILD = true: the same code builds that table (rd_set_prefix_table): "read" g is the pk-base prefix whose base-4 number is g, it
-// runs its pk steps from the zero row, and instead of the FC epilogue the workgroup writes the state - the two fp16 arrays of h
-// as they stand in LDS and the cell state as it stands in the registers - into row g (through `logits`, which then points to the
-// table). Building with the classifying code is what makes a table start bit-identical to stepping over the bases.
+// BUILD = true: the same code builds that table, one level per launch (rd_set_prefix_table): "read" g of level j = rb.pk is the
+// j-base prefix whose base-4 number is g; it starts from row g >> 2 of the level j-1 table (rb.ptab; level 1: a zero row), steps
+// over its last base g & 3, and instead of the FC epilogue the workgroup writes the state - the two fp16 arrays of h as they stand
+// in LDS and the cell state as it stands in the registers - into row g of the level-j table (`logits` then points to it).
+// Building with the classifying code is what makes a table start bit-identical to stepping over the bases; building level by
+// level costs 4/3 4^k steps instead of k 4^k.
 template <bool BUILD>
 __global__ __launch_bounds__(256, 1) void rd_lstm_mfma_f16x3_t32_kernel(DevModel d, ReadBatch rb, float *__restrict__ logits,
                                                                         uint8_t *__restrict__ labels) {
@@ -329,7 +331,7 @@ __global__ __launch_bounds__(256, 1) void rd_lstm_mfma_f16x3_t32_kernel(DevModel
     const int row = tid >> 2, piece = tid & 3;
     const int64_t g = (int64_t)blockIdx.x * 64 + row;
     const bool valid = g < rb.n;
-    const int nz = rb.pk > 0 ? 1 << (2 * rb.pk) : 0;                                               // the zero row
+    const int nz = BUILD ? 0 : (rb.pk > 0 ? 1 << (2 * rb.pk) : 0);   // the zero row (BUILD: only level 1 starts there, from a one-row table)
     const int64_t gc0 = (int64_t)blockIdx.x * 64 + j, gc1 = gc0 + 32;
     const bool use_pfx = !BUILD && rb.pfx != nullptr;
     int orig = -1, oc0 = -1, oc1 = -1;
@@ -373,7 +375,8 @@ __global__ __launch_bounds__(256, 1) void rd_lstm_mfma_f16x3_t32_kernel(DevModel
     int T = 0, lr = 0, k0 = 0, prow = nz, pc0 = nz, pc1 = nz;
     long long off = 0;
     if (BUILD) {
-        if (valid) { T = rb.pk; lr = rb.pk; }
+        if (valid) { T = 1; lr = 1; if (rb.pk > 1) prow = (int)(g >> 2); }
+        if (rb.pk > 1) { if (gc0 < rb.n) pc0 = (int)(gc0 >> 2); if (gc1 < rb.n) pc1 = (int)(gc1 >> 2); }
     } else if (valid) {                                                                            // round trip 2
         T = rd_T(rb.steps, orig, rb.max_len);
         lr = rd_T(rb.len, orig, rb.max_len);
@@ -384,14 +387,13 @@ __global__ __launch_bounds__(256, 1) void rd_lstm_mfma_f16x3_t32_kernel(DevModel
         if (oc0 >= 0) pc0 = rb.pfx[oc0];
         if (oc1 >= 0) pc1 = rb.pfx[oc1];
     }
-    if (prow != nz) { k0 = rb.pk; lr -= k0; off += k0; }      // the row covers the first pk bases: the kernel steps over the rest
+    if (!BUILD && prow != nz) { k0 = rb.pk; lr -= k0; off += k0; }      // the row covers the first pk bases: the kernel steps over the rest
     load_row_tile(std::integral_constant<int, 1>());
     const uint8_t *src0 = rb.arena + off;
     u32x4 raw0, raw1 = {0u, 0u, 0u, 0u};   // both code buffers are free now: reads of up to 128 steps never stage inside the phase loop
-    if (BUILD) {   // the bases of prefix g, first base = most significant digit (rd_steps_kernel numbers prefixes the same way)
+    if (BUILD) {   // the last base of prefix g = its least significant digit (rd_steps_kernel: first base = most significant digit)
         raw0 = u32x4{0u, 0u, 0u, 0u};
-        if (valid && piece == 0)
-            for (int t = 0; t < rb.pk; ++t) raw0[t >> 2] |= (uint32_t)"ACGT"[(g >> (2 * (rb.pk - 1 - t))) & 3] << (8 * (t & 3));
+        if (valid && piece == 0) raw0[0] = (uint32_t)"ACGT"[g & 3];
     } else {
         raw0 = rd_codes_load(lr, src0, 0);                                                         // round trip 3
         if (lr > TC16) raw1 = rd_codes_load(lr, src0, 1);

@@ -50,6 +50,7 @@ class SeqModel:
         self._variant = "auto"
         self._semantics = "packed"
         self._refine = None
+        self._refine_async = False
         self._prefix = os.environ.get("RD_PREFIX_K", "auto")   # prefix-state table: "auto" | 0 (none) | 4..13 (set_prefix_table)
         self._ptab = None
         self._ws = None
@@ -101,6 +102,8 @@ class SeqModel:
         if self._refine is not None:
             self.set_refine(self._refine)
         self.set_prefix_table(self._prefix)
+        if self._refine_async:
+            self.set_refine_async(True)
 
     def to(self, device, non_blocking=False):
         device = torch.device(device)
@@ -146,6 +149,22 @@ class SeqModel:
 
     REFINE_DEFAULT = 2.5e-4
 
+    def set_refine_async(self, on=True):
+        """C ABI rd_set_refine_async: the float64 pass of classify_bytes runs on a stream the model owns and is joined by the next
+        classify_bytes / refine call or by sync_results() - see include/ribodetector_amd.h for the buffer contract. forward()
+        (the reference-compatible call) always returns final logits."""
+        self._refine_async = bool(on)
+        if self._handle is not None:
+            N.check(N.lib().rd_set_refine_async(self._handle, 1 if on else 0), "rd_set_refine_async")
+        return self
+
+    def sync_results(self):
+        """everything issued later on the current stream sees the final results of all earlier classify_bytes calls"""
+        if self._handle is not None:
+            with torch.cuda.device(self.device):
+                N.check(N.lib().rd_sync_results(self._handle, N.stream_ptr(self.device)), "rd_sync_results")
+        return self
+
     def set_prefix_table(self, k="auto"):
         """Prefix-state table of the default kernel (C ABI rd_set_prefix_table): the recurrence state after every
         possible sequence of k bases, (4^k + 1) KiB of HBM, built by the kernel itself in milliseconds; a read then starts k steps
@@ -172,9 +191,10 @@ class SeqModel:
             if k == int(lib.rd_prefix_k(self._handle)) and (k == 0 or self._ptab is not None):
                 return self
             tab = torch.empty(int(lib.rd_prefix_table_bytes(k)), dtype=torch.uint8, device=self.device) if k else None
-            N.check(lib.rd_set_prefix_table(self._handle, k, N.ptr(tab), 0 if tab is None else tab.numel(), N.stream_ptr(self.device)),
-                    "rd_set_prefix_table")
-            self._ptab = tab
+            scr = torch.empty(int(lib.rd_prefix_scratch_bytes(k)), dtype=torch.uint8, device=self.device) if k else None
+            N.check(lib.rd_set_prefix_table(self._handle, k, N.ptr(tab), 0 if tab is None else tab.numel(), N.ptr(scr),
+                                            0 if scr is None else scr.numel(), N.stream_ptr(self.device)), "rd_set_prefix_table")
+            self._ptab = tab                             # (the scratch - the level below, a quarter of the table - is released here)
         return self
 
     @property
@@ -263,6 +283,7 @@ class SeqModel:
         self.set_semantics("padded")
         try:
             logits, _ = self.classify_bytes(arena, offsets, lens, L, want_labels=False)
+            self.sync_results()
         finally:
             self.set_semantics(prev)
         return logits
@@ -304,6 +325,7 @@ class SeqModel:
         lens[sorted_idx] = len_sorted.to(torch.int32)
         offsets = torch.arange(n, dtype=torch.int64, device=dev) * tmax
         logits, _ = self.classify_bytes(arena.reshape(-1), offsets, lens, tmax, want_labels=False)
+        self.sync_results()
         return logits
 
     __call__ = forward

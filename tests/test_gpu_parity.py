@@ -659,6 +659,71 @@ def test_logit_tail_against_the_oracle_at_one_million_reads(gpu_model, oracle, r
     assert (margin[bad] < 2e-4).all()
 
 
+def test_refine_async_equals_inline(gpu_model):
+    """rd_set_refine_async: the float64 pass on the model's own stream, joined by the next call or rd_sync_results. Same bits as
+    the inline pass - with alternating buffer sets (the pass of call i overlaps the recurrence of call i+1), with ONE set reused
+    by every call (the library sees the clash and joins first), through forward() (always final) and inside a hipGraph capture
+    (inline by design). The band is widened to 0.5 so that every batch holds hundreds of candidates."""
+    from ribodetector_amd import synth
+    from torch.nn.utils.rnn import pack_sequence
+    n, L, dev = 8192, 100, "cuda"
+    batches = [synth.reads_torch(n, L, seed=900 + i, device=dev, rrna_frac=0.3) for i in range(6)]
+    offs, lens = batches[0][1][:-1].contiguous(), batches[0][2]
+    try:
+        gpu_model.set_refine(0.5)
+        want = [tuple(t.clone() for t in gpu_model.classify_bytes(b[0], offs, lens, L)) for b in batches]
+        raw = gpu_model.set_refine(0.0).classify_bytes(batches[0][0], offs, lens, L)[0].clone()
+        gpu_model.set_refine(0.5)
+        assert int((raw != want[0][0]).any(dim=1).sum()) > 50                       # the pass really changes rows at this band
+        gpu_model.set_refine_async(True)
+        # (1) two alternating sets of output buffers; results of call i read after call i+1 was issued
+        lg = [torch.empty((n, 2), dtype=torch.float32, device=dev) for _ in range(2)]
+        lb = [torch.empty((n,), dtype=torch.uint8, device=dev) for _ in range(2)]
+        of2, ln2 = [offs.clone(), offs.clone()], [lens.clone(), lens.clone()]      # inputs alternate too (a shared pointer = a clash)
+        got = []
+        for i, b in enumerate(batches):
+            gpu_model.classify_bytes(b[0], of2[i & 1], ln2[i & 1], L, logits=lg[i & 1], labels=lb[i & 1])
+            if i:
+                got.append((lg[(i - 1) & 1].clone(), lb[(i - 1) & 1].clone()))      # joined by the call just issued
+        gpu_model.sync_results()
+        got.append((lg[(len(batches) - 1) & 1].clone(), lb[(len(batches) - 1) & 1].clone()))
+        torch.cuda.synchronize()
+        for i, (w, g) in enumerate(zip(want, got)):
+            assert torch.equal(w[0], g[0]) and torch.equal(w[1], g[1]), i
+        # (2) one set of buffers for every call: the clash is detected, the pending pass is joined before the next launch
+        for i, b in enumerate(batches[:3]):
+            gpu_model.classify_bytes(b[0], offs, lens, L, logits=lg[0], labels=lb[0])
+            gpu_model.sync_results()
+            assert torch.equal(lg[0], want[i][0]) and torch.equal(lb[0], want[i][1]), i
+        for i, b in enumerate(batches[:3]):                                          # ... also without the explicit sync in between
+            gpu_model.classify_bytes(b[0], offs, lens, L, logits=lg[0], labels=lb[0])
+        gpu_model.sync_results()
+        assert torch.equal(lg[0], want[2][0]) and torch.equal(lb[0], want[2][1])
+        # (3) the reference-compatible call returns final logits
+        a = batches[1][0].view(n, L)[:512]
+        code = torch.full((256,), 4, dtype=torch.int64, device=dev)
+        for k, ch in enumerate(b"ACGT"):
+            code[ch] = k
+        oh = torch.nn.functional.one_hot(code[a.long()], 5)[:, :, :4].float()
+        out = gpu_model(pack_sequence([oh[i] for i in range(512)], enforce_sorted=False))
+        assert torch.equal(out, want[1][0][:512])
+        # (4) captured in a graph the pass stays inside the call
+        buf = batches[2][0].clone()
+        gpu_model.classify_bytes(buf, offs, lens, L, logits=lg[1], labels=lb[1])
+        gpu_model.sync_results()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            gpu_model.classify_bytes(buf, offs, lens, L, logits=lg[1], labels=lb[1])
+        buf.copy_(batches[3][0])
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(lg[1], want[3][0]) and torch.equal(lb[1], want[3][1])
+    finally:
+        gpu_model.set_refine_async(False)
+        gpu_model.set_refine(gpu_model.REFINE_DEFAULT)
+
+
 def test_classify_is_capturable_in_a_hip_graph(gpu_model):
     """every launch of rd_classify (memset, steps, bucketing, recurrence, refine) is asynchronous on the caller's stream and nothing
     synchronises, so a caller with small batches (the reference's 16,384-read batch) can capture the call in a hipGraph; the replay

@@ -124,12 +124,15 @@ def test_auto_and_argument_checks(model):
     lib = N.lib()
     assert lib.rd_prefix_table_bytes(3) == 0 and lib.rd_prefix_table_bytes(14) == 0 and lib.rd_prefix_table_bytes(0) == 0
     assert lib.rd_prefix_table_bytes(4) == (4 ** 4 + 1) * 1024 and lib.rd_prefix_table_bytes(13) == (4 ** 13 + 1) * 1024
+    assert lib.rd_prefix_scratch_bytes(4) == 4 ** 3 * 1024 and lib.rd_prefix_scratch_bytes(3) == 0
     buf = torch.empty((4 ** 4 + 1) * 1024 + 256, dtype=torch.uint8, device="cuda:0")
+    scr = torch.empty(4 ** 3 * 1024, dtype=torch.uint8, device="cuda:0")
     st = N.stream_ptr(model.device)
-    assert lib.rd_set_prefix_table(model._handle, 3, N.ptr(buf), buf.numel(), st) != 0 and b"out of range" in lib.rd_last_error()
-    assert lib.rd_set_prefix_table(model._handle, 4, N.ptr(buf), 1024, st) != 0 and b"too small" in lib.rd_last_error()
-    assert lib.rd_set_prefix_table(model._handle, 4, C.c_void_p(buf.data_ptr() + 8), buf.numel() - 8, st) != 0 and b"aligned" in lib.rd_last_error()
-    assert lib.rd_set_prefix_table(model._handle, 4, None, 0, st) != 0
+    assert lib.rd_set_prefix_table(model._handle, 3, N.ptr(buf), buf.numel(), N.ptr(scr), scr.numel(), st) != 0 and b"out of range" in lib.rd_last_error()
+    assert lib.rd_set_prefix_table(model._handle, 4, N.ptr(buf), 1024, N.ptr(scr), scr.numel(), st) != 0 and b"table too small" in lib.rd_last_error()
+    assert lib.rd_set_prefix_table(model._handle, 4, N.ptr(buf), buf.numel(), N.ptr(scr), 1024, st) != 0 and b"scratch too small" in lib.rd_last_error()
+    assert lib.rd_set_prefix_table(model._handle, 4, C.c_void_p(buf.data_ptr() + 8), buf.numel() - 8, N.ptr(scr), scr.numel(), st) != 0 and b"aligned" in lib.rd_last_error()
+    assert lib.rd_set_prefix_table(model._handle, 4, None, 0, None, 0, st) != 0
     assert model.prefix_k == 0                                           # a refused call leaves the model as it was
     with pytest.raises(RuntimeError):
         model.set_prefix_table(3)

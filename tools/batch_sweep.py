@@ -42,6 +42,34 @@ def main():
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t) / reps
         out[n] = {"us_per_call": dt * 1e6, "reads_per_s": n / dt, "read_steps_per_s": n * L / dt}
+        # the float64 pass: inline (above), switched off, and deferred (rd_set_refine_async: on the model's own stream, joined by the
+        # next call behind its recurrence launch; two alternating sets of buffers, as the contract of the mode asks)
+        a2, _, _ = synth.reads_torch(n, L, seed=4, device=torch.device("cuda", 0))
+        sets = [(arena, offs, lens, logits, labels),
+                (a2, offs.clone(), lens.clone(), torch.empty_like(logits), torch.empty_like(labels))]
+
+        def timed_calls(k=reps):
+            for i in range(3):
+                s = sets[i & 1]
+                model.classify_bytes(s[0], s[1], s[2], L, logits=s[3], labels=s[4])
+            model.sync_results()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(k):
+                s = sets[i & 1]
+                model.classify_bytes(s[0], s[1], s[2], L, logits=s[3], labels=s[4])
+            model.sync_results()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / k
+        d_inline = timed_calls()
+        model.set_refine(0.0)
+        d_off = timed_calls()
+        model.set_refine(M.SeqModel.REFINE_DEFAULT)
+        model.set_refine_async(True)
+        d_async = timed_calls()
+        model.set_refine_async(False)
+        out[n].update({"two_sets_us_inline": d_inline * 1e6, "two_sets_us_refine_off": d_off * 1e6, "two_sets_us_async": d_async * 1e6,
+                       "async_over_off": d_async / d_off, "inline_over_off": d_inline / d_off})
         # the same call captured in a hipGraph (every launch of rd_classify is asynchronous on the caller's stream, so it can be
         # captured as is): what the seven launches per call cost at small batches
         for refine in (True, False):

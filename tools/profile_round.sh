@@ -10,7 +10,7 @@ O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/p_$TAG
-BF="--steps 3 --warmup 1 --no-cpu-baseline --no-alt --no-encoder --traffic off"
+BF="--steps 3 --warmup 1 --no-cpu-baseline --no-alt --no-encoder --no-e2e --traffic off"
 stats() {   # stats <name> <command...>: kernel trace + stats of a command
   local name=$1; shift
   (rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_$TAG/$name -o x -- "$@") > $O/$name.log 2>&1
@@ -27,7 +27,7 @@ pmc() {     # pmc <name> <counters...> -- <command...>
 # 1. the metric's workload (pe100, default kernel) and the other BASELINE configs / the exact-fp32 kernel
 stats pe100 python $R/bench.py $BF
 for wl in se100 pe150 var300; do stats $wl python $R/bench.py $BF --workload $wl; done
-stats pe100_mfma_f32 python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alt --no-encoder --traffic off --variant mfma_f32
+stats pe100_mfma_f32 python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alt --no-encoder --no-e2e --traffic off --variant mfma_f32
 # 2. HBM traffic and SQ counters of the recurrence kernel (resident inputs, everything on one stream: no kernel runs beside the one counted)
 for c in FETCH_SIZE WRITE_SIZE; do pmc pmc_$c $c -- python $R/bench.py $BF --resident-only --inline-refine; done
 pmc pmc_sq GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU -- python $R/bench.py $BF --resident-only --inline-refine
