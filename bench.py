@@ -146,7 +146,7 @@ def pmc_traffic(args, kernel_substr, timeout_s=240):
         for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
             with open(path) as fh:
                 for row in csv.DictReader(fh):
-                    if kernel_substr in row["Kernel_Name"] and row["Counter_Name"] == ctr:
+                    if kernel_substr in row["Kernel_Name"] and "kernel<true>" not in row["Kernel_Name"] and row["Counter_Name"] == ctr:   # <true> = the table build
                         vals.append(float(row["Counter_Value"]))
         shutil.rmtree(d, ignore_errors=True)
         if not vals:
@@ -182,10 +182,13 @@ def e2e_record(torch, synth, arenas, offsets, lens, L, ensure):
             t0 = time.perf_counter()
             pr = detect.main(argv)
             dt = time.perf_counter() - t0
-            rec[call] = {"seconds": dt, "reads_per_s": len(ins) * n / dt, "main_thread_s": {k: round(v, 4) for k, v in pr._stage_s.items()}}
+            rec[call] = {"seconds": dt, "reads_per_s": len(ins) * n / dt, "main_thread_s": {k: round(v, 4) for k, v in pr._stage_s.items()},
+                         "load_model_s": round(pr.timing["load_model_s"], 4), "detect_s": round(pr.timing["detect_s"], 4),
+                         "prefix_k": pr.timing["prefix_k"], "reads_per_s_after_model_load": len(ins) * n / pr.timing["detect_s"]}
             del pr
         out_bytes = sum(os.path.getsize(p) for p in outs + rrs)
         return {"reads_per_s": rec["second_call"]["reads_per_s"], "seconds": rec["second_call"]["seconds"], "files": len(ins),
+                "reads_per_s_after_model_load": rec["second_call"]["reads_per_s_after_model_load"],
                 "records_per_file": n, "input_bytes": sum(os.path.getsize(p) for p in ins), "output_bytes": out_bytes,
                 "what": "whole detect.main() call on FASTQ in tmpfs, plain -> plain, default -t 10: model load + prefix table build + "
                         "parse + H2D + kernels + D2H + write; second of two calls", "calls": rec}

@@ -333,6 +333,92 @@ def get_seq_chunks(seq_file, chunk_size=1048576, byte_range=None):
         r.close()
 
 
+def plan_segments(seq_file, chunk_size, byte_range=None, first_chunk=1 << 18):
+    """Record-aligned byte segments of a plain file holding about `chunk_size` records each (the first ones fewer: `first_chunk`,
+    doubling, so that the first kernels start while the rest of the file is still being parsed). The record size is estimated
+    from the head of the range; the cuts are found with rd_host_find_record_start (the same resynchronisation the multi-rank byte
+    ranges use). Segments concatenate to the range, so their records concatenate to the range's records."""
+    size = file_info(seq_file)[0]
+    b0, b1 = (0, size) if byte_range is None else (int(byte_range[0]), int(byte_range[1]))
+    if b1 <= b0:
+        return []
+    head = find_record_start(seq_file, min(b1, b0 + (1 << 18)))
+    head = min(max(head, b0), b1)
+    nrec = count_records(seq_file, b0, head) if head > b0 else 0
+    est = (head - b0) / nrec if nrec else float(b1 - b0)
+    segs, pos, want = [], b0, max(1, min(first_chunk, chunk_size))
+    while pos < b1:
+        target = pos + max(1, int(want * est))
+        nxt = b1 if target >= b1 else min(max(find_record_start(seq_file, target), pos), b1)
+        if nxt <= pos:                               # a record longer than the step: take everything up to the next boundary
+            nxt = min(find_record_start(seq_file, pos + 1), b1)
+            if nxt <= pos:
+                nxt = b1
+        segs.append((pos, nxt))
+        pos = nxt
+        want = min(chunk_size, want * 2)
+    return segs
+
+
+def get_seq_chunks_parallel(seq_file, chunk_size=1048576, byte_range=None, workers=2, first_chunk=1 << 18):
+    """The chunks of a PLAIN file parsed by `workers` reader threads over consecutive byte segments (plan_segments), delivered in
+    file order. One librd_host.so reader delivers ~34 M reads/s of 100 bp FASTQ - the GPU path takes as much - so a single-end run
+    was bound by its one parser thread; chunks hold about chunk_size records instead of exactly that many
+    (the reference's --chunk_size bounds memory, it is not a framing promise: seq_encoder.py:75-87)."""
+    import threading
+    segs = plan_segments(seq_file, chunk_size, byte_range, first_chunk)
+    if len(segs) <= 1 or workers <= 1:
+        yield from get_seq_chunks(seq_file, chunk_size, byte_range)
+        return
+    results = [None] * len(segs)                      # per segment: list of chunks | exception
+    done = [threading.Event() for _ in segs]
+    ahead = threading.Semaphore(workers + 1)          # segments parsed but not yet consumed: bounds the pinned memory in flight
+    nxt = [0]
+    lock = threading.Lock()
+    stop = threading.Event()
+
+    def work():
+        while not stop.is_set():
+            ahead.acquire()
+            with lock:
+                i = nxt[0]
+                nxt[0] += 1
+            if i >= len(segs) or stop.is_set():
+                ahead.release()
+                return
+            try:
+                r = NativeReader(seq_file, byte_range=segs[i])
+                out = []
+                try:
+                    est_n = int((segs[i][1] - segs[i][0]) / max(r.est, 1)) + 1024
+                    while True:
+                        c = r.read(max(est_n, 1024))
+                        if c is None:
+                            break
+                        out.append(c)
+                finally:
+                    r.close()
+                results[i] = out
+            except BaseException as e:               # noqa: BLE001 - surfaced by the consumer
+                results[i] = e
+            done[i].set()
+    th = [threading.Thread(target=work, daemon=True) for _ in range(workers)]
+    [t.start() for t in th]
+    try:
+        for i in range(len(segs)):
+            done[i].wait()
+            res, results[i] = results[i], None
+            if isinstance(res, BaseException):
+                raise res
+            for c in res:
+                yield c
+            ahead.release()
+    finally:
+        stop.set()
+        for _ in th:
+            ahead.release()
+
+
 def get_pairedread_chunks(r1_seq_file, r2_seq_file, chunk_size=1048576):
     """zip of the two mates' chunk streams (reference seq_encoder.py:90-92)."""
     for c1, c2 in zip(get_seq_chunks(r1_seq_file, chunk_size), get_seq_chunks(r2_seq_file, chunk_size)):

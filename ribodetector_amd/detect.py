@@ -99,6 +99,23 @@ class Predictor:
             raise RuntimeError("config.json kernel.prefix_k must be \"auto\", 0 or an integer in [4, 13]; got %r" % (pk,))
         return {"variant": variant, "semantics": sem, "refine": refine, "prefix_k": pk}
 
+    def prefix_k_for_input(self):
+        """k of the prefix-state table that pays off for THIS run: a row saves k steps per read, level k costs 4^k one-step
+        workgroup slots to build (measured on MI355X, tools/time_setup.py: k = 8 / 10 / 11 / 12 take 0.4 / 1.7 / 6.3 / 22 ms with
+        their allocation; one read-step is worth 0.3 ns), so k+1 beats k from about 3 * 4^k reads on. The read count is estimated
+        from the input sizes (gzip: x4.5) and -l; under torchrun every rank sees its share."""
+        from .data_loader import fastx_parser as fx
+        n = 0.0
+        for path in self.args.input or []:
+            try:
+                size, gz = fx.file_info(path)
+                fa = fx.get_seq_format(path).startswith("fa")
+            except Exception:      # the run itself reports unreadable inputs
+                continue
+            n += size * (4.5 if gz else 1.0) / ((1 if fa else 2) * max(self.args.len, 30) + 30)
+        n /= max(1, int(os.environ.get("WORLD_SIZE", "1")))
+        return 8 if n < 2e6 else 10 if n < 14e6 else 11 if n < 49e6 else 12
+
     def load_model(self):
         """Load the model onto the GPU (reference detect.py:84-119). Raises RuntimeError without a visible device."""
         kcfg = self.kernel_config()
@@ -124,6 +141,8 @@ class Predictor:
             self.device, colors.BOLD, colors.OKCYAN, self.len, colors.ENDC))
         if kcfg["prefix_k"] is not None:
             model.set_prefix_table(kcfg["prefix_k"])     # recorded now, built by .to()
+        elif "RD_PREFIX_K" not in os.environ:
+            model.set_prefix_table("auto", cap=self.prefix_k_for_input())
         self.model = model.to(self.device)
         self.model.set_variant(kcfg["variant"])
         self.model.set_semantics(kcfg["semantics"])
@@ -213,7 +232,13 @@ class Predictor:
 
         def work():
             try:
-                for c in fx.get_seq_chunks(path, chunk_size=chunk_reads, byte_range=byte_range):
+                # one plain input file: its parser thread was the slowest stage of the pipeline - two readers over byte segments,
+                # small first chunks (mate files keep one reader each and exact chunk sizes: their chunks must pair up)
+                if len(self.input) == 1 and not fx.file_info(path)[1] and int(self.args.threads) >= 4:
+                    stream = fx.get_seq_chunks_parallel(path, chunk_size=chunk_reads, byte_range=byte_range, workers=2)
+                else:
+                    stream = fx.get_seq_chunks(path, chunk_size=chunk_reads, byte_range=byte_range)
+                for c in stream:
                     q.put(c)
                 q.put(None)
             except BaseException as e:      # surface parser errors on the main thread
@@ -479,8 +504,11 @@ def main(argv=None):
     config = ConfigParser.from_json(config_file)
     seq_pred = Predictor(config, args)
     try:
+        t0 = time.perf_counter()
         seq_pred.load_model()
+        t1 = time.perf_counter()
         seq_pred.detect()
+        seq_pred.timing = {"load_model_s": t1 - t0, "detect_s": time.perf_counter() - t1, "prefix_k": seq_pred.model.prefix_k}
     except BaseException:
         for f in seq_pred._part_files:           # a failed sharded run leaves no '<out>.partN' / '<out>.joining' files behind
             try:

@@ -52,6 +52,7 @@ class SeqModel:
         self._refine = None
         self._refine_async = False
         self._prefix = os.environ.get("RD_PREFIX_K", "auto")   # prefix-state table: "auto" | 0 (none) | 4..13 (set_prefix_table)
+        self._prefix_cap = None
         self._ptab = None
         self._ws = None
         self.training = True
@@ -165,14 +166,17 @@ class SeqModel:
                 N.check(N.lib().rd_sync_results(self._handle, N.stream_ptr(self.device)), "rd_sync_results")
         return self
 
-    def set_prefix_table(self, k="auto"):
+    def set_prefix_table(self, k="auto", cap=None):
         """Prefix-state table of the default kernel (C ABI rd_set_prefix_table): the recurrence state after every
         possible sequence of k bases, (4^k + 1) KiB of HBM, built by the kernel itself in milliseconds; a read then starts k steps
         in, with bit-identical logits. k = 0: none; 4..13: exactly that; "auto" (default; environment RD_PREFIX_K overrides): 12
-        (16 GiB) when that is at most a quarter of the free device memory, else the largest k that is, else none."""
+        (16 GiB) when that is at most a quarter of the free device memory, else the largest k that is, else none. `cap` bounds
+        what "auto" picks (the CLI passes the k that pays off for the size of its input: building level k costs 4^k steps)."""
         if isinstance(k, str) and k != "auto":
             k = int(k)
         self._prefix = k
+        if cap is not None or k != "auto":
+            self._prefix_cap = cap
         if self._handle is None:
             return self
         lib = N.lib()
@@ -180,7 +184,7 @@ class SeqModel:
             if k == "auto":
                 free, _ = torch.cuda.mem_get_info(self.device)
                 free += torch.cuda.memory_reserved(self.device) - torch.cuda.memory_allocated(self.device)   # cached blocks are reusable
-                k = N.PREFIX_K_AUTO
+                k = N.PREFIX_K_AUTO if self._prefix_cap is None else max(0, min(N.PREFIX_K_AUTO, int(self._prefix_cap)))
                 while k >= N.PREFIX_K_MIN and int(lib.rd_prefix_table_bytes(k)) > free // 4:
                     k -= 1
                 if k < N.PREFIX_K_MIN:

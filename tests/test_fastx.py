@@ -447,3 +447,53 @@ def test_count_records_counts_an_empty_last_fastq_record(tmp_path):
     for world in (2, 3):
         plans = _plan_all([p1, p2], world)                                       # round 2: 'paired-end files have different numbers of records'
         assert [len(_range_records(p1, byte_range=pl[0])) for pl in plans] == [len(_range_records(p2, byte_range=pl[1])) for pl in plans]
+
+
+@pytest.mark.parametrize("workers", [2, 3])
+def test_parallel_segment_reader_equals_sequential(tmp_path, workers):
+    """get_seq_chunks_parallel (several reader threads over record-aligned byte segments of a plain file, small first chunks)
+    delivers the records of the sequential reader, in order: FASTQ with qualities full of '@' and '+', CRLF, multi-line FASTA
+    with empty-sequence records, files smaller than one segment, an empty file, and inside a byte range of the multi-rank CLI."""
+    rng = np.random.default_rng(workers)
+    fq = str(tmp_path / "p.fastq")
+    with open(fq, "w", newline="") as fh:
+        for i in range(6000):
+            L = int(rng.integers(1, 200))
+            s = "".join("ACGTN"[k] for k in rng.integers(0, 5, L))
+            q = "".join("@+I#F"[k] for k in rng.integers(0, 5, L))
+            fh.write("@r%d %s\r\n%s\r\n+\r\n%s\r\n" % (i, "x" * int(rng.integers(0, 60)), s, q))
+    fa = str(tmp_path / "p.fa")
+    with open(fa, "w") as fh:
+        for i in range(3000):
+            s = "".join("ACGT"[k] for k in rng.integers(0, 4, int(rng.integers(0, 300))))
+            fh.write(">s%d\n" % i + "\n".join(s[k:k + 50] for k in range(0, len(s), 50)) + "\n")
+        fh.write(">tail\nACGT\n")
+    tiny = str(tmp_path / "t.fq")
+    open(tiny, "w").write("@a\nAC\n+\nII\n")
+    empty = str(tmp_path / "e.fq")
+    open(empty, "w").close()
+
+    def recs(gen):
+        out = []
+        for c in gen:
+            b = c.buf.tobytes()
+            out += [b[c.rec_start[i]:c.rec_start[i + 1]] for i in range(len(c.seq_len))]
+        return out
+    for path in (fq, fa, tiny, empty):
+        want = recs(fx.get_seq_chunks(path, chunk_size=700))
+        for chunk, first in ((700, 64), (5000, 1 << 18), (97, 1)):
+            segs = fx.plan_segments(path, chunk, first_chunk=first)
+            assert all(a[1] == b[0] for a, b in zip(segs[:-1], segs[1:])) and (not segs or (segs[0][0] == 0 and segs[-1][1] == os.path.getsize(path)))
+            got = recs(fx.get_seq_chunks_parallel(path, chunk_size=chunk, workers=workers, first_chunk=first))
+            assert got == want, (path, chunk, first, len(got), len(want))
+    # inside a rank's byte range
+    for world in (2, 3):
+        for r in range(world):
+            br = fx.plan_ranges([fq], r, world)[0]
+            assert recs(fx.get_seq_chunks_parallel(fq, chunk_size=500, byte_range=br, workers=workers, first_chunk=32)) == \
+                recs(fx.get_seq_chunks(fq, chunk_size=500, byte_range=br))
+    # a parser error inside a worker reaches the consumer
+    bad = str(tmp_path / "bad.fq")
+    open(bad, "w").write("@a\nAC\n+\nII\n" * 4000 + "@b\nAC\n+\n")          # truncated last record
+    with pytest.raises(ValueError, match="truncated"):
+        recs(fx.get_seq_chunks_parallel(bad, chunk_size=300, workers=workers, first_chunk=16))

@@ -34,7 +34,7 @@ def main():
         p = detect.main(["-l", "100", "-i", *inputs, "-o", *outputs, *extra])      # default chunking: 1 Mi reads per chunk
         dt = time.perf_counter() - t
         out[tag] = {"reads_per_s": len(inputs) * a.reads / dt, "seconds": dt, "rrna": p.num_rrna, "non_rrna": p.num_nonrrna,
-                    "main_thread_s": {k: round(v, 3) for k, v in p._stage_s.items()}}
+                    "main_thread_s": {k: round(v, 3) for k, v in p._stage_s.items()}, "timing": {k: round(v, 4) for k, v in p.timing.items()}}
 
     o = lambda n: os.path.join(d, n)     # noqa: E731
     run("first_call_se_plain", [files[1]], [o("w.fq")])        # includes HIP start-up, model load, first pinned allocations
