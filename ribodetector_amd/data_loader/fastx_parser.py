@@ -319,13 +319,17 @@ def plan_ranges(paths, rank, world, all_gather=None):
     return [(starts[rank][f], starts[rank + 1][f] if rank + 1 < world else sizes[f]) for f in range(len(paths))]
 
 
-def get_seq_chunks(seq_file, chunk_size=1048576, byte_range=None):
+def get_seq_chunks(seq_file, chunk_size=1048576, byte_range=None, first_chunk=None):
     """Chunks of at most `chunk_size` records (reference seq_encoder.py:75-87), as `Chunk` arrays, parsed by librd_host.so.
-    byte_range: parse only that part of a plain file (multi-rank CLI, plan_ranges)."""
+    byte_range: parse only that part of a plain file (multi-rank CLI, plan_ranges). first_chunk: the first chunk holds that many
+    records, the following ones twice as many each up to chunk_size (the kernels start earlier; mate files given the same
+    schedule still pair up chunk by chunk)."""
     r = NativeReader(seq_file, byte_range=byte_range)
+    want = chunk_size if not first_chunk else max(1, min(int(first_chunk), chunk_size))
     try:
         while True:
-            c = r.read(chunk_size)
+            c = r.read(want)
+            want = min(chunk_size, want * 2)
             if c is None:
                 return
             yield c
@@ -357,6 +361,16 @@ def plan_segments(seq_file, chunk_size, byte_range=None, first_chunk=1 << 18):
         segs.append((pos, nxt))
         pos = nxt
         want = min(chunk_size, want * 2)
+    # ... and small last chunks: what runs after the last byte was parsed (the last chunk's kernels and its write) is not hidden
+    # behind anything, so the last segment is halved until it is down to the size of the first
+    small = max(1, int(min(first_chunk, chunk_size) * est))
+    while len(segs) > 1 and segs[-1][1] - segs[-1][0] > 2 * small:
+        a, b = segs.pop()
+        mid = min(max(find_record_start(seq_file, (a + b) // 2), a), b)
+        if mid <= a or mid >= b:
+            segs.append((a, b))
+            break
+        segs += [(a, mid), (mid, b)]
     return segs
 
 

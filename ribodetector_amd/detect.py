@@ -237,7 +237,7 @@ class Predictor:
                 if len(self.input) == 1 and not fx.file_info(path)[1] and int(self.args.threads) >= 4:
                     stream = fx.get_seq_chunks_parallel(path, chunk_size=chunk_reads, byte_range=byte_range, workers=2)
                 else:
-                    stream = fx.get_seq_chunks(path, chunk_size=chunk_reads, byte_range=byte_range)
+                    stream = fx.get_seq_chunks(path, chunk_size=chunk_reads, byte_range=byte_range, first_chunk=1 << 17)
                 for c in stream:
                     q.put(c)
                 q.put(None)
