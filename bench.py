@@ -353,7 +353,7 @@ def main():
                 module_arch.count_labels(lab8, counts)
                 lab = lab8.view(torch.int8)
             fin = after(lab) if after else None
-            ev_post[k] = torch.cuda.Event()
+            ev_post[k] = torch.cuda.Event(blocking=True)   # the host SLEEPS in .synchronize() (8 ranks share 16 host cores)
             ev_post[k].record(post)
         return ev_post[k], fin
 

@@ -78,7 +78,8 @@ def seq_parser(seq_fh, seq_type):
 # A chunk of records as arrays.  buf: uint8 arena holding the record text; rec_start int64[n+1]: byte range of record i
 # (verbatim text incl. its final newline, valid when `verbatim`); seq_off int64[n] / seq_len int32[n]: the bases.
 # tensors: (buf, seq_off, seq_len) as (pinned) torch tensors when the chunk came from the native reader, else None.
-Chunk = namedtuple("Chunk", "buf rec_start seq_off seq_len verbatim records tensors", defaults=(None,))
+# release: called by the last consumer of a chunk whose buffers are a slot of a ShmArena; shm: where such a chunk lives.
+Chunk = namedtuple("Chunk", "buf rec_start seq_off seq_len verbatim records tensors release shm", defaults=(None, None, None))
 
 _WS = np.zeros(256, dtype=bool)
 _WS[[9, 10, 11, 12, 13, 32]] = True
@@ -188,12 +189,83 @@ def get_seq_chunks_numpy(seq_file, chunk_size=1048576):
             yield from _fasta_chunks(fh, chunk_size)
 
 
+def _shm_layout(cap_n, cap_b):
+    """byte offsets of (rec_start int64[cap_n+1], seq_off int64[cap_n], seq_len int32[cap_n], buf uint8[cap_b]) in a slot file"""
+    al = lambda x: (x + 4095) // 4096 * 4096    # noqa: E731
+    o_rs = 0
+    o_so = al(o_rs + 8 * (cap_n + 1))
+    o_sl = al(o_so + 8 * cap_n)
+    o_buf = al(o_sl + 4 * cap_n)
+    return o_rs, o_so, o_sl, o_buf, o_buf + cap_b
+
+
+def _shm_views(path, cap_n, cap_b, create):
+    import torch
+    o_rs, o_so, o_sl, o_buf, total = _shm_layout(cap_n, cap_b)
+    mm = np.memmap(path, dtype=np.uint8, mode="w+" if create else "r+", shape=(total,))
+    t = lambda a: torch.from_numpy(a)           # noqa: E731
+    return (t(mm[o_buf:o_buf + cap_b]), t(mm[o_rs:o_rs + 8 * (cap_n + 1)].view(np.int64)), t(mm[o_so:o_so + 8 * cap_n].view(np.int64)),
+            t(mm[o_sl:o_sl + 4 * cap_n].view(np.int32)))
+
+
+class ShmArena:
+    """Chunk buffers in /dev/shm, for the multi-rank CLI on gzip input (one DEFLATE stream: not splittable): the node's rank 0
+    inflates and parses the stream ONCE, straight into a slot of this arena; the other ranks map the slot and take the bases of
+    their share of the records (round 2: every rank inflated and parsed the whole stream, W times the work on the same cores).
+    A slot is one file (offset arrays + record text) and is reused once its chunk has been written out, so the pages are faulted
+    in once. describe()/attach() are the two ends of the per-chunk message."""
+
+    def __init__(self, tag):
+        import os
+        import threading
+        self.dir = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
+        self.tag, self.slots, self.lock = tag, [], threading.Lock()
+
+    def alloc(self, nbytes, nrec):
+        import os
+        with self.lock:
+            for sl in self.slots:
+                if not sl["busy"] and sl["cap_b"] >= nbytes and sl["cap_n"] >= nrec:
+                    sl["busy"] = True
+                    return sl["views"], sl
+            cap_n, cap_b = int(nrec * 1.05) + 16, int(nbytes * 1.15) + 4096
+            path = os.path.join(self.dir, "%s.%d" % (self.tag, len(self.slots)))
+            sl = {"path": path, "cap_n": cap_n, "cap_b": cap_b, "busy": True, "views": _shm_views(path, cap_n, cap_b, True)}
+            self.slots.append(sl)
+            return sl["views"], sl
+
+    def free(self, sl):
+        with self.lock:
+            sl["busy"] = False
+
+    def close(self):
+        import os
+        for sl in self.slots:
+            try:
+                os.remove(sl["path"])
+            except OSError:
+                pass
+        self.slots = []
+
+    _attached = {}
+
+    @classmethod
+    def attach(cls, shm):
+        """the Chunk another rank described (Chunk.shm), mapped read-write-shared; mappings are cached per slot file"""
+        path, cap_n, cap_b, n, nb = shm
+        key = (path, cap_n, cap_b)
+        if key not in cls._attached:
+            cls._attached[key] = _shm_views(path, cap_n, cap_b, False)
+        buf, rs, so, sl = cls._attached[key]
+        return Chunk(buf[:nb].numpy(), rs[:n + 1].numpy(), so[:n].numpy(), sl[:n].numpy(), True, None, (buf[:nb], so[:n], sl[:n]))
+
+
 class NativeReader:
     """librd_host.so reader: records are parsed in C++ straight into (pinned) buffers that go to the GPU as they are."""
 
     h = None
 
-    def __init__(self, path, est_record_bytes=320, byte_range=None):
+    def __init__(self, path, est_record_bytes=320, byte_range=None, arena=None):
         """byte_range = (start, end): parse only those bytes of a plain file; both must be record boundaries (plan_ranges)."""
         import torch
         self._torch = torch
@@ -208,6 +280,7 @@ class NativeReader:
                          "rd_reader_open_range")
         self.est = est_record_bytes
         self.eof = False
+        self.arena = arena                          # ShmArena: chunk buffers in shared memory instead of pinned memory
 
     def close(self):
         if self.h:
@@ -218,6 +291,9 @@ class NativeReader:
         self.close()
 
     def _alloc(self, nbytes, nrec):
+        if self.arena is not None:
+            views, self._slot = self.arena.alloc(nbytes, nrec)
+            return views
         t = self._torch
         kw = dict(pin_memory=True) if self._pin else {}
         return (t.empty(nbytes, dtype=t.uint8, **kw), t.empty(nrec + 1, dtype=t.int64, **kw), t.empty(nrec, dtype=t.int64, **kw),
@@ -248,16 +324,26 @@ class NativeReader:
                 self.eof = True
                 break
             if n_tot < want:                            # buffer full before `want` records: grow and continue
+                old_slot = getattr(self, "_slot", None)
                 grown = self._alloc(max(2 * buf.numel(), b_tot + (want - n_tot) * self.est + (1 << 16), b_tot + hint + (1 << 16)), want)
                 grown[0][:b_tot] = buf[:b_tot]
                 grown[1][:n_tot + 1] = rs[:n_tot + 1]
                 grown[2][:n_tot] = so[:n_tot]
                 grown[3][:n_tot] = sl[:n_tot]
                 buf, rs, so, sl = grown
+                if self.arena is not None:
+                    self.arena.free(old_slot)
         if n_tot == 0:
+            if self.arena is not None:
+                self.arena.free(self._slot)
             return None
+        release = shm = None
+        if self.arena is not None:
+            slot, arena = self._slot, self.arena
+            release = lambda: arena.free(slot)      # noqa: E731
+            shm = (slot["path"], slot["cap_n"], slot["cap_b"], n_tot, b_tot)
         return Chunk(buf[:b_tot].numpy(), rs[:n_tot + 1].numpy(), so[:n_tot].numpy(), sl[:n_tot].numpy(), True, None,
-                     (buf[:b_tot], so[:n_tot], sl[:n_tot]))
+                     (buf[:b_tot], so[:n_tot], sl[:n_tot]), release, shm)
 
 
 def _fmt_id(path):
@@ -319,12 +405,12 @@ def plan_ranges(paths, rank, world, all_gather=None):
     return [(starts[rank][f], starts[rank + 1][f] if rank + 1 < world else sizes[f]) for f in range(len(paths))]
 
 
-def get_seq_chunks(seq_file, chunk_size=1048576, byte_range=None, first_chunk=None):
+def get_seq_chunks(seq_file, chunk_size=1048576, byte_range=None, first_chunk=None, arena=None):
     """Chunks of at most `chunk_size` records (reference seq_encoder.py:75-87), as `Chunk` arrays, parsed by librd_host.so.
     byte_range: parse only that part of a plain file (multi-rank CLI, plan_ranges). first_chunk: the first chunk holds that many
     records, the following ones twice as many each up to chunk_size (the kernels start earlier; mate files given the same
     schedule still pair up chunk by chunk)."""
-    r = NativeReader(seq_file, byte_range=byte_range)
+    r = NativeReader(seq_file, byte_range=byte_range, arena=arena)
     want = chunk_size if not first_chunk else max(1, min(int(first_chunk), chunk_size))
     try:
         while True:

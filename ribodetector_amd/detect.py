@@ -67,6 +67,7 @@ class Predictor:
         self.chunk_size = self.args.chunk_size
         self.rank, self.world, self.local_rank = 0, 1, 0
         self.multi = False                       # collectives in use: several ranks (or one rank under RD_FORCE_DIST=1, dist.py)
+        self._arenas = []                        # shared-memory chunk arenas of this rank (rank 0, gzip input, several ranks)
         self._part_files = []                    # this rank's part files of a sharded-parse run (removed if the run fails)
         self.sharded_parse = False               # several ranks, plain input: every rank parses its own byte range
 
@@ -227,17 +228,17 @@ class Predictor:
         th.start()
         return th
 
-    def _reader_queue(self, path, chunk_reads, depth=2, byte_range=None):
+    def _reader_queue(self, path, chunk_reads, depth=2, byte_range=None, arena=None):
         q = queue.Queue(maxsize=depth)
 
         def work():
             try:
                 # one plain input file: its parser thread was the slowest stage of the pipeline - two readers over byte segments,
                 # small first chunks (mate files keep one reader each and exact chunk sizes: their chunks must pair up)
-                if len(self.input) == 1 and not fx.file_info(path)[1] and int(self.args.threads) >= 4:
+                if arena is None and len(self.input) == 1 and not fx.file_info(path)[1] and int(self.args.threads) >= 4:
                     stream = fx.get_seq_chunks_parallel(path, chunk_size=chunk_reads, byte_range=byte_range, workers=2)
                 else:
-                    stream = fx.get_seq_chunks(path, chunk_size=chunk_reads, byte_range=byte_range, first_chunk=1 << 17)
+                    stream = fx.get_seq_chunks(path, chunk_size=chunk_reads, byte_range=byte_range, first_chunk=1 << 17, arena=arena)
                 for c in stream:
                     q.put(c)
                 q.put(None)
@@ -246,27 +247,58 @@ class Predictor:
         self._spawn(work)
         return q
 
+    def _shared_decode(self):
+        """several ranks of ONE node on gzip input: rank 0 inflates and parses the stream once into shared memory (fx.ShmArena)
+        and tells the others where each chunk lies; they map it and take their share of the records. (Ranks spread over several
+        nodes cannot share memory: there every rank decodes the stream itself, as in round 2.)"""
+        return (self.multi and not self.sharded_parse and self.world > 1 and
+                int(os.environ.get("LOCAL_WORLD_SIZE", str(self.world))) == self.world and os.environ.get("RD_SHARED_DECODE", "1") != "0")
+
     def _chunk_stream(self, chunk_reads):
+        import torch.distributed as dist
+        from . import _native
+        shared = self._shared_decode()
+        if shared and self.rank != 0:                # chunks arrive as descriptions of rank 0's shared-memory slots
+            while True:
+                msg = [None]
+                t0 = time.perf_counter()
+                dist.broadcast_object_list(msg, src=0)
+                self._stage_s["wait_reader"] += time.perf_counter() - t0
+                if msg[0] is None:
+                    return
+                if isinstance(msg[0], str):
+                    raise RuntimeError("rank 0: " + msg[0])
+                yield tuple(fx.ShmArena.attach(d) for d in msg[0])
         ranges = self._ranges if self.sharded_parse else [None] * len(self.input)
         # -t/--threads also bounds the decoder threads of .gz inputs (parallel DEFLATE decoding, csrc/rd_pgzip.h): what is left after
-        # the parser threads and this one, divided among the input files
-        from . import _native
-        # (under torchrun every rank decodes the stream itself, on the same host: the budget is shared among the ranks too)
-        _native.host_lib().rd_host_set_gz_threads(max(2, min(12, (int(self.args.threads) - 2) // max(1, len(self.input) * self.world))))
-        qs = [self._reader_queue(p, chunk_reads, byte_range=r) for p, r in zip(self.input, ranges)]
+        # the parser threads and this one, divided among the input files - and among the ranks when every rank decodes for itself
+        sharers = len(self.input) * (1 if shared else self.world)
+        _native.host_lib().rd_host_set_gz_threads(max(2, min(12, (int(self.args.threads) - 2) // max(1, sharers))))
+        arenas = [None] * len(self.input)
+        if shared:
+            tag = "rd_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getpid())
+            arenas = [fx.ShmArena("%s_f%d" % (tag, i)) for i in range(len(self.input))]
+            self._arenas += arenas
+        qs = [self._reader_queue(p, chunk_reads, byte_range=r, arena=a) for p, r, a in zip(self.input, ranges, arenas)]
         while True:
             cs = []
+            err = None
             for q in qs:
                 t0 = time.perf_counter()
                 c = q.get()
                 self._stage_s["wait_reader"] += time.perf_counter() - t0
                 if isinstance(c, BaseException):
-                    raise c
+                    err = c
+                    break
                 cs.append(c)
+            if err is None and not all(c is None for c in cs) and (any(c is None for c in cs) or len({len(c.seq_len) for c in cs}) != 1):
+                err = ValueError("paired-end files have different numbers of records")
+            if shared:                                # (an error is passed on, so that no rank waits for a chunk that never comes)
+                dist.broadcast_object_list([str(err) if err is not None else None if cs[0] is None else [c.shm for c in cs]], src=0)
+            if err is not None:
+                raise err
             if all(c is None for c in cs):
                 return
-            if any(c is None for c in cs) or len({len(c.seq_len) for c in cs}) != 1:
-                raise ValueError("paired-end files have different numbers of records")
             yield tuple(cs)
 
     def run_with_chunks(self, chunk_reads=None):
@@ -331,6 +363,8 @@ class Predictor:
                         chunk, labels = item
                         for lab, handles in fhs.items():
                             handles[e].write_selected(chunk, labels, lab)
+                        if chunk.release is not None:   # a shared-memory slot: free for the next chunk once its text is written
+                            chunk.release()
                 except BaseException as ex:
                     werr.append(ex)
                     while q.get() is not None:   # keep draining so that the producer never blocks
@@ -375,6 +409,7 @@ class Predictor:
                 th.join()
         if werr:
             raise werr[0]
+        self._close_arenas()
         if writer:
             self.writer_threads = sorted({fh.threads for handles in fhs.values() for fh in handles})
             for handles in fhs.values():
@@ -416,6 +451,11 @@ class Predictor:
                 self.logger.info('Discarded {}{}{}{} unclassified sequences'.format(
                     colors.BOLD, colors.OKCYAN, num_unknown, colors.ENDC))
         self.num_read, self.num_nonrrna, self.num_rrna, self.num_unknown = num_read, num_nonrrna, num_rrna, num_unknown
+
+    def _close_arenas(self):
+        for a in self._arenas:
+            a.close()
+        self._arenas = []
 
     def run(self):
         """Whole-file mode of the reference (detect.py:121-324): same outputs; streamed here in 1 Mi-record chunks
@@ -510,6 +550,7 @@ def main(argv=None):
         seq_pred.detect()
         seq_pred.timing = {"load_model_s": t1 - t0, "detect_s": time.perf_counter() - t1, "prefix_k": seq_pred.model.prefix_k}
     except BaseException:
+        seq_pred._close_arenas()
         for f in seq_pred._part_files:           # a failed sharded run leaves no '<out>.partN' / '<out>.joining' files behind
             try:
                 os.remove(f)

@@ -101,12 +101,13 @@ def test_cli_fasta_and_cpu_semantics(tmp_path, oracle):
         assert _read(out) == want
 
 
-@pytest.mark.parametrize("suffix,world", [("", 2), (".gz", 2), ("", 3)])
-def test_cli_two_ranks_match_one(tmp_path, suffix, world):
+@pytest.mark.parametrize("suffix,world,shared", [("", 2, "1"), (".gz", 2, "1"), ("", 3, "1"), (".gz", 3, "1"), (".gz", 2, "0")])
+def test_cli_two_ranks_match_one(tmp_path, suffix, world, shared):
     """torchrun x2 (both ranks on this box's one GPU, exchange over gloo) must write the same files as one process.
     Plain input: every rank parses only its own byte range (mates cut at the same record index), writes its own parts, rank 0
-    joins them - each rank reads about half of the bytes. gzip input: every rank parses the stream, classifies a work-balanced
-    shard of each chunk, rank 0 gathers the labels and writes."""
+    joins them - each rank reads about half of the bytes. gzip input: rank 0 inflates and parses the stream ONCE into shared
+    memory, the other ranks map each chunk and take their work-balanced share of its records (RD_SHARED_DECODE=0: every rank
+    decodes the stream itself, the round-2 behaviour and what ranks on different nodes do); rank 0 gathers the labels and writes."""
     import re
     import socket
     import subprocess
@@ -126,12 +127,13 @@ def test_cli_two_ranks_match_one(tmp_path, suffix, world):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    env = dict(os.environ, RD_DIST_BACKEND="gloo", RD_LOCAL_DEVICE="0", PYTHONPATH=root)
+    env = dict(os.environ, RD_DIST_BACKEND="gloo", RD_LOCAL_DEVICE="0", PYTHONPATH=root, RD_SHARED_DECODE=shared)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(port), "-m", "ribodetector_amd.detect", "-l", "120", "-i", i1, i2, "-o", *two[:2], "-r", *two[2:],
            "-e", "both", "--chunk_size", "1", "-m", "3"]
     r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert not [f for f in os.listdir("/dev/shm") if f.startswith("rd_%d_" % port)]   # the shared-memory chunk slots are gone
     assert p.num_read == n and p.num_unknown > 0
     for a, b in zip(one, two):
         assert _read(a) == _read(b) and len(_read(a)) > 0
@@ -176,6 +178,35 @@ def test_cli_failing_rank_ends_the_job(tmp_path):
     r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and time.time() - t0 < 200
     assert "truncated FASTQ record" in r.stderr + r.stdout
+
+
+def test_cli_damaged_gz_under_two_ranks_ends_the_job(tmp_path):
+    """shared decode: rank 0 hits the damage, passes the error on instead of a chunk, and every rank leaves with it"""
+    import socket
+    import subprocess
+    import sys
+    import time
+    from ribodetector_amd import synth
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    arena, off, _ = synth.reads_numpy(30000, 100, seed=61)
+    good = str(tmp_path / "r.fq.gz")
+    synth.write_fastq(good, arena, off, 1)
+    blob = open(good, "rb").read()
+    cut = str(tmp_path / "cut.fq.gz")
+    open(cut, "wb").write(blob[: len(blob) // 2])
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, RD_DIST_BACKEND="gloo", RD_LOCAL_DEVICE="0", PYTHONPATH=root)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "-m", "ribodetector_amd.detect", "-l", "100", "-i", cut, "-o", str(tmp_path / "o.fq"),
+           "--chunk_size", "1", "-m", "3"]
+    t0 = time.time()
+    r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and time.time() - t0 < 200
+    assert "ended before the end-of-stream marker" in r.stderr + r.stdout
+    assert not [f for f in os.listdir("/dev/shm") if f.startswith("rd_%d_" % port)]
 
 
 def test_cli_damaged_input_is_an_error(tmp_path):

@@ -83,7 +83,7 @@ def test_kernel_against_the_reference_at_scale(gpu_model, sets, report, name, va
     assert a["rms"] < 6e-6 and a["p999"] < 5e-5, (name, variant, a)   # observed: rms 2.8e-6 ... 4.8e-6, p99.9 1.4e-5 ... 4.1e-5
     # (b) no further from the exact function than the reference itself is (its own tail: fixture stats)
     loose = 2.0 if variant == "simple" else 1.35                      # the plain-FMA cross-check accumulates k-ascending: a longer chain
-    assert b["rms"] < loose * c["rms"] and b["p999"] < loose * 1.2 * c["p999"], (name, variant, b, c)
+    assert b["rms"] < loose * c["rms"] and b["p999"] < loose * (1.5 if variant == "simple" else 1.2) * c["p999"], (name, variant, b, c)
     assert b["n_over_1e-4"] <= c["n_over_1e-4"] + (0 if s.max_len <= 100 else 2), (name, variant, b, c)
     # (c) labels: identical to the reference's on every read (the smallest float64 margin of the sets is 1.5e-5; a mismatch would
     # have to sit inside the two noises, and then it is reported, not hidden)
