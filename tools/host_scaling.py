@@ -51,10 +51,10 @@ def run_bench(world, pairs):
             "host_cores_busy": c["host_cores_busy"], "host_cores_usable": c["host_cores_usable"], "dist_backend": c["dist_backend"]}
 
 
-def run_cli(world, inputs, outdir, tag, threads):
+def run_cli(world, inputs, outdir, tag, threads, shared_decode="1"):
     outs = [os.path.join(outdir, "%s_w%d_%d.fq" % (tag, world, i)) for i in range(len(inputs))]
     base = ["-l", "100", "-i", *inputs, "-o", *outs, "-t", str(threads)] + (["-e", "rrna"] if len(inputs) == 2 else [])
-    env = dict(os.environ, RD_PREFIX_K="12")
+    env = dict(os.environ, RD_PREFIX_K="12", RD_SHARED_DECODE=shared_decode)
     if world == 1:
         cmd = [sys.executable, "-m", "ribodetector_amd.detect"] + base
     else:
@@ -99,8 +99,18 @@ def main():
             rows = []
             for w in (1, 8):
                 rows.append(run_cli(w, ins, d, tag, threads=10 if w == 1 else 2))
-            same = all("output_sha1" in r for r in rows) and rows[0]["output_sha1"] == rows[1]["output_sha1"]
+            if tag == "pe_gz":     # round-2 behaviour for comparison: every rank inflates and parses the whole stream itself
+                rows.append(dict(run_cli(8, ins, d, tag, threads=2, shared_decode="0"), every_rank_decodes=True))
+            same = all("output_sha1" in r for r in rows) and all(r["output_sha1"] == rows[0]["output_sha1"] for r in rows)
             out["cli"][tag] = {"runs": rows, "outputs_identical_w1_w8": same}
+        g, p = out["cli"]["pe_gz"]["runs"], out["cli"]["pe_plain"]["runs"]
+        if all("cpu_s_all_ranks" in r for r in g + p):
+            # what reading .gz costs on top of reading plain text, in CPU seconds: once at W = 1; at W = 8 the same amount if the
+            # stream is decoded once per node, eight times that if every rank decodes it (each process also pays ~2.5 s of
+            # interpreter + torch start-up, which is why the totals are compared as differences)
+            out["gz_over_plain_cpu_s"] = {"w1": g[0]["cpu_s_all_ranks"] - p[0]["cpu_s_all_ranks"],
+                                          "w8_one_decode_per_node": g[1]["cpu_s_all_ranks"] - p[1]["cpu_s_all_ranks"],
+                                          "w8_every_rank_decodes": g[2]["cpu_s_all_ranks"] - p[1]["cpu_s_all_ranks"]}
     finally:
         shutil.rmtree(d, ignore_errors=True)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
