@@ -103,3 +103,70 @@ def test_single_process_passthrough():
     assert rdist.gather_labels(x, 5) is x
     c = torch.tensor([1, 2, 3])
     assert rdist.reduce_counts(c) is c
+
+
+def _shm_worker(rank, world, port, path, tmp):
+    """the per-chunk message of the one-decode-per-node mode (detect.Predictor._chunk_stream): rank 0 parses a .gz once into
+    shared-memory slots and broadcasts where each chunk lies; the other ranks map the slot"""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import hashlib
+    from ribodetector_amd import dist as rdist
+    from ribodetector_amd.data_loader import fastx_parser as fx
+    rdist.init_from_env(backend="gloo")
+    h = hashlib.sha256()
+    n_rec = n_chunks = 0
+    if rank == 0:
+        arena = fx.ShmArena("rd_test_%d_%d" % (port, os.getpid()))
+        try:
+            held = []
+            for c in fx.get_seq_chunks(path, chunk_size=1000, first_chunk=250, arena=arena):
+                dist.broadcast_object_list([[c.shm]], src=0)
+                h.update(c.buf.tobytes()); h.update(c.seq_off.tobytes()); h.update(c.seq_len.tobytes())
+                n_rec += len(c.seq_len)
+                n_chunks += 1
+                held.append(c)
+                if len(held) > 2:                       # the writer of the CLI releases a slot once its chunk is written
+                    dist.barrier()                      # (here: once every rank has hashed the chunk)
+                    held.pop(0).release()
+                else:
+                    dist.barrier()
+            dist.broadcast_object_list([None], src=0)
+            slots = len(arena.slots)
+        finally:
+            arena.close()
+        assert slots <= 7 and slots < n_chunks // 2, (slots, n_chunks)   # slots are reused (the ramp of chunk sizes adds a few small ones)
+    else:
+        while True:
+            msg = [None]
+            dist.broadcast_object_list(msg, src=0)
+            if msg[0] is None:
+                break
+            c = fx.ShmArena.attach(msg[0][0])
+            h.update(c.buf.tobytes()); h.update(c.seq_off.tobytes()); h.update(c.seq_len.tobytes())
+            n_rec += len(c.seq_len)
+            n_chunks += 1
+            dist.barrier()
+    open(os.path.join(tmp, "shm%d.txt" % rank), "w").write("%s %d %d" % (h.hexdigest(), n_rec, n_chunks))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shared_memory_chunks_reach_the_other_ranks(tmp_path):
+    import hashlib
+    from ribodetector_amd import synth
+    from ribodetector_amd.data_loader import fastx_parser as fx
+    a, o, _ = synth.reads_numpy(20000, (30, 150), seed=8)
+    path = str(tmp_path / "r.fq.gz")
+    synth.write_fastq(path, a, o, 1)
+    port = _free_port()
+    mp.spawn(_shm_worker, args=(3, port, path, str(tmp_path)), nprocs=3, join=True)
+    h = hashlib.sha256()
+    n = 0
+    for c in fx.get_seq_chunks(path, chunk_size=1000, first_chunk=250):
+        h.update(c.buf.tobytes()); h.update(c.seq_off.tobytes()); h.update(c.seq_len.tobytes())
+        n += len(c.seq_len)
+    got = [open(str(tmp_path / ("shm%d.txt" % r))).read().split() for r in range(3)]
+    assert all(g[0] == h.hexdigest() and int(g[1]) == n == 20000 for g in got), got
+    assert int(got[0][2]) >= 20                                                  # many chunks, ramped sizes
+    assert not [f for f in os.listdir("/dev/shm") if f.startswith("rd_test_%d_" % port)]
