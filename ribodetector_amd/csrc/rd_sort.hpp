@@ -164,10 +164,13 @@ __global__ __launch_bounds__(256) void rd_steps_kernel(const uint8_t *__restrict
                 int prow = 1 << (2 * pk);
                 if (T > pk && lr >= pk) {
                     const uint8_t *p = arena + off[i];
+                    u32x4 raw = {0u, 0u, 0u, 0u};                      // the first pk <= 13 bases: ONE unaligned 16-byte load when the
+                    if (lr >= 16) __builtin_memcpy(&raw, p, 16);       // read has 16 bytes (never past its end), else byte by byte
+                    else for (int t = 0; t < pk; ++t) raw[t >> 2] |= (uint32_t)p[t] << (8 * (t & 3));
                     uint32_t idx = 0;
                     bool ok = true;
                     for (int t = 0; t < pk; ++t) {
-                        const int c = rd_code(p[t]);
+                        const int c = rd_code((raw[t >> 2] >> (8 * (t & 3))) & 0xffu);
                         ok = ok && c < 4;
                         idx = idx * 4u + (uint32_t)(c & 3);
                     }
