@@ -98,18 +98,22 @@ int rd_set_semantics(rd_model *m, int semantics);
  *     the GPU idle. A pipelined caller switches the inline pass off (rd_set_refine(m, 0)) and issues rd_refine(..., thresh)
  *     on a second stream, where it overlaps the next batch's recurrence (bench.py and the CLI do).
  * One launch: each workgroup scans 512 logit rows and re-evaluates the candidates among them itself.
- * rd_set_refine_async(m, 1) moves the pass off the caller's critical path without a second stream on the caller's side (opt-in):
- * rd_classify then issues it on a stream the model owns and returns with it pending; it is joined into the caller's stream
- *   (a) by the NEXT rd_classify / rd_refine of this model - behind that call's recurrence launch, so that the pass overlaps it,
- *   (b) by rd_sync_results(m, stream), (c) by rd_model_destroy.
- * Contract of the mode: the logits / labels of a call are final, and its input buffers may be overwritten, only after one of
- * (a)-(c) has been issued on the stream that consumes them - i.e. a streaming caller alternates two sets of buffers and reads
- * the results of call i after issuing call i+1 (what the reference's loop cannot do: it synchronises on .tolist() every batch,
- * reference detect.py:288,481). A next call that passes one of the pending call's pointers, or overlapping output ranges, is
- * detected and joins first (correct results, no overlap). A call captured in a hipGraph keeps the pass inline. */
+ * rd_set_refine_async(m, K), K in [1, 16], moves the pass off the caller's critical path without a second stream on the caller's
+ * side (opt-in; 0 = back to the inline pass): rd_classify then only RECORDS its candidates (where their bases lie, where their
+ * results go) in a queue the model owns, and the candidates of K consecutive calls are evaluated together - one workgroup each, so
+ * all of them in the 0.3 ms one takes - on a stream the model owns, beside the recurrence of the call that follows the group.
+ * A call's logits / labels are final, and its input buffers may be overwritten, for work issued on the caller's stream
+ *   (a) after the K-th call that follows it has been issued (K = 1: after the next call), or
+ *   (b) after rd_sync_results(m, stream) - which evaluates whatever waits, on the model's stream, and makes `stream` wait for it.
+ * Until then the buffers of those calls must stay as they are: a streaming caller cycles K + 1 sets of buffers and consumes the
+ * results of a call K calls later (what the reference's loop cannot do: it synchronises on .tolist() every batch, reference
+ * detect.py:288,481). A call that passes a pointer of a waiting call, or overlapping output ranges, is detected and synchronises
+ * first (correct results, no overlap). rd_refine synchronises first too. A call captured in a hipGraph keeps the pass inline.
+ * Candidates beyond the queue's 8,192 entries are evaluated inside rd_classify. rd_model_destroy / changing K require
+ * rd_sync_results first (candidates still waiting at destroy keep their fp32 results). */
 #define RD_REFINE_DEFAULT 2.5e-4f
 int rd_set_refine(rd_model *m, float thresh);
-int rd_set_refine_async(rd_model *m, int enable);
+int rd_set_refine_async(rd_model *m, int calls_per_group);
 int rd_sync_results(rd_model *m, void *stream);
 int rd_refine(const rd_model *m, const uint8_t *arena, const int64_t *seq_off, const int32_t *seq_len, int64_t n,
               int32_t max_len, float *logits, uint8_t *labels, const float *mate_logits, float thresh, void *stream);

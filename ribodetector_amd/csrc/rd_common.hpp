@@ -95,14 +95,16 @@ struct rd_model {
     int prefix_k;         // bases covered by a row of the attached prefix-state table (0 = none attached)
     const uint8_t *ptab;  // the table (caller-owned memory, rd_set_prefix_table), (4^prefix_k + 1) rows of 1 KiB
     DevModel d;
-    // deferred float64 pass (rd_set_refine_async): issued on a stream the model owns, joined into the caller's stream by the NEXT
-    // rd_classify (behind that call's recurrence launch), by rd_sync_results or by rd_model_destroy
-    int refine_async;
-    int refine_pending;
+    // deferred float64 pass (rd_set_refine_async, rd_kernels.hip): the candidates of refine_async consecutive calls are recorded
+    // in a device queue and evaluated together on a stream the model owns; two queues alternate
+    int refine_async;              // calls per group (0 = the pass runs inline in rd_classify)
     hipStream_t side;
-    hipEvent_t ev_fork, ev_join;
-    const void *pend_ptr[5];   // arena, seq_off, seq_len, logits, labels of the pending call (reuse by the next call = join first)
-    int64_t pend_n;
+    hipEvent_t ev_fork, ev_join[2];
+    void *q_e[2];                  // RefineEntry[RD_REFINE_QCAP]
+    uint32_t *q_count[2];
+    int q_cur, q_calls, q_flushing[2];
+    struct { const void *p[5]; int64_t n; int max_len, sem; } q_pend[2][16];   // buffers of the calls whose candidates wait in queue x
+    int q_npend[2];
     // profiling of the recurrence kernel (bench.py roofline)
     int prof_enabled;
     int prof_count;

@@ -98,7 +98,11 @@ void rd_model_destroy(rd_model *m) {
     hipSetDevice(m->device);
     if (m->side) { hipStreamSynchronize(m->side); hipStreamDestroy(m->side); }
     if (m->ev_fork) hipEventDestroy(m->ev_fork);
-    if (m->ev_join) hipEventDestroy(m->ev_join);
+    for (int x = 0; x < 2; ++x) {
+        if (m->ev_join[x]) hipEventDestroy(m->ev_join[x]);
+        if (m->q_e[x]) hipFree(m->q_e[x]);
+        if (m->q_count[x]) hipFree(m->q_count[x]);
+    }
     hipFree(m->d.raw); hipFree(m->d.wpack32); hipFree(m->d.wt_hh); hipFree(m->d.in_lut);
     hipFree(m->d.rev_lut); hipFree(m->d.rev_tab); hipFree(m->d.w_out); hipFree(m->d.b_out);
     if (m->d.wpack16b) hipFree(m->d.wpack16b);
@@ -149,9 +153,60 @@ int rd_set_refine(rd_model *m, float thresh) {
     return RD_OK;
 }
 
-int rd_set_refine_async(rd_model *m, int enable) {
+constexpr uint32_t RD_REFINE_QCAP = 8192;   // candidates a queue holds (what does not fit is evaluated inside rd_classify)
+
+static RefineQueue rd_queue(const rd_model *m, int x) { return RefineQueue{(RefineEntry *)m->q_e[x], m->q_count[x], RD_REFINE_QCAP}; }
+
+// evaluate the candidates waiting in queue x on the model's stream, beside whatever `st` does next
+static int rd_async_flush(rd_model *m, hipStream_t st, int x) {
+    RD_HIP(hipEventRecord(m->ev_fork, st));
+    RD_HIP(hipStreamWaitEvent(m->side, m->ev_fork, 0));
+    hipLaunchKernelGGL(rd_refine_flush_kernel, dim3(REFINE_FLUSH_WGS), dim3(1024), 0, m->side, m->d, rd_queue(m, x));
+    for (int k = 0; k < m->q_npend[x]; ++k) {   // second tier: launches that return at once unless the queue overflowed
+        const auto &pd = m->q_pend[x][k];
+        ReadBatch rb{(const uint8_t *)pd.p[0], (const int64_t *)pd.p[1], (const int32_t *)pd.p[2], nullptr, nullptr, pd.n, pd.max_len, pd.sem,
+                     m->d.rev_tab, nullptr, nullptr, 0, RefineQueue{nullptr, nullptr, 0}, 0.0f};
+        const int64_t nb = (pd.n + REFINE_SLICE - 1) / REFINE_SLICE;
+        hipLaunchKernelGGL(rd_refine_kernel, dim3((unsigned)nb), dim3(1024), 0, m->side, m->d, rb, (const float2 *)nullptr, m->refine_thresh,
+                           (float *)pd.p[3], (uint8_t *)pd.p[4], rd_queue(m, x), (const uint32_t *)m->q_count[x]);
+    }
+    RD_HIP(hipGetLastError());
+    RD_HIP(hipMemsetAsync(m->q_count[x], 0, sizeof(uint32_t), m->side));
+    RD_HIP(hipEventRecord(m->ev_join[x], m->side));
+    m->q_flushing[x] = 1;
+    return RD_OK;
+}
+
+// everything issued on `st` from here on sees the results of the calls whose candidates were in queue x
+static int rd_async_join(rd_model *m, hipStream_t st, int x) {
+    if (m->q_flushing[x]) {
+        RD_HIP(hipStreamWaitEvent(st, m->ev_join[x], 0));
+        m->q_flushing[x] = 0;
+        m->q_npend[x] = 0;
+    }
+    return RD_OK;
+}
+
+int rd_sync_results(rd_model *m, void *stream) {
+    if (!m) RD_FAIL(RD_E_INVALID, "rd_sync_results: null model");
+    if (!m->refine_async) return RD_OK;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = RD_OK;
+    if (m->q_calls > 0) {
+        rc = rd_async_flush(m, st, m->q_cur);
+        if (rc) return rc;
+        m->q_calls = 0;
+    }
+    for (int x = 0; x < 2 && !rc; ++x) rc = rd_async_join(m, st, x);
+    return rc;
+}
+
+int rd_set_refine_async(rd_model *m, int calls) {
     if (!m) RD_FAIL(RD_E_INVALID, "rd_set_refine_async: null model");
-    if (enable && !m->side) {
+    if (calls < 0 || calls > 16) RD_FAIL(RD_E_INVALID, "rd_set_refine_async: calls per group %d out of range [0, 16]", calls);
+    if (m->q_calls || m->q_flushing[0] || m->q_flushing[1])
+        RD_FAIL(RD_E_INVALID, "rd_set_refine_async: calls are pending - rd_sync_results first");
+    if (calls && !m->side) {
         RD_HIP(hipSetDevice(m->device));
         // highest priority: when a CU becomes free its workgroups go first - a workgroup of the float64 pass needs a whole CU (1,024
         // threads), and so does every workgroup of the recurrence kernel that the pass is meant to run beside
@@ -159,27 +214,22 @@ int rd_set_refine_async(rd_model *m, int enable) {
         RD_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
         RD_HIP(hipStreamCreateWithPriority(&m->side, hipStreamNonBlocking, hi));
         RD_HIP(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
-        RD_HIP(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
+        for (int x = 0; x < 2; ++x) {
+            RD_HIP(hipEventCreateWithFlags(&m->ev_join[x], hipEventDisableTiming));
+            RD_HIP(hipMalloc(&m->q_e[x], sizeof(RefineEntry) * RD_REFINE_QCAP));
+            RD_HIP(hipMalloc((void **)&m->q_count[x], sizeof(uint32_t)));
+            RD_HIP(hipMemset(m->q_count[x], 0, sizeof(uint32_t)));
+        }
     }
-    if (!enable && m->refine_pending) RD_HIP(hipStreamSynchronize(m->side));   // leaving the mode: nothing stays in flight
-    if (!enable) m->refine_pending = 0;
-    m->refine_async = enable ? 1 : 0;
-    return RD_OK;
-}
-
-int rd_sync_results(rd_model *m, void *stream) {
-    if (!m) RD_FAIL(RD_E_INVALID, "rd_sync_results: null model");
-    if (m->refine_pending) {
-        RD_HIP(hipStreamWaitEvent((hipStream_t)stream, m->ev_join, 0));
-        m->refine_pending = 0;
-    }
+    m->refine_async = calls;
     return RD_OK;
 }
 
 static int rd_refine_launch(rd_model *m, const ReadBatch &rb, float *logits, uint8_t *labels, const float *mate_logits, float thresh,
                             hipStream_t st) {
     const int64_t nb = (rb.n + REFINE_SLICE - 1) / REFINE_SLICE;
-    hipLaunchKernelGGL(rd_refine_kernel, dim3((unsigned)nb), dim3(1024), 0, st, m->d, rb, (const float2 *)mate_logits, thresh, logits, labels);
+    hipLaunchKernelGGL(rd_refine_kernel, dim3((unsigned)nb), dim3(1024), 0, st, m->d, rb, (const float2 *)mate_logits, thresh, logits, labels,
+                       RefineQueue{nullptr, nullptr, 0}, (const uint32_t *)nullptr);
     RD_HIP(hipGetLastError());
     return RD_OK;
 }
@@ -195,14 +245,15 @@ int rd_refine(const rd_model *cm, const uint8_t *arena, const int64_t *seq_off, 
     if (n == 0 || thresh <= 0.0f) return RD_OK;
     if (!arena || !seq_off || !seq_len) RD_FAIL(RD_E_INVALID, "rd_refine: null input pointer");
     hipStream_t st = (hipStream_t)stream;
-    if (m->refine_pending) { RD_HIP(hipStreamWaitEvent(st, m->ev_join, 0)); m->refine_pending = 0; }
+    if (m->refine_async) { int rc0 = rd_sync_results(m, stream); if (rc0) return rc0; }   // the logits it reads may have candidates waiting
     // padded semantics: the reverse-half table is built by rd_classify for ITS max_len, on ITS stream. Rebuilding it here - typically
     // on a side stream, while a recurrence kernel of the main stream reads it - would be a data race (advisor finding, round 2), so
     // the pass refuses a max_len the table was not built for: it re-evaluates reads of an earlier rd_classify call by definition.
     if (m->semantics == RD_SEM_PADDED && m->rev_tab_len != max_len)
         RD_FAIL(RD_E_INVALID, "rd_refine: padded semantics needs a preceding rd_classify with the same max_len (table built for %d, got %d)",
                 m->rev_tab_len, max_len);
-    ReadBatch rb{arena, seq_off, seq_len, nullptr, nullptr, n, max_len, m->semantics, m->d.rev_tab, nullptr, nullptr, 0};
+    ReadBatch rb{arena, seq_off, seq_len, nullptr, nullptr, n, max_len, m->semantics, m->d.rev_tab, nullptr, nullptr, 0,
+                 RefineQueue{nullptr, nullptr, 0}, 0.0f};
     return rd_refine_launch(m, rb, logits, labels, mate_logits, thresh, st);
 }
 
@@ -239,7 +290,8 @@ int rd_set_prefix_table(rd_model *m, int32_t k, void *table, size_t table_bytes,
     for (int j = 1; j <= k; ++j) {
         uint8_t *dst = ((k - j) & 1) ? scr : tab;
         const int64_t rows = (int64_t)1 << (2 * j);
-        ReadBatch rb{nullptr, nullptr, nullptr, nullptr, nullptr, rows, 1, RD_SEM_PACKED, nullptr, prev, nullptr, j};
+        ReadBatch rb{nullptr, nullptr, nullptr, nullptr, nullptr, rows, 1, RD_SEM_PACKED, nullptr, prev, nullptr, j,
+                     RefineQueue{nullptr, nullptr, 0}, 0.0f};
         hipLaunchKernelGGL(rd_lstm_mfma_f16x3_t32_kernel<true>, dim3((unsigned)((rows + 63) / 64)), dim3(256), 0, st, m->d, rb, (float *)dst, (uint8_t *)nullptr);
         prev = dst;
     }
@@ -301,20 +353,44 @@ int rd_classify(const rd_model *cm, const uint8_t *arena, const int64_t *seq_off
         hipLaunchKernelGGL(rd_revtab_kernel, dim3(1), dim3(512), 0, st, m->d, max_len);
         m->rev_tab_len = max_len;
     }
-    // deferred float64 pass of the previous call (rd_set_refine_async): normally joined BEHIND this call's recurrence so that the two
-    // overlap; if this call touches a buffer of that one, it is joined first (correct, no overlap)
-    if (m->refine_pending) {
-        const char *lo = (const char *)m->pend_ptr[3], *la = (const char *)m->pend_ptr[4];
-        const bool clash = arena == m->pend_ptr[0] || seq_off == m->pend_ptr[1] || seq_len == m->pend_ptr[2] ||
-                           ((const char *)logits < lo + 8 * m->pend_n && lo < (const char *)logits + 8 * n) ||
-                           (labels && la && (const char *)labels < la + m->pend_n && la < (const char *)labels + n);
-        if (clash) { RD_HIP(hipStreamWaitEvent(st, m->ev_join, 0)); m->refine_pending = 0; }
+    // deferred float64 pass (rd_set_refine_async): not inside a stream capture (a captured call stays self-contained)
+    bool deferred = false;
+    int join_after_launch = -1;
+    if (m->refine_async && m->refine_thresh > 0.0f) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(st, &cap);
+        deferred = cap == hipStreamCaptureStatusNone;
+    }
+    if (deferred) {
+        // a call that touches a buffer of a call whose candidates still wait (or are being evaluated) gets the finished results first
+        bool clash = false;
+        for (int x = 0; x < 2 && !clash; ++x)
+            for (int k = 0; k < m->q_npend[x] && !clash; ++k) {
+                const auto &pd = m->q_pend[x][k];
+                const char *lo = (const char *)pd.p[3], *la = (const char *)pd.p[4];
+                clash = (m->semantics == RD_SEM_PADDED && pd.max_len != max_len) ||   // (the padded table would be rebuilt under the flush)
+                        arena == pd.p[0] || seq_off == pd.p[1] || seq_len == pd.p[2] ||
+                        ((const char *)logits < lo + 8 * pd.n && lo < (const char *)logits + 8 * n) ||
+                        (labels && la && (const char *)labels < la + pd.n && la < (const char *)labels + n);
+            }
+        if (clash) { int rc0 = rd_sync_results(m, stream); if (rc0) return rc0; }
+        if (m->q_calls >= m->refine_async) {   // the group is complete: its candidates are evaluated beside THIS call's recurrence
+            const int old = m->q_cur;
+            int rc0 = rd_async_flush(m, st, old);
+            if (rc0) return rc0;
+            m->q_cur ^= 1;
+            m->q_calls = 0;
+            rc0 = rd_async_join(m, st, m->q_cur);   // the other queue's flush was issued a whole group ago
+            if (rc0) return rc0;
+            join_after_launch = old;
+        }
     }
     int32_t *steps = nullptr, *order = nullptr, *pfx = nullptr;
     const int pk = m->variant == RD_VARIANT_MFMA_F16X3_T32 ? m->prefix_k : 0;      // the table holds THAT kernel's state
     int rc = run_steps_and_buckets(arena, seq_off, seq_len, n, max_len, m->semantics, workspace, workspace_bytes, steps, order, pk, pfx, st);
     if (rc) return rc;
-    ReadBatch rb{arena, seq_off, seq_len, steps, order, n, max_len, m->semantics, m->d.rev_tab, pk > 0 ? m->ptab : m->d.zero_row, pfx, pk};
+    ReadBatch rb{arena, seq_off, seq_len, steps, order, n, max_len, m->semantics, m->d.rev_tab, pk > 0 ? m->ptab : m->d.zero_row, pfx, pk,
+                 deferred ? rd_queue(m, m->q_cur) : RefineQueue{nullptr, nullptr, 0}, m->refine_thresh};
     hipEvent_t *ev = nullptr;
     if (m->prof_enabled) {
         if (m->prof_count == 512) { rc = rd_profile_drain(m); if (rc) return rc; }
@@ -366,23 +442,16 @@ int rd_classify(const rd_model *cm, const uint8_t *arena, const int64_t *seq_off
     }
     RD_HIP(hipGetLastError());
     if (ev) { RD_HIP(hipEventRecord(ev[1], st)); m->prof_count++; }
-    if (m->refine_pending) {   // the previous call's float64 pass ran beside this call's recurrence; everything later on `st` sees its results
-        RD_HIP(hipStreamWaitEvent(st, m->ev_join, 0));
-        m->refine_pending = 0;
+    if (join_after_launch >= 0) {   // everything issued on `st` from here on sees the final results of the group just evaluated
+        rc = rd_async_join(m, st, join_after_launch);
+        if (rc) return rc;
     }
     if (m->refine_thresh > 0.0f) {
-        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        if (m->refine_async) (void)hipStreamIsCapturing(st, &cap);
-        if (!m->refine_async || cap != hipStreamCaptureStatusNone)      // (a captured call stays self-contained: no open fork at EndCapture)
-            return rd_refine_launch(m, rb, logits, labels, nullptr, m->refine_thresh, st);
-        RD_HIP(hipEventRecord(m->ev_fork, st));
-        RD_HIP(hipStreamWaitEvent(m->side, m->ev_fork, 0));
-        rc = rd_refine_launch(m, rb, logits, labels, nullptr, m->refine_thresh, m->side);
-        if (rc) return rc;
-        RD_HIP(hipEventRecord(m->ev_join, m->side));
-        m->refine_pending = 1;
-        m->pend_ptr[0] = arena; m->pend_ptr[1] = seq_off; m->pend_ptr[2] = seq_len; m->pend_ptr[3] = logits; m->pend_ptr[4] = labels;
-        m->pend_n = n;
+        if (!deferred) return rd_refine_launch(m, rb, logits, labels, nullptr, m->refine_thresh, st);
+        auto &pd = m->q_pend[m->q_cur][m->q_npend[m->q_cur]++];   // (the recurrence kernel's epilogue recorded the candidates)
+        pd.p[0] = arena; pd.p[1] = seq_off; pd.p[2] = seq_len; pd.p[3] = logits; pd.p[4] = labels;
+        pd.n = n; pd.max_len = max_len; pd.sem = m->semantics;
+        m->q_calls++;
     }
     return RD_OK;
 }

@@ -9,6 +9,22 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 // shared pieces of the recurrence kernels
 // ------------------------------------------------------------------------------------------------
+// a candidate waiting in the model's queue (rd_set_refine_async): where its bases lie, where its results go
+struct RefineEntry {
+    const uint8_t *bases;
+    float *logits;       // the read's logit row
+    uint8_t *label;      // or nullptr
+    int32_t lr;          // readable bytes = min(len, max_len)
+    int32_t max_len;
+    int32_t sem;
+    int32_t pad_;
+};
+struct RefineQueue {
+    RefineEntry *e;
+    uint32_t *count;
+    uint32_t cap;
+};
+
 struct ReadBatch {
     const uint8_t *arena;
     const int64_t *off;
@@ -25,6 +41,9 @@ struct ReadBatch {
     const uint8_t *ptab;
     const int32_t *pfx;
     int pk;
+    // deferred float64 pass (rd_set_refine_async): the epilogue records the reads whose margin is below rthresh in rq
+    RefineQueue rq;
+    float rthresh;
 };
 constexpr int PFX_ROW = 1024;   // bytes per table row: 2^11 h_hi fp16[128] | residual fp16[128] | KT c fp32[128]
 
@@ -54,6 +73,13 @@ __device__ __forceinline__ void rd_fc_epilogue(int nrows, HL hl, const int *Trow
         if (orig >= 0) {
             logits[(size_t)orig * 2 + k] = s;
             if (labels && k == 0) labels[orig] = other > s ? 1 : 0;   // torch.argmax: first max wins ties -> 0
+            if (rb.rq.e && k == 0 && fabsf(other - s) < rb.rthresh) {   // inside the fp32 noise band: float64 later (rd_refine.hpp)
+                const uint32_t slot = atomicAdd(rb.rq.count, 1u);      // (a count beyond cap tells the flush that entries are missing)
+                const int k0 = k0row ? k0row[row] : 0;
+                if (slot < rb.rq.cap)
+                    rb.rq.e[slot] = RefineEntry{rb.arena + offrow[row] - k0, logits + (size_t)orig * 2, labels ? labels + orig : nullptr,
+                                                Lrow[row] + k0, rb.max_len, rb.sem, 0};
+            }
         }
     }
 }

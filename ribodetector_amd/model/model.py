@@ -50,7 +50,7 @@ class SeqModel:
         self._variant = "auto"
         self._semantics = "packed"
         self._refine = None
-        self._refine_async = False
+        self._refine_async = 0
         self._prefix = os.environ.get("RD_PREFIX_K", "auto")   # prefix-state table: "auto" | 0 (none) | 4..13 (set_prefix_table)
         self._prefix_cap = None
         self._ptab = None
@@ -104,7 +104,7 @@ class SeqModel:
             self.set_refine(self._refine)
         self.set_prefix_table(self._prefix)
         if self._refine_async:
-            self.set_refine_async(True)
+            self.set_refine_async(self._refine_async)
 
     def to(self, device, non_blocking=False):
         device = torch.device(device)
@@ -150,13 +150,17 @@ class SeqModel:
 
     REFINE_DEFAULT = 2.5e-4
 
-    def set_refine_async(self, on=True):
-        """C ABI rd_set_refine_async: the float64 pass of classify_bytes runs on a stream the model owns and is joined by the next
-        classify_bytes / refine call or by sync_results() - see include/ribodetector_amd.h for the buffer contract. forward()
-        (the reference-compatible call) always returns final logits."""
-        self._refine_async = bool(on)
+    def set_refine_async(self, calls=1):
+        """C ABI rd_set_refine_async: classify_bytes only records the reads inside the noise band; the candidates of `calls`
+        consecutive calls (1..16; True = 1; 0 / False = the inline pass) are re-evaluated in float64 together on a stream the model
+        owns, beside the recurrence of the next call. A call's results are final once `calls` further calls have been issued or
+        after sync_results() - see include/ribodetector_amd.h for the buffer contract. forward() (the reference-compatible call)
+        always returns final logits."""
+        k = 1 if calls is True else 0 if calls is False else int(calls)
         if self._handle is not None:
-            N.check(N.lib().rd_set_refine_async(self._handle, 1 if on else 0), "rd_set_refine_async")
+            self.sync_results()
+            N.check(N.lib().rd_set_refine_async(self._handle, k), "rd_set_refine_async")
+        self._refine_async = k
         return self
 
     def sync_results(self):

@@ -660,10 +660,11 @@ def test_logit_tail_against_the_oracle_at_one_million_reads(gpu_model, oracle, r
 
 
 def test_refine_async_equals_inline(gpu_model):
-    """rd_set_refine_async: the float64 pass on the model's own stream, joined by the next call or rd_sync_results. Same bits as
-    the inline pass - with alternating buffer sets (the pass of call i overlaps the recurrence of call i+1), with ONE set reused
-    by every call (the library sees the clash and joins first), through forward() (always final) and inside a hipGraph capture
-    (inline by design). The band is widened to 0.5 so that every batch holds hundreds of candidates."""
+    """rd_set_refine_async: the recurrence kernel's epilogue records the candidates, the candidates of K calls are evaluated
+    together on the model's own stream and joined by the K-th following call or rd_sync_results. Same bits as the inline pass -
+    with rotating buffer sets (K = 1 and K = 3), with ONE set reused by every call (the library sees the clash and synchronises
+    first), through forward() (always final), inside a hipGraph capture (inline by design), and with more candidates than the queue
+    holds (second tier). The band is widened to 0.5 so that every batch holds hundreds of candidates."""
     from ribodetector_amd import synth
     from torch.nn.utils.rnn import pack_sequence
     n, L, dev = 8192, 100, "cuda"
@@ -690,6 +691,21 @@ def test_refine_async_equals_inline(gpu_model):
         torch.cuda.synchronize()
         for i, (w, g) in enumerate(zip(want, got)):
             assert torch.equal(w[0], g[0]) and torch.equal(w[1], g[1]), i
+        # (1b) groups of 3 calls, 4 sets of buffers: nothing is final before the sync / the third following call; everything after
+        gpu_model.set_refine_async(3)
+        lg4 = [torch.empty((n, 2), dtype=torch.float32, device=dev) for _ in range(6)]
+        lb4 = [torch.empty((n,), dtype=torch.uint8, device=dev) for _ in range(6)]
+        of6, ln6 = [offs.clone() for _ in range(6)], [lens.clone() for _ in range(6)]
+        for i, b in enumerate(batches):
+            gpu_model.classify_bytes(b[0], of6[i], ln6[i], L, logits=lg4[i], labels=lb4[i])
+        first_group = [(lg4[i].clone(), lb4[i].clone()) for i in range(3)]      # calls 0-2: evaluated beside call 3, joined by it
+        gpu_model.sync_results()
+        torch.cuda.synchronize()
+        for i in range(3):
+            assert torch.equal(first_group[i][0], want[i][0]) and torch.equal(first_group[i][1], want[i][1]), i
+        for i in range(6):
+            assert torch.equal(lg4[i], want[i][0]) and torch.equal(lb4[i], want[i][1]), i
+        gpu_model.set_refine_async(1)
         # (2) one set of buffers for every call: the clash is detected, the pending pass is joined before the next launch
         for i, b in enumerate(batches[:3]):
             gpu_model.classify_bytes(b[0], offs, lens, L, logits=lg[0], labels=lb[0])
@@ -719,8 +735,24 @@ def test_refine_async_equals_inline(gpu_model):
         g.replay()
         torch.cuda.synchronize()
         assert torch.equal(lg[1], want[3][0]) and torch.equal(lb[1], want[3][1])
+        # (5) more candidates than the queue holds (8,192): the second tier re-evaluates the calls of the group, same bits again
+        nb = 1 << 17
+        big = [synth.reads_torch(nb, L, seed=950 + i, device=dev, rrna_frac=0.3) for i in range(2)]
+        ob, lnb = big[0][1][:-1].contiguous(), big[0][2]
+        gpu_model.set_refine_async(0)
+        wantb = [tuple(t.clone() for t in gpu_model.classify_bytes(b[0], ob, lnb, L)) for b in big]
+        rawb = gpu_model.set_refine(0.0).classify_bytes(big[0][0], ob, lnb, L)[0].clone()
+        gpu_model.set_refine(0.5)
+        assert int((rawb != wantb[0][0]).any(dim=1).sum()) > 8192
+        gpu_model.set_refine_async(2)
+        outs = [gpu_model.classify_bytes(b[0], ob.clone(), lnb.clone(), L) for b in big]
+        gpu_model.sync_results()
+        torch.cuda.synchronize()
+        for i in range(2):
+            assert torch.equal(outs[i][0], wantb[i][0]) and torch.equal(outs[i][1], wantb[i][1]), i
     finally:
-        gpu_model.set_refine_async(False)
+        gpu_model.sync_results()
+        gpu_model.set_refine_async(0)
         gpu_model.set_refine(gpu_model.REFINE_DEFAULT)
 
 

@@ -42,21 +42,23 @@ def main():
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t) / reps
         out[n] = {"us_per_call": dt * 1e6, "reads_per_s": n / dt, "read_steps_per_s": n * L / dt}
-        # the float64 pass: inline (above), switched off, and deferred (rd_set_refine_async: on the model's own stream, joined by the
-        # next call behind its recurrence launch; two alternating sets of buffers, as the contract of the mode asks)
+        # the float64 pass: inline (above), switched off, and deferred (rd_set_refine_async: the candidates of 1 / 8 consecutive calls
+        # recorded in the model's queue and evaluated together on its own stream; ten sets of buffers in rotation, as the contract
+        # of the mode asks; the two batches alternate, so about every call of 65,536 reads holds a candidate)
         a2, _, _ = synth.reads_torch(n, L, seed=4, device=torch.device("cuda", 0))
-        sets = [(arena, offs, lens, logits, labels),
-                (a2, offs.clone(), lens.clone(), torch.empty_like(logits), torch.empty_like(labels))]
+        NSETS = 18                                        # deferred mode with groups of up to 16 calls: results consumed 16 calls later
+        sets = [((arena if i % 2 == 0 else a2).clone(), offs.clone(), lens.clone(), torch.empty_like(logits), torch.empty_like(labels))
+                for i in range(NSETS)]
 
         def timed_calls(k=reps):
             for i in range(3):
-                s = sets[i & 1]
+                s = sets[i % NSETS]
                 model.classify_bytes(s[0], s[1], s[2], L, logits=s[3], labels=s[4])
             model.sync_results()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for i in range(k):
-                s = sets[i & 1]
+                s = sets[i % NSETS]
                 model.classify_bytes(s[0], s[1], s[2], L, logits=s[3], labels=s[4])
             model.sync_results()
             torch.cuda.synchronize()
@@ -65,11 +67,17 @@ def main():
         model.set_refine(0.0)
         d_off = timed_calls()
         model.set_refine(M.SeqModel.REFINE_DEFAULT)
-        model.set_refine_async(True)
-        d_async = timed_calls()
-        model.set_refine_async(False)
-        out[n].update({"two_sets_us_inline": d_inline * 1e6, "two_sets_us_refine_off": d_off * 1e6, "two_sets_us_async": d_async * 1e6,
-                       "async_over_off": d_async / d_off, "inline_over_off": d_inline / d_off})
+        model.set_refine_async(1)
+        d_async1 = timed_calls()
+        model.set_refine_async(8)
+        d_async8 = timed_calls()
+        model.set_refine_async(16)
+        d_async16 = timed_calls()
+        model.set_refine_async(0)
+        out[n].update({"us_inline": d_inline * 1e6, "us_refine_off": d_off * 1e6, "us_deferred_groups_of_1": d_async1 * 1e6,
+                       "us_deferred_groups_of_8": d_async8 * 1e6, "inline_over_off": d_inline / d_off,
+                       "us_deferred_groups_of_16": d_async16 * 1e6, "deferred1_over_off": d_async1 / d_off,
+                       "deferred8_over_off": d_async8 / d_off, "deferred16_over_off": d_async16 / d_off})
         # the same call captured in a hipGraph (every launch of rd_classify is asynchronous on the caller's stream, so it can be
         # captured as is): what the seven launches per call cost at small batches
         for refine in (True, False):
