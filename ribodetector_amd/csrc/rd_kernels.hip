@@ -349,10 +349,6 @@ int rd_classify(const rd_model *cm, const uint8_t *arena, const int64_t *seq_off
     hipStream_t st = (hipStream_t)stream;
     const SortPlan sp = sort_plan(n, max_len);
     if (workspace_bytes < sp.total) RD_FAIL(RD_E_WORKSPACE, "workspace too small: %zu < %zu", workspace_bytes, sp.total);
-    if (m->semantics == RD_SEM_PADDED && m->rev_tab_len != max_len) {
-        hipLaunchKernelGGL(rd_revtab_kernel, dim3(1), dim3(512), 0, st, m->d, max_len);
-        m->rev_tab_len = max_len;
-    }
     // deferred float64 pass (rd_set_refine_async): not inside a stream capture (a captured call stays self-contained)
     bool deferred = false;
     int join_after_launch = -1;
@@ -384,6 +380,10 @@ int rd_classify(const rd_model *cm, const uint8_t *arena, const int64_t *seq_off
             if (rc0) return rc0;
             join_after_launch = old;
         }
+    }
+    if (m->semantics == RD_SEM_PADDED && m->rev_tab_len != max_len) {   // (after the block above: candidates of another max_len that
+        hipLaunchKernelGGL(rd_revtab_kernel, dim3(1), dim3(512), 0, st, m->d, max_len);   // still waited have been evaluated by now)
+        m->rev_tab_len = max_len;
     }
     int32_t *steps = nullptr, *order = nullptr, *pfx = nullptr;
     const int pk = m->variant == RD_VARIANT_MFMA_F16X3_T32 ? m->prefix_k : 0;      // the table holds THAT kernel's state
