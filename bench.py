@@ -92,6 +92,21 @@ def cpu_baseline(arena_np, n_reads, target_s=12.0):
                       % (n, cores, os.cpu_count() or 0, dt)}
 
 
+def thread_cpu():
+    """CPU seconds (user + system) of every thread of this process, by thread id: {tid: (name, seconds)}"""
+    out = {}
+    tick = os.sysconf("SC_CLK_TCK")
+    for tid in os.listdir("/proc/self/task"):
+        try:
+            st = open("/proc/self/task/%s/stat" % tid).read()
+            name = st[st.index("(") + 1:st.rindex(")")]
+            f = st[st.rindex(")") + 2:].split()
+            out[tid] = (name, (int(f[11]) + int(f[12])) / tick)
+        except Exception:
+            pass
+    return out
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -409,8 +424,9 @@ def main():
             if i + 1 < nsteps:
                 h2d(i + 1)
             cur.wait_event(ev_ready[s])
-            if ev_free[s] is not None:
-                ev_free[s].synchronize()                   # the host consumed the labels of step i-2 (bounds the run-ahead)
+            if ev_free[s] is not None:                     # the host consumed the labels of step i-2 (bounds the run-ahead)
+                while not ev_free[s].query():              # sleep-poll: hipEventSynchronize spins a host core per rank, and the 8
+                    time.sleep(2e-4)                       # ranks of a node share 16 of them (0.2 ms against a 60 ms step)
 
             def after(lab, s=s):
                 host_lab[s].copy_(lab, non_blocking=True)  # 1 B per pair into pinned memory, behind the post-pass
@@ -432,10 +448,14 @@ def main():
     counts.zero_()
     model.profile_enable(True)
     sync()
+    th0 = thread_cpu()
     t0, c0 = time.perf_counter(), time.process_time()
     timed_path(args.steps)
     sync()
     dt, cpu_s = time.perf_counter() - t0, time.process_time() - c0      # cpu_s: user + system time of ALL threads of this rank
+    th1 = thread_cpu()
+    by_thread = sorted(((th1[t][1] - th0.get(t, (None, 0.0))[1], th1[t][0]) for t in th1), reverse=True)
+    by_thread = [{"thread": nm, "cpu_s": round(c, 3)} for c, nm in by_thread if c >= 0.01][:6]
     launches, kms = model.profile_read()
     model.profile_enable(False)
     rdist.reduce_counts(counts)
@@ -517,6 +537,7 @@ def main():
                        "parallelism": "reads sharded x%d, label gather to rank 0" % world,
                        "host_cpu_seconds_per_rank_in_timed_region": [round(c, 4) for c in cpu_ranks],
                        "host_cores_busy": sum(cpu_ranks) / dt, "host_cores_usable": usable_cores(),
+                       "host_cpu_seconds_by_thread_rank0": by_thread,
                        "rccl_ranks": world, "dist_backend": backend, "forced_dist": bool(multi and world == 1),
                        "prefix_table": {"k": PK, "bytes": (4 ** PK + 1) * 1024 if PK else 0,
                                         "what": "recurrence state after every sequence of k bases, built by the kernel itself at model load; "

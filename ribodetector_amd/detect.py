@@ -211,7 +211,8 @@ class Predictor:
         if self.multi and not self.sharded_parse:
             labels = tk["finish"]()
             return None if self.rank != 0 else labels.cpu().numpy()
-        tk["done"].synchronize()
+        while not tk["done"].query():              # sleep-poll instead of hipEventSynchronize: that one spins a host core for the
+            time.sleep(2e-4)                       # whole run, and the ranks of a node share their cores with readers and writers
         return tk["host"].numpy()
 
     def classify_chunk(self, chunks):
