@@ -405,17 +405,56 @@ def plan_ranges(paths, rank, world, all_gather=None):
     return [(starts[rank][f], starts[rank + 1][f] if rank + 1 < world else sizes[f]) for f in range(len(paths))]
 
 
-def get_seq_chunks(seq_file, chunk_size=1048576, byte_range=None, first_chunk=None, arena=None):
+def chunk_schedule(seq_file, chunk_size, byte_range=None, first_chunk=1 << 17):
+    """Record counts of the successive chunks of a plain file for readers that cannot use byte segments (mate files: chunk i of
+    R1 and chunk i of R2 must hold the same records, so both follow ONE schedule, computed from the first file): small first
+    chunks, doubling up to chunk_size, and a last chunk_size worth of records cut into halves down to first_chunk - what runs
+    after the last byte was parsed (the last chunk's kernels and its write) is hidden behind nothing. The number of records is
+    an estimate from the head of the file; the readers keep reading small chunks if the schedule ends before the file does."""
+    size = file_info(seq_file)[0]
+    b0, b1 = (0, size) if byte_range is None else (int(byte_range[0]), int(byte_range[1]))
+    if b1 <= b0:
+        return []
+    head = min(max(find_record_start(seq_file, min(b1, b0 + (1 << 18))), b0), b1)
+    nrec = count_records(seq_file, b0, head) if head > b0 else 0
+    if not nrec:
+        return []
+    total = int((b1 - b0) / ((head - b0) / nrec))
+    first = max(1, min(first_chunk, chunk_size))
+    top = chunk_size                                   # largest chunk: chunk_size, or less when the file is too small for the two ramps
+    while True:
+        up, t = [], first
+        while t < top:
+            up.append(t)
+            t *= 2
+        down, t = [], top // 2
+        while t >= first:
+            down.append(t)
+            t //= 2
+        down.append(first)
+        if sum(up) + top + sum(down) <= total or top <= first:
+            break
+        top //= 2
+    body = max(0, total - sum(up) - sum(down))
+    rest = body % top
+    return up + [top] * (body // top) + ([rest] if rest >= first else []) + down
+
+
+def get_seq_chunks(seq_file, chunk_size=1048576, byte_range=None, first_chunk=None, arena=None, schedule=None):
     """Chunks of at most `chunk_size` records (reference seq_encoder.py:75-87), as `Chunk` arrays, parsed by librd_host.so.
     byte_range: parse only that part of a plain file (multi-rank CLI, plan_ranges). first_chunk: the first chunk holds that many
     records, the following ones twice as many each up to chunk_size (the kernels start earlier; mate files given the same
     schedule still pair up chunk by chunk)."""
     r = NativeReader(seq_file, byte_range=byte_range, arena=arena)
     want = chunk_size if not first_chunk else max(1, min(int(first_chunk), chunk_size))
+    sched = list(schedule) if schedule else None    # explicit record counts (chunk_schedule); afterwards: chunks of its last entry
     try:
         while True:
+            if sched is not None:
+                want = sched.pop(0) if len(sched) > 1 else sched[0]
             c = r.read(want)
-            want = min(chunk_size, want * 2)
+            if sched is None:
+                want = min(chunk_size, want * 2)
             if c is None:
                 return
             yield c

@@ -229,7 +229,7 @@ class Predictor:
         th.start()
         return th
 
-    def _reader_queue(self, path, chunk_reads, depth=2, byte_range=None, arena=None):
+    def _reader_queue(self, path, chunk_reads, depth=2, byte_range=None, arena=None, schedule=None):
         q = queue.Queue(maxsize=depth)
 
         def work():
@@ -239,7 +239,8 @@ class Predictor:
                 if arena is None and len(self.input) == 1 and not fx.file_info(path)[1] and int(self.args.threads) >= 4:
                     stream = fx.get_seq_chunks_parallel(path, chunk_size=chunk_reads, byte_range=byte_range, workers=2)
                 else:
-                    stream = fx.get_seq_chunks(path, chunk_size=chunk_reads, byte_range=byte_range, first_chunk=1 << 17, arena=arena)
+                    stream = fx.get_seq_chunks(path, chunk_size=chunk_reads, byte_range=byte_range, first_chunk=1 << 17, arena=arena,
+                                               schedule=schedule)
                 for c in stream:
                     q.put(c)
                 q.put(None)
@@ -280,7 +281,11 @@ class Predictor:
             tag = "rd_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getpid())
             arenas = [fx.ShmArena("%s_f%d" % (tag, i)) for i in range(len(self.input))]
             self._arenas += arenas
-        qs = [self._reader_queue(p, chunk_reads, byte_range=r, arena=a) for p, r, a in zip(self.input, ranges, arenas)]
+        schedule = None
+        if len(self.input) == 2 and not shared and not any(fx.file_info(p)[1] for p in self.input):
+            # plain mate files: one schedule of chunk sizes for both readers (small first AND last chunks), from the first file
+            schedule = fx.chunk_schedule(self.input[0], chunk_reads, byte_range=ranges[0]) or None
+        qs = [self._reader_queue(p, chunk_reads, byte_range=r, arena=a, schedule=schedule) for p, r, a in zip(self.input, ranges, arenas)]
         while True:
             cs = []
             err = None

@@ -497,3 +497,28 @@ def test_parallel_segment_reader_equals_sequential(tmp_path, workers):
     open(bad, "w").write("@a\nAC\n+\nII\n" * 4000 + "@b\nAC\n+\n")          # truncated last record
     with pytest.raises(ValueError, match="truncated"):
         recs(fx.get_seq_chunks_parallel(bad, chunk_size=300, workers=workers, first_chunk=16))
+
+
+def test_chunk_schedule_pairs_up_mate_files(tmp_path):
+    """fx.chunk_schedule: ONE list of chunk sizes for both mate readers - small first and last chunks, chunk_size in between - so
+    that chunk i of R1 and chunk i of R2 hold the same records whatever their byte sizes; the records are those of the plain
+    sequential read; a schedule that ends early (the record count is an estimate) is continued with small chunks"""
+    rng = np.random.default_rng(4)
+    r1, r2 = str(tmp_path / "s_1.fq"), str(tmp_path / "s_2.fq")
+    n = 30000
+    with open(r1, "w") as f1, open(r2, "w") as f2:
+        for i in range(n):
+            L1, L2 = int(rng.integers(30, 150)), int(rng.integers(30, 150))
+            f1.write("@r%d/1\n%s\n+\n%s\n" % (i, "A" * L1, "I" * L1))
+            f2.write("@r%d/2 %s\n%s\n+\n%s\n" % (i, "x" * int(rng.integers(0, 90)), "C" * L2, "I" * L2))
+    for chunk, first in ((4096, 256), (1 << 20, 512), (100, 100)):
+        sched = fx.chunk_schedule(r1, chunk, first_chunk=first)
+        assert sched and sched[0] == min(first, chunk) and max(sched) <= chunk and sched[-1] <= max(sched)
+        assert abs(sum(sched) - n) < 0.1 * n                                       # an estimate from the head of the file
+        c1 = [len(c.seq_len) for c in fx.get_seq_chunks(r1, chunk, schedule=sched)]
+        c2 = [len(c.seq_len) for c in fx.get_seq_chunks(r2, chunk, schedule=sched)]
+        assert c1 == c2 and sum(c1) == n
+        assert c1[:len(sched) - 1] == sched[:len(c1)][:len(sched) - 1][:len(c1[:len(sched) - 1])]   # the schedule is followed while the file lasts
+    short = [len(c.seq_len) for c in fx.get_seq_chunks(r1, 4096, schedule=[1000, 500])]        # ends early: chunks of its last entry
+    assert short[:2] == [1000, 500] and set(short[2:-1]) == {500} and sum(short) == n
+    assert fx.chunk_schedule(str(tmp_path / "s_1.fq"), 4096, byte_range=(0, 0)) == []
