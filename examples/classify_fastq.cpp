@@ -74,6 +74,16 @@ int main(int argc, char **argv) {
     rd_weights w = {t[0].data(), t[1].data(), t[2].data(), t[3].data(), t[4].data(), t[5].data(), t[6].data(), t[7].data(), t[8].data(), t[9].data(), 4, 128, 2};
     rd_model *model = nullptr;
     RD_CHECK(rd_model_create(&w, 0, &model));
+    // optional: the prefix-state table (include/ribodetector_amd.h) - the recurrence state after every sequence of k bases in
+    // caller-owned memory, built in milliseconds; reads then start k steps in with the same logits. Here k = 10: 1 GiB.
+    void *d_table = nullptr, *d_scratch = nullptr;
+    const int prefix_k = getenv("RD_PREFIX_K") ? atoi(getenv("RD_PREFIX_K")) : 10;
+    if (prefix_k) {
+        HIP_OK(hipMalloc(&d_table, rd_prefix_table_bytes(prefix_k)));
+        HIP_OK(hipMalloc(&d_scratch, rd_prefix_scratch_bytes(prefix_k)));
+        RD_CHECK(rd_set_prefix_table(model, prefix_k, d_table, rd_prefix_table_bytes(prefix_k), d_scratch, rd_prefix_scratch_bytes(prefix_k), nullptr));
+        HIP_OK(hipFree(d_scratch));   // only the build needs it
+    }
 
     // ---- read the file in chunks, classify each on the GPU ----
     rd_reader *reader = nullptr;
@@ -129,6 +139,7 @@ int main(int argc, char **argv) {
            (unsigned long long)c[0], (unsigned long long)c[1]);
     rd_reader_close(reader);
     rd_model_destroy(model);
+    if (d_table) hipFree(d_table);   // after the model that used it
     hipFree(d_arena); hipFree(d_off); hipFree(d_len); hipFree(d_logits); hipFree(d_labels); hipFree(d_ws); hipFree(d_counts);
     return 0;
 }
