@@ -307,7 +307,8 @@ int run_steps_and_buckets(const uint8_t *arena, const int64_t *seq_off, const in
     // one workgroup per CU at most: every workgroup ends with one global atomic per non-empty bin, and with fixed-length
     // reads they all hit the same bin
     int64_t nb = (n + 255) / 256;
-    if (nb > 256) nb = 256;
+    const int64_t nb_max = pk > 0 ? 2048 : 256;   // with a prefix table every read costs a (latency-bound) load of its first bases: more
+    if (nb > nb_max) nb = nb_max;                 // workgroups in flight; the few atomics per workgroup stay few
     hipLaunchKernelGGL(rd_steps_kernel, dim3((unsigned)nb), dim3(256), sh, st, arena, seq_off, seq_len, n, max_len, sem, steps, ghist, pk, pfx);
     hipLaunchKernelGGL(rd_bucket_scan_kernel, dim3(1), dim3(256), 0, st, ghist, max_len, cursor);
     int64_t nbs = (n + BK_ITEMS - 1) / BK_ITEMS;
