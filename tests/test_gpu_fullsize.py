@@ -1,10 +1,12 @@
 """BASELINE.json configs at their real per-GPU sizes, end to end through the `ribodetector` CLI (reference flow detect.py:464-499):
 synthetic FASTQ files built in tmpfs, the CLI's output files compared - read by read, in order - with ONE in-HBM classification of
 the same reads (bit-for-bit labels: every read is computed independently of batch and chunk boundaries), the counters compared,
-and a sample of the reads that straddle the chunk boundaries checked against the CPU oracle.
+and a sample of the reads around the multiples of the nominal chunk size checked against the CPU oracle. (Since round 3 the
+CLI's chunks hold ABOUT --chunk_size x batch records: small first and last chunks, byte segments for a single plain file,
+data_loader/fastx_parser.py; the comparison with one in-HBM classification covers every read whatever the cuts are.)
 
-    configs[1]  10 M single-end 100 bp, --chunk_size 256 -m 32  (chunks of 8,388,608 reads -> 2 chunks)
-    configs[2]  10 M pairs 100 bp, --ensure rrna                (chunks of 4,194,304 pairs -> 3 chunks)
+    configs[1]  10 M single-end 100 bp, --chunk_size 256 -m 32  (nominal chunks of 8,388,608 reads)
+    configs[2]  10 M pairs 100 bp, --ensure rrna                (nominal chunks of 4,194,304 pairs)
     configs[3]  per-GPU shard of 50 M pairs 150 bp on 8 GPUs: 6.25 M pairs, -l 150
     configs[4]  per-GPU shard of 100 M reads 40-300 bp on 8 GPUs: 12.5 M reads, -l 300 (length-bucketed)
 RD_FULLSIZE_SCALE (default 1.0) scales the read counts for quick runs."""
