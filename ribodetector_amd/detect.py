@@ -98,7 +98,8 @@ class Predictor:
         pk = kcfg.get('prefix_k', None)           # prefix-state table: absent = the model's default (RD_PREFIX_K or "auto")
         if pk is not None and pk != 'auto' and not (isinstance(pk, int) and (pk == 0 or 4 <= pk <= 13)):
             raise RuntimeError("config.json kernel.prefix_k must be \"auto\", 0 or an integer in [4, 13]; got %r" % (pk,))
-        return {"variant": variant, "semantics": sem, "refine": refine, "prefix_k": pk}
+        lazy = bool(getattr(self.args, 'lazy_mate', False) or kcfg.get('lazy_mate', False))
+        return {"variant": variant, "semantics": sem, "refine": refine, "prefix_k": pk, "lazy_mate": lazy}
 
     def prefix_k_for_input(self):
         """k of the prefix-state table that pays off for THIS run: a row saves k steps per read, level k costs 4^k one-step
@@ -150,6 +151,7 @@ class Predictor:
         # margin band of the float64 re-evaluation (config.json kernel.refine; 0 = off; default 2.5e-4). The CLI issues the pass
         # itself on a side stream (submit_chunk), so the one inside rd_classify is switched off.
         self.refine_band = kcfg["refine"]
+        self.lazy_mate = kcfg["lazy_mate"]
         self.model.set_refine(0.0)
         self.model.eval()
 
@@ -180,7 +182,20 @@ class Predictor:
         dev_in = [self._to_device(c, lo, hi, cs) for c in chunks]
         cur = torch.cuda.current_stream(self.device)
         cur.wait_stream(cs)
-        outs = [self.model.classify_bytes(a, o, l, self.len, want_labels=not self.is_paired) for a, o, l in dev_in]
+        # --lazy_mate (extension, off by default): under --ensure rrna a pair is rRNA only if BOTH mates are (reference
+        # detect.py:620-630), under norrna non-rRNA only if both are (:631-641) - so a first mate that says "non-rRNA" (resp. "rRNA")
+        # from outside the float64 band has decided its pair, and the second mate is given length 0: zero steps instead of 100.
+        # The pair labels, counters and files are those of the full evaluation; only the never-used logits of those mates differ.
+        lazy = self.lazy_mate and self.is_paired and self.args.ensure in ('rrna', 'norrna')
+        outs, use_in = [], list(dev_in)             # (dev_in stays referenced by the ticket: its tensors were allocated on the copy
+        for k, (a, o, l) in enumerate(dev_in):      # stream and must not return to that stream's pool while other streams read them)
+            if lazy and k == 1:
+                m = outs[0][0][:, 1] - outs[0][0][:, 0]
+                band = float(self.refine_band)
+                decided = (m <= -band) if self.args.ensure == 'rrna' else ((m >= band) if band > 0 else (m > 0))
+                l = torch.where(decided, torch.zeros_like(l), l)
+                use_in[1] = (a, o, l)
+            outs.append(self.model.classify_bytes(a, o, l, self.len, want_labels=not self.is_paired))
         main_done = torch.cuda.Event()
         main_done.record(cur)
         # post-pass on its own stream: it overlaps the recurrences of the next chunk (the float64 refine pass has the latency of
@@ -189,7 +204,7 @@ class Predictor:
         with torch.cuda.stream(post):
             post.wait_event(main_done)
             pair_none = self.is_paired and self.args.ensure == 'none'   # pair label = argmax of the SUMMED logits (detect.py:657)
-            for k, (a, o, l) in enumerate(dev_in):
+            for k, (a, o, l) in enumerate(use_in):
                 mate = outs[1 - k][0] if pair_none else None
                 self.model.refine(a, o, l, self.len, outs[k][0], outs[k][1], mate, thresh=self.refine_band)
             if self.is_paired:
@@ -204,7 +219,7 @@ class Predictor:
                 _, finish = rdist.gather_labels(labels, n, dst=0, bounds=bounds, async_op=True)
             done = torch.cuda.Event()
             done.record(post)
-        return {"n": n, "bounds": bounds, "labels": labels, "host": host, "finish": finish, "done": done, "keep": (dev_in, outs)}
+        return {"n": n, "bounds": bounds, "labels": labels, "host": host, "finish": finish, "done": done, "keep": (dev_in, use_in, outs)}
 
     def collect_chunk(self, tk):
         """Labels of a submitted chunk: int8 numpy on rank 0 (whole chunk, input order), None elsewhere."""
@@ -540,6 +555,9 @@ none: give label based on the mean probability of read pair.
     args.add_argument('--semantics', default=None, choices=['gpu', 'cpu'],
                       help='(extension) which reference product to reproduce for reads shorter than --len or ending in N:\n'
                            'gpu = ribodetector (packed sequences, default); cpu = ribodetector_cpu (zero-padded input).')
+    args.add_argument('--lazy_mate', action='store_true',
+                      help='(extension) with -e rrna / norrna: skip the second mate of a pair whose first mate has already decided\n'
+                           'the pair label (same labels, counters and output files; about half the GPU work on typical data).')
     args.add_argument('-v', '--version', action='version', version='%(prog)s {version}'.format(version=__version__))
     return args
 
