@@ -177,8 +177,7 @@ int rd_encode_onehot_padded(const uint8_t *arena, const int64_t *seq_off, const 
  *   rd_pack_plan: fills sorted_idx [dev] int64[n] (lengths descending, ties by input index), unsorted_idx [dev]
  *     int64[n], batch_sizes [dev] int64[max_len] (entries past the longest read are 0) and total_steps [dev]
  *     int64[1] = sum_i min(len_i,max_len).  workspace as for rd_classify. API parity only: rd_classify does NOT call it (it
- *     buckets by step count with atomics, order inside a bucket free); this stable sort keeps a single-workgroup scan
- *     (rd_len_scan_kernel, 127 us per 2^20 reads) because nothing on the product path waits for it.
+ *     buckets by step count with atomics, order inside a bucket free).
  *   rd_pack_onehot: writes data [dev] float[total_steps*4], time-major over the sorted reads. */
 int rd_pack_plan(const int32_t *seq_len, int64_t n, int32_t max_len, int64_t *sorted_idx, int64_t *unsorted_idx,
                  int64_t *batch_sizes, int64_t *total_steps, void *workspace, size_t workspace_bytes, void *stream);

@@ -9,7 +9,7 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 // length bucketing: order[] = read indices sorted by T = min(len,max_len) descending (pack_sequence's sort,
 // detect.py:685). Ties are ordered by input index (stable) so that the order is deterministic.
-// Three kernels: per-block histograms -> exclusive scan over (length desc, block asc) -> stable scatter.
+// Kernels: per-block histograms -> exclusive scan over (length desc, block asc) in three small launches -> stable scatter.
 // ------------------------------------------------------------------------------------------------
 constexpr int SORT_BLOCK = 256;
 constexpr int SORT_ITEMS = 2048;   // reads per block
@@ -30,22 +30,45 @@ __global__ void rd_len_hist_kernel(const int32_t *__restrict__ len, int64_t n, i
     for (int i = threadIdx.x; i <= max_len; i += blockDim.x) hist[(size_t)i * nblk + blockIdx.x] = sh[i];
 }
 
-// single block: exclusive scan of hist in the order (T descending, blk ascending); also per-length totals:
-// len_start[T] = first sorted position of length T; batch_sizes[t] = #reads with T > t; total_steps.
-// Each thread sums a contiguous run of the (max_len+1) x nblk counts, one 256-wide scan of the run sums, then each thread
-// rewrites its run (the first version walked the array 256 elements at a time: 202 dependent block scans, 186 us per 2^20 reads).
-__global__ __launch_bounds__(SORT_BLOCK) void rd_len_scan_kernel(uint32_t *__restrict__ hist, int max_len, int nblk,
-                                                                 int64_t *__restrict__ len_start, int64_t *__restrict__ batch_sizes,
-                                                                 int64_t *__restrict__ total_steps) {
+// Exclusive scan of hist in the order (T descending, blk ascending), in three small launches (rounds 1-2 did it in ONE workgroup:
+// 127 us per 2^20 reads - API parity only, but flagged twice): (1) one workgroup per length T scans its row of nblk counts in place
+// and leaves the row total; (2) one workgroup scans the max_len+1 row totals, longest first: len_start[T] = first sorted position of
+// length T, batch_sizes[t] = #reads with T > t (= len_start[t]: lengths are descending), total_steps; (3) the rows get their start.
+__global__ __launch_bounds__(SORT_BLOCK) void rd_len_rowscan_kernel(uint32_t *__restrict__ hist, int nblk, uint32_t *__restrict__ row_total) {
+    __shared__ uint32_t part[SORT_BLOCK];
+    const int tid = threadIdx.x;
+    uint32_t *row = hist + (size_t)blockIdx.x * nblk;
+    const int per = (nblk + SORT_BLOCK - 1) / SORT_BLOCK, e0 = tid * per, e1 = min(nblk, e0 + per);
+    uint32_t s = 0;
+    for (int e = e0; e < e1; ++e) s += row[e];
+    part[tid] = s;
+    __syncthreads();
+    for (int d = 1; d < SORT_BLOCK; d <<= 1) {
+        const uint32_t v = tid >= d ? part[tid - d] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[tid] - s;
+    for (int e = e0; e < e1; ++e) {
+        const uint32_t v = row[e];
+        row[e] = run;
+        run += v;
+    }
+    if (tid == SORT_BLOCK - 1) row_total[blockIdx.x] = part[tid];
+}
+
+__global__ __launch_bounds__(SORT_BLOCK) void rd_len_rowstart_kernel(const uint32_t *__restrict__ row_total, int max_len,
+                                                                     int64_t *__restrict__ len_start, int64_t *__restrict__ batch_sizes,
+                                                                     int64_t *__restrict__ total_steps) {
     __shared__ unsigned long long part[SORT_BLOCK];
     __shared__ unsigned long long wsum[SORT_BLOCK / 64];
-    const int tid = threadIdx.x;
-    const int64_t total = (int64_t)(max_len + 1) * nblk;
-    const int64_t per = (total + SORT_BLOCK - 1) / SORT_BLOCK;
-    const int64_t e0 = (int64_t)tid * per, e1 = e0 + per < total ? e0 + per : total;
-    auto at = [&](int64_t e) -> size_t { return (size_t)(max_len - (int)(e / nblk)) * nblk + (size_t)(e % nblk); };   // scan position -> hist index
+    const int tid = threadIdx.x, nb = max_len + 1, per = (nb + SORT_BLOCK - 1) / SORT_BLOCK;
     unsigned long long s = 0;
-    for (int64_t e = e0; e < e1; ++e) s += hist[at(e)];
+    for (int k = 0; k < per; ++k) {
+        const int e = tid * per + k;   // scan position e <-> T = max_len - e
+        if (e < nb) s += row_total[max_len - e];
+    }
     part[tid] = s;
     __syncthreads();
     for (int d = 1; d < SORT_BLOCK; d <<= 1) {
@@ -55,15 +78,14 @@ __global__ __launch_bounds__(SORT_BLOCK) void rd_len_scan_kernel(uint32_t *__res
         __syncthreads();
     }
     unsigned long long run = part[tid] - s;
-    for (int64_t e = e0; e < e1; ++e) {
-        const size_t i = at(e);
-        const uint32_t v = hist[i];
-        hist[i] = (uint32_t)run;   // n < 2^31
-        if ((e % nblk) == 0 && len_start) len_start[max_len - (int)(e / nblk)] = (int64_t)run;
-        run += v;
+    for (int k = 0; k < per; ++k) {
+        const int e = tid * per + k;
+        if (e < nb) {
+            len_start[max_len - e] = (int64_t)run;
+            run += row_total[max_len - e];
+        }
     }
     if (batch_sizes || total_steps) {
-        // reads with T > t occupy sorted positions [0, len_start[t]) because lengths are descending: batch_sizes[t] = len_start[t]
         __threadfence_block();
         __syncthreads();
         unsigned long long acc = 0;
@@ -81,6 +103,12 @@ __global__ __launch_bounds__(SORT_BLOCK) void rd_len_scan_kernel(uint32_t *__res
             *total_steps = (int64_t)t;
         }
     }
+}
+
+__global__ __launch_bounds__(SORT_BLOCK) void rd_len_rowadd_kernel(uint32_t *__restrict__ hist, int nblk, const int64_t *__restrict__ len_start) {
+    uint32_t *row = hist + (size_t)blockIdx.x * nblk;
+    const uint32_t base = (uint32_t)len_start[blockIdx.x];   // n < 2^31
+    for (int e = threadIdx.x; e < nblk; e += SORT_BLOCK) row[e] += base;
 }
 
 // stable scatter: one wave-serial pass per block keeps input order inside a length bucket.
@@ -283,8 +311,10 @@ int run_sort(const int32_t *seq_len, int64_t n, int max_len, void *workspace, si
     len_start = (int64_t *)(w + p.hist_bytes + p.order_bytes);
     const size_t sh = (size_t)(max_len + 1) * sizeof(uint32_t);
     hipLaunchKernelGGL(rd_len_hist_kernel, dim3(p.nblk), dim3(SORT_BLOCK), sh, st, seq_len, n, max_len, p.nblk, hist);
-    hipLaunchKernelGGL(rd_len_scan_kernel, dim3(1), dim3(SORT_BLOCK), 0, st, hist, max_len, p.nblk, len_start, batch_sizes,
-                       total_steps);
+    uint32_t *row_total = (uint32_t *)(len_start + (max_len + 1));              // second half of the lenstart area
+    hipLaunchKernelGGL(rd_len_rowscan_kernel, dim3(max_len + 1), dim3(SORT_BLOCK), 0, st, hist, p.nblk, row_total);
+    hipLaunchKernelGGL(rd_len_rowstart_kernel, dim3(1), dim3(SORT_BLOCK), 0, st, row_total, max_len, len_start, batch_sizes, total_steps);
+    hipLaunchKernelGGL(rd_len_rowadd_kernel, dim3(max_len + 1), dim3(SORT_BLOCK), 0, st, hist, p.nblk, len_start);
     hipLaunchKernelGGL(rd_len_scatter_kernel, dim3(p.nblk), dim3(SORT_BLOCK), sh, st, seq_len, n, max_len, p.nblk, hist, order,
                        sorted_idx, unsorted_idx);
     RD_HIP(hipGetLastError());
