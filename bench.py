@@ -585,17 +585,21 @@ def main():
         if world == 1 and not args.no_alt and PK:
             # the same steps without the prefix-state table (every read steps over all its bases)
             model.set_prefix_table(0)
-            model.profile_enable(True)
+            timed_path(1)                                  # same timed region as `value` (ii unless --resident-only), same step count
             sync()
+            model.profile_enable(True)
             t1 = time.perf_counter()
-            run_resident(4)
+            timed_path(args.steps)
             sync()
             d1 = time.perf_counter() - t1
             l2, k2 = model.profile_read()
             model.profile_enable(False)
             model.set_prefix_table(PK)
             a2 = flops_per_launch / (k2 / max(l2, 1) * 1e-3) / 1e12
-            out["alt_no_prefix_table"] = {"kernel": kname, "value": mult * P * 4 / d1, "unit": "reads/s", "steps": 4, "timed_region": "i",
+            out["alt_no_prefix_table"] = {"kernel": kname, "value": mult * P * args.steps / d1, "unit": "reads/s", "steps": args.steps,
+                                          "timed_region": "i" if args.resident_only else "ii",
+                                          "what": "the same timed region and steps as `value` with every read stepping over all its bases "
+                                                  "(k = 0): the rate and roofline to quote if the prefix-state table is not credited",
                                           "roofline": {"bound": "mfma", "achieved": a2, "peak": peak, "unit": "TFLOP/s", "frac": a2 / peak,
                                                        "avg_launch_ms": k2 / max(l2, 1)}}
         if world == 1 and not args.no_encoder:
