@@ -38,9 +38,30 @@ def test_bench_single_gpu_contract():
     assert j["config"]["timed_region"] == "ii" and j["config"]["kernel_only_reads_per_s"] > 1e6
     assert j["config"]["host_labels_nonzero_last_step"] > 0           # the labels really arrived in host memory
     assert j["ms_per_step"] >= 2 * rf["avg_launch_ms"] * 0.999        # a step = two launches of the recurrence kernel
+    # round 3: the prefix-state table is reported with what the MFMAs execute; timed region (iii) = the whole CLI on a FASTQ built
+    # from the same stream rides along (--no-alt here, so no alt_* records)
+    pt = j["config"]["prefix_table"]
+    assert pt["k"] in range(0, 14) and (pt["k"] == 0 or pt["bytes"] == (4 ** pt["k"] + 1) * 1024)
+    assert 0.8 < rf["steps_executed_over_steps"] <= 1.0 and (pt["k"] == 0) == (rf["steps_executed_over_steps"] == 1.0)
+    assert j["config"]["e2e_cli_reads_per_s"] > 1e5 and j["e2e_cli"]["records_per_file"] == 65536 and j["e2e_cli"]["files"] == 2
+    assert j["e2e_cli"]["calls"]["second_call"]["prefix_k"] == 8            # the CLI sizes its table by its input
+    assert 0 < j["config"]["host_cores_busy"] < 4
     enc = j["encoder"]["kernels"]
     assert set(enc) == {"rd_encode_codes_kernel", "rd_encode_onehot_padded_kernel", "rd_pack_onehot_kernel"}
     assert all(v["achieved"] > 50 for v in enc.values())
+
+
+def test_bench_reports_the_rate_without_the_prefix_table():
+    """alt_no_prefix_table: same timed region, same steps, k = 0 - lower rate, same roofline definition; alt_fp32_kernel rides along"""
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "4", "--warmup", "2", "--pairs-per-step", "524288", "--no-cpu-baseline",
+                        "--no-encoder", "--no-e2e", "--traffic", "off"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _line(r.stdout)
+    a = j["alt_no_prefix_table"]
+    assert j["config"]["prefix_table"]["k"] >= 4 and a["timed_region"] == "ii" and a["steps"] == 4
+    assert 0.75 * j["value"] < a["value"] < 1.02 * j["value"], (a["value"], j["value"])     # (wall clock over 4 steps: noisy)
+    assert a["roofline"]["avg_launch_ms"] > 1.05 * j["roofline"]["avg_launch_ms"]             # (hipEvents around the launches: not noisy)
+    assert j["alt_fp32_kernel"]["roofline"]["frac"] > 0.5
 
 
 def test_bench_self_launches_two_ranks_one_gpu():
