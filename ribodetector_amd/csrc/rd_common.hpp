@@ -103,7 +103,7 @@ struct rd_model {
     void *q_e[2];                  // RefineEntry[RD_REFINE_QCAP]
     uint32_t *q_count[2];
     int q_cur, q_calls, q_flushing[2];
-    struct { const void *p[5]; int64_t n; int max_len, sem; } q_pend[2][16];   // buffers of the calls whose candidates wait in queue x
+    struct { const void *p[5]; int64_t n; int max_len, sem; float thresh; } q_pend[2][16];   // buffers of the calls whose candidates wait in queue x
     int q_npend[2];
     // profiling of the recurrence kernel (bench.py roofline)
     int prof_enabled;

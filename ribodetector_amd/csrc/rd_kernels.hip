@@ -153,7 +153,7 @@ int rd_set_refine(rd_model *m, float thresh) {
     return RD_OK;
 }
 
-constexpr uint32_t RD_REFINE_QCAP = 8192;   // candidates a queue holds (what does not fit is evaluated inside rd_classify)
+constexpr uint32_t RD_REFINE_QCAP = 8192;   // candidates a queue holds (an overflow is caught by the second tier of rd_async_flush)
 
 static RefineQueue rd_queue(const rd_model *m, int x) { return RefineQueue{(RefineEntry *)m->q_e[x], m->q_count[x], RD_REFINE_QCAP}; }
 
@@ -167,7 +167,7 @@ static int rd_async_flush(rd_model *m, hipStream_t st, int x) {
         ReadBatch rb{(const uint8_t *)pd.p[0], (const int64_t *)pd.p[1], (const int32_t *)pd.p[2], nullptr, nullptr, pd.n, pd.max_len, pd.sem,
                      m->d.rev_tab, nullptr, nullptr, 0, RefineQueue{nullptr, nullptr, 0}, 0.0f};
         const int64_t nb = (pd.n + REFINE_SLICE - 1) / REFINE_SLICE;
-        hipLaunchKernelGGL(rd_refine_kernel, dim3((unsigned)nb), dim3(1024), 0, m->side, m->d, rb, (const float2 *)nullptr, m->refine_thresh,
+        hipLaunchKernelGGL(rd_refine_kernel, dim3((unsigned)nb), dim3(1024), 0, m->side, m->d, rb, (const float2 *)nullptr, pd.thresh,
                            (float *)pd.p[3], (uint8_t *)pd.p[4], rd_queue(m, x), (const uint32_t *)m->q_count[x]);
     }
     RD_HIP(hipGetLastError());
@@ -450,7 +450,7 @@ int rd_classify(const rd_model *cm, const uint8_t *arena, const int64_t *seq_off
         if (!deferred) return rd_refine_launch(m, rb, logits, labels, nullptr, m->refine_thresh, st);
         auto &pd = m->q_pend[m->q_cur][m->q_npend[m->q_cur]++];   // (the recurrence kernel's epilogue recorded the candidates)
         pd.p[0] = arena; pd.p[1] = seq_off; pd.p[2] = seq_len; pd.p[3] = logits; pd.p[4] = labels;
-        pd.n = n; pd.max_len = max_len; pd.sem = m->semantics;
+        pd.n = n; pd.max_len = max_len; pd.sem = m->semantics; pd.thresh = m->refine_thresh;
         m->q_calls++;
     }
     return RD_OK;
