@@ -325,6 +325,7 @@ def main():
     # prefix-state table: a read whose first k bases are A/C/G/T(U) starts from its table row, k steps in. The
     # algorithmic FLOPs above stay those of SURVEY §8d (every step of every read); what the MFMAs execute is counted separately.
     PK = model.prefix_k if variant == "mfma_f16x3_t32" else 0
+    bytes_survey = bytes_per_launch
     steps_full = torch.clamp(lens, max=MAXLEN).to(torch.int64)
     steps_exec = steps_full
     if PK:
@@ -332,7 +333,8 @@ def main():
         isb[[65, 67, 71, 84, 85]] = True
         first = isb[r1[0][0].view(P, RL)[:, :PK].long()].all(1) & (steps_full > PK)
         steps_exec = steps_full - PK * first.to(torch.int64)
-        bytes_per_launch += P * 1024.0                        # one table row per read
+        bytes_survey = bytes_per_launch                       # read bytes + index + results (113 B per 100 bp read)
+        bytes_per_launch += P * 1024.0                        # + ONE 1 KiB table row per read: what a start from the table costs
     exec_steps_frac = float(steps_exec.sum().item()) / float(steps_full.sum().item())
     nm = 2 if paired else 1
     # two sets of result buffers: the post-pass of step i (side stream) runs while the recurrences of step i+1 (main stream) write
@@ -561,6 +563,10 @@ def main():
                          "kernel": kname, "launches": launches, "avg_launch_ms": avg_ms,
                          "algorithmic_flops_per_launch": flops_per_launch,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "algorithmic_bytes_per_launch_without_table_rows": bytes_survey,
+                         "traffic_note": "traffic = read bytes + index + results (SURVEY 8d) + one 1 KiB prefix-state row per read that starts "
+                                         "from the table: rows read ONCE, no re-reads; they buy k of the T steps (alt_no_prefix_table: "
+                                         "137 MB per launch)" if PK else None,
                          "mfma_flops_executed_per_algorithmic_flop": MFMA_FLOPS_PER_ALGO_FLOP[base] * exec_steps_frac,
                          "mfma_pipe_frac": (achieved * MFMA_FLOPS_PER_ALGO_FLOP[base] * exec_steps_frac / peak) if achieved else None,
                          "steps_executed_over_steps": exec_steps_frac},
