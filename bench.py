@@ -4,9 +4,10 @@
 A "step" = one pass of the hot path over one batch of synthetic read pairs (timed region (ii)):
     read bytes in PINNED HOST memory -> H2D on a copy stream (double buffered: the bytes of step k+1 travel while step k
     computes) -> rd_classify(R1) + rd_classify(R2) (length bucketing, fused encoder, LSTM recurrence, FC, argmax)
-    -> rd_refine (float64 re-evaluation of the ~15 reads per million whose margin is inside the fp32 noise band)
+    -> float64 re-evaluation of the ~15 reads per million whose margin is inside the fp32 noise band (deferred pass: the recurrence
+       kernel's epilogue records them, rd_sync_results evaluates them, one workgroup each, beside the next step's recurrences)
     -> rd_pair_fuse(--ensure rrna) + counters -> D2H of the 1-byte pair labels into pinned host memory,
-    and for N>1 the RCCL gather of the labels to rank 0. The post-pass of a step (refine, fusion, D2H, gather) runs on a side
+    and for N>1 the RCCL gather of the labels to rank 0. The post-pass of a step (float64 pass, fusion, D2H, gather) runs on a side
     stream and overlaps the recurrences of the next step; everything is inside the timed region.
 Workload = BASELINE.json configs[2] ("10M paired-end 100 bp reads with --ensure rrna, 1 MI355X"): with the default
 --steps 10 x 1,048,576 pairs/step = 10.5 M pairs (21 M reads) are classified inside the timed region.
@@ -16,10 +17,12 @@ torch.distributed.run with N ranks (backend nccl = RCCL); launched under torchru
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus
   config.kernel_only_reads_per_s - timed region (i): the same steps with the read bytes already resident in HBM
-  roofline     - the recurrence kernel against the dense MFMA peak: algorithmic FLOPs (T*131072+1024 per read)
-                 / average launch duration measured with hipEvents on the launch stream inside the timed region
-                 (C ABI rd_profile_*); traffic = HBM bytes per launch from FETCH_SIZE/WRITE_SIZE collected by rocprofv3
-                 --pmc passes over a child run of this same command (gfx950 correction: FETCH_SIZE x2)
+  roofline     - the recurrence kernel against the dense MFMA peak: the algorithmic FLOPs of the steps the kernel EXECUTES
+                 (steps x 131072 + 1024 per read; the steps a prefix-state table row stands for are not counted -
+                 frac_counting_table_steps has them) / average launch duration measured with hipEvents on the launch stream inside
+                 the timed region (C ABI rd_profile_*); traffic = HBM bytes per launch from FETCH_SIZE/WRITE_SIZE collected by
+                 rocprofv3 --pmc passes over a child run of this same command (gfx950 correction: FETCH_SIZE x2), against SURVEY
+                 §8d's algorithmic bytes (113 B per 100 bp read) with the table rows and the 8-byte offsets listed separately
   encoder      - the standalone HBM-bound encoder kernels (reference tensor layouts): achieved GB/s against 8 TB/s
   cpu_baseline - the CPU oracle's restatement of ribodetector_cpu (padded BiLSTM over all L steps, batch 1024,
                  one batch per thread) timed on this box's host cores on a bounded sample of the same reads.
@@ -181,40 +184,97 @@ def shutil_free(path):
         return 0
 
 
-def e2e_record(torch, synth, arenas, offsets, lens, L, ensure):
+def gzip_file(src, dst, level=4):
+    """src -> dst as ONE gzip member (what a sequencer's .fastq.gz is: one DEFLATE stream). libdeflate when the box has it
+    (outside every timed region: the input of the gz -> gz measurement), zlib otherwise."""
+    import ctypes as C
+    import zlib
+    data = open(src, "rb").read()
+    try:
+        ld = C.CDLL("libdeflate.so.0")
+        ld.libdeflate_alloc_compressor.restype = C.c_void_p
+        ld.libdeflate_alloc_compressor.argtypes = [C.c_int]
+        ld.libdeflate_gzip_compress_bound.restype = C.c_size_t
+        ld.libdeflate_gzip_compress_bound.argtypes = [C.c_void_p, C.c_size_t]
+        ld.libdeflate_gzip_compress.restype = C.c_size_t
+        ld.libdeflate_gzip_compress.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        ld.libdeflate_free_compressor.argtypes = [C.c_void_p]
+        c = ld.libdeflate_alloc_compressor(level)
+        cap = ld.libdeflate_gzip_compress_bound(c, len(data))
+        buf = C.create_string_buffer(cap)
+        n = ld.libdeflate_gzip_compress(c, data, len(data), buf, cap)
+        ld.libdeflate_free_compressor(c)
+        if n == 0:
+            raise OSError("libdeflate_gzip_compress failed")
+        with open(dst, "wb") as fh:
+            fh.write(memoryview(buf)[:n])
+        return "libdeflate level %d" % level
+    except OSError:
+        co = zlib.compressobj(1, zlib.DEFLATED, 31)
+        with open(dst, "wb") as fh:
+            for i in range(0, len(data), 1 << 24):
+                fh.write(co.compress(data[i:i + (1 << 24)]))
+            fh.write(co.flush())
+        return "zlib level 1"
+
+
+def e2e_record(torch, synth, arenas, offsets, lens, L, ensure, timed_calls=1, gz=False):
     """Timed region (iii) of SURVEY §8d: the whole `ribodetector` CLI - detect.main(): model load (incl. building the prefix-state
     table), native FASTQ parse, H2D, kernels, label D2H, output write - on a FASTQ file (pair) built from the rank-0 stream of this
-    run in tmpfs, plain -> plain (the reference flow: detect.py:464-499). Two calls; the second one is reported (the first pays
-    one-off costs of the process: first pinned allocations, page cache)."""
+    run in tmpfs (the reference flow: detect.py:464-499). One warm call (it pays one-off costs of the process: first pinned
+    allocations, page cache), then `timed_calls` calls; the MEDIAN is reported. gz: the inputs are single-member .gz files and the
+    outputs are written as .gz (the reference compresses by extension at level 5, detect.py:729-741) - the form sequencer data
+    arrives in, bound by the host's inflate / deflate threads."""
     import shutil
     import tempfile
+    import threading
     from ribodetector_amd import detect
     d = tempfile.mkdtemp(prefix="rd_e2e_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     try:
         n = int(lens.numel())
-        ins = []
+        ins, how = [], None
         for m, a in enumerate(arenas):
             p = os.path.join(d, "r_%d.fq" % (m + 1))
             synth.fastq_image_torch(a, offsets, lens, mate=m + 1).cpu().numpy().tofile(p)
             ins.append(p)
-        outs = [os.path.join(d, "non_%d.fq" % (m + 1)) for m in range(len(ins))]
-        rrs = [os.path.join(d, "rrna_%d.fq" % (m + 1)) for m in range(len(ins))]
+        plain_bytes = sum(os.path.getsize(p) for p in ins)
+        if gz:
+            res = [None] * len(ins)
+
+            def comp(i):
+                res[i] = gzip_file(ins[i], ins[i] + ".gz")
+            ths = [threading.Thread(target=comp, args=(i,)) for i in range(len(ins))]
+            for t in ths:
+                t.start()
+            for t in ths:
+                t.join()
+            for p in ins:
+                os.remove(p)
+            ins, how = [p + ".gz" for p in ins], res[0]
+        ext = ".fq.gz" if gz else ".fq"
+        outs = [os.path.join(d, "non_%d%s" % (m + 1, ext)) for m in range(len(ins))]
+        rrs = [os.path.join(d, "rrna_%d%s" % (m + 1, ext)) for m in range(len(ins))]
         argv = ["-l", str(L), "-i", *ins, "-o", *outs, "-r", *rrs] + (["-e", ensure] if len(ins) == 2 else [])
-        rec = {}
-        for call in ("first_call", "second_call"):
+        calls = []
+        for call in range(1 + timed_calls):
             t0 = time.perf_counter()
             pr = detect.main(argv)
             dt = time.perf_counter() - t0
-            rec[call] = {"seconds": dt, "reads_per_s": len(ins) * n / dt, "main_thread_s": {k: round(v, 4) for k, v in pr._stage_s.items()},
-                         "load_model_s": round(pr.timing["load_model_s"], 4), "detect_s": round(pr.timing["detect_s"], 4),
-                         "prefix_k": pr.timing["prefix_k"], "reads_per_s_after_model_load": len(ins) * n / pr.timing["detect_s"]}
+            calls.append({"seconds": dt, "reads_per_s": len(ins) * n / dt, "main_thread_s": {k: round(v, 4) for k, v in pr._stage_s.items()},
+                          "load_model_s": round(pr.timing["load_model_s"], 4), "detect_s": round(pr.timing["detect_s"], 4),
+                          "prefix_k": pr.timing["prefix_k"], "reads_per_s_after_model_load": len(ins) * n / pr.timing["detect_s"]})
             del pr
+        timed = sorted(calls[1:], key=lambda c: c["seconds"])
+        med = timed[len(timed) // 2]
         out_bytes = sum(os.path.getsize(p) for p in outs + rrs)
-        return {"reads_per_s": rec["second_call"]["reads_per_s"], "seconds": rec["second_call"]["seconds"], "files": len(ins),
-                "reads_per_s_after_model_load": rec["second_call"]["reads_per_s_after_model_load"],
-                "records_per_file": n, "input_bytes": sum(os.path.getsize(p) for p in ins), "output_bytes": out_bytes,
-                "what": "whole detect.main() call on FASTQ in tmpfs, plain -> plain, default -t 10: model load + prefix table build + "
-                        "parse + H2D + kernels + D2H + write; second of two calls", "calls": rec}
+        return {"reads_per_s": med["reads_per_s"], "seconds": med["seconds"], "files": len(ins),
+                "reads_per_s_after_model_load": med["reads_per_s_after_model_load"], "timed_calls": timed_calls,
+                "spread": (timed[-1]["seconds"] - timed[0]["seconds"]) / med["seconds"],
+                "records_per_file": n, "input_bytes": sum(os.path.getsize(p) for p in ins), "plain_input_bytes": plain_bytes,
+                "output_bytes": out_bytes, "input_compressor": how,
+                "what": "whole detect.main() call on FASTQ in tmpfs, %s, default -t 10: model load + prefix table build + parse + H2D + "
+                        "kernels + D2H + write; median of %d call(s) after one warm call" % ("gz -> gz" if gz else "plain -> plain", timed_calls),
+                "warm_call": calls[0], "calls": calls[1:]}
     finally:
         shutil.rmtree(d, ignore_errors=True)
 
@@ -277,6 +337,8 @@ def main():
     ap.add_argument("--no-alt", action="store_true", help="skip the short extra measurement of the exact-fp32 MFMA kernel")
     ap.add_argument("--no-encoder", action="store_true", help="skip the standalone encoder kernels")
     ap.add_argument("--no-e2e", action="store_true", help="skip timed region (iii): the whole CLI on a FASTQ file built from the rank-0 stream")
+    ap.add_argument("--e2e-records", type=int, default=1 << 24,
+                    help="records per file of the long region-(iii) measurement (default 16 Mi; 0 = only the one-step batch)")
     ap.add_argument("--traffic", default="live", choices=["live", "off"],
                     help="live: collect FETCH_SIZE/WRITE_SIZE with rocprofv3 --pmc over a child run of this command (adds ~40 s)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
@@ -306,6 +368,7 @@ def main():
     model.load_state_dict(cfg.load_state_dict("mcc"))
     model.to(dev).eval()
     model.set_variant(args.variant)
+    model.set_prefix_table(os.environ.get("RD_PREFIX_K", "auto"))   # opt-in since round 4 (SeqModel.to() allocates nothing by itself)
     variant = "mfma_f16x3_t32" if args.variant == "auto" else args.variant
 
     P = args.pairs_per_step
@@ -320,22 +383,32 @@ def main():
         g = torch.Generator(device=dev)
         g.manual_seed(4 + rank)
         lens = torch.randint(40, 301, (P,), generator=g, device=dev, dtype=torch.int32)
-    flops_per_launch = float((torch.clamp(lens, max=MAXLEN).to(torch.float64) * 131072 + 1024).sum().item())
-    bytes_per_launch = float(lens.to(torch.float64).sum().item()) + P * (4 + 8 + 8 + 1)
-    # prefix-state table: a read whose first k bases are A/C/G/T(U) starts from its table row, k steps in. The
-    # algorithmic FLOPs above stay those of SURVEY §8d (every step of every read); what the MFMAs execute is counted separately.
-    PK = model.prefix_k if variant == "mfma_f16x3_t32" else 0
-    bytes_survey = bytes_per_launch
+    # FLOPs/read = T x 131072 + 1024 (forward recurrence + FC), bytes/read = T + 4 (len) + 8 (logits) + 1 (label).
+    # With a prefix-state table a read whose first k bases are A/C/G/T(U) starts from its table row, k steps in:
+    # those k steps are looked up, not computed. roofline.achieved counts the steps the kernel EXECUTES (what the MFMA pipe does);
+    # counting every step of every read (the table's steps as if computed) is reported beside it as *_counting_table_steps.
+    PK = model.prefix_k
     steps_full = torch.clamp(lens, max=MAXLEN).to(torch.int64)
-    steps_exec = steps_full
-    if PK:
+    def executed(pk):
+        """(steps the kernel executes per launch, table rows read per launch), averaged over the launches of the run's batches"""
+        if not pk:
+            return float(steps_full.sum().item()), 0.0
         isb = torch.zeros(256, dtype=torch.bool, device=dev)
         isb[[65, 67, 71, 84, 85]] = True
-        first = isb[r1[0][0].view(P, RL)[:, :PK].long()].all(1) & (steps_full > PK)
-        steps_exec = steps_full - PK * first.to(torch.int64)
-        bytes_survey = bytes_per_launch                       # read bytes + index + results (113 B per 100 bp read)
-        bytes_per_launch += P * 1024.0                        # + ONE 1 KiB table row per read: what a start from the table costs
-    exec_steps_frac = float(steps_exec.sum().item()) / float(steps_full.sum().item())
+        se, rr, nl = 0.0, 0.0, 0
+        for t in r1 + (r2 or []):
+            first = isb[t[0].view(P, RL)[:, :pk].long()].all(1) & (steps_full > pk)
+            se += float((steps_full - pk * first.to(torch.int64)).sum().item())
+            rr += float(first.sum().item())
+            nl += 1
+        return se / nl, rr / nl
+    steps_exec_sum, rows_read = executed(PK)
+    flops_all_steps = float(steps_full.sum().item()) * 131072 + 1024.0 * P
+    flops_per_launch = steps_exec_sum * 131072 + 1024.0 * P
+    bytes_survey = float(steps_full.sum().item()) + P * (4 + 8 + 1)       # SURVEY §8d: 113 B per 100 bp read
+    bytes_offsets = P * 8.0                                               # this ABI's int64 start offset per read (not in §8d's count)
+    bytes_table = rows_read * 1024.0                                      # ONE 1 KiB table row per read that starts from the table
+    exec_steps_frac = steps_exec_sum / float(steps_full.sum().item())
     nm = 2 if paired else 1
     # two sets of result buffers: the post-pass of step i (side stream) runs while the recurrences of step i+1 (main stream) write
     # the other set
@@ -346,8 +419,11 @@ def main():
     cur = torch.cuda.current_stream(dev)
     side = torch.cuda.Stream(dev)
     pipelined = not (args.inline_refine or args.pmc_child)   # counter passes: one stream, so that no other kernel runs beside the one counted
-    if pipelined:                                          # the float64 refine pass is issued by this script on the side stream
-        model.set_refine(0.0)
+    if pipelined:
+        # deferred float64 pass (C ABI rd_set_refine_async): the recurrence kernel's epilogue records the reads inside the noise band;
+        # rd_sync_results - called on the SIDE stream, in the step's post-pass - evaluates them, one workgroup each, on the model's
+        # stream beside the next step's recurrences. No scan launch over the logits (rounds 2-3 issued rd_refine here: 1.4 ms each).
+        model.set_refine_async(16)
     ev_post = [None, None]                                 # post-pass that last read result set k
 
     def compute(i, a1, a2, after=None):
@@ -366,15 +442,14 @@ def main():
         post = side if pipelined else cur
         with torch.cuda.stream(post):
             post.wait_event(ev_main)
+            if pipelined:
+                model.sync_results()                       # (current stream = the side stream: the main stream never waits)
             if paired:
-                pair_none = args.ensure == "none"
-                if pipelined or pair_none:
-                    model.refine(a1, offs, lens, MAXLEN, lg[0], None, lg[1] if pair_none else None)
-                    model.refine(a2, offs, lens, MAXLEN, lg[1], None, lg[0] if pair_none else None)
+                if args.ensure == "none":                  # pair margin decides (reference detect.py:657): the scan form, with the mate
+                    model.refine(a1, offs, lens, MAXLEN, lg[0], None, lg[1])
+                    model.refine(a2, offs, lens, MAXLEN, lg[1], None, lg[0])
                 lab = module_arch.pair_fuse(lg[0], lg[1], args.ensure, counts)
             else:
-                if pipelined:
-                    model.refine(a1, offs, lens, MAXLEN, lg[0], lab8)
                 module_arch.count_labels(lab8, counts)
                 lab = lab8.view(torch.int8)
             fin = after(lab) if after else None
@@ -555,43 +630,38 @@ def main():
                                                 "tests/test_gpu_prefix.py); alt_no_prefix_table = the same steps with k = 0"},
                        "refine": {"band": module_arch.SeqModel.REFINE_DEFAULT, "what": "reads whose margin is inside the band are "
                                   "re-evaluated in float64 (labels of the exact function); inside the timed region",
-                                  "placement": "side stream, overlapping the next step's recurrences" if pipelined else "inline in rd_classify"},
+                                  "placement": ("deferred (rd_set_refine_async): candidates recorded by the recurrence kernel's epilogue, "
+                                                "evaluated by rd_sync_results on the post-pass stream beside the next step's recurrences")
+                                  if pipelined else "inline in rd_classify"},
                        "label_counts": {"non_rrna": c[0], "rrna": c[1], "unclassified": c[2]},
                        "host_labels_nonzero_last_step": host_check},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": (achieved / peak) if achieved else None, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": kname, "launches": launches, "avg_launch_ms": avg_ms,
+                         "what": "achieved = algorithmic FLOPs of the steps the kernel EXECUTES (steps x 131072 + 1024 per read, SURVEY 8d) / "
+                                 "avg_launch_ms; the steps a prefix-state table row stands for are looked up, not computed, and are not "
+                                 "counted here (frac_counting_table_steps counts them: reads/s x SURVEY 8d FLOPs per read / peak)",
                          "algorithmic_flops_per_launch": flops_per_launch,
-                         "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "algorithmic_bytes_per_launch_without_table_rows": bytes_survey,
-                         "traffic_note": "traffic = read bytes + index + results (SURVEY 8d) + one 1 KiB prefix-state row per read that starts "
-                                         "from the table: rows read ONCE, no re-reads; they buy k of the T steps (alt_no_prefix_table: "
-                                         "137 MB per launch)" if PK else None,
-                         "mfma_flops_executed_per_algorithmic_flop": MFMA_FLOPS_PER_ALGO_FLOP[base] * exec_steps_frac,
-                         "mfma_pipe_frac": (achieved * MFMA_FLOPS_PER_ALGO_FLOP[base] * exec_steps_frac / peak) if achieved else None,
-                         "steps_executed_over_steps": exec_steps_frac},
+                         "algorithmic_flops_per_launch_counting_table_steps": flops_all_steps,
+                         "achieved_counting_table_steps": (flops_all_steps / (avg_ms * 1e-3) / 1e12) if launches else None,
+                         "frac_counting_table_steps": (flops_all_steps / (avg_ms * 1e-3) / 1e12 / peak) if launches else None,
+                         "steps_executed_over_steps": exec_steps_frac,
+                         "mfma_flops_executed_per_algorithmic_flop": MFMA_FLOPS_PER_ALGO_FLOP[base],
+                         "mfma_pipe_frac": (achieved * MFMA_FLOPS_PER_ALGO_FLOP[base] / peak) if achieved else None,
+                         "algorithmic_bytes_per_launch": bytes_survey,
+                         "table_bytes_per_launch": bytes_table,
+                         "offset_bytes_per_launch": bytes_offsets,
+                         "traffic_over_algorithmic": (traffic / bytes_survey) if traffic else None,
+                         "traffic_over_algorithmic_plus_table_and_offsets": (traffic / (bytes_survey + bytes_table + bytes_offsets)) if traffic else None,
+                         "traffic_note": "algorithmic_bytes_per_launch = SURVEY 8d (T + 4 + 8 + 1 B per read). The kernel also reads an 8-byte "
+                                         "start offset per read (this ABI's index) and, with the prefix-state table, ONE 1 KiB row per read "
+                                         "that starts from it (table_bytes_per_launch: ~9x the 8d bytes, read once, 40 GB/s of the 8 TB/s; "
+                                         "they buy k of the T steps - alt_no_prefix_table runs without them)" if PK else
+                                         "algorithmic_bytes_per_launch = SURVEY 8d (T + 4 + 8 + 1 B per read); + an 8-byte start offset per read"},
         }
-        if world == 1 and not args.no_alt and base != "mfma_f32":
-            # the same step on the exact-fp32 MFMA kernel (v_mfma_f32_16x16x4_f32), for the fp32-MFMA roofline of SURVEY §8d
-            model.set_variant("mfma_f32")
-            model.profile_enable(True)
-            sync()
-            t1 = time.perf_counter()
-            run_resident(2)
-            sync()
-            d1 = time.perf_counter() - t1
-            l2, k2 = model.profile_read()
-            model.profile_enable(False)
-            model.set_variant(args.variant)
-            a2 = flops_per_launch / (k2 / max(l2, 1) * 1e-3) / 1e12
-            out["alt_fp32_kernel"] = {"kernel": "rd_lstm_mfma_f32_kernel", "value": mult * P * 2 / d1, "unit": "reads/s", "steps": 2,
-                                      "timed_region": "i",
-                                      "roofline": {"bound": "mfma", "achieved": a2, "peak": PEAKS["mfma_f32"], "unit": "TFLOP/s",
-                                                   "frac": a2 / PEAKS["mfma_f32"], "avg_launch_ms": k2 / max(l2, 1)}}
-        if world == 1 and not args.no_alt and PK:
-            # the same steps without the prefix-state table (every read steps over all its bases)
-            model.set_prefix_table(0)
-            timed_path(1)                                  # same timed region as `value` (ii unless --resident-only), same step count
+        def alt_run(label):
+            """the same timed region and step count as `value` with the model as it is configured now"""
+            timed_path(1)
             sync()
             model.profile_enable(True)
             t1 = time.perf_counter()
@@ -600,14 +670,39 @@ def main():
             d1 = time.perf_counter() - t1
             l2, k2 = model.profile_read()
             model.profile_enable(False)
+            return d1, k2 / max(l2, 1), l2
+
+        if world == 1 and not args.no_alt and base != "mfma_f32":
+            # the same steps on the exact-fp32 MFMA kernel (v_mfma_f32_16x16x4_f32) - the strict-precision line, against the fp32-MFMA
+            # roofline of SURVEY §8d. Same timed region and step count as `value`; the kernel has its own prefix-state table (round 4:
+            # set_variant rebuilds the table with the kernel that will use it), so the same steps are executed / looked up.
+            model.set_variant("mfma_f32")
+            pk32 = model.prefix_k
+            se32, _ = executed(pk32)
+            d1, ms32, l2 = alt_run("fp32")
+            model.set_variant(args.variant)
+            f_exec, pk_f = se32 * 131072 + 1024.0 * P, PEAKS["mfma_f32"]
+            out["alt_fp32_kernel"] = {"kernel": "rd_lstm_mfma_f32_kernel", "value": mult * P * args.steps / d1, "unit": "reads/s",
+                                      "steps": args.steps, "ms_per_step": 1e3 * d1 / args.steps,
+                                      "timed_region": "i" if args.resident_only else "ii", "dtype": "f32", "prefix_k": pk32,
+                                      "what": "the same timed region and steps as `value` on the exact-fp32 MFMA kernel with its own prefix-state "
+                                              "table: the line for a reader who does not credit the f16x3 split",
+                                      "roofline": {"bound": "mfma", "achieved": f_exec / (ms32 * 1e-3) / 1e12, "peak": pk_f, "unit": "TFLOP/s",
+                                                   "frac": f_exec / (ms32 * 1e-3) / 1e12 / pk_f, "avg_launch_ms": ms32, "launches": l2,
+                                                   "frac_counting_table_steps": flops_all_steps / (ms32 * 1e-3) / 1e12 / pk_f,
+                                                   "steps_executed_over_steps": se32 / float(steps_full.sum().item())}}
+        if world == 1 and not args.no_alt and PK:
+            # the same steps without the prefix-state table (every read steps over all its bases)
+            model.set_prefix_table(0)
+            d1, ms0, l2 = alt_run("k0")
             model.set_prefix_table(PK)
-            a2 = flops_per_launch / (k2 / max(l2, 1) * 1e-3) / 1e12
+            a2 = flops_all_steps / (ms0 * 1e-3) / 1e12
             out["alt_no_prefix_table"] = {"kernel": kname, "value": mult * P * args.steps / d1, "unit": "reads/s", "steps": args.steps,
-                                          "timed_region": "i" if args.resident_only else "ii",
+                                          "ms_per_step": 1e3 * d1 / args.steps, "timed_region": "i" if args.resident_only else "ii",
                                           "what": "the same timed region and steps as `value` with every read stepping over all its bases "
-                                                  "(k = 0): the rate and roofline to quote if the prefix-state table is not credited",
+                                                  "(k = 0): the rate to quote if the prefix-state table is not credited",
                                           "roofline": {"bound": "mfma", "achieved": a2, "peak": peak, "unit": "TFLOP/s", "frac": a2 / peak,
-                                                       "avg_launch_ms": k2 / max(l2, 1)}}
+                                                       "avg_launch_ms": ms0, "launches": l2}}
         if world == 1 and not args.no_encoder:
             try:
                 out["encoder"] = encoder_record(torch, N, dev, r1[0][0], offs, lens, P, MAXLEN)
@@ -615,20 +710,36 @@ def main():
                 out["encoder"] = {"error": repr(e)}
         if world == 1 and not args.no_e2e and not multi:
             try:
+                # the batch of one step: the pipeline-fill-bound point (a 2 M-read input is 0.15 s of CLI)
                 ne = min(P, 1 << 20)
                 e2e = e2e_record(torch, synth, [r1[0][0][: ne * RL]] + ([r2[0][0][: ne * RL]] if paired else []),
                                  r1[0][1][: ne + 1], lens[:ne].contiguous(), MAXLEN, args.ensure)
-                out["config"]["e2e_cli_reads_per_s"] = e2e["reads_per_s"]
-                out["e2e_cli"] = e2e
-                # the same on all the slices of the stream (4 x the records): less of the call is pipeline fill and drain
-                free_shm = shutil_free("/dev/shm")
-                if nslices > 1 and ne == P and free_shm > 6 * nslices * nm * P * (2 * RL + 20):
-                    offs_l = torch.arange(nslices * P + 1, dtype=torch.int64, device=dev) * RL
-                    lens_l = lens.repeat(nslices)
-                    big = e2e_record(torch, synth, [torch.cat([t[0] for t in r1])] + ([torch.cat([t[0] for t in r2])] if paired else []),
-                                     offs_l, lens_l, MAXLEN, args.ensure)
-                    out["e2e_cli"]["large"] = {k: big[k] for k in ("reads_per_s", "seconds", "records_per_file", "reads_per_s_after_model_load", "calls")}
-                    out["config"]["e2e_cli_large_reads_per_s"] = big["reads_per_s"]
+                out["e2e_cli"] = {"one_step_batch": e2e}
+                # long enough to be a number: every slice of the stream, repeated up to 16 Mi records per file (>= 1.5 s of CLI);
+                # median of three calls after a warm one. Then the same flow gz -> gz on the un-repeated slices.
+                if nslices > 1 and ne == P and args.e2e_records > 0:
+                    free_shm = shutil_free("/dev/shm")
+                    rec_bytes = nm * (2 * RL + 20)
+                    rep = max(1, args.e2e_records // (nslices * P))
+                    while rep > 1 and free_shm < 2.6 * rep * nslices * P * rec_bytes:
+                        rep //= 2
+                    if free_shm > 2.6 * rep * nslices * P * rec_bytes:
+                        nbig = rep * nslices * P
+                        offs_l = torch.arange(nbig + 1, dtype=torch.int64, device=dev) * RL
+                        big = e2e_record(torch, synth, [torch.cat([t[0] for t in r1] * rep)] + ([torch.cat([t[0] for t in r2] * rep)] if paired else []),
+                                         offs_l, lens.repeat(rep * nslices), MAXLEN, args.ensure, timed_calls=3)
+                        out["e2e_cli"]["large"] = big
+                        out["e2e_cli"].update({k: big[k] for k in ("reads_per_s", "seconds", "records_per_file", "files", "spread", "what")})
+                        out["config"]["e2e_cli_reads_per_s"] = big["reads_per_s"]
+                        ng = nslices * P
+                        gzr = e2e_record(torch, synth, [torch.cat([t[0] for t in r1])] + ([torch.cat([t[0] for t in r2])] if paired else []),
+                                         offs_l[: ng + 1], lens.repeat(nslices), MAXLEN, args.ensure, timed_calls=2, gz=True)
+                        out["e2e_cli"]["gz_to_gz"] = gzr
+                        out["e2e_cli"]["gz_to_gz_reads_per_s"] = gzr["reads_per_s"]
+                        out["config"]["e2e_cli_gz_to_gz_reads_per_s"] = gzr["reads_per_s"]
+                if "reads_per_s" not in out["e2e_cli"]:
+                    out["e2e_cli"].update({k: e2e[k] for k in ("reads_per_s", "seconds", "records_per_file", "files", "spread", "what")})
+                    out["config"]["e2e_cli_reads_per_s"] = e2e["reads_per_s"]
             except Exception as e:
                 out["e2e_cli"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1 and args.workload in ("pe100", "se100"):

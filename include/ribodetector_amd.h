@@ -105,6 +105,10 @@ int rd_set_semantics(rd_model *m, int semantics);
  * A call's logits / labels are final, and its input buffers may be overwritten, for work issued on the caller's stream
  *   (a) after the K-th call that follows it has been issued (K = 1: after the next call), or
  *   (b) after rd_sync_results(m, stream) - which evaluates whatever waits, on the model's stream, and makes `stream` wait for it.
+ *       `stream` need not be the stream the calls were issued on, as long as it is ordered behind them (an event): a pipelined
+ *       caller gives its post-processing stream, so that the evaluation and what consumes it (pair fusion, label D2H) run beside the
+ *       next batch's recurrences while the calls' own stream never waits (bench.py and the CLI do, since round 4). Calls issued
+ *       after it record into the model's other queue. All rd_classify calls of a model in this mode go to ONE stream.
  * Until then the buffers of those calls must stay as they are: a streaming caller cycles K + 1 sets of buffers and consumes the
  * results of a call K calls later (what the reference's loop cannot do: it synchronises on .tolist() every batch, reference
  * detect.py:288,481). A call that passes a pointer of a waiting call, or overlapping output ranges, is detected and synchronises
@@ -118,7 +122,7 @@ int rd_sync_results(rd_model *m, void *stream);
 int rd_refine(const rd_model *m, const uint8_t *arena, const int64_t *seq_off, const int32_t *seq_len, int64_t n,
               int32_t max_len, float *logits, uint8_t *labels, const float *mate_logits, float thresh, void *stream);
 
-/* Prefix-state table of the default kernel (an extension; nothing in the reference to replace - its cuDNN call steps over every
+/* Prefix-state table (an extension; nothing in the reference to replace - its cuDNN call steps over every
  * base, reference model/model.py:33). The forward recurrence is a pure function of the bases read so far, and there are only 4^k
  * sequences of k bases: row p of the table is the recurrence state (h as the kernel's two fp16 arrays, the cell state in fp32;
  * 1 KiB) after the k bases whose base-4 number is p, computed by the classifying kernel itself, so that a read whose first k bases
@@ -130,7 +134,10 @@ int rd_refine(const rd_model *m, const uint8_t *arena, const int64_t *seq_off, c
  *   rd_set_prefix_table: builds the table for the model's weights into caller-owned `table` (256-byte aligned, >= that many
  *     bytes; it must stay allocated until the model is destroyed or another / no table is set) and attaches it: k launches, level
  *     j = the states after every j-base prefix from level j-1 by ONE step (4/3 4^k steps in all: 15 ms at k = 12). k = 0 (pointers
- *     may be NULL) detaches. Synchronous on `stream`. Only RD_VARIANT_MFMA_F16X3_T32 uses the table; the other kernels ignore it.
+ *     may be NULL) detaches. Synchronous on `stream`. The rows are the state of the kernel that builds them - the model's CURRENT
+ *     variant: RD_VARIANT_MFMA_F16X3_T32 (h as two fp16 arrays + fp32 cell state) or RD_VARIANT_MFMA_F32 (h and c in fp32; same 1 KiB,
+ *     same addressing); RD_VARIANT_SIMPLE has none (RD_E_UNSUPPORTED). rd_classify uses the table only while the model's variant is
+ *     the one that built it (after rd_set_variant to another kernel the reads run all their steps until the table is rebuilt).
  *   rd_prefix_k: k of the attached table, 0 if none. */
 #define RD_PREFIX_K_MIN 4
 #define RD_PREFIX_K_MAX 13

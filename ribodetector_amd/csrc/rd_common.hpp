@@ -94,6 +94,7 @@ struct rd_model {
     float refine_thresh;  // margin below which a read is re-evaluated in float64 (rd_refine.hpp); 0 = off
     int prefix_k;         // bases covered by a row of the attached prefix-state table (0 = none attached)
     const uint8_t *ptab;  // the table (caller-owned memory, rd_set_prefix_table), (4^prefix_k + 1) rows of 1 KiB
+    int ptab_variant;     // the kernel whose state the rows hold (the variant that was current when the table was built)
     DevModel d;
     // deferred float64 pass (rd_set_refine_async, rd_kernels.hip): the candidates of refine_async consecutive calls are recorded
     // in a device queue and evaluated together on a stream the model owns; two queues alternate
@@ -103,6 +104,7 @@ struct rd_model {
     void *q_e[2];                  // RefineEntry[RD_REFINE_QCAP]
     uint32_t *q_count[2];
     int q_cur, q_calls, q_flushing[2];
+    int q_wait[2];                 // a flush of queue x has been issued: whoever records into x next waits for ev_join[x] first
     struct { const void *p[5]; int64_t n; int max_len, sem; float thresh; } q_pend[2][16];   // buffers of the calls whose candidates wait in queue x
     int q_npend[2];
     // profiling of the recurrence kernel (bench.py roofline)

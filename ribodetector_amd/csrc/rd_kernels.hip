@@ -174,6 +174,18 @@ static int rd_async_flush(rd_model *m, hipStream_t st, int x) {
     RD_HIP(hipMemsetAsync(m->q_count[x], 0, sizeof(uint32_t), m->side));
     RD_HIP(hipEventRecord(m->ev_join[x], m->side));
     m->q_flushing[x] = 1;
+    m->q_wait[x] = 1;
+    return RD_OK;
+}
+
+// queue x is about to take the candidates of a call issued on `st`: its last flush (and the reset of its counter) comes first. The
+// stream that joined that flush has waited already; a rd_sync_results on ANOTHER stream (a caller's post-processing stream) has not
+// ordered `st` behind it - the flush is long finished by then (it takes 0.3 ms, a recurrence launch tens), this makes it formal.
+static int rd_async_acquire(rd_model *m, hipStream_t st, int x) {
+    if (m->q_wait[x]) {
+        RD_HIP(hipStreamWaitEvent(st, m->ev_join[x], 0));
+        m->q_wait[x] = 0;
+    }
     return RD_OK;
 }
 
@@ -195,6 +207,7 @@ int rd_sync_results(rd_model *m, void *stream) {
     if (m->q_calls > 0) {
         rc = rd_async_flush(m, st, m->q_cur);
         if (rc) return rc;
+        m->q_cur ^= 1;   // calls issued from here on (on whatever stream) record into the other queue while this one is evaluated
         m->q_calls = 0;
     }
     for (int x = 0; x < 2 && !rc; ++x) rc = rd_async_join(m, st, x);
@@ -274,8 +287,11 @@ int rd_set_prefix_table(rd_model *m, int32_t k, void *table, size_t table_bytes,
     if (k == 0) {
         m->prefix_k = 0;
         m->ptab = m->d.zero_row;
+        m->ptab_variant = 0;
         return RD_OK;
     }
+    if (m->variant != RD_VARIANT_MFMA_F16X3_T32 && m->variant != RD_VARIANT_MFMA_F32)
+        RD_FAIL(RD_E_UNSUPPORTED, "rd_set_prefix_table: kernel variant %d has no prefix-state table (mfma_f16x3_t32 and mfma_f32 do)", m->variant);
     const size_t need = rd_prefix_table_bytes(k), need_s = rd_prefix_scratch_bytes(k);
     if (!need) RD_FAIL(RD_E_INVALID, "rd_set_prefix_table: k=%d out of range [%d,%d] (or 0 = none)", k, RD_PREFIX_K_MIN, RD_PREFIX_K_MAX);
     if (!table || ((uintptr_t)table & 255) || !scratch || ((uintptr_t)scratch & 255))
@@ -292,7 +308,11 @@ int rd_set_prefix_table(rd_model *m, int32_t k, void *table, size_t table_bytes,
         const int64_t rows = (int64_t)1 << (2 * j);
         ReadBatch rb{nullptr, nullptr, nullptr, nullptr, nullptr, rows, 1, RD_SEM_PACKED, nullptr, prev, nullptr, j,
                      RefineQueue{nullptr, nullptr, 0}, 0.0f};
-        hipLaunchKernelGGL(rd_lstm_mfma_f16x3_t32_kernel<true>, dim3((unsigned)((rows + 63) / 64)), dim3(256), 0, st, m->d, rb, (float *)dst, (uint8_t *)nullptr);
+        const dim3 grid((unsigned)((rows + 63) / 64)), blk(256);
+        if (m->variant == RD_VARIANT_MFMA_F32)   // the rows are the state of the kernel that builds them: each kernel its own table
+            hipLaunchKernelGGL((rd_lstm_mfma_f32_kernel<2, 0, 0, true>), grid, blk, 0, st, m->d, rb, (float *)dst, (uint8_t *)nullptr);
+        else
+            hipLaunchKernelGGL(rd_lstm_mfma_f16x3_t32_kernel<true>, grid, blk, 0, st, m->d, rb, (float *)dst, (uint8_t *)nullptr);
         prev = dst;
     }
     RD_HIP(hipGetLastError());
@@ -300,6 +320,7 @@ int rd_set_prefix_table(rd_model *m, int32_t k, void *table, size_t table_bytes,
     RD_HIP(hipStreamSynchronize(st));
     m->prefix_k = k;
     m->ptab = tab;
+    m->ptab_variant = m->variant;
     return RD_OK;
 }
 
@@ -380,13 +401,15 @@ int rd_classify(const rd_model *cm, const uint8_t *arena, const int64_t *seq_off
             if (rc0) return rc0;
             join_after_launch = old;
         }
+        int rc1 = rd_async_acquire(m, st, m->q_cur);
+        if (rc1) return rc1;
     }
     if (m->semantics == RD_SEM_PADDED && m->rev_tab_len != max_len) {   // (after the block above: candidates of another max_len that
         hipLaunchKernelGGL(rd_revtab_kernel, dim3(1), dim3(512), 0, st, m->d, max_len);   // still waited have been evaluated by now)
         m->rev_tab_len = max_len;
     }
     int32_t *steps = nullptr, *order = nullptr, *pfx = nullptr;
-    const int pk = m->variant == RD_VARIANT_MFMA_F16X3_T32 ? m->prefix_k : 0;      // the table holds THAT kernel's state
+    const int pk = m->variant == m->ptab_variant ? m->prefix_k : 0;      // the rows hold the state of the kernel that built them
     int rc = run_steps_and_buckets(arena, seq_off, seq_len, n, max_len, m->semantics, workspace, workspace_bytes, steps, order, pk, pfx, st);
     if (rc) return rc;
     ReadBatch rb{arena, seq_off, seq_len, steps, order, n, max_len, m->semantics, m->d.rev_tab, pk > 0 ? m->ptab : m->d.zero_row, pfx, pk,

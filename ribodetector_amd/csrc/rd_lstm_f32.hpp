@@ -31,8 +31,37 @@ struct __attribute__((aligned(16))) LstmSmem {
     int Lr[BT];       // readable bytes of the read = min(len, max_len)
     long long off[BT];
     int orig[BT];
+    int k0[BT];       // bases of the read covered by its prefix-table row (0 or pk)
+    int prow[BT];     // the table row the read starts from
     int tmax;
 };
+
+// Prefix-state table of THIS kernel (round 4; the default kernel's is described in rd_lstm_t32.hpp / DESIGN.md §3.9): a row is the
+// state as this kernel holds it - h fp32[128] | c fp32[128], 1 KiB, same addressing as the default kernel's rows - so that a start
+// from the table is the same bits as stepping over the bases. The rows of one model's table belong to the kernel that built it
+// (rd_set_prefix_table builds with the model's current variant; rd_classify uses the table only with that variant).
+__device__ __forceinline__ void rd_f32_load_h(LstmSmem &S, const uint8_t *ptab, int read) {   // thread (read, piece): 32 floats of h
+    const int piece = threadIdx.x & 3;
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(ptab + (size_t)S.prow[read] * PFX_ROW) + 8 * piece;
+    f32x4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = src[k];
+    f32x4 *dst = reinterpret_cast<f32x4 *>(&S.Hs[read >> 4][read & 15][32 * piece]);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) dst[k] = v[k];
+}
+__device__ __forceinline__ void rd_f32_load_c(LstmSmem &S, const uint8_t *ptab, int tile) {   // the lane's own 8 cells of the tile
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, l15 = lane & 15;
+    f32x4 a, b;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float *c = reinterpret_cast<const float *>(ptab + (size_t)S.prow[tile * 16 + 4 * q + r] * PFX_ROW + 512) + 32 * wave + l15;
+        a[r] = c[0];
+        b[r] = c[16];
+    }
+    S.cA[tile][tid] = a;
+    S.cB[tile][tid] = b;
+}
 
 __device__ __forceinline__ void rd_stage_codes(LstmSmem &S, const ReadBatch &rb, int chunk) {
     const int t0 = chunk * TC;
@@ -62,7 +91,9 @@ __device__ __forceinline__ float act_tanh(float x) {
 
 // ACT: 0 = compensated exp, 1 = plain v_exp_f32 forms (round 1), 2 = shared reciprocals (the product).  SCHED: 0 = compiler's own order, 1 = LDS reads of the gate math
 // pinned to the top of the phase + explicit MFMA/VALU interleave (sched_group_barrier).
-template <int ACT, int SCHED, int DIAG = 0>   // DIAG (bench diagnosis only, wrong results): 1 = no gate math, 2 = no MFMA
+// BUILD = true: the same code builds the table one level per launch (as rd_lstm_mfma_f16x3_t32_kernel<true> does): "read" g of level
+// rb.pk starts from row g >> 2 of the level below (rb.ptab), steps over base g & 3 and writes its state into row g of `logits`.
+template <int ACT, int SCHED, int DIAG = 0, bool BUILD = false>   // DIAG (bench diagnosis only, wrong results): 1 = no gate math, 2 = no MFMA
 __global__ __launch_bounds__(256, 1) void rd_lstm_mfma_f32_kernel(DevModel d, ReadBatch rb, float *__restrict__ logits,
                                                                   uint8_t *__restrict__ labels) {
     __shared__ LstmSmem S;
@@ -71,21 +102,27 @@ __global__ __launch_bounds__(256, 1) void rd_lstm_mfma_f32_kernel(DevModel d, Re
     const int q = lane >> 4, l15 = lane & 15;
 
     // ---- per-read metadata, zero state ---------------------------------------------------------
+    const int nz = BUILD ? 0 : (rb.pk > 0 ? 1 << (2 * rb.pk) : 0);   // the zero row (without a table: row 0 of the model's one-row table)
     if (tid < BT) {
         const int64_t g = (int64_t)blockIdx.x * BT + tid;
-        int T = 0, lr = 0, orig = -1;
+        int T = 0, lr = 0, orig = -1, k0 = 0, prow = nz;
         long long off = 0;
-        if (g < rb.n) {
+        if (BUILD) {
+            if (g < rb.n) { orig = (int)g; T = 1; lr = 1; if (rb.pk > 1) prow = (int)(g >> 2); }
+        } else if (g < rb.n) {
             orig = rb.order ? rb.order[g] : (int)g;
             T = rd_T(rb.steps, orig, rb.max_len);
             lr = rd_T(rb.len, orig, rb.max_len);
             off = rb.off[orig];
+            if (rb.pfx) {
+                prow = rb.pfx[orig];
+                if (prow != nz) { k0 = rb.pk; lr -= k0; off += k0; }   // the row covers the first pk bases (rd_steps_kernel took them off T)
+            }
         }
-        S.T[tid] = T; S.Lr[tid] = lr; S.off[tid] = off; S.orig[tid] = orig;
+        S.T[tid] = T; S.Lr[tid] = lr; S.off[tid] = off; S.orig[tid] = orig; S.k0[tid] = k0; S.prow[tid] = prow;
     }
     if (tid == 0) S.tmax = 0;
-    for (int i = tid; i < NT * 16 * HSTR; i += 256) { (&S.Hs[0][0][0])[i] = 0.0f; (&S.Hl[0][0][0])[i] = 0.0f; }
-    for (int i = tid; i < NT * 256; i += 256) { (&S.cA[0][0])[i] = f32x4{0, 0, 0, 0}; (&S.cB[0][0])[i] = f32x4{0, 0, 0, 0}; }
+    for (int i = tid; i < NT * 16 * HSTR; i += 256) (&S.Hl[0][0][0])[i] = 0.0f;
     for (int i = tid; i < 5 * G4; i += 256) {      // i = ((code*4 + w)*16 + l15)*8 + c
         const int c = i & 7, l = (i >> 3) & 15, w = (i >> 7) & 3, code = i >> 9;
         (reinterpret_cast<float *>(&S.lut[0][0][0][0]))[i] = d.in_lut[code * G4 + gate_col(w, c, l)];
@@ -93,7 +130,20 @@ __global__ __launch_bounds__(256, 1) void rd_lstm_mfma_f32_kernel(DevModel d, Re
     S.wout[tid >> 7][tid & 127] = d.w_out[(tid >> 7) * 256 + (tid & 127)];
     __syncthreads();
     if (tid < BT) atomicMax(&S.tmax, S.T[tid]);
-    rd_stage_codes(S, rb, 0);
+    // start state: the read's table row (the zero row without a table). Thread (read, piece) moves 128 B of h; a lane takes the cells
+    // it owns. Tile NT-1 is loaded AGAIN after the first phase: the dummy gate pass before t = 0 (ptile = NT-1, masked by `live`)
+    // writes a zero state there, which is harmless for a zero start and would wipe a loaded one.
+    rd_f32_load_h(S, rb.ptab, tid >> 2);
+#pragma unroll
+    for (int tl = 0; tl < NT; ++tl) rd_f32_load_c(S, rb.ptab, tl);
+    if (BUILD) {   // the one base of prefix g = its least significant base-4 digit
+        for (int idx = tid; idx < BT * TC; idx += 256) {
+            const int row = idx / TC, tt = idx % TC;
+            S.codes[0][tt][row] = (uint8_t)((tt == 0 && S.T[row] > 0) ? (int)(((int64_t)blockIdx.x * BT + row) & 3) : 4);
+        }
+    } else {
+        rd_stage_codes(S, rb, 0);
+    }
 
     // ---- resident weights: 8 column tiles x 32 k-steps, one f32 per lane each ------------------
     float Wr[8][32];
@@ -120,7 +170,7 @@ __global__ __launch_bounds__(256, 1) void rd_lstm_mfma_f32_kernel(DevModel d, Re
     for (int c = 0; c < 8; ++c) accP[c] = f32x4{0, 0, 0, 0};
     f32x4 hA[8];     // A fragments of the current phase: h[read l15][16m + 4q .. +3]
 #pragma unroll
-    for (int m = 0; m < 8; ++m) hA[m] = f32x4{0, 0, 0, 0};
+    for (int m = 0; m < 8; ++m) hA[m] = *reinterpret_cast<const f32x4 *>(&S.Hs[0][l15][16 * m + 4 * q]);
 
     int tile = 0, t = 0;          // current phase
     int ptile = NT - 1, pt = -1;  // previous phase (dummy before the first: its state update is masked to zero)
@@ -237,6 +287,10 @@ __global__ __launch_bounds__(256, 1) void rd_lstm_mfma_f32_kernel(DevModel d, Re
             }
         }
         if (DIAG != 3) __syncthreads();
+        if (p == 0 && (BUILD || rb.pfx)) {   // tile NT-1's start state, wiped by the dummy gate pass above (first read at p = NT-2)
+            if (wave == 3) rd_f32_load_h(S, rb.ptab, tid >> 2);
+            rd_f32_load_c(S, rb.ptab, NT - 1);
+        }
 #pragma unroll
         for (int c = 0; c < 8; ++c) accP[c] = acc[c];
 #pragma unroll
@@ -252,9 +306,37 @@ __global__ __launch_bounds__(256, 1) void rd_lstm_mfma_f32_kernel(DevModel d, Re
         S.Hl[0][l15][tid & 127] = sink;
         __syncthreads();
     }
-    // ---- epilogue: FC + reverse table + argmax ----------------------------------------------------
-    rd_fc_epilogue(
-        BT, [&](int row, int u) { return S.Hl[row >> 4][row & 15][u]; }, S.T, S.Lr, S.off, S.orig, &S.wout[0][0], d, rb, logits, labels);
+    if constexpr (BUILD) {   // row g of the level-rb.pk table <- the state after the step (layout: see rd_f32_load_h / _c)
+        uint8_t *tab = reinterpret_cast<uint8_t *>(logits);
+        const int64_t g0 = (int64_t)blockIdx.x * BT;
+        {
+            const int read = tid >> 2, piece = tid & 3;
+            if (g0 + read < rb.n) {
+                f32x4 *dst = reinterpret_cast<f32x4 *>(tab + (size_t)(g0 + read) * PFX_ROW) + 8 * piece;
+                const f32x4 *src = reinterpret_cast<const f32x4 *>(&S.Hs[read >> 4][read & 15][32 * piece]);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) dst[k] = src[k];
+            }
+        }
+#pragma unroll
+        for (int tl = 0; tl < NT; ++tl) {
+            const f32x4 a = S.cA[tl][tid], b = S.cB[tl][tid];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t g = g0 + tl * 16 + 4 * q + r;
+                if (g < rb.n) {
+                    float *c = reinterpret_cast<float *>(tab + (size_t)g * PFX_ROW + 512) + 32 * wave + l15;
+                    c[0] = a[r];
+                    c[16] = b[r];
+                }
+            }
+        }
+    } else {
+        // ---- epilogue: FC + reverse table + argmax ----------------------------------------------------
+        rd_fc_epilogue(
+            BT, [&](int row, int u) { return S.Hl[row >> 4][row & 15][u]; }, S.T, S.Lr, S.off, S.orig, &S.wout[0][0], d, rb, logits, labels,
+            S.k0);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

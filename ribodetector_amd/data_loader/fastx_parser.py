@@ -202,7 +202,24 @@ def _shm_layout(cap_n, cap_b):
 def _shm_views(path, cap_n, cap_b, create):
     import torch
     o_rs, o_so, o_sl, o_buf, total = _shm_layout(cap_n, cap_b)
-    mm = np.memmap(path, dtype=np.uint8, mode="w+" if create else "r+", shape=(total,))
+    if create:
+        # reserve the pages NOW: a sparse file in a full /dev/shm (Docker's default is 64 MB) would kill the process with SIGBUS at
+        # the first store past the capacity - no Python exception, no message to the other ranks. posix_fallocate fails with
+        # ENOSPC instead, which travels the parser-error path like any other exception.
+        import os
+        fd = os.open(path, os.O_CREAT | os.O_RDWR | os.O_TRUNC, 0o600)
+        try:
+            os.posix_fallocate(fd, 0, total)
+        except OSError as e:
+            os.close(fd)
+            try:
+                os.remove(path)
+            except OSError:
+                pass
+            raise OSError(e.errno, "shared-memory chunk slot %s (%d bytes): %s - set RD_SHARED_DECODE=0 (every rank decodes for itself) "
+                                   "or enlarge /dev/shm" % (path, total, os.strerror(e.errno)))
+        os.close(fd)
+    mm = np.memmap(path, dtype=np.uint8, mode="r+", shape=(total,))
     t = lambda a: torch.from_numpy(a)           # noqa: E731
     return (t(mm[o_buf:o_buf + cap_b]), t(mm[o_rs:o_rs + 8 * (cap_n + 1)].view(np.int64)), t(mm[o_so:o_so + 8 * cap_n].view(np.int64)),
             t(mm[o_sl:o_sl + 4 * cap_n].view(np.int32)))
@@ -246,6 +263,39 @@ class ShmArena:
             except OSError:
                 pass
         self.slots = []
+
+    SLOTS_PER_FILE = 6      # chunks in flight per input file: reader queue + GPU pipeline + writer queue
+
+    @classmethod
+    def fits(cls, nfiles, chunk_records, record_bytes):
+        """enough free space under the arena's directory for the slots a run will hold (with a margin)? Checked before the shared
+        decode is switched on; the slots themselves are fallocate'd, so a wrong estimate is an exception, not a SIGBUS."""
+        import os
+        import shutil
+        d = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
+        need = int(1.3 * cls.SLOTS_PER_FILE * nfiles * chunk_records * (record_bytes * 1.15 + 20))
+        try:
+            return shutil.disk_usage(d).free >= need, need
+        except OSError:
+            return False, need
+
+    @staticmethod
+    def sweep_stale(prefix="rd_"):
+        """remove slot files whose creating process is gone (tag = rd_<port>_<pid>_f<i>.<slot>): a run that was killed (SIGKILL, a
+        node reset) cannot clean up after itself, and the files are RAM"""
+        import os
+        import re
+        d = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
+        n = 0
+        for name in os.listdir(d):
+            m = re.match(r"rd_\d+_(\d+)_f\d+\.\d+$", name)
+            if m and not os.path.exists("/proc/%s" % m.group(1)):
+                try:
+                    os.remove(os.path.join(d, name))
+                    n += 1
+                except OSError:
+                    pass
+        return n
 
     _attached = {}
 

@@ -70,6 +70,46 @@ class Predictor:
         self._arenas = []                        # shared-memory chunk arenas of this rank (rank 0, gzip input, several ranks)
         self._part_files = []                    # this rank's part files of a sharded-parse run (removed if the run fails)
         self.sharded_parse = False               # several ranks, plain input: every rank parses its own byte range
+        self._shared = None                      # gzip input, several ranks of one node: one decode per node (decided once per run)
+        self._chunk_reads = None
+        self._install_cleanup()
+
+    # ---- cleanup ------------------------------------------------------------------------------------
+    def cleanup(self):
+        """what a run must not leave behind, whichever way it ends: the shared-memory chunk slots (they are RAM) and this rank's
+        '<out>.partN' / '<out>.joining' files"""
+        self._close_arenas()
+        for f in self._part_files:
+            try:
+                os.remove(f)
+            except OSError:
+                pass
+        self._part_files = []
+
+    def _install_cleanup(self):
+        """atexit + SIGTERM: when ANOTHER rank fails, torch.distributed.run sends this one SIGTERM - the default action would end the
+        process without running any Python, and rank 0's slot files would stay in /dev/shm until the node reboots"""
+        import atexit
+        import signal
+        import weakref
+        ref = weakref.ref(self)
+
+        def run():
+            me = ref()
+            if me is not None:
+                me.cleanup()
+        atexit.register(run)
+        if threading.current_thread() is threading.main_thread():
+            prev = signal.getsignal(signal.SIGTERM)
+
+            def on_term(signum, frame):
+                run()
+                signal.signal(signal.SIGTERM, prev if callable(prev) or prev in (signal.SIG_DFL, signal.SIG_IGN) else signal.SIG_DFL)
+                os.kill(os.getpid(), signal.SIGTERM)
+            try:
+                signal.signal(signal.SIGTERM, on_term)
+            except (ValueError, OSError):
+                pass
 
     # ---- model -------------------------------------------------------------------------------------
     def get_state_dict(self):
@@ -98,8 +138,7 @@ class Predictor:
         pk = kcfg.get('prefix_k', None)           # prefix-state table: absent = the model's default (RD_PREFIX_K or "auto")
         if pk is not None and pk != 'auto' and not (isinstance(pk, int) and (pk == 0 or 4 <= pk <= 13)):
             raise RuntimeError("config.json kernel.prefix_k must be \"auto\", 0 or an integer in [4, 13]; got %r" % (pk,))
-        lazy = bool(getattr(self.args, 'lazy_mate', False) or kcfg.get('lazy_mate', False))
-        return {"variant": variant, "semantics": sem, "refine": refine, "prefix_k": pk, "lazy_mate": lazy}
+        return {"variant": variant, "semantics": sem, "refine": refine, "prefix_k": pk}
 
     def prefix_k_for_input(self):
         """k of the prefix-state table that pays off for THIS run: a row saves k steps per read, level k costs 4^k one-step
@@ -148,11 +187,12 @@ class Predictor:
         self.model = model.to(self.device)
         self.model.set_variant(kcfg["variant"])
         self.model.set_semantics(kcfg["semantics"])
-        # margin band of the float64 re-evaluation (config.json kernel.refine; 0 = off; default 2.5e-4). The CLI issues the pass
-        # itself on a side stream (submit_chunk), so the one inside rd_classify is switched off.
+        # margin band of the float64 re-evaluation (config.json kernel.refine; 0 = off; default 2.5e-4), as the deferred pass of the
+        # C ABI (rd_set_refine_async): the recurrence kernel's epilogue records the reads inside the band, and submit_chunk's
+        # post-pass evaluates them (rd_sync_results on the post stream) beside the next chunk's recurrences.
         self.refine_band = kcfg["refine"]
-        self.lazy_mate = kcfg["lazy_mate"]
-        self.model.set_refine(0.0)
+        self.model.set_refine(self.refine_band)
+        self.model.set_refine_async(16 if self.refine_band > 0 else 0)
         self.model.eval()
 
     # ---- classification of one chunk ------------------------------------------------------------------
@@ -182,20 +222,9 @@ class Predictor:
         dev_in = [self._to_device(c, lo, hi, cs) for c in chunks]
         cur = torch.cuda.current_stream(self.device)
         cur.wait_stream(cs)
-        # --lazy_mate (extension, off by default): under --ensure rrna a pair is rRNA only if BOTH mates are (reference
-        # detect.py:620-630), under norrna non-rRNA only if both are (:631-641) - so a first mate that says "non-rRNA" (resp. "rRNA")
-        # from outside the float64 band has decided its pair, and the second mate is given length 0: zero steps instead of 100.
-        # The pair labels, counters and files are those of the full evaluation; only the never-used logits of those mates differ.
-        lazy = self.lazy_mate and self.is_paired and self.args.ensure in ('rrna', 'norrna')
-        outs, use_in = [], list(dev_in)             # (dev_in stays referenced by the ticket: its tensors were allocated on the copy
-        for k, (a, o, l) in enumerate(dev_in):      # stream and must not return to that stream's pool while other streams read them)
-            if lazy and k == 1:
-                m = outs[0][0][:, 1] - outs[0][0][:, 0]
-                band = float(self.refine_band)
-                decided = (m <= -band) if self.args.ensure == 'rrna' else ((m >= band) if band > 0 else (m > 0))
-                l = torch.where(decided, torch.zeros_like(l), l)
-                use_in[1] = (a, o, l)
-            outs.append(self.model.classify_bytes(a, o, l, self.len, want_labels=not self.is_paired))
+        # (dev_in stays referenced by the ticket: its tensors were allocated on the copy stream and must not return to that
+        # stream's pool while other streams read them - and the deferred float64 pass reads the bases until the post-pass has run)
+        outs = [self.model.classify_bytes(a, o, l, self.len, want_labels=not self.is_paired) for a, o, l in dev_in]
         main_done = torch.cuda.Event()
         main_done.record(cur)
         # post-pass on its own stream: it overlaps the recurrences of the next chunk (the float64 refine pass has the latency of
@@ -203,10 +232,12 @@ class Predictor:
         post = self._post_stream
         with torch.cuda.stream(post):
             post.wait_event(main_done)
-            pair_none = self.is_paired and self.args.ensure == 'none'   # pair label = argmax of the SUMMED logits (detect.py:657)
-            for k, (a, o, l) in enumerate(use_in):
-                mate = outs[1 - k][0] if pair_none else None
-                self.model.refine(a, o, l, self.len, outs[k][0], outs[k][1], mate, thresh=self.refine_band)
+            self.model.sync_results()                # the reads inside the noise band, in float64 (current stream = post)
+            if self.is_paired and self.args.ensure == 'none' and self.refine_band > 0:
+                # pair label = argmax of the SUMMED logits (reference detect.py:657): also the reads whose PAIR margin is inside the
+                # band - only both mates' logits together say which, so this mode keeps the scan form of the pass (rd_refine)
+                for k, (a, o, l) in enumerate(dev_in):
+                    self.model.refine(a, o, l, self.len, outs[k][0], outs[k][1], outs[1 - k][0], thresh=self.refine_band)
             if self.is_paired:
                 labels = module_arch.pair_fuse(outs[0][0], outs[1][0], self.args.ensure)
             else:
@@ -219,7 +250,7 @@ class Predictor:
                 _, finish = rdist.gather_labels(labels, n, dst=0, bounds=bounds, async_op=True)
             done = torch.cuda.Event()
             done.record(post)
-        return {"n": n, "bounds": bounds, "labels": labels, "host": host, "finish": finish, "done": done, "keep": (dev_in, use_in, outs)}
+        return {"n": n, "bounds": bounds, "labels": labels, "host": host, "finish": finish, "done": done, "keep": (dev_in, outs)}
 
     def collect_chunk(self, tk):
         """Labels of a submitted chunk: int8 numpy on rank 0 (whole chunk, input order), None elsewhere."""
@@ -268,8 +299,26 @@ class Predictor:
         """several ranks of ONE node on gzip input: rank 0 inflates and parses the stream once into shared memory (fx.ShmArena)
         and tells the others where each chunk lies; they map it and take their share of the records. (Ranks spread over several
         nodes cannot share memory: there every rank decodes the stream itself, as in round 2.)"""
-        return (self.multi and not self.sharded_parse and self.world > 1 and
-                int(os.environ.get("LOCAL_WORLD_SIZE", str(self.world))) == self.world and os.environ.get("RD_SHARED_DECODE", "1") != "0")
+        if self._shared is None:
+            import torch.distributed as dist
+            # one node only - and only when the launcher SAYS so (torchrun sets LOCAL_WORLD_SIZE; a launcher that sets just
+            # RANK / WORLD_SIZE may have spread the ranks over several hosts, whose /dev/shm are different memories)
+            ok = (self.multi and not self.sharded_parse and self.world > 1 and os.environ.get("RD_SHARED_DECODE", "1") != "0" and
+                  os.environ.get("LOCAL_WORLD_SIZE") is not None and int(os.environ["LOCAL_WORLD_SIZE"]) == self.world)
+            if ok:                                   # rank 0 owns the slots: its /dev/shm must hold them (all ranks take its answer)
+                msg = [None]
+                if self.rank == 0:
+                    fx.ShmArena.sweep_stale()
+                    chunk = self._chunk_reads or DEFAULT_CHUNK_READS
+                    fits, need = fx.ShmArena.fits(len(self.input), chunk, 2 * max(self.len, 50) + 80)
+                    msg = [bool(fits)]
+                    if not fits:
+                        self.logger.info('Shared gzip decode needs about {} MB of /dev/shm, which is not free: every rank decodes '
+                                         'the input itself'.format(need >> 20))
+                dist.broadcast_object_list(msg, src=0)
+                ok = bool(msg[0])
+            self._shared = ok
+        return self._shared
 
     def _chunk_stream(self, chunk_reads):
         import torch.distributed as dist
@@ -326,6 +375,7 @@ class Predictor:
         """Classify the input in chunks and write the outputs (reference detect.py:326-523)."""
         if chunk_reads is None:
             chunk_reads = self.batch_size * self.chunk_size
+        self._chunk_reads, self._shared = chunk_reads, None
         # plain inputs under several ranks: every rank parses, classifies and writes its own byte range (no label exchange)
         self.sharded_parse = self.multi and not any(fx.file_info(p)[1] for p in self.input)
         self.bytes_parsed = None
@@ -555,9 +605,6 @@ none: give label based on the mean probability of read pair.
     args.add_argument('--semantics', default=None, choices=['gpu', 'cpu'],
                       help='(extension) which reference product to reproduce for reads shorter than --len or ending in N:\n'
                            'gpu = ribodetector (packed sequences, default); cpu = ribodetector_cpu (zero-padded input).')
-    args.add_argument('--lazy_mate', action='store_true',
-                      help='(extension) with -e rrna / norrna: skip the second mate of a pair whose first mate has already decided\n'
-                           'the pair label (same labels, counters and output files; about half the GPU work on typical data).')
     args.add_argument('-v', '--version', action='version', version='%(prog)s {version}'.format(version=__version__))
     return args
 
@@ -574,12 +621,7 @@ def main(argv=None):
         seq_pred.detect()
         seq_pred.timing = {"load_model_s": t1 - t0, "detect_s": time.perf_counter() - t1, "prefix_k": seq_pred.model.prefix_k}
     except BaseException:
-        seq_pred._close_arenas()
-        for f in seq_pred._part_files:           # a failed sharded run leaves no '<out>.partN' / '<out>.joining' files behind
-            try:
-                os.remove(f)
-            except OSError:
-                pass
+        seq_pred.cleanup()                       # a failed run leaves no slot, '<out>.partN' or '<out>.joining' files behind
         if seq_pred.multi:
             # a rank that fails must not leave the others waiting in a collective (and must not wait in one itself while the
             # interpreter shuts down): report and leave at once - torch.distributed.run then tears the other ranks down

@@ -11,7 +11,9 @@ Entries:
   * `classify_bytes(arena, offsets, lens, max_len)` - the native fast entry: raw ASCII reads resident in HBM,
     encoder + recurrence + FC + argmax fused on the device.
 """
+import contextlib
 import ctypes as C
+import logging
 import os
 
 import numpy as np
@@ -19,6 +21,32 @@ import torch
 from torch.nn.utils.rnn import PackedSequence
 
 from .. import _native as N
+
+log = logging.getLogger("ribodetector_amd")
+
+
+@contextlib.contextmanager
+def _device_lock(device):
+    """One process at a time sizes and allocates a prefix-state table on a device: ranks that share a GPU would otherwise all read
+    the same "free" figure and allocate against it together. An flock on a file named after the device's UUID (advisory, released
+    with the process)."""
+    import fcntl
+    import tempfile
+    try:
+        uid = str(torch.cuda.get_device_properties(device).uuid)
+    except Exception:
+        uid = "dev%d" % (device.index if device.index is not None else torch.cuda.current_device())
+    path = os.path.join(tempfile.gettempdir(), "rd_prefix_%s.lock" % "".join(ch for ch in uid if ch.isalnum() or ch in "-_"))
+    fd = os.open(path, os.O_CREAT | os.O_RDWR, 0o666)
+    try:
+        fcntl.flock(fd, fcntl.LOCK_EX)
+        yield
+    finally:
+        try:
+            fcntl.flock(fd, fcntl.LOCK_UN)
+        finally:
+            os.close(fd)
+
 
 STATE_KEYS = ["rnn.weight_ih_l0", "rnn.weight_hh_l0", "rnn.bias_ih_l0", "rnn.bias_hh_l0",
               "rnn.weight_ih_l0_reverse", "rnn.weight_hh_l0_reverse", "rnn.bias_ih_l0_reverse",
@@ -51,9 +79,12 @@ class SeqModel:
         self._semantics = "packed"
         self._refine = None
         self._refine_async = 0
-        self._prefix = os.environ.get("RD_PREFIX_K", "auto")   # prefix-state table: "auto" | 0 (none) | 4..13 (set_prefix_table)
+        # prefix-state table (set_prefix_table): none unless asked for - RD_PREFIX_K, config.json kernel.prefix_k (the CLI) or an
+        # explicit call; the reference's .to(device) has no side allocations (reference detect.py:93,115-119) and neither has this one
+        self._prefix = os.environ.get("RD_PREFIX_K", 0)
         self._prefix_cap = None
         self._ptab = None
+        self._ptab_variant = None
         self._ws = None
         self.training = True
 
@@ -87,6 +118,7 @@ class SeqModel:
             N.lib().rd_model_destroy(self._handle)
             self._handle = None
         self._ptab = None
+        self._ptab_variant = None
 
     def _create(self):
         self._destroy()
@@ -130,7 +162,16 @@ class SeqModel:
         self._variant = name
         if self._handle is not None:
             N.check(N.lib().rd_set_variant(self._handle, N.VARIANTS[name]), "rd_set_variant")
+            if self._ptab is not None and self._ptab_variant != self._kernel():
+                self.set_prefix_table(self._prefix, self._prefix_cap)   # the rows are the state of the kernel that built them
         return self
+
+    def _kernel(self):
+        return "mfma_f16x3_t32" if self._variant == "auto" else self._variant
+
+    def _built_k(self):
+        """k of the table in self._ptab ((4^k + 1) KiB), whichever kernel's rows it holds"""
+        return 0 if self._ptab is None else (int(self._ptab.numel()) // 1024 - 1).bit_length() // 2
 
     def set_semantics(self, name):
         """'packed' (default): the reference GPU product, forward1 over min(len, max_len) real timesteps.
@@ -171,11 +212,15 @@ class SeqModel:
         return self
 
     def set_prefix_table(self, k="auto", cap=None):
-        """Prefix-state table of the default kernel (C ABI rd_set_prefix_table): the recurrence state after every
-        possible sequence of k bases, (4^k + 1) KiB of HBM, built by the kernel itself in milliseconds; a read then starts k steps
-        in, with bit-identical logits. k = 0: none; 4..13: exactly that; "auto" (default; environment RD_PREFIX_K overrides): 12
-        (16 GiB) when that is at most a quarter of the free device memory, else the largest k that is, else none. `cap` bounds
-        what "auto" picks (the CLI passes the k that pays off for the size of its input: building level k costs 4^k steps)."""
+        """Prefix-state table (C ABI rd_set_prefix_table): the recurrence state after every possible sequence of k
+        bases, (4^k + 1) KiB of HBM, built in milliseconds by the kernel that will use it (mfma_f16x3_t32 and mfma_f32 each have
+        their own rows; `simple` has none); a read then starts k steps in, with bit-identical logits. Opt-in: a model builds no
+        table unless this is called (or RD_PREFIX_K / config.json kernel.prefix_k is set; the CLI and bench.py do ask).
+        k = 0: none; 4..13: that; "auto": 12 (16 GiB) when table + build scratch (a quarter more) fit a quarter of the free device
+        memory, else the largest k that does, else none. `cap` bounds what "auto" picks (the CLI passes the k that pays off for the
+        size of its input: building level k costs 4^k steps). If the allocation fails anyway (another process took the memory),
+        the next smaller k is tried, down to none - never an exception for want of memory. Sizing and allocation run under a
+        per-device lock, so that ranks sharing a GPU do not size against the same free bytes at once."""
         if isinstance(k, str) and k != "auto":
             k = int(k)
         self._prefix = k
@@ -184,25 +229,51 @@ class SeqModel:
         if self._handle is None:
             return self
         lib = N.lib()
-        with torch.cuda.device(self.device):
+        if self._kernel() not in ("mfma_f16x3_t32", "mfma_f32") and k != 0:
+            log.info("prefix-state table: kernel %s has none (k = 0)", self._kernel())
+            k = 0
+        with torch.cuda.device(self.device), _device_lock(self.device):
             if k == "auto":
                 free, _ = torch.cuda.mem_get_info(self.device)
                 free += torch.cuda.memory_reserved(self.device) - torch.cuda.memory_allocated(self.device)   # cached blocks are reusable
                 k = N.PREFIX_K_AUTO if self._prefix_cap is None else max(0, min(N.PREFIX_K_AUTO, int(self._prefix_cap)))
-                while k >= N.PREFIX_K_MIN and int(lib.rd_prefix_table_bytes(k)) > free // 4:
+                while k >= N.PREFIX_K_MIN and int(lib.rd_prefix_table_bytes(k)) + int(lib.rd_prefix_scratch_bytes(k)) > free // 4:
                     k -= 1
                 if k < N.PREFIX_K_MIN:
                     k = 0
             k = int(k)
             if k != 0 and not (N.PREFIX_K_MIN <= k <= N.PREFIX_K_MAX):
                 raise RuntimeError("SeqModel.set_prefix_table: k must be 0, 'auto' or in [%d, %d]; got %r" % (N.PREFIX_K_MIN, N.PREFIX_K_MAX, k))
-            if k == int(lib.rd_prefix_k(self._handle)) and (k == 0 or self._ptab is not None):
+            if k == int(lib.rd_prefix_k(self._handle)) and (k == 0 or (self._ptab is not None and self._ptab_variant == self._kernel())):
                 return self
-            tab = torch.empty(int(lib.rd_prefix_table_bytes(k)), dtype=torch.uint8, device=self.device) if k else None
-            scr = torch.empty(int(lib.rd_prefix_scratch_bytes(k)), dtype=torch.uint8, device=self.device) if k else None
-            N.check(lib.rd_set_prefix_table(self._handle, k, N.ptr(tab), 0 if tab is None else tab.numel(), N.ptr(scr),
-                                            0 if scr is None else scr.numel(), N.stream_ptr(self.device)), "rd_set_prefix_table")
-            self._ptab = tab                             # (the scratch - the level below, a quarter of the table - is released here)
+            self.sync_results()
+            asked = k
+            while True:
+                tab = scr = None
+                if k:
+                    try:
+                        if self._ptab is not None and self._built_k() == k:
+                            tab = self._ptab                        # same size, another kernel's rows: rebuilt in place
+                        else:
+                            self._ptab = None
+                            N.check(lib.rd_set_prefix_table(self._handle, 0, None, 0, None, 0, N.stream_ptr(self.device)), "rd_set_prefix_table")
+                            tab = torch.empty(int(lib.rd_prefix_table_bytes(k)), dtype=torch.uint8, device=self.device)
+                        scr = torch.empty(int(lib.rd_prefix_scratch_bytes(k)), dtype=torch.uint8, device=self.device)
+                    except torch.OutOfMemoryError:
+                        tab = scr = None
+                        torch.cuda.empty_cache()
+                        k = k - 1 if k > N.PREFIX_K_MIN else 0
+                        continue
+                N.check(lib.rd_set_prefix_table(self._handle, k, N.ptr(tab), 0 if tab is None else tab.numel(), N.ptr(scr),
+                                                0 if scr is None else scr.numel(), N.stream_ptr(self.device)), "rd_set_prefix_table")
+                self._ptab = tab                         # (the scratch - the level below, a quarter of the table - is released here)
+                self._ptab_variant = self._kernel() if k else None
+                break
+            if k:
+                log.info("prefix-state table: k = %d, %d bytes of HBM (+ %d scratch during the build), kernel %s%s", k, tab.numel(),
+                         scr.numel(), self._variant, "" if k == asked else " - k = %d did not fit" % asked)
+            elif asked:
+                log.warning("prefix-state table: not enough device memory for k = %d or any smaller table - none attached", asked)
         return self
 
     @property

@@ -45,7 +45,9 @@ def gpu_model():
     cfg = ConfigParser.from_json(os.path.join(ROOT, "ribodetector_amd", "config.json"))
     m = cfg.init_obj("arch", module_arch)
     m.load_state_dict(cfg.load_state_dict("mcc"))
-    return m.to("cuda:0").eval()
+    m.to("cuda:0").eval()
+    m.set_prefix_table("auto")       # the configuration the CLI and bench.py run (the table is opt-in for a bare SeqModel)
+    return m
 
 
 @pytest.fixture(scope="session")

@@ -97,4 +97,4 @@ def test_config_rejects_bad_kernel_block(tmp_path):
             p.load_model()
     # the shipped block passes the check (and then fails later only for want of a GPU)
     p = detect.Predictor(ConfigParser.from_json(os.path.join(ROOT, "ribodetector_amd", "config.json")), args)
-    assert p.kernel_config() == {"variant": "auto", "semantics": "gpu", "refine": 2.5e-4, "prefix_k": None, "lazy_mate": False}
+    assert p.kernel_config() == {"variant": "auto", "semantics": "gpu", "refine": 2.5e-4, "prefix_k": None}

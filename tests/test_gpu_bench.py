@@ -23,7 +23,7 @@ def _line(out):
 
 def test_bench_single_gpu_contract():
     r = subprocess.run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--pairs-per-step", "65536", "--no-alt",
-                        "--no-cpu-baseline", "--traffic", "off"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+                        "--no-cpu-baseline", "--traffic", "off", "--e2e-records", "0"], cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     j = _line(r.stdout)
     for k in KEYS:
@@ -43,8 +43,16 @@ def test_bench_single_gpu_contract():
     pt = j["config"]["prefix_table"]
     assert pt["k"] in range(0, 14) and (pt["k"] == 0 or pt["bytes"] == (4 ** pt["k"] + 1) * 1024)
     assert 0.8 < rf["steps_executed_over_steps"] <= 1.0 and (pt["k"] == 0) == (rf["steps_executed_over_steps"] == 1.0)
-    assert j["config"]["e2e_cli_reads_per_s"] > 1e5 and j["e2e_cli"]["records_per_file"] == 65536 and j["e2e_cli"]["files"] == 2
-    assert j["e2e_cli"]["calls"]["second_call"]["prefix_k"] == 8            # the CLI sizes its table by its input
+    # round 4: frac counts the steps the kernel EXECUTES (a table row's steps are looked up, not computed); three byte fields
+    assert abs(rf["frac"] - rf["mfma_pipe_frac"] / 3) < 0.005 and rf["mfma_flops_executed_per_algorithmic_flop"] == 3
+    assert abs(rf["frac"] - rf["frac_counting_table_steps"] * (rf["algorithmic_flops_per_launch"] / rf["algorithmic_flops_per_launch_counting_table_steps"])) < 1e-9
+    assert rf["frac"] <= rf["frac_counting_table_steps"]
+    assert rf["algorithmic_bytes_per_launch"] == 65536 * 113 and rf["offset_bytes_per_launch"] == 65536 * 8
+    assert (pt["k"] == 0) == (rf["table_bytes_per_launch"] == 0) and rf["table_bytes_per_launch"] <= 65536 * 1024
+    assert j["config"]["refine"]["placement"].startswith("deferred")
+    e = j["e2e_cli"]["one_step_batch"]
+    assert j["config"]["e2e_cli_reads_per_s"] > 1e5 and e["records_per_file"] == 65536 and e["files"] == 2 and e["timed_calls"] == 1
+    assert e["calls"][0]["prefix_k"] == 8                                    # the CLI sizes its table by its input
     assert 0 < j["config"]["host_cores_busy"] < 4
     enc = j["encoder"]["kernels"]
     assert set(enc) == {"rd_encode_codes_kernel", "rd_encode_onehot_padded_kernel", "rd_pack_onehot_kernel"}
@@ -61,7 +69,12 @@ def test_bench_reports_the_rate_without_the_prefix_table():
     assert j["config"]["prefix_table"]["k"] >= 4 and a["timed_region"] == "ii" and a["steps"] == 4
     assert 0.75 * j["value"] < a["value"] < 1.02 * j["value"], (a["value"], j["value"])     # (wall clock over 4 steps: noisy)
     assert a["roofline"]["avg_launch_ms"] > 1.05 * j["roofline"]["avg_launch_ms"]             # (hipEvents around the launches: not noisy)
-    assert j["alt_fp32_kernel"]["roofline"]["frac"] > 0.5
+    # the strict-fp32 line: same region, same steps, its own prefix-state table, executed-work roofline
+    f = j["alt_fp32_kernel"]
+    assert f["steps"] == j["steps"] == 4 and f["timed_region"] == "ii" and f["ms_per_step"] > 0 and f["prefix_k"] == j["config"]["prefix_table"]["k"]
+    assert f["roofline"]["frac"] > 0.5 and f["roofline"]["launches"] == 2 * 4
+    assert abs(f["roofline"]["steps_executed_over_steps"] - j["roofline"]["steps_executed_over_steps"]) < 1e-9
+    assert abs(f["value"] - 2 * 524288 * 4 / (f["ms_per_step"] * 4e-3)) < 1e-6 * f["value"]
 
 
 def test_bench_self_launches_two_ranks_one_gpu():

@@ -151,26 +151,6 @@ def test_cli_two_ranks_match_one(tmp_path, suffix, world, shared):
         assert "parses" not in text
 
 
-@pytest.mark.parametrize("ensure", ["rrna", "norrna", "both", "none"])
-def test_cli_lazy_mate_writes_the_same_files(tmp_path, ensure):
-    """--lazy_mate (extension): the second mate of a pair whose first mate has decided the pair label is not stepped through the
-    recurrence; labels, counters and all output files equal those of the full evaluation, in every --ensure mode (the flag only
-    acts under rrna / norrna)"""
-    from ribodetector_amd import detect, synth
-    n = 40000
-    a1, o1, _ = synth.reads_numpy(n, (40, 140), seed=91, rrna_frac=0.4)
-    a2, o2, _ = synth.reads_numpy(n, (40, 140), seed=92, rrna_frac=0.4)
-    i1, i2 = str(tmp_path / "r_1.fq"), str(tmp_path / "r_2.fq")
-    synth.write_fastq(i1, a1, o1, 1)
-    synth.write_fastq(i2, a2, o2, 2)
-    res = {}
-    for tag, extra in (("full", []), ("lazy", ["--lazy_mate"])):
-        outs = [str(tmp_path / ("%s_%s.fq" % (tag, x))) for x in ("n1", "n2", "r1", "r2")]
-        p = detect.main(["-l", "100", "-i", i1, i2, "-o", *outs[:2], "-r", *outs[2:], "-e", ensure, "--chunk_size", "1", "-m", "3"] + extra)
-        res[tag] = ([_read(x) for x in outs], (p.num_read, p.num_nonrrna, p.num_rrna, p.num_unknown))
-    assert res["full"] == res["lazy"] and res["full"][1][0] == n and res["full"][1][1] > 0 and res["full"][1][2] > 0
-
-
 def test_cli_failing_rank_ends_the_job(tmp_path):
     """two ranks, plain FASTQ cut inside its last record: only rank 1's byte range holds the damage. Rank 1 reports it and leaves;
     rank 0 must not wait forever in the closing all-reduce - the launcher ends the job with a non-zero status"""

@@ -751,6 +751,32 @@ def test_refine_async_equals_inline(gpu_model):
         torch.cuda.synchronize()
         for i in range(2):
             assert torch.equal(outs[i][0], wantb[i][0]) and torch.equal(outs[i][1], wantb[i][1]), i
+        # (6) the pipelined caller's form (bench.py, the CLI): calls on the main stream, rd_sync_results on a SIDE stream that is ordered
+        # behind them by an event; the side stream consumes the results while the main stream goes on with the next batch (which
+        # records into the model's other queue). Two alternating buffer sets, reuse ordered by the consumer's event.
+        gpu_model.set_refine_async(0)
+        gpu_model.set_refine(0.5)
+        gpu_model.set_refine_async(16)
+        side, cur = torch.cuda.Stream(), torch.cuda.current_stream()
+        consumed, got6 = [None, None], []
+        for rep in range(3):
+            for i, b in enumerate(batches):
+                k = i & 1
+                if consumed[k] is not None:
+                    cur.wait_event(consumed[k])
+                gpu_model.classify_bytes(b[0], of2[k], ln2[k], L, logits=lg[k], labels=lb[k])
+                ev = torch.cuda.Event()
+                ev.record(cur)
+                with torch.cuda.stream(side):
+                    side.wait_event(ev)
+                    gpu_model.sync_results()
+                    got6.append((lg[k].clone(), lb[k].clone()))
+                    consumed[k] = torch.cuda.Event()
+                    consumed[k].record(side)
+        torch.cuda.synchronize()
+        for i, g in enumerate(got6):
+            w = want[i % len(batches)]
+            assert torch.equal(w[0], g[0]) and torch.equal(w[1], g[1]), i
     finally:
         gpu_model.sync_results()
         gpu_model.set_refine_async(0)

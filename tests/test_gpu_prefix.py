@@ -1,4 +1,5 @@
-"""Prefix-state table of the default kernel (include/ribodetector_amd.h rd_set_prefix_table).
+"""Prefix-state table (include/ribodetector_amd.h rd_set_prefix_table): the default kernel's and, since round 4,
+the exact-fp32 kernel's own (each kernel's rows are its own state representation).
 
 The table is built by the classifying kernel itself, so starting a read from its row must give the SAME BITS as stepping over
 the bases: every test here compares logits with torch.equal against the model without a table, whose parity with the
@@ -58,10 +59,12 @@ def _edge_reads(seed=5):
     return reads
 
 
+@pytest.mark.parametrize("variant", ["auto", "mfma_f32"])
 @pytest.mark.parametrize("sem", ["packed", "padded"])
 @pytest.mark.parametrize("max_len", [100, 37, 300, 13, 12])
-def test_table_start_is_bit_identical(model, sem, max_len):
+def test_table_start_is_bit_identical(model, sem, max_len, variant):
     a, o, l = _batch(_edge_reads())
+    model.set_variant(variant)
     model.set_semantics(sem)
     try:
         model.set_prefix_table(0)
@@ -77,6 +80,29 @@ def test_table_start_is_bit_identical(model, sem, max_len):
     finally:
         model.set_semantics("packed")
         model.set_prefix_table(0)
+        model.set_variant("auto")
+
+
+def test_table_start_is_bit_identical_at_scale_fp32(model):
+    """the exact-fp32 kernel from ITS table (k = 12), 2^18 reads of fixed and of variable length"""
+    from ribodetector_amd import synth
+    n = 1 << 18
+    a, off, lens = synth.reads_torch(n, 100, seed=78, device="cuda:0")
+    o = off[:-1].contiguous()
+    g = torch.Generator(device="cuda:0")
+    g.manual_seed(4)
+    vl = torch.randint(1, 101, (n,), generator=g, device="cuda:0", dtype=torch.int32)
+    try:
+        model.set_variant("mfma_f32")
+        model.set_prefix_table(0)
+        ref, refv = model.classify_bytes(a, o, lens, 100)[0].clone(), model.classify_bytes(a, o, vl, 100)[0].clone()
+        model.set_prefix_table(12)
+        assert model.prefix_k == 12
+        assert torch.equal(model.classify_bytes(a, o, lens, 100)[0], ref)
+        assert torch.equal(model.classify_bytes(a, o, vl, 100)[0], refv)
+    finally:
+        model.set_prefix_table(0)
+        model.set_variant("auto")
 
 
 def test_table_start_is_bit_identical_at_scale(model, report):
@@ -105,18 +131,91 @@ def test_table_start_is_bit_identical_at_scale(model, report):
         model.set_prefix_table(0)
 
 
-def test_other_kernels_ignore_the_table(model):
+def test_each_kernel_its_own_rows(model):
+    """The rows are the state of the kernel that built them. SeqModel.set_variant rebuilds an attached table for the new kernel;
+    at the C ABI a table built for another kernel is ignored (the reads run all their steps) rather than misread; the plain-FMA
+    cross-check kernel has no table at all."""
+    from ribodetector_amd import _native as N
+    lib = N.lib()
     a, o, l = _batch(_edge_reads(9)[:400])
     try:
-        for v in ("mfma_f32", "simple"):
+        refs = {}
+        for v in ("auto", "mfma_f32", "simple"):
             model.set_variant(v)
             model.set_prefix_table(0)
-            ref = model.classify_bytes(a, o, l, 100)[0].clone()
-            model.set_prefix_table(6)
-            assert torch.equal(model.classify_bytes(a, o, l, 100)[0], ref)
+            refs[v] = model.classify_bytes(a, o, l, 100)[0].clone()
+        model.set_variant("auto")
+        model.set_prefix_table(6)
+        tab = model._ptab
+        assert model._ptab_variant == "mfma_f16x3_t32"
+        model.set_variant("mfma_f32")                                       # rebuilt in place, for the fp32 kernel
+        assert model.prefix_k == 6 and model._ptab_variant == "mfma_f32" and model._ptab is tab
+        assert torch.equal(model.classify_bytes(a, o, l, 100)[0], refs["mfma_f32"])
+        # C ABI only: switch the kernel under the table - the fp32 rows must NOT be read as the default kernel's state
+        N.check(lib.rd_set_variant(model._handle, N.VARIANTS["auto"]), "rd_set_variant")
+        ws = model._workspace(len(l), 100)
+        lg = torch.empty((len(l), 2), dtype=torch.float32, device="cuda:0")
+        N.check(lib.rd_classify(model._handle, N.ptr(a), N.ptr(o), N.ptr(l), len(l), 100, N.ptr(lg), None, N.ptr(ws), ws.numel(),
+                                N.stream_ptr(model.device)), "rd_classify")
+        assert torch.equal(lg, refs["auto"])
+        model.set_variant("simple")                                         # no table for this kernel: detached, same results
+        model.set_prefix_table(6)
+        assert model.prefix_k == 0
+        assert torch.equal(model.classify_bytes(a, o, l, 100)[0], refs["simple"])
+        st = N.stream_ptr(model.device)
+        buf = torch.empty(int(lib.rd_prefix_table_bytes(4)), dtype=torch.uint8, device="cuda:0")
+        scr = torch.empty(int(lib.rd_prefix_scratch_bytes(4)), dtype=torch.uint8, device="cuda:0")
+        assert lib.rd_set_prefix_table(model._handle, 4, N.ptr(buf), buf.numel(), N.ptr(scr), scr.numel(), st) == -3   # RD_E_UNSUPPORTED
+        assert b"no prefix-state table" in lib.rd_last_error()
     finally:
         model.set_variant("auto")
         model.set_prefix_table(0)
+
+
+def test_no_table_unless_asked_and_small_memory_falls_back(caplog):
+    """SeqModel.to('cuda') allocates nothing by itself (the reference's .to(device) has no side allocations, detect.py:93,115-119);
+    'auto' sizes table + scratch against a quarter of the free memory; when the allocation fails anyway the next smaller k is
+    tried; one log line says what was built."""
+    import logging
+    from ribodetector_amd.model import model as module_arch
+    from ribodetector_amd.parse_config import ConfigParser
+    cfg = ConfigParser.from_json(os.path.join(ROOT, "ribodetector_amd", "config.json"))
+    m = cfg.init_obj("arch", module_arch)
+    m.load_state_dict(cfg.load_state_dict("mcc"))
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    before = torch.cuda.mem_get_info()[0]
+    m.to("cuda:0").eval()
+    assert m.prefix_k == 0 and m._ptab is None and before - torch.cuda.mem_get_info()[0] < (64 << 20)   # weights + tables: ~2 MB
+    a, o, l = _batch(_edge_reads(3)[:300])
+    ref = m.classify_bytes(a, o, l, 100)[0].clone()
+    free, total = torch.cuda.mem_get_info()
+    hog = []
+    try:
+        # leave less than 8 GiB free: 'auto' must come out below 12 (16 GiB), and still work
+        left = 6 << 30
+        while free - left > (1 << 30):
+            chunk = min(free - left, 64 << 30)
+            hog.append(torch.empty(chunk, dtype=torch.uint8, device="cuda:0"))
+            free, _ = torch.cuda.mem_get_info()
+        with caplog.at_level(logging.INFO, logger="ribodetector_amd"):
+            m.set_prefix_table("auto")
+        k_auto = m.prefix_k
+        assert 4 <= k_auto < 12 and (4 ** k_auto + 1) * 1024 * 1.25 <= (8 << 30) / 4 + 1024
+        assert any("prefix-state table: k = %d" % k_auto in r.getMessage() for r in caplog.records)
+        assert torch.equal(m.classify_bytes(a, o, l, 100)[0], ref)
+        # an explicit k that cannot be allocated falls back instead of raising
+        m.set_prefix_table(0)
+        caplog.clear()
+        with caplog.at_level(logging.INFO, logger="ribodetector_amd"):
+            m.set_prefix_table(12)
+        assert 0 <= m.prefix_k < 12
+        assert any("did not fit" in r.getMessage() or "not enough device memory" in r.getMessage() for r in caplog.records)
+        assert torch.equal(m.classify_bytes(a, o, l, 100)[0], ref)
+    finally:
+        m.set_prefix_table(0)
+        del hog
+        torch.cuda.empty_cache()
 
 
 def test_auto_and_argument_checks(model):

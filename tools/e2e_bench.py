@@ -43,7 +43,6 @@ def main():
     run("se_gz_to_plain", [files[1] + ".gz"], [o("b.fq")])
     run("se_gz_to_gz", [files[1] + ".gz"], [o("c.fq.gz")])
     run("pe_plain_to_plain", [files[1], files[2]], [o("d1.fq"), o("d2.fq")], ["-e", "rrna"])
-    run("pe_plain_to_plain_lazy_mate", [files[1], files[2]], [o("g1.fq"), o("g2.fq")], ["-e", "rrna", "--lazy_mate"])
     run("pe_gz_to_plain", [files[1] + ".gz", files[2] + ".gz"], [o("e1.fq"), o("e2.fq")], ["-e", "rrna"])
     run("pe_gz_to_gz", [files[1] + ".gz", files[2] + ".gz"], [o("f1.fq.gz"), o("f2.fq.gz")], ["-e", "rrna"])
     shutil.rmtree(d, ignore_errors=True)
