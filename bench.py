@@ -257,6 +257,9 @@ def e2e_record(torch, synth, arenas, offsets, lens, L, ensure, timed_calls=1, gz
         argv = ["-l", str(L), "-i", *ins, "-o", *outs, "-r", *rrs] + (["-e", ensure] if len(ins) == 2 else [])
         calls = []
         for call in range(1 + timed_calls):
+            for q in outs + rrs:                      # every call writes NEW files (truncating GBs of tmpfs pages is not the CLI's work)
+                if os.path.exists(q):
+                    os.remove(q)
             t0 = time.perf_counter()
             pr = detect.main(argv)
             dt = time.perf_counter() - t0
