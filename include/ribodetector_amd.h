@@ -191,6 +191,25 @@ int rd_pack_plan(const int32_t *seq_len, int64_t n, int32_t max_len, int64_t *so
 int rd_pack_onehot(const uint8_t *arena, const int64_t *seq_off, const int32_t *seq_len, int64_t n, int32_t max_len,
                    const int64_t *sorted_idx, const int64_t *batch_sizes, float *data, void *stream);
 
+/* Device-side gzip of the output files (round 4). Replaces, for the GPU path: gzip.open(out, 'wt', compresslevel=5) fed with the
+ * records of one label in input order (reference detect.py:485-492,729-741: the writer compresses by file extension). The records of
+ * a chunk (its text is already in HBM: the read bytes travel as the chunk's text) whose label equals `label` become a sequence of
+ * complete gzip members in `out`, ready to be appended to the file - in BGZF framing (one member per 65,280 input bytes, 'B','C'
+ * extra subfield), so that the file is also what bgzip writes: indexable, and decodable member by member in parallel. DEFLATE is
+ * done by hand-written kernels: LZ77 with per-wave hash tables in LDS, one dynamic-Huffman block per member, CRC-32 on the device.
+ *   text [dev] the chunk's bytes; rec_start [dev] int64[n+1]: record i = bytes [rec_start[i], rec_start[i+1]) (verbatim, with its
+ *   newline); labels [dev] int8[n] (rd_pair_fuse's pair labels, or rd_classify's uint8 labels); label: the value to select.
+ *   out [dev] >= rd_gz_out_bound(text_bytes) bytes is always enough (256-byte aligned); info [dev] int64[4]:
+ *     info[0] = bytes written to out (if > out_cap: out was too small and is incomplete), info[1] = uncompressed bytes,
+ *     info[2] = members. Asynchronous on `stream`; the caller copies info and out[0, info[0]) to the host afterwards.
+ *   rd_gz_eof_block: [host] BGZF's 28-byte end-of-file marker (an empty member), to be appended once when the file is closed. */
+size_t rd_gz_workspace_bytes(int64_t n, int64_t text_bytes);
+size_t rd_gz_out_bound(int64_t text_bytes);
+int rd_gz_compress_selected(const uint8_t *text, int64_t text_bytes, const int64_t *rec_start, const int8_t *labels, int64_t n,
+                            int32_t label, uint8_t *out, size_t out_cap, int64_t *info, void *workspace, size_t workspace_bytes,
+                            void *stream);
+int rd_gz_eof_block(uint8_t *dst, size_t cap);
+
 /* Timing of the dominant kernel, for bench.py's roofline: rd_classify records hipEvents around the recurrence
  * kernel on the launch stream when enabled. rd_profile_read synchronises those events and returns the number of
  * recorded launches and their total duration. */

@@ -87,6 +87,10 @@ int rd_writer_threads(const rd_writer *w);
 /* append, in input order, every record i of the chunk with labels[i] == want */
 int rd_writer_write_selected(rd_writer *w, const uint8_t *buf, const int64_t *rec_start, int64_t n, const int8_t *labels,
                              int32_t want);
+/* append complete gzip members made elsewhere (the GPU: librd_hip.so rd_gz_compress_selected) to a gzip output, as they are; data
+ * the host path has buffered for the file is compressed and written first (input order). A file that received such members is
+ * closed with BGZF's end-of-file marker. */
+int rd_writer_write_members(rd_writer *w, const uint8_t *members, int64_t len);
 int rd_writer_close(rd_writer *w);
 
 const char *rd_host_last_error(void);

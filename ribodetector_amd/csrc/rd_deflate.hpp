@@ -1,0 +1,663 @@
+// rd_deflate.hpp - label-partitioned records of a chunk -> gzip (BGZF) members, on the device (rd_gz_* kernels)
+// Part of the single translation unit rd_kernels.hip (included from there, in order); DESIGN.md §3.10 has the numbers.
+//
+// Replaces, for the GPU path, the reference's output side: `gzip.open(out, 'wt', compresslevel=5)` fed with the records of one label
+// in input order (reference detect.py:485-492,729-741). The records of a chunk are already in HBM (the read bytes travel as the
+// chunk's text) and so are the labels; round 3 shipped the labels to the host, which gathered and deflated the records on its 16
+// cores - 13-20 % of the device rate, flat in the GPU count. Here the chunk's records of one label become gzip members without
+// leaving the device; the host appends the compressed bytes to the file.
+//
+//   rd_gz_sel_* / rd_gz_pack_kernel   selected records -> one contiguous byte stream (scan of the selected lengths + coalesced copy)
+//   rd_gz_deflate_kernel              one workgroup per member of 65,280 input bytes (BGZF's block size: the file is valid BGZF -
+//                                     bgzip / htslib index it, this build's reader inflates its members in parallel):
+//        wave w owns quarter w (16,320 bytes) and its own 4,096-entry hash table in LDS (8-byte hashes, nearest earlier
+//        occurrence); a STRIP of 64 consecutive positions is handled at once, one per lane: hash, candidate lookup (positions before
+//        the strip), distance-1 candidate (runs), match length by 4-byte compares in LDS; then the 64 positions are inserted; then the
+//        strip's parse is resolved from the ballot of match lanes (lazy rule: a match shorter than 32 yields to a longer one at the
+//        next position); tokens go to a scratch in HBM, symbol counts to per-wave LDS histograms;
+//        ONE dynamic-Huffman block per member: lengths by two-queue merge over the rank-sorted used symbols, limited to 15 bits the
+//        way zlib's gen_bitlen does it, canonical codes; code lengths sent without the run-length symbols (+0.2 %); every wave emits
+//        its quarter's tokens with a prefix sum of bit lengths and LDS atomic-or; stored block if that is smaller; CRC-32 of the
+//        member from 255 per-thread CRCs combined with x^n mod P multiplications (zlib's crc32_combine identity).
+//   rd_gz_moff_kernel / rd_gz_compact_kernel   member sizes -> offsets, members -> one contiguous stream for the D2H copy
+// Matches of 8+ bytes only (runs: 6+): on FASTQ shorter matches cost more bits than the 2-bit literals they replace; measured with
+// the lane-for-lane CPU model tools/gzdev_model.c against zlib level 5: 1.00 / 1.05 / 0.94 of its size on three FASTQ profiles.
+#pragma once
+#include "rd_common.hpp"
+
+namespace {
+
+constexpr int GZ_MEMBER = 65280;                       // input bytes per member (BGZF_BLOCK_SIZE 0xff00)
+constexpr int GZ_NQ = 4, GZ_QUARTER = GZ_MEMBER / GZ_NQ;
+constexpr int GZ_HBITS = 12;
+constexpr int GZ_MINM = 8, GZ_MINRUN = 6, GZ_MAXM = 258, GZ_LAZY = 32;
+constexpr int GZ_SLOT = 65536;                         // output bytes reserved per member (BGZF: total block size <= 65536)
+constexpr int GZ_HDR = 18, GZ_TRL = 8;
+constexpr int GZ_NSYM = 320;                           // 0..285 literal/length symbols, 286..315 distance symbols
+constexpr int GZ_MAX_GRID = 512;
+
+__constant__ uint16_t GZ_LBASE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+__constant__ uint8_t GZ_LEXTRA[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+__constant__ uint16_t GZ_DBASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+__constant__ uint8_t GZ_DEXTRA[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+__constant__ uint8_t GZ_CLORD[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+// x^(2^i) mod P of the (reflected) CRC-32 polynomial: zlib's x2n_table
+__constant__ uint32_t GZ_X2N[32] = {0x40000000u, 0x20000000u, 0x08000000u, 0x00800000u, 0x00008000u, 0xedb88320u, 0xb1e6b092u, 0xa06a2517u,
+                                    0xed627daeu, 0x88d14467u, 0xd7bbfe6au, 0xec447f11u, 0x8e7ea170u, 0x6427800eu, 0x4d47bae0u, 0x09fe548fu,
+                                    0x83852d0fu, 0x30362f1au, 0x7b5a9cc3u, 0x31fec169u, 0x9fec022au, 0x6c8dedc4u, 0x15d6874du, 0x5fde7a4eu,
+                                    0xbad90e37u, 0x2e4e5eefu, 0x4eaba214u, 0xa8a472c0u, 0x429a969eu, 0x148d302au, 0xc40ba6d0u, 0xc4e22c3cu};
+
+// ------------------------------------------------------------------------------------------------
+// selection: out_off[i] = bytes of the selected records before record i (record i is selected when labels[i] == label)
+// ------------------------------------------------------------------------------------------------
+constexpr int GZ_SCAN_ITEMS = 2048;   // records per workgroup (256 threads x 8)
+
+__device__ __forceinline__ int64_t gz_sel_len(const int64_t *rec_start, const int8_t *labels, int64_t i, int64_t n, int label) {
+    return (i < n && labels[i] == (int8_t)label) ? rec_start[i + 1] - rec_start[i] : 0;
+}
+
+__device__ __forceinline__ int64_t gz_block_scan(int64_t v, int64_t *sh, int64_t &total) {   // exclusive scan over the 256 threads
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int64_t inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int64_t t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) sh[wave] = inc;
+    __syncthreads();
+    int64_t base = 0;
+    for (int w = 0; w < wave; ++w) base += sh[w];
+    total = sh[0] + sh[1] + sh[2] + sh[3];
+    __syncthreads();
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(256) void rd_gz_sel_sum_kernel(const int64_t *__restrict__ rec_start, const int8_t *__restrict__ labels,
+                                                           int64_t n, int label, int64_t *__restrict__ bsum) {
+    __shared__ int64_t sh[4];
+    const int64_t i0 = (int64_t)blockIdx.x * GZ_SCAN_ITEMS + threadIdx.x * 8;
+    int64_t s = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += gz_sel_len(rec_start, labels, i0 + k, n, label);
+    int64_t total;
+    gz_block_scan(s, sh, total);
+    if (threadIdx.x == 0) bsum[blockIdx.x] = total;
+}
+
+// one workgroup: bsum[] -> exclusive bases in place; info = {compressed bytes (filled later), plain bytes, members}
+__global__ __launch_bounds__(256) void rd_gz_sel_base_kernel(int64_t *__restrict__ bsum, int nb, int64_t *__restrict__ info) {
+    __shared__ int64_t sh[4];
+    __shared__ int64_t run_s;
+    if (threadIdx.x == 0) run_s = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < nb; b0 += 256) {
+        const int b = b0 + threadIdx.x;
+        const int64_t v = b < nb ? bsum[b] : 0;
+        int64_t total;
+        const int64_t ex = gz_block_scan(v, sh, total);
+        const int64_t run = run_s;
+        if (b < nb) bsum[b] = run + ex;
+        __syncthreads();
+        if (threadIdx.x == 0) run_s = run + total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        info[0] = 0;
+        info[1] = run_s;
+        info[2] = (run_s + GZ_MEMBER - 1) / GZ_MEMBER;
+    }
+}
+
+__global__ __launch_bounds__(256) void rd_gz_sel_off_kernel(const int64_t *__restrict__ rec_start, const int8_t *__restrict__ labels,
+                                                           int64_t n, int label, const int64_t *__restrict__ bbase,
+                                                           int64_t *__restrict__ out_off) {
+    __shared__ int64_t sh[4];
+    const int64_t i0 = (int64_t)blockIdx.x * GZ_SCAN_ITEMS + threadIdx.x * 8;
+    int64_t v[8], s = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { v[k] = gz_sel_len(rec_start, labels, i0 + k, n, label); s += v[k]; }
+    int64_t total;
+    int64_t run = bbase[blockIdx.x] + gz_block_scan(s, sh, total);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if (i0 + k <= n) out_off[i0 + k] = run;   // (entry n = the total)
+        run += v[k];
+    }
+}
+
+// selected records -> plain[out_off[i] ...): a workgroup takes 256 consecutive records, whose output range is contiguous, and its
+// threads take 16-byte pieces of that range (a piece finds its record by bisection over the 257 staged offsets)
+constexpr int GZ_PACK_RECS = 256;
+__global__ __launch_bounds__(256) void rd_gz_pack_kernel(const uint8_t *__restrict__ text, const int64_t *__restrict__ rec_start,
+                                                        const int64_t *__restrict__ out_off, int64_t n, uint8_t *__restrict__ plain) {
+    __shared__ int64_t offs[GZ_PACK_RECS + 1];
+    __shared__ int64_t srcs[GZ_PACK_RECS];
+    const int64_t r0 = (int64_t)blockIdx.x * GZ_PACK_RECS;
+    const int nr = (int)(n - r0 < GZ_PACK_RECS ? n - r0 : GZ_PACK_RECS);
+    for (int k = threadIdx.x; k <= nr; k += 256) offs[k] = out_off[r0 + k];
+    for (int k = threadIdx.x; k < nr; k += 256) srcs[k] = rec_start[r0 + k];
+    __syncthreads();
+    const int64_t ob = offs[0], oe = offs[nr];
+    for (int64_t o = (ob & ~(int64_t)15) + 16 * (int64_t)threadIdx.x; o < oe; o += 16 * 256) {
+        int64_t a = o < ob ? ob : o;                    // the piece is [a, e) (its neighbours in other workgroups write the rest)
+        const int64_t e = o + 16 < oe ? o + 16 : oe;
+        int lo = 0, hi = nr;                            // largest r with offs[r] <= a (records of zero length share an offset:
+        while (hi - lo > 1) {                           // the LAST of them is the one that holds byte a)
+            const int mid = (lo + hi) >> 1;
+            if (offs[mid] <= a) lo = mid; else hi = mid;
+        }
+        int r = lo;
+        if (a == o && e == o + 16 && offs[r + 1] >= e) {   // a whole piece from one record: one unaligned 16-byte load, one aligned store
+            u32x4 v;
+            __builtin_memcpy(&v, text + srcs[r] + (a - offs[r]), 16);
+            *reinterpret_cast<u32x4 *>(plain + o) = v;
+            continue;
+        }
+        while (a < e) {
+            while (offs[r + 1] <= a) ++r;
+            const int64_t stop = offs[r + 1] < e ? offs[r + 1] : e;
+            const uint8_t *src = text + srcs[r] + (a - offs[r]);
+            for (; a < stop; ++a) plain[a] = *src++;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// DEFLATE of one member
+// ------------------------------------------------------------------------------------------------
+struct __attribute__((aligned(16))) GzSmem {
+    uint32_t text[(GZ_MEMBER + 16) / 4];      // the member's bytes (+ zero pad); after the parse: the output (header, deflate data, trailer)
+    uint16_t tab[GZ_NQ][1 << GZ_HBITS];       // per wave: hash -> position in its quarter + 1
+    uint32_t hist[GZ_NQ][GZ_NSYM];            // per wave: symbol counts of its quarter
+    uint32_t freq[GZ_NSYM];
+    uint8_t lens[GZ_NSYM];
+    uint16_t codes[GZ_NSYM];
+    uint32_t clfreq[19];
+    uint8_t cllen[19];
+    uint16_t clcode[19];
+    uint16_t order[288];                      // tree scratch: used symbols by (frequency, symbol)
+    uint32_t w[576];
+    uint16_t parent[576];
+    uint8_t depth[576];
+    uint32_t crc_tab[256];
+    uint8_t lsym[256];                        // match length - 3 -> length symbol - 257
+    uint8_t dsym[512];                        // zlib's _dist_code
+    uint32_t scan[4];
+    uint32_t qbits[GZ_NQ], qtok[GZ_NQ];
+    uint32_t crc;
+    int used, hlit, hdist, hclen;
+};
+
+__device__ __forceinline__ uint32_t gz_ld32(const uint32_t *T, int i) {   // 4 bytes at byte offset i (any alignment)
+    const uint32_t *q = T + (i >> 2);
+    return __builtin_amdgcn_alignbyte(q[1], q[0], (uint32_t)(i & 3));
+}
+
+__device__ __forceinline__ int gz_mlen(const uint32_t *T, int p, int c, int lim) {
+    int k = 0;
+    while (k < lim) {
+        const uint32_t x = gz_ld32(T, p + k) ^ gz_ld32(T, c + k);
+        if (x) { k += __builtin_ctz(x) >> 3; break; }
+        k += 4;
+    }
+    return k < lim ? k : lim;
+}
+
+__device__ __forceinline__ uint32_t gz_multmodp(uint32_t a, uint32_t b) {   // zlib's multmodp: a(x) b(x) mod P, reflected
+    uint32_t m = 1u << 31, p = 0;
+    for (;;) {
+        if (a & m) {
+            p ^= b;
+            if ((a & (m - 1)) == 0) break;
+        }
+        m >>= 1;
+        b = (b & 1) ? (b >> 1) ^ 0xedb88320u : b >> 1;
+    }
+    return p;
+}
+__device__ __forceinline__ uint32_t gz_x8n(uint32_t nbytes) {   // x^(8 nbytes) mod P
+    uint32_t p = 1u << 31;
+    for (int k = 3; nbytes; nbytes >>= 1, ++k)
+        if (nbytes & 1) p = gz_multmodp(GZ_X2N[k & 31], p);
+    return p;
+}
+
+__device__ __forceinline__ uint32_t gz_scan256(uint32_t v, uint32_t *sh, uint32_t &total) {   // exclusive, 256 threads
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) sh[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int w = 0; w < wave; ++w) base += sh[w];
+    total = sh[0] + sh[1] + sh[2] + sh[3];
+    __syncthreads();
+    return base + inc - v;
+}
+
+__device__ __forceinline__ void gz_or_bits(uint32_t *out, uint32_t bitpos, uint64_t bits, int nb) {   // nb <= 48
+    if (nb <= 0) return;
+    const uint32_t sh = bitpos & 31u;
+    uint32_t *w = out + (bitpos >> 5);
+    const uint32_t w0 = (uint32_t)(bits << sh);
+    const uint64_t rest = sh ? bits >> (32 - sh) : bits >> 32;
+    if (w0) atomicOr(w, w0);
+    if ((uint32_t)rest) atomicOr(w + 1, (uint32_t)rest);
+    if (rest >> 32) atomicOr(w + 2, (uint32_t)(rest >> 32));
+}
+
+// Code lengths of an alphabet of N symbols (frequencies in LDS), at most MAXB bits: rank sort of the used symbols (all threads), then
+// one thread: two-queue merge, depths, zlib's repair of the lengths beyond MAXB, the rarest leaves get the longest codes; canonical
+// codes (bit-reversed: DEFLATE sends Huffman codes MSB first) by all threads. Called by all 256 threads.
+template <int N, int MAXB>
+__device__ void gz_huff(GzSmem &S, uint32_t *freq, uint8_t *lens, uint16_t *codes) {
+    const int tid = threadIdx.x;
+    const int i0 = tid, i1 = tid + 256;
+    const uint32_t f0 = i0 < N ? freq[i0] : 0, f1 = i1 < N ? freq[i1] : 0;
+    int used = __syncthreads_count(f0 != 0) + __syncthreads_count(f1 != 0);
+    if (used < 2) {   // at least two codes (zlib build_tree): a decoder never sees a 0-bit code
+        if (tid == 0)
+            for (int i = 0; used < 2 && i < N; ++i)
+                if (!freq[i]) { freq[i] = 1; ++used; }
+        used = 2;
+        __syncthreads();
+    }
+    if (i0 < N) lens[i0] = 0;
+    if (i1 < N) lens[i1] = 0;
+#pragma unroll
+    for (int rep = 0; rep < 2; ++rep) {
+        const int i = rep ? i1 : i0;
+        const uint32_t f = i < N ? freq[i] : 0;
+        if (f) {
+            int r = 0;
+            for (int j = 0; j < N; ++j) {
+                const uint32_t g = freq[j];
+                r += (g != 0 && (g < f || (g == f && j < i))) ? 1 : 0;
+            }
+            S.order[r] = (uint16_t)i;
+            S.w[r] = f;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const int ns = used;
+        int a = 0, b = ns, nn = ns;
+        while (nn < 2 * ns - 1) {
+            int pick0, pick1;
+            if (a < ns && (b >= nn || S.w[a] <= S.w[b])) pick0 = a++; else pick0 = b++;
+            if (a < ns && (b >= nn || S.w[a] <= S.w[b])) pick1 = a++; else pick1 = b++;
+            S.w[nn] = S.w[pick0] + S.w[pick1];
+            S.parent[pick0] = (uint16_t)nn;
+            S.parent[pick1] = (uint16_t)nn;
+            ++nn;
+        }
+        S.depth[nn - 1] = 0;
+        for (int i = nn - 2; i >= 0; --i) S.depth[i] = (uint8_t)(S.depth[S.parent[i]] + 1);   // (<= 287: fits)
+        int bl[MAXB + 1];
+#pragma unroll
+        for (int k = 0; k <= MAXB; ++k) bl[k] = 0;
+        long K = 0;
+        for (int i = 0; i < ns; ++i) {
+            int d = S.depth[i];
+            if (d > MAXB) d = MAXB;
+#pragma unroll
+            for (int k = 1; k <= MAXB; ++k) bl[k] += (k == d) ? 1 : 0;
+            K += 1L << (MAXB - d);
+        }
+        while (K > (1L << MAXB)) {   // zlib gen_bitlen: a leaf moves one level down and takes an overflowed leaf as its brother
+            int bits = MAXB - 1;
+            for (;;) {
+                int c = 0;
+#pragma unroll
+                for (int k = 1; k <= MAXB; ++k) c = (k == bits) ? bl[k] : c;
+                if (c) break;
+                --bits;
+            }
+#pragma unroll
+            for (int k = 1; k <= MAXB; ++k) {
+                if (k == bits) bl[k] -= 1;
+                if (k == bits + 1) bl[k] += 2;
+            }
+            bl[MAXB] -= 1;
+            K -= 1;
+        }
+        int i = 0;
+#pragma unroll
+        for (int k = MAXB; k >= 1; --k)
+            for (int c = 0; c < bl[k]; ++c) lens[S.order[i++]] = (uint8_t)k;
+    }
+    __syncthreads();
+    // canonical codes
+#pragma unroll
+    for (int rep = 0; rep < 2; ++rep) {
+        const int i = rep ? i1 : i0;
+        if (i < N) {
+            const int L = lens[i];
+            uint32_t code = 0;
+            if (L) {
+                uint32_t cnt_shorter = 0, same_before = 0;   // code = sum over shorter lengths l of count(l) 2^(L-l)  +  rank among equals
+                for (int j = 0; j < N; ++j) {
+                    const int lj = lens[j];
+                    if (lj && lj < L) cnt_shorter += 1u << (L - lj);
+                    same_before += (lj == L && j < i) ? 1u : 0u;
+                }
+                code = cnt_shorter + same_before;
+                code = __brev(code) >> (32 - L);
+            }
+            codes[i] = (uint16_t)code;
+        }
+    }
+    __syncthreads();
+}
+
+// plain: the selected records of the chunk as one stream (info[1] bytes); member m = bytes [65280 m, ...). toks: 65,280 words of
+// scratch per workgroup. slots: GZ_SLOT bytes per member; msize[m] = the member's size.
+__global__ __launch_bounds__(256) void rd_gz_deflate_kernel(const uint8_t *__restrict__ plain, const int64_t *__restrict__ info,
+                                                           uint32_t *__restrict__ toks, uint8_t *__restrict__ slots,
+                                                           uint32_t *__restrict__ msize) {
+    __shared__ GzSmem S;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t total = info[1];
+    const int64_t nmem = (total + GZ_MEMBER - 1) / GZ_MEMBER;
+    {   // tables, once per workgroup
+        uint32_t c = (uint32_t)tid;
+        for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0xedb88320u : c >> 1;
+        S.crc_tab[tid] = c;
+        int ls = 28;
+        while (GZ_LBASE[ls] > tid + 3) --ls;
+        S.lsym[tid] = (uint8_t)(tid + 3 == 258 ? 28 : ls);
+        for (int k = tid; k < 512; k += 256) {
+            const int d = k < 256 ? k + 1 : ((k - 256) << 7) + 1;   // a distance of the range the entry stands for
+            int ds = 29;
+            while (GZ_DBASE[ds] > d) --ds;
+            S.dsym[k] = (uint8_t)ds;
+        }
+    }
+    uint32_t *mytoks = toks + (size_t)blockIdx.x * GZ_MEMBER;
+    for (int64_t m = blockIdx.x; m < nmem; m += gridDim.x) {
+        const int len = (int)(total - m * GZ_MEMBER < GZ_MEMBER ? total - m * GZ_MEMBER : GZ_MEMBER);
+        __syncthreads();
+        {   // member -> LDS (dword loads: plain is 256-byte aligned and GZ_MEMBER a multiple of 4), zero pad; tables cleared
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(plain + m * GZ_MEMBER);
+            const int nw = (len + 3) >> 2;
+            for (int k = tid; k < (GZ_MEMBER + 16) / 4; k += 256) {
+                uint32_t v = 0;
+                if (k < nw) {
+                    v = src[k];
+                    if (4 * k + 4 > len) v &= 0xffffffffu >> (8 * (4 * k + 4 - len));
+                }
+                S.text[k] = v;
+            }
+            uint32_t *z = reinterpret_cast<uint32_t *>(&S.tab[0][0]);
+            for (int k = tid; k < GZ_NQ * (1 << GZ_HBITS) / 2; k += 256) z[k] = 0;
+            for (int k = tid; k < GZ_NQ * GZ_NSYM; k += 256) (&S.hist[0][0])[k] = 0;
+            if (tid == 0) S.crc = 0;
+        }
+        __syncthreads();
+        // ---- CRC-32: thread t < 255 takes bytes [256 t, 256 t + 256), the pieces are combined with x^(8 bytes after) mod P ----------------
+        if (tid < 255 && 256 * tid < len) {
+            const int b0 = 256 * tid, b1 = b0 + 256 < len ? b0 + 256 : len;
+            uint32_t c = 0xffffffffu;
+            for (int b = b0; b < b1; b += 4) {
+                const uint32_t v = S.text[b >> 2];
+                const int nb = b1 - b < 4 ? b1 - b : 4;
+                for (int k = 0; k < nb; ++k) c = S.crc_tab[(c ^ (v >> (8 * k))) & 0xffu] ^ (c >> 8);
+            }
+            c = ~c;
+            c = gz_multmodp(gz_x8n((uint32_t)(len - b1)), c);
+            atomicXor(&S.crc, c);
+        }
+        // ---- parse: wave w, quarter w ---------------------------------------------------------------------------------------------------
+        const int q0 = wave * GZ_QUARTER, q1 = len < q0 + GZ_QUARTER ? len : q0 + GZ_QUARTER;
+        uint32_t *qt = mytoks + q0;
+        int ntok = 0, carry = 0;
+        const uint8_t *tb = reinterpret_cast<const uint8_t *>(S.text);
+        for (int s0 = q0; s0 < q1; s0 += 64) {
+            const int n = q1 - s0 < 64 ? q1 - s0 : 64;
+            const int p = s0 + lane;
+            const bool in = lane < n;
+            const int lim = q1 - p < GZ_MAXM ? q1 - p : GZ_MAXM;
+            const bool hv = in && p + 8 <= q1;
+            const int pl = in ? p : s0;                 // (lanes past the quarter's end load somewhere harmless)
+            const uint32_t w0 = gz_ld32(S.text, pl), w1 = gz_ld32(S.text, pl + 4);
+            const uint32_t h = (((w0 * 0x9E3779B1u) ^ (w1 * 0x85EBCA77u)) * 0xC2B2AE3Du) >> (32 - GZ_HBITS);
+            int L = 0, D = 0;
+            if (carry < 64) {   // (else every position of the strip lies inside a match: nothing to find, only to insert)
+                if (hv) {
+                    const int c = S.tab[wave][h];
+                    if (c) {
+                        const int k = gz_mlen(S.text, p, q0 + c - 1, lim);
+                        if (k >= GZ_MINM) { L = k; D = p - (q0 + c - 1); }
+                    }
+                }
+                if (in && p > q0) {
+                    const int k = gz_mlen(S.text, p, p - 1, lim);
+                    if (k >= GZ_MINRUN && k >= L) { L = k; D = 1; }
+                }
+            }
+            if (hv) S.tab[wave][h] = (uint16_t)(p - q0 + 1);   // (lanes with the same hash: any of them is a valid earlier position)
+            if (carry >= n) { carry -= n; continue; }
+            const int Ln = __shfl_down(L, 1);
+            const bool defer = L > 0 && L < GZ_LAZY && lane + 1 < n && Ln > L;
+            const bool eff = in && L > 0 && !defer;
+            const uint64_t mm = __ballot(eff);
+            const uint64_t all = n == 64 ? ~0ull : ((1ull << n) - 1);
+            uint64_t sel = 0;
+            int pos = carry;
+            while (pos < n) {
+                const uint64_t from = ~0ull << pos;
+                const uint64_t m2 = mm & from;
+                if (!m2) { sel |= all & from; pos = n; break; }
+                const int f = __builtin_ctzll(m2);
+                sel |= (f == 63 ? ~0ull : ((2ull << f) - 1)) & from;
+                pos = f + __builtin_amdgcn_readlane(L, f);
+            }
+            carry = pos - n;
+            const bool tk = (sel >> lane) & 1ull;
+            const bool ismatch = tk && eff;
+            const uint32_t byte = tb[pl];
+            if (tk) {
+                const int idx = __popcll(sel & ((1ull << lane) - 1));
+                qt[ntok + idx] = ismatch ? ((uint32_t)L << 16) | (uint32_t)D : byte;
+                if (ismatch) {
+                    atomicAdd(&S.hist[wave][257 + S.lsym[L - 3]], 1u);
+                    atomicAdd(&S.hist[wave][286 + S.dsym[D <= 256 ? D - 1 : 256 + ((D - 1) >> 7)]], 1u);
+                } else {
+                    atomicAdd(&S.hist[wave][byte], 1u);
+                }
+            }
+            ntok += __popcll(sel);
+        }
+        if (lane == 0) S.qtok[wave] = (uint32_t)ntok;
+        __syncthreads();
+        // ---- codes --------------------------------------------------------------------------------------------------------------------
+        for (int s = tid; s < GZ_NSYM; s += 256) {
+            uint32_t f = S.hist[0][s] + S.hist[1][s] + S.hist[2][s] + S.hist[3][s];
+            if (s == 256) f += 1;   // end of block
+            S.freq[s] = f;
+        }
+        __syncthreads();
+        gz_huff<286, 15>(S, S.freq, S.lens, S.codes);
+        gz_huff<30, 15>(S, S.freq + 286, S.lens + 286, S.codes + 286);
+        if (tid == 0) {
+            int hlit = 286, hdist = 30;
+            while (hlit > 257 && S.lens[hlit - 1] == 0) --hlit;
+            while (hdist > 1 && S.lens[286 + hdist - 1] == 0) --hdist;
+            S.hlit = hlit; S.hdist = hdist;
+        }
+        if (tid < 19) S.clfreq[tid] = 0;
+        __syncthreads();
+        const int hlit = S.hlit, hdist = S.hdist, nseq = hlit + hdist;
+        // the code lengths are sent one by one (no run-length symbols 16-18: about 30 bytes more per member, nothing sequential)
+        int sq[2];
+#pragma unroll
+        for (int rep = 0; rep < 2; ++rep) {
+            const int i = tid + 256 * rep;
+            sq[rep] = i < nseq ? (i < hlit ? S.lens[i] : S.lens[286 + i - hlit]) : -1;
+            if (sq[rep] >= 0) atomicAdd(&S.clfreq[sq[rep]], 1u);
+        }
+        __syncthreads();
+        gz_huff<19, 7>(S, S.clfreq, S.cllen, S.clcode);
+        if (tid == 0) {
+            int hclen = 19;
+            while (hclen > 4 && S.cllen[GZ_CLORD[hclen - 1]] == 0) --hclen;
+            S.hclen = hclen;
+        }
+        // bits of every quarter's tokens
+        {
+            uint32_t b = 0;
+            for (int s = lane; s < GZ_NSYM; s += 64) {
+                const uint32_t extra = s >= 286 ? GZ_DEXTRA[s - 286 < 30 ? s - 286 : 0] : s >= 257 ? GZ_LEXTRA[s - 257] : 0;
+                if (s < 316) b += S.hist[wave][s] * (S.lens[s] + extra);
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) b += __shfl_xor(b, o);
+            if (lane == 0) S.qbits[wave] = b;
+        }
+        __syncthreads();
+        const int hclen = S.hclen;
+        const uint32_t c0 = sq[0] >= 0 ? S.cllen[sq[0]] : 0, c1 = sq[1] >= 0 ? S.cllen[sq[1]] : 0;
+        uint32_t seqbits_lo, seqbits_total;
+        // (thread t holds entries t and t + 256: two scans, so that the entries stay in order)
+        const uint32_t ex0 = gz_scan256(c0, S.scan, seqbits_lo);
+        const uint32_t ex1 = seqbits_lo + gz_scan256(c1, S.scan, seqbits_total);
+        seqbits_total += seqbits_lo;
+        const uint32_t hdr_bits = 3 + 5 + 5 + 4 + 3 * (uint32_t)hclen + seqbits_total;
+        const uint32_t tok_bits = S.qbits[0] + S.qbits[1] + S.qbits[2] + S.qbits[3] + S.lens[256];
+        const uint32_t cbytes_dyn = (hdr_bits + tok_bits + 7) >> 3;
+        const uint32_t cbytes_sto = 5 + (uint32_t)len;
+        const uint32_t crc = S.crc;
+        uint8_t *slot = slots + (size_t)m * GZ_SLOT;
+        __syncthreads();
+        if (cbytes_dyn >= cbytes_sto) {
+            // ---- stored block (text that does not compress): header, LEN, NLEN, the bytes as they are -----------------------------------
+            const uint32_t tot = GZ_HDR + cbytes_sto + GZ_TRL;
+            if (tid == 0) {
+                uint32_t *sw = reinterpret_cast<uint32_t *>(slot);   // 18 header bytes, then 01 | LEN | NLEN: 23 bytes in six words
+                const uint32_t ul = (uint32_t)len, nl = ~ul & 0xffffu;
+                sw[0] = 0x04088b1fu; sw[1] = 0; sw[2] = 0x0006ff00u; sw[3] = 0x00024342u;
+                sw[4] = ((tot - 1) & 0xffffu) | (1u << 16) | ((ul & 0xffu) << 24);
+                sw[5] = (ul >> 8) | (nl << 8);                       // (byte 23, the first data byte, is written below)
+                uint8_t *t = slot + GZ_HDR + cbytes_sto;
+                for (int k = 0; k < 4; ++k) { t[k] = (uint8_t)(crc >> (8 * k)); t[4 + k] = (uint8_t)((uint32_t)len >> (8 * k)); }
+                msize[m] = tot;
+            }
+            for (int k = tid; k < len; k += 256) slot[GZ_HDR + 5 + k] = tb[k];
+            continue;
+        }
+        // ---- output buffer = the text's LDS: header | dynamic block | trailer -----------------------------------------------------------
+        for (int k = tid; k < (GZ_MEMBER + 16) / 4; k += 256) S.text[k] = 0;
+        __syncthreads();
+        uint32_t *out = S.text;
+        const uint32_t tot = GZ_HDR + cbytes_dyn + GZ_TRL;
+        constexpr uint32_t B0 = GZ_HDR * 8;   // first bit of the deflate data
+        if (tid == 0) {
+            out[0] = 0x04088b1fu; out[1] = 0; out[2] = 0x0006ff00u; out[3] = 0x00024342u;   // 1f 8b 08 04 | mtime | xfl os xlen | 'B' 'C' 2 0
+            out[4] = (tot - 1) & 0xffffu;                                                   // BSIZE; the deflate data follows in the same word
+            gz_or_bits(out, B0, 1u | (2u << 1) | ((uint32_t)(hlit - 257) << 3) | ((uint32_t)(hdist - 1) << 8) | ((uint32_t)(hclen - 4) << 13), 17);
+            gz_or_bits(out, B0 + hdr_bits + tok_bits - S.lens[256], S.codes[256], S.lens[256]);   // end of block
+        }
+        if (tid < hclen) gz_or_bits(out, B0 + 17 + 3 * tid, S.cllen[GZ_CLORD[tid]], 3);
+        if (sq[0] >= 0) gz_or_bits(out, B0 + 17 + 3 * hclen + ex0, S.clcode[sq[0]], (int)c0);
+        if (sq[1] >= 0) gz_or_bits(out, B0 + 17 + 3 * hclen + ex1, S.clcode[sq[1]], (int)c1);
+        {   // tokens of this wave's quarter
+            uint32_t bit = B0 + hdr_bits;
+            for (int v = 0; v < wave; ++v) bit += S.qbits[v];
+            const int nt = (int)S.qtok[wave];
+            for (int t0 = 0; t0 < nt; t0 += 64) {
+                const int t = t0 + lane;
+                uint64_t bits = 0;
+                int nb = 0;
+                if (t < nt) {
+                    const uint32_t tv = qt[t];
+                    const uint32_t L = tv >> 16;
+                    if (L) {
+                        const uint32_t D = tv & 0xffffu;
+                        const int ls = S.lsym[L - 3], ds = S.dsym[D <= 256 ? D - 1 : 256 + ((D - 1) >> 7)];
+                        bits = S.codes[257 + ls];
+                        nb = S.lens[257 + ls];
+                        bits |= (uint64_t)(L - GZ_LBASE[ls]) << nb;
+                        nb += GZ_LEXTRA[ls];
+                        bits |= (uint64_t)S.codes[286 + ds] << nb;
+                        nb += S.lens[286 + ds];
+                        bits |= (uint64_t)(D - GZ_DBASE[ds]) << nb;
+                        nb += GZ_DEXTRA[ds];
+                    } else {
+                        bits = S.codes[tv];
+                        nb = S.lens[tv];
+                    }
+                }
+                uint32_t inc = (uint32_t)nb;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const uint32_t u = __shfl_up(inc, o);
+                    if (lane >= o) inc += u;
+                }
+                gz_or_bits(out, bit + inc - (uint32_t)nb, bits, nb);
+                bit += __shfl(inc, 63);
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {   // trailer: CRC-32, ISIZE (byte-granular position)
+            uint8_t *ob = reinterpret_cast<uint8_t *>(out) + GZ_HDR + cbytes_dyn;
+            for (int k = 0; k < 4; ++k) { ob[k] = (uint8_t)(crc >> (8 * k)); ob[4 + k] = (uint8_t)((uint32_t)len >> (8 * k)); }
+            msize[m] = tot;
+        }
+        __syncthreads();
+        uint32_t *dst = reinterpret_cast<uint32_t *>(slot);
+        for (int k = tid; k < (int)((tot + 3) >> 2); k += 256) dst[k] = out[k];
+    }
+}
+
+// member sizes -> offsets (one workgroup), info[0] = bytes of the compressed stream
+__global__ __launch_bounds__(256) void rd_gz_moff_kernel(const uint32_t *__restrict__ msize, int64_t *__restrict__ moff, int64_t *__restrict__ info) {
+    __shared__ int64_t sh[4];
+    __shared__ int64_t run_s;
+    const int64_t nmem = info[2];
+    if (threadIdx.x == 0) run_s = 0;
+    __syncthreads();
+    for (int64_t b0 = 0; b0 < nmem; b0 += 256) {
+        const int64_t b = b0 + threadIdx.x;
+        const int64_t v = b < nmem ? (int64_t)msize[b] : 0;
+        int64_t total;
+        const int64_t ex = gz_block_scan(v, sh, total);
+        const int64_t run = run_s;
+        if (b < nmem) moff[b] = run + ex;
+        __syncthreads();
+        if (threadIdx.x == 0) run_s = run + total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) info[0] = run_s;
+}
+
+// members -> one contiguous stream (byte-granular destinations: dword loads from the slot, byte stores)
+__global__ __launch_bounds__(256) void rd_gz_compact_kernel(const uint8_t *__restrict__ slots, const uint32_t *__restrict__ msize,
+                                                           const int64_t *__restrict__ moff, const int64_t *__restrict__ info,
+                                                           uint8_t *__restrict__ out, int64_t out_cap) {
+    const int64_t nmem = info[2];
+    for (int64_t m = blockIdx.x; m < nmem; m += gridDim.x) {
+        const uint32_t sz = msize[m];
+        const int64_t o = moff[m];
+        if (o + sz > out_cap) continue;   // (the host sees info[0] > out_cap and reports it)
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(slots + (size_t)m * GZ_SLOT);
+        uint8_t *dst = out + o;
+        const int head = (int)((4 - (o & 3)) & 3);   // bytes up to the first dword boundary of the destination
+        for (int k = threadIdx.x; k < head && k < (int)sz; k += 256) dst[k] = (uint8_t)(src[0] >> (8 * k));
+        const int nw = sz > (uint32_t)head ? (int)((sz - head) >> 2) : 0;
+        uint32_t *d32 = reinterpret_cast<uint32_t *>(dst + head);
+        for (int k = threadIdx.x; k < nw; k += 256) {
+            const int sb = head + 4 * k;              // source byte offset
+            const uint32_t lo = src[sb >> 2], hi = src[(sb >> 2) + 1];
+            d32[k] = __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)(sb & 3));
+        }
+        for (int k = head + 4 * nw + threadIdx.x; k < (int)sz; k += 256) dst[k] = (uint8_t)(src[k >> 2] >> (8 * (k & 3)));
+    }
+}
+
+}  // namespace

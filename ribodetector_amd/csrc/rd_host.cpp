@@ -198,6 +198,7 @@ struct rd_writer {
     int threads;
     std::vector<uint8_t> pending;   // gz only: selected record bytes not yet compressed
     std::vector<void *> comp;       // gz only: one libdeflate compressor per worker slot (empty: zlib)
+    bool bgzf = false;              // members written by rd_writer_write_members (BGZF blocks made on the GPU)
 };
 
 // libdeflate (a system library of this image, libdeflate0 1.10) compresses level 5 ~2.5x faster than zlib at the same
@@ -868,12 +869,28 @@ int rd_writer_write_selected(rd_writer *w, const uint8_t *buf, const int64_t *re
     return 0;
 }
 
+// Complete gzip members made elsewhere - on the GPU (librd_hip.so rd_gz_compress_selected: the chunk's records of one label, deflated
+// where they already lie) - appended as they are. Whatever the host path has buffered for this file comes first (input order).
+int rd_writer_write_members(rd_writer *w, const uint8_t *members, int64_t len) {
+    if (!w || len < 0 || (!members && len)) RDH_FAIL("rd_writer_write_members: bad argument");
+    if (!w->gz) RDH_FAIL("rd_writer_write_members: not a gzip output (the name does not end with 'gz')");
+    if (!w->pending.empty() && gz_flush(w, w->pending.size()) != 0) RDH_FAIL("gzip compression/write failed");
+    if (len && !pwrite_all(w->fd, members, (size_t)len, w->off)) RDH_FAIL("write failed");
+    w->off += len;
+    w->bgzf = true;
+    return 0;
+}
+
 int rd_writer_close(rd_writer *w) {
     if (!w) return 0;
     int rc = 0;
     if (w->gz) {
         if (!w->pending.empty()) rc = gz_flush(w, w->pending.size());
-        else if (w->off == 0) {   // an empty .gz must still be a valid gzip file (one empty member)
+        if (w->bgzf) {            // device-written members are BGZF blocks: the file ends with BGZF's end-of-file marker (an empty member)
+            static const uint8_t eof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            if (rc == 0 && pwrite_all(w->fd, eof, sizeof(eof), w->off)) w->off += (int64_t)sizeof(eof);
+            else rc = -1;
+        } else if (w->off == 0) {   // an empty .gz must still be a valid gzip file (one empty member)
             std::vector<uint8_t> m;
             rc = gz_member(nullptr, 0, m, nullptr) && pwrite_all(w->fd, m.data(), m.size(), 0) ? 0 : -1;
         }

@@ -24,6 +24,7 @@
 //   rd_refine_kernel                   float64 re-evaluation of the reads whose margin is inside the fp32 noise band
 //   rd_encode_* / rd_pack_onehot       standalone encoder kernels (reference tensor layouts), HBM-bound
 //   rd_pair_fuse_kernel, rd_count_kernel
+//   rd_gz_*                            records of one label -> gzip (BGZF) members on the device (rd_deflate.hpp)
 #include "rd_common.hpp"
 #include "rd_prep.hpp"
 #include "rd_recurrence.hpp"
@@ -35,6 +36,7 @@
 #endif
 #include "rd_refine.hpp"
 #include "rd_encode.hpp"
+#include "rd_deflate.hpp"
 
 // ================================================================================================
 // C ABI
@@ -564,6 +566,84 @@ int rd_pack_onehot(const uint8_t *arena, const int64_t *seq_off, const int32_t *
     if (nb > 0x7fffffffLL) RD_FAIL(RD_E_INVALID, "rd_pack_onehot: n too large");
     hipLaunchKernelGGL(rd_pack_onehot_kernel, dim3((unsigned)nb), dim3(256), 0, st, arena, seq_off, seq_len, n, max_len, sorted_idx,
                        batch_sizes, (f32x4 *)data);
+    RD_HIP(hipGetLastError());
+    return RD_OK;
+}
+
+// ---- device-side gzip of the label-partitioned records (rd_deflate.hpp) ------------------------------------------------------------
+namespace {
+struct GzPlan {
+    int nb;                 // scan blocks
+    int64_t cap_members;    // members the chunk can have at most (every record selected)
+    int grid;               // workgroups of the deflate kernel
+    size_t off_bytes, bsum_bytes, plain_bytes, toks_bytes, slots_bytes, msize_bytes, moff_bytes, total;
+};
+GzPlan gz_plan(int64_t n, int64_t text_bytes) {
+    GzPlan p;
+    p.nb = (int)((n + 1 + GZ_SCAN_ITEMS - 1) / GZ_SCAN_ITEMS);
+    p.cap_members = (text_bytes + GZ_MEMBER - 1) / GZ_MEMBER;
+    if (p.cap_members < 1) p.cap_members = 1;
+    p.grid = (int)(p.cap_members < GZ_MAX_GRID ? p.cap_members : GZ_MAX_GRID);
+    p.off_bytes = align_up((size_t)(n + 1) * 8, 256);
+    p.bsum_bytes = align_up((size_t)p.nb * 8, 256);
+    p.plain_bytes = align_up((size_t)p.cap_members * GZ_MEMBER + 256, 256);
+    p.toks_bytes = align_up((size_t)p.grid * GZ_MEMBER * 4, 256);
+    p.slots_bytes = (size_t)p.cap_members * GZ_SLOT;
+    p.msize_bytes = align_up((size_t)p.cap_members * 4, 256);
+    p.moff_bytes = align_up((size_t)p.cap_members * 8, 256);
+    p.total = p.off_bytes + p.bsum_bytes + p.plain_bytes + p.toks_bytes + p.slots_bytes + p.msize_bytes + p.moff_bytes;
+    return p;
+}
+}  // namespace
+
+size_t rd_gz_workspace_bytes(int64_t n, int64_t text_bytes) {
+    if (n < 0 || text_bytes < 0) return 0;
+    return gz_plan(n, text_bytes).total;
+}
+
+size_t rd_gz_out_bound(int64_t text_bytes) {
+    if (text_bytes < 0) return 0;
+    const int64_t members = (text_bytes + GZ_MEMBER - 1) / GZ_MEMBER;
+    return (size_t)members * (GZ_HDR + 5 + GZ_TRL) + (size_t)text_bytes;   // every member as a stored block
+}
+
+int rd_gz_eof_block(uint8_t *dst, size_t cap) {   // BGZF's end-of-file marker: an empty member (28 bytes)
+    static const uint8_t eof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (!dst || cap < sizeof(eof)) RD_FAIL(RD_E_INVALID, "rd_gz_eof_block: need 28 bytes");
+    memcpy(dst, eof, sizeof(eof));
+    return (int)sizeof(eof);
+}
+
+int rd_gz_compress_selected(const uint8_t *text, int64_t text_bytes, const int64_t *rec_start, const int8_t *labels, int64_t n,
+                            int32_t label, uint8_t *out, size_t out_cap, int64_t *info, void *workspace, size_t workspace_bytes,
+                            void *stream) {
+    if (n < 0 || n > 0x7fffffffLL || text_bytes < 0) RD_FAIL(RD_E_INVALID, "rd_gz_compress_selected: bad n or text_bytes");
+    if (!info) RD_FAIL(RD_E_INVALID, "rd_gz_compress_selected: null info");
+    if (label < -128 || label > 127) RD_FAIL(RD_E_INVALID, "rd_gz_compress_selected: label %d is not an int8 value", label);
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 0) {
+        RD_HIP(hipMemsetAsync(info, 0, 4 * sizeof(int64_t), st));
+        return RD_OK;
+    }
+    if ((!text && text_bytes > 0) || !rec_start || !labels || !out || !workspace) RD_FAIL(RD_E_INVALID, "rd_gz_compress_selected: null pointer");
+    if (((uintptr_t)workspace & 255) || ((uintptr_t)out & 255)) RD_FAIL(RD_E_INVALID, "rd_gz_compress_selected: workspace and out must be 256-byte aligned");
+    const GzPlan p = gz_plan(n, text_bytes);
+    if (workspace_bytes < p.total) RD_FAIL(RD_E_WORKSPACE, "rd_gz_compress_selected: workspace too small: %zu < %zu", workspace_bytes, p.total);
+    char *w = (char *)workspace;
+    int64_t *out_off = (int64_t *)w; w += p.off_bytes;
+    int64_t *bsum = (int64_t *)w; w += p.bsum_bytes;
+    uint8_t *plain = (uint8_t *)w; w += p.plain_bytes;
+    uint32_t *toks = (uint32_t *)w; w += p.toks_bytes;
+    uint8_t *slots = (uint8_t *)w; w += p.slots_bytes;
+    uint32_t *msize = (uint32_t *)w; w += p.msize_bytes;
+    int64_t *moff = (int64_t *)w;
+    hipLaunchKernelGGL(rd_gz_sel_sum_kernel, dim3(p.nb), dim3(256), 0, st, rec_start, labels, n, label, bsum);
+    hipLaunchKernelGGL(rd_gz_sel_base_kernel, dim3(1), dim3(256), 0, st, bsum, p.nb, info);
+    hipLaunchKernelGGL(rd_gz_sel_off_kernel, dim3(p.nb), dim3(256), 0, st, rec_start, labels, n, label, bsum, out_off);
+    hipLaunchKernelGGL(rd_gz_pack_kernel, dim3((unsigned)((n + GZ_PACK_RECS - 1) / GZ_PACK_RECS)), dim3(256), 0, st, text, rec_start, out_off, n, plain);
+    hipLaunchKernelGGL(rd_gz_deflate_kernel, dim3(p.grid), dim3(256), 0, st, plain, info, toks, slots, msize);
+    hipLaunchKernelGGL(rd_gz_moff_kernel, dim3(1), dim3(256), 0, st, msize, moff, info);
+    hipLaunchKernelGGL(rd_gz_compact_kernel, dim3(p.grid), dim3(256), 0, st, slots, msize, moff, info, out, (int64_t)out_cap);
     RD_HIP(hipGetLastError());
     return RD_OK;
 }

@@ -77,7 +77,7 @@ def seq_parser(seq_fh, seq_type):
 
 # A chunk of records as arrays.  buf: uint8 arena holding the record text; rec_start int64[n+1]: byte range of record i
 # (verbatim text incl. its final newline, valid when `verbatim`); seq_off int64[n] / seq_len int32[n]: the bases.
-# tensors: (buf, seq_off, seq_len) as (pinned) torch tensors when the chunk came from the native reader, else None.
+# tensors: (buf, seq_off, seq_len, rec_start) as (pinned) torch tensors when the chunk came from the native reader, else None.
 # release: called by the last consumer of a chunk whose buffers are a slot of a ShmArena; shm: where such a chunk lives.
 Chunk = namedtuple("Chunk", "buf rec_start seq_off seq_len verbatim records tensors release shm", defaults=(None, None, None))
 
@@ -307,7 +307,7 @@ class ShmArena:
         if key not in cls._attached:
             cls._attached[key] = _shm_views(path, cap_n, cap_b, False)
         buf, rs, so, sl = cls._attached[key]
-        return Chunk(buf[:nb].numpy(), rs[:n + 1].numpy(), so[:n].numpy(), sl[:n].numpy(), True, None, (buf[:nb], so[:n], sl[:n]))
+        return Chunk(buf[:nb].numpy(), rs[:n + 1].numpy(), so[:n].numpy(), sl[:n].numpy(), True, None, (buf[:nb], so[:n], sl[:n], rs[:n + 1]))
 
 
 class NativeReader:
@@ -393,7 +393,7 @@ class NativeReader:
             release = lambda: arena.free(slot)      # noqa: E731
             shm = (slot["path"], slot["cap_n"], slot["cap_b"], n_tot, b_tot)
         return Chunk(buf[:b_tot].numpy(), rs[:n_tot + 1].numpy(), so[:n_tot].numpy(), sl[:n_tot].numpy(), True, None,
-                     (buf[:b_tot], so[:n_tot], sl[:n_tot]), release, shm)
+                     (buf[:b_tot], so[:n_tot], sl[:n_tot], rs[:n_tot + 1]), release, shm)
 
 
 def _fmt_id(path):
@@ -654,6 +654,10 @@ class NativeWriter:
         rs = np.ascontiguousarray(chunk.rec_start, dtype=np.int64)
         N.host_check(N.host_lib().rd_writer_write_selected(self.h, buf.ctypes.data, rs.ctypes.data, len(labels), labels.ctypes.data,
                                                            int(want)), "rd_writer_write_selected")
+
+    def write_members(self, ptr, nbytes):
+        """append complete gzip members made on the GPU (ribodetector_amd/gz.py); ptr: host address of the bytes"""
+        N.host_check(N.host_lib().rd_writer_write_members(self.h, ptr, int(nbytes)), "rd_writer_write_members")
 
     def close(self):
         if self.h:

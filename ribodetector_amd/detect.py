@@ -59,6 +59,8 @@ def part_path(path, rank):
 class Predictor:
     """Main class of predictor for rRNA, non-rRNA sequences (interface of reference detect.py:34-43)."""
 
+    GZ_RING = 5          # device gzip: sets of output buffers in flight (submitted, collected, queued x2, being written)
+
     def __init__(self, config, args):
         self.config = config
         self.args = args
@@ -138,7 +140,11 @@ class Predictor:
         pk = kcfg.get('prefix_k', None)           # prefix-state table: absent = the model's default (RD_PREFIX_K or "auto")
         if pk is not None and pk != 'auto' and not (isinstance(pk, int) and (pk == 0 or 4 <= pk <= 13)):
             raise RuntimeError("config.json kernel.prefix_k must be \"auto\", 0 or an integer in [4, 13]; got %r" % (pk,))
-        return {"variant": variant, "semantics": sem, "refine": refine, "prefix_k": pk}
+        gz = os.environ.get("RD_DEVICE_GZIP") or kcfg.get("gzip", "device")     # who deflates .gz outputs: the GPU (BGZF members) or the host
+        gz = {"1": "device", "0": "host"}.get(gz, gz)
+        if gz not in ("device", "host"):
+            raise RuntimeError("config.json kernel.gzip must be \"device\" or \"host\"; got %r" % (gz,))
+        return {"variant": variant, "semantics": sem, "refine": refine, "prefix_k": pk, "gzip": gz}
 
     def prefix_k_for_input(self):
         """k of the prefix-state table that pays off for THIS run: a row saves k steps per read, level k costs 4^k one-step
@@ -191,6 +197,7 @@ class Predictor:
         # C ABI (rd_set_refine_async): the recurrence kernel's epilogue records the reads inside the band, and submit_chunk's
         # post-pass evaluates them (rd_sync_results on the post stream) beside the next chunk's recurrences.
         self.refine_band = kcfg["refine"]
+        self.gzip_on_device = kcfg["gzip"] == "device"
         self.model.set_refine(self.refine_band)
         self.model.set_refine_async(16 if self.refine_band > 0 else 0)
         self.model.eval()
@@ -201,7 +208,7 @@ class Predictor:
         straight into pinned buffers, so there is no staging copy."""
         b0 = int(chunk.rec_start[lo])
         b1 = int(chunk.rec_start[hi])
-        tbuf, toff, tlen = chunk.tensors
+        tbuf, toff, tlen = chunk.tensors[:3]
         with torch.cuda.stream(stream):
             arena = tbuf[b0:b1].to(self.device, non_blocking=True) if b1 > b0 else torch.zeros(1, dtype=torch.uint8, device=self.device)
             off = toff[lo:hi].to(self.device, non_blocking=True) - b0
@@ -243,14 +250,30 @@ class Predictor:
             else:
                 labels = outs[0][1].view(torch.int8)
             host = finish = None
+            gzparts = {}
             if not self.multi or self.sharded_parse:
                 host = torch.empty(labels.shape, dtype=torch.int8, pin_memory=True)
                 host.copy_(labels, non_blocking=True)
+                # .gz outputs: the records of every label file of this chunk are deflated here, where the chunk's text already is
+                # (BGZF members, csrc/rd_deflate.hpp), beside the next chunk's recurrences; the writer threads fetch the compressed
+                # bytes and append them (reference: gzip.open(..., compresslevel=5) on the host, detect.py:729-741)
+                if self._gz_files and all(c.tensors is not None and len(c.tensors) > 3 and c.verbatim for c in chunks):
+                    ring = self._gz_seq % self.GZ_RING
+                    self._gz_seq += 1
+                    for e, lab in self._gz_files:
+                        c = chunks[e]
+                        b0 = int(c.rec_start[lo])
+                        rs = c.tensors[3][lo:hi + 1].to(self.device, non_blocking=True) - b0
+                        out, info = self._gz.compress_selected(dev_in[e][0], rs, labels.view(torch.int8), lab, slot=(e, lab, ring))
+                        ih = torch.empty(4, dtype=torch.int64, pin_memory=True)
+                        ih.copy_(info, non_blocking=True)
+                        gzparts[(e, lab)] = (out, ih)
             else:                                    # label gather (1 B per read) queued behind the kernels, collected later
                 _, finish = rdist.gather_labels(labels, n, dst=0, bounds=bounds, async_op=True)
             done = torch.cuda.Event()
             done.record(post)
-        return {"n": n, "bounds": bounds, "labels": labels, "host": host, "finish": finish, "done": done, "keep": (dev_in, outs)}
+        return {"n": n, "bounds": bounds, "labels": labels, "host": host, "finish": finish, "done": done, "keep": (dev_in, outs),
+                "gz": gzparts}
 
     def collect_chunk(self, tk):
         """Labels of a submitted chunk: int8 numpy on rank 0 (whole chunk, input order), None elsewhere."""
@@ -421,19 +444,46 @@ class Predictor:
         self._stage_s = {"wait_reader": 0.0, "classify": 0.0, "wait_writer": 0.0}   # main-thread seconds per pipeline stage
         self._copy_stream = torch.cuda.Stream(self.device)
         self._post_stream = torch.cuda.Stream(self.device)
+        # which (mate, label) files are gzip outputs deflated on the device: every rank writes its own records there (one rank, or
+        # the sharded parse of plain inputs); under the label gather rank 0 holds only its shard of the text, so the host compresses
+        self._gz_files, self._gz_seq = [], 0
+        if writer and self.gzip_on_device and (not self.multi or self.sharded_parse):
+            from .gz import DeviceGzip
+            self._gz_files = [(e, lab) for lab, names in ((1, self.rrna), (0, self.output)) if names is not None for e in ends
+                              if names[e].endswith('gz')]
+            if -1 in fhs:
+                self._gz_files += [(e, -1) for e in ends]
+            if self._gz_files:
+                self._gz = DeviceGzip(self.device)
 
         # writer threads (rank 0): one per mate, records of every label file in input order
         wq, werr, wth = [], [], []
         if writer:
             def write_end(e, q):
+                stage = [None]                          # pinned staging buffer of this thread
+                gz_copy = torch.cuda.Stream(self.device) if self._gz_files else None
                 try:
                     while True:
                         item = q.get()
                         if item is None:
                             return
-                        chunk, labels = item
+                        chunk, labels, gzparts = item
                         for lab, handles in fhs.items():
-                            handles[e].write_selected(chunk, labels, lab)
+                            part = gzparts.get((e, lab)) if gzparts else None
+                            if part is None:
+                                handles[e].write_selected(chunk, labels, lab)
+                                continue
+                            out, info = part            # members made on the GPU: fetch the compressed bytes, append them
+                            nb = int(info[0])
+                            if nb > out.numel():
+                                raise RuntimeError("device gzip: output buffer too small (%d > %d)" % (nb, out.numel()))
+                            if nb:
+                                if stage[0] is None or stage[0].numel() < nb:
+                                    stage[0] = torch.empty(max(nb, 1 << 24) * 5 // 4, dtype=torch.uint8, pin_memory=True)
+                                with torch.cuda.stream(gz_copy):
+                                    stage[0][:nb].copy_(out[:nb], non_blocking=True)
+                                gz_copy.synchronize()
+                                handles[e].write_members(stage[0].data_ptr(), nb)
                         if chunk.release is not None:   # a shared-memory slot: free for the next chunk once its text is written
                             chunk.release()
                 except BaseException as ex:
@@ -470,7 +520,7 @@ class Predictor:
                     num_unknown += int((labels == -1).sum())
                     t0 = time.perf_counter()
                     for e in ends:
-                        wq[e].put((chunks[e], labels))
+                        wq[e].put((chunks[e], labels, tk.get("gz")))
                     self._stage_s["wait_writer"] += time.perf_counter() - t0
                     log('{}{}{} sequences finished!'.format(colors.OKGREEN, num_read, colors.ENDC))
         finally:

@@ -72,6 +72,50 @@ def test_cli_paired(tmp_path, oracle, ensure):
         assert _read(outs[0] + ".unclassified.gz") == _fastq_text(a1, o1, 1, np.flatnonzero(lab == -1))
 
 
+@pytest.mark.parametrize("paired", [False, True])
+def test_cli_gz_outputs_are_deflated_on_the_device(tmp_path, paired, monkeypatch):
+    """.gz outputs (reference detect.py:729-741: gzip level 5 by extension): by default the records are deflated on the GPU into BGZF
+    members (csrc/rd_deflate.hpp); RD_DEVICE_GZIP=0 keeps the host's libdeflate writer. Same decompressed files either way, in
+    input order; the device-written file is valid BGZF (every member carries its size, the file ends with the EOF marker), about
+    the size of the host's level-5 output, and this build's own reader takes it back."""
+    import struct
+    from ribodetector_amd import detect, synth
+    from ribodetector_amd.data_loader import fastx_parser as fx
+    from ribodetector_amd.gz import eof_block
+    n = 60000
+    ins = []
+    for m in range(2 if paired else 1):
+        a, o, _ = synth.reads_numpy(n, (40, 140), seed=61 + m, rrna_frac=0.4)
+        ins.append(str(tmp_path / ("r_%d.fq" % (m + 1))))
+        synth.write_fastq(ins[-1], a, o, m + 1)
+    res = {}
+    for tag, env in (("device", None), ("host", "0")):
+        if env is None:
+            monkeypatch.delenv("RD_DEVICE_GZIP", raising=False)
+        else:
+            monkeypatch.setenv("RD_DEVICE_GZIP", env)
+        outs = [str(tmp_path / ("%s_n%d.fq.gz" % (tag, m))) for m in range(len(ins))]
+        rrs = [str(tmp_path / ("%s_r%d.fq.gz" % (tag, m))) for m in range(len(ins))]
+        p = detect.main(["-l", "100", "-i", *ins, "-o", *outs, "-r", *rrs, "--chunk_size", "1", "-m", "3"] + (["-e", "both"] if paired else []))
+        files = outs + rrs + ([o + ".unclassified.gz" for o in outs] if paired else [])
+        res[tag] = (files, (p.num_read, p.num_nonrrna, p.num_rrna, p.num_unknown))
+    assert res["device"][1] == res["host"][1] and res["device"][1][0] == n and res["device"][1][2] > 0
+    for fd, fh in zip(res["device"][0], res["host"][0]):
+        text = _read(fd)
+        assert text == _read(fh) and len(text) > 0
+        raw = open(fd, "rb").read()
+        assert raw.endswith(eof_block()) and not open(fh, "rb").read().endswith(eof_block())
+        pos, members = 0, 0
+        while pos < len(raw):                                          # a chain of BGZF blocks, nothing else
+            assert raw[pos:pos + 4] == b"\x1f\x8b\x08\x04" and raw[pos + 12:pos + 16] == b"BC\x02\x00"
+            pos += struct.unpack("<H", raw[pos + 16:pos + 18])[0] + 1
+            members += 1
+        assert pos == len(raw) and members >= 2
+        assert len(raw) < 1.10 * os.path.getsize(fh)                   # (the host writes libdeflate level 5 in 4 MiB members)
+        back = b"".join(c.buf[c.rec_start[0]:c.rec_start[-1]].tobytes() for c in fx.get_seq_chunks(fd, chunk_size=7777))
+        assert back.decode() == text
+
+
 def test_cli_argument_errors(tmp_path):
     from ribodetector_amd import detect
     with pytest.raises(RuntimeError):

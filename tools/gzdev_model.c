@@ -6,7 +6,8 @@
 // header, BGZF framing) in a form that zlib's inflate checks on this machine. The kernel follows the same steps:
 //
 //   member  = 65,280 input bytes (BGZF's block size: the output is a valid BGZF file), one workgroup;
-//   quarter = 16,320 bytes, one wave: its own 4,096-entry hash table (4-byte hashes, nearest earlier occurrence);
+//   quarter = 16,320 bytes, one wave: its own 4,096-entry hash table (8-byte hashes, nearest earlier occurrence; matches of 8+
+//             bytes only: on FASTQ the shorter ones cost more bits than the 2-bit literals they replace - measured here);
 //   strip   = 64 consecutive positions, one per lane: every lane hashes its position, looks its candidate up (positions before the
 //             strip), also tries distance 1 (runs), measures the match; then all 64 positions are inserted (the highest lane wins a
 //             slot); then the parse of the strip is resolved left to right: lazy rule (a match shorter than 32 is dropped for a
@@ -24,10 +25,10 @@
 #define HBITS 12
 #endif
 #ifndef HBYTES
-#define HBYTES 4
+#define HBYTES 8
 #endif
 #ifndef MINM
-#define MINM 4
+#define MINM 8
 #endif
 #ifndef NQ
 #define NQ 4
@@ -54,7 +55,10 @@ static int dist_sym(int d) {
 
 static uint32_t load32(const uint8_t *p) { uint32_t v; memcpy(&v, p, 4); return v; }
 static int hash4(uint32_t v) { return (int)((v * 2654435761u) >> (32 - HBITS)); }
-static int hashn(const uint8_t *p) { uint64_t v = 0; memcpy(&v, p, HBYTES); return (int)((v * 0x9E3779B97F4A7C15ull) >> (64 - HBITS)); }
+static int hashn(const uint8_t *p) {   // the kernel's hash: two dwords, 32-bit multiplies
+    if (HBYTES == 8) { const uint32_t a = load32(p), b = load32(p + 4); return (int)((((a * 0x9E3779B1u) ^ (b * 0x85EBCA77u)) * 0xC2B2AE3Du) >> (32 - HBITS)); }
+    uint64_t v = 0; memcpy(&v, p, HBYTES); return (int)((v * 0x9E3779B97F4A7C15ull) >> (64 - HBITS));
+}
 
 static int mlen(const uint8_t *m, int p, int c, int lim) {
     int l = 0;
@@ -62,7 +66,7 @@ static int mlen(const uint8_t *m, int p, int c, int lim) {
     return l;
 }
 
-static int opt_dist1_min = 4, opt_lazy = 1, opt_two = 0;
+static int opt_dist1_min = 6, opt_lazy = 1, opt_two = 0;
 
 // one quarter [q0, q1) of the member m; returns the number of tokens
 static int parse_quarter(const uint8_t *m, int q0, int q1, Tok *out) {
