@@ -525,11 +525,53 @@ def main():
         for f in pend:
             f()
 
+    rank_info = None
     if multi:                                               # create the communicators (incl. the point-to-point ones the gather
-        f = exchange(torch.zeros((P,), dtype=torch.int8, device=dev))   # uses) outside the timed region, whatever --warmup is
+        t0 = time.perf_counter()                            # uses) outside the timed region, whatever --warmup is
+        f = exchange(torch.zeros((P,), dtype=torch.int8, device=dev))
         if f:
             f()
         sync()
+        first_gather_s = time.perf_counter() - t0
+        # Self-check of the exchange before anything is timed (the first N > 1 run on real hardware is a one-shot): step 0 of this
+        # rank's shard once WITHOUT the gather -> this rank's own label counts, once THROUGH it -> rank 0 counts the slice it
+        # received from every rank. Any difference ends the run with exit code 4 on every rank.
+        keep = {}
+        ev, _ = compute(0, r1[0][0], r2[0][0] if paired else None, lambda lab: keep.__setitem__("lab", lab.clone()))
+        ev.synchronize()
+        mine = [int((keep["lab"] == v).sum()) for v in (0, 1, -1)]
+        ev, f = compute(1, r1[0][0], r2[0][0] if paired else None, exchange)
+        if f:
+            f()
+        sync()
+        try:
+            uuid = str(torch.cuda.get_device_properties(dev).uuid)
+        except Exception:
+            uuid = "?"
+        infos = [None] * world
+        dist.all_gather_object(infos, {"rank": rank, "local_rank": local, "device": str(dev), "device_uuid": uuid, "pid": os.getpid(),
+                                       "first_gather_s": round(first_gather_s, 4), "step0_label_counts": mine})
+        verdict = [None]
+        if rank == 0:
+            bad = []
+            if os.environ.get("RD_BENCH_CORRUPT_GATHER") == "1":      # (tests: the check must catch a wrong gather)
+                gathered[P * world - 1] = 1 - gathered[P * world - 1]
+            for r in range(world):
+                sl = gathered[r * P:(r + 1) * P]
+                got = [int((sl == v).sum()) for v in (0, 1, -1)]
+                if got != infos[r]["step0_label_counts"]:
+                    bad.append({"rank": r, "gathered": got, "local": infos[r]["step0_label_counts"]})
+            verdict = [bad]
+            if len({i["device_uuid"] for i in infos}) != world and "RD_LOCAL_DEVICE" not in os.environ:
+                sys.stderr.write("bench.py: WARNING: %d ranks on %d distinct devices\n" % (world, len({i["device_uuid"] for i in infos})))
+        dist.broadcast_object_list(verdict, src=0)
+        if verdict[0]:
+            if rank == 0:
+                sys.stderr.write("bench.py: label gather self-check FAILED: %s\n" % json.dumps(verdict[0]))
+            dist.barrier()
+            raise SystemExit(4)
+        rank_info = infos
+        counts.zero_()
     timed_path = run_resident if args.resident_only else run_device_path
     timed_path(args.warmup)
     sync()
@@ -627,6 +669,7 @@ def main():
                        "host_cores_busy": sum(cpu_ranks) / dt, "host_cores_usable": usable_cores(),
                        "host_cpu_seconds_by_thread_rank0": by_thread,
                        "rccl_ranks": world, "dist_backend": backend, "forced_dist": bool(multi and world == 1),
+                       "ranks": rank_info, "gather_self_check": "passed" if rank_info else None,
                        "prefix_table": {"k": PK, "bytes": (4 ** PK + 1) * 1024 if PK else 0,
                                         "what": "recurrence state after every sequence of k bases, built by the kernel itself at model load; "
                                                 "a read whose first k bases are A/C/G/T starts from its row (bit-identical logits, "

@@ -15,12 +15,7 @@ VARIANTS = {"auto": 0, "mfma_f32": 1, "simple": 2, "mfma_f16x3_t32": 4}      # w
 # A/B and diagnostic instantiations: only in librd_hip_diag.so (built with -DRD_DIAG by __graft_entry__.build_diag(), selected
 # with RD_HIP_LIB=.../librd_hip_diag.so by the scripts under tools/). Several compute wrong results by design.
 DIAG_VARIANTS = {"mfma_f32_a0s0": 10, "mfma_f32_a1s0": 11, "mfma_f32_a0s1": 12, "mfma_f32_a1s1": 13,
-                 "mfma_f32_diag_noew": 20, "mfma_f32_diag_nomfma": 21, "mfma_f32_diag_mfmaonly": 22, "mfma_f32_diag_mfmabar": 23,
-                 "mfma_f16x3_t32_fill0": 40, "mfma_f16x3_t32_diag_mfmaonly": 41, "mfma_f16x3_t32_diag_nobarrier": 42,
-                 # accuracy experiments on the default kernel (rd_lstm_t32.hpp ACC bits): id = 50 + ACC
-                 "t32_acc0": 50, "t32_acc1_4prod": 51, "t32_acc2_smallfirst": 52, "t32_acc4_exparg": 54, "t32_acc8_newton": 58,
-                 "t32_acc15_all": 65, "t32_acc16_ops24": 66, "t32_acc32_creg": 82, "t32_acc48_ops24_creg": 98,
-                 "t32_acc112_hlskip": 162, "t32_acc240_sharedrcp": 290, "t32_acc752_onercp": 802, "t32_acc248_sharedrcp_newton": 298, "t32_diag_nolut": 418, "t32_diag_mfma16": 1314}
+                 "mfma_f32_diag_noew": 20, "mfma_f32_diag_nomfma": 21, "mfma_f32_diag_mfmaonly": 22, "mfma_f32_diag_mfmabar": 23}
 if os.path.basename(LIB_PATH).startswith("librd_hip_diag"):
     VARIANTS = dict(VARIANTS, **DIAG_VARIANTS)
 

@@ -10,8 +10,8 @@
 //   rd_gz_sel_* / rd_gz_pack_kernel   selected records -> one contiguous byte stream (scan of the selected lengths + coalesced copy)
 //   rd_gz_deflate_kernel              one workgroup per member of 65,280 input bytes (BGZF's block size: the file is valid BGZF -
 //                                     bgzip / htslib index it, this build's reader inflates its members in parallel):
-//        wave w owns quarter w (16,320 bytes) and its own 4,096-entry hash table in LDS (8-byte hashes, nearest earlier
-//        occurrence); a STRIP of 64 consecutive positions is handled at once, one per lane: hash, candidate lookup (positions before
+//        wave w owns quarter w (16,320 bytes) and its own 4,096-entry, two-way hash table in LDS (8-byte hashes, the two nearest
+//        earlier occurrences); a STRIP of 64 consecutive positions is handled at once, one per lane: hash, candidate lookup (positions before
 //        the strip), distance-1 candidate (runs), match length by 4-byte compares in LDS; then the 64 positions are inserted; then the
 //        strip's parse is resolved from the ballot of match lanes (lazy rule: a match shorter than 32 yields to a longer one at the
 //        next position); tokens go to a scratch in HBM, symbol counts to per-wave LDS histograms;
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void rd_gz_pack_kernel(const uint8_t *__restri
 // ------------------------------------------------------------------------------------------------
 struct __attribute__((aligned(16))) GzSmem {
     uint32_t text[(GZ_MEMBER + 16) / 4];      // the member's bytes (+ zero pad); after the parse: the output (header, deflate data, trailer)
-    uint16_t tab[GZ_NQ][1 << GZ_HBITS];       // per wave: hash -> position in its quarter + 1
+    uint32_t tab[GZ_NQ][1 << GZ_HBITS];       // per wave: hash -> two earlier positions in its quarter (+ 1): low half = the nearest
     uint32_t hist[GZ_NQ][GZ_NSYM];            // per wave: symbol counts of its quarter
     uint32_t freq[GZ_NSYM];
     uint8_t lens[GZ_NSYM];
@@ -394,8 +394,7 @@ __global__ __launch_bounds__(256) void rd_gz_deflate_kernel(const uint8_t *__res
                 }
                 S.text[k] = v;
             }
-            uint32_t *z = reinterpret_cast<uint32_t *>(&S.tab[0][0]);
-            for (int k = tid; k < GZ_NQ * (1 << GZ_HBITS) / 2; k += 256) z[k] = 0;
+            for (int k = tid; k < GZ_NQ * (1 << GZ_HBITS); k += 256) (&S.tab[0][0])[k] = 0;
             for (int k = tid; k < GZ_NQ * GZ_NSYM; k += 256) (&S.hist[0][0])[k] = 0;
             if (tid == 0) S.crc = 0;
         }
@@ -428,20 +427,26 @@ __global__ __launch_bounds__(256) void rd_gz_deflate_kernel(const uint8_t *__res
             const uint32_t w0 = gz_ld32(S.text, pl), w1 = gz_ld32(S.text, pl + 4);
             const uint32_t h = (((w0 * 0x9E3779B1u) ^ (w1 * 0x85EBCA77u)) * 0xC2B2AE3Du) >> (32 - GZ_HBITS);
             int L = 0, D = 0;
+            const uint32_t ent = hv ? S.tab[wave][h] : 0u;   // two ways: the nearest earlier position with this hash and the one before it
             if (carry < 64) {   // (else every position of the strip lies inside a match: nothing to find, only to insert)
-                if (hv) {
-                    const int c = S.tab[wave][h];
-                    if (c) {
-                        const int k = gz_mlen(S.text, p, q0 + c - 1, lim);
-                        if (k >= GZ_MINM) { L = k; D = p - (q0 + c - 1); }
-                    }
+                if (ent & 0xffffu) {
+                    const int c = q0 + (int)(ent & 0xffffu) - 1;
+                    const int k = gz_mlen(S.text, p, c, lim);
+                    if (k >= GZ_MINM) { L = k; D = p - c; }
+                }
+                if (ent >> 16) {
+                    const int c = q0 + (int)(ent >> 16) - 1;
+                    const int k = gz_mlen(S.text, p, c, lim);
+                    if (k >= GZ_MINM && k > L) { L = k; D = p - c; }
                 }
                 if (in && p > q0) {
                     const int k = gz_mlen(S.text, p, p - 1, lim);
                     if (k >= GZ_MINRUN && k >= L) { L = k; D = 1; }
                 }
             }
-            if (hv) S.tab[wave][h] = (uint16_t)(p - q0 + 1);   // (lanes with the same hash: any of them is a valid earlier position)
+            // insert: the occupant from before this strip moves to the second way (lanes of this strip with the same hash: one of them
+            // wins the store - any of them is a valid earlier position for the strips that follow)
+            if (hv) S.tab[wave][h] = (ent << 16) | (uint32_t)(p - q0 + 1);
             if (carry >= n) { carry -= n; continue; }
             const int Ln = __shfl_down(L, 1);
             const bool defer = L > 0 && L < GZ_LAZY && lane + 1 < n && Ln > L;

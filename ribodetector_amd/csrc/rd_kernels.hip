@@ -31,9 +31,6 @@
 #include "rd_sort.hpp"
 #include "rd_lstm_f32.hpp"
 #include "rd_lstm_t32.hpp"
-#ifdef RD_DIAG
-#include "rd_lstm_t32_diag.hpp"   // A/B and accuracy experiments: diagnostic builds only
-#endif
 #include "rd_refine.hpp"
 #include "rd_encode.hpp"
 #include "rd_deflate.hpp"
@@ -115,15 +112,15 @@ void rd_model_destroy(rd_model *m) {
     delete m;
 }
 
-// Product build: the three kernels that compute the function (AUTO = the split-precision MFMA kernel). The A/B and
-// diagnostic instantiations (ids >= 10; several of them compute WRONG results by design: gate math or MFMAs removed, barrier
-// removed) exist only in the -DRD_DIAG build (librd_hip_diag.so, tools/), never in librd_hip.so.
+// Product build: the three kernels that compute the function (AUTO = the split-precision MFMA kernel). The A/B and diagnostic
+// instantiations of the exact-fp32 kernel (ids 10-23; several compute WRONG results by design: gate math or MFMAs removed) exist
+// only in the -DRD_DIAG build (librd_hip_diag.so, tools/), never in librd_hip.so. (The experiment copy of the default kernel of
+// rounds 1-3, rd_lstm_t32_diag.hpp, was removed in round 4: ONE body of that kernel; its results are in profiles/ and DESIGN.md §8.)
 static bool rd_variant_known(int v) {
     if (v == RD_VARIANT_MFMA_F32 || v == RD_VARIANT_SIMPLE || v == RD_VARIANT_MFMA_F16X3_T32) return true;
 #ifdef RD_DIAG
     switch (v) {
-    case 10: case 11: case 12: case 13: case 20: case 21: case 22: case 23: case 40: case 41: case 42:
-    case 50: case 51: case 52: case 54: case 58: case 65: case 66: case 82: case 98: case 162: case 290: case 418: case 802: case 298: case 1314: return true;
+    case 10: case 11: case 12: case 13: case 20: case 21: case 22: case 23: return true;
     default: break;
     }
 #endif
@@ -442,25 +439,6 @@ int rd_classify(const rd_model *cm, const uint8_t *arena, const int64_t *seq_off
         case 21: hipLaunchKernelGGL((rd_lstm_mfma_f32_kernel<1, 0, 2>), grid, blk, 0, st, m->d, rb, logits, labels); break;
         case 22: hipLaunchKernelGGL((rd_lstm_mfma_f32_kernel<1, 0, 3>), grid, blk, 0, st, m->d, rb, logits, labels); break;
         case 23: hipLaunchKernelGGL((rd_lstm_mfma_f32_kernel<1, 0, 4>), grid, blk, 0, st, m->d, rb, logits, labels); break;
-        case 40: hipLaunchKernelGGL(t32diag::rd_lstm_mfma_f16x3_t32_kernel<0>, grid, blk, 0, st, m->d, rb, logits, labels); break;
-        case 41: hipLaunchKernelGGL(t32diag::rd_lstm_mfma_f16x3_t32_kernel<-1>, grid, blk, 0, st, m->d, rb, logits, labels); break;
-        case 42: hipLaunchKernelGGL(t32diag::rd_lstm_mfma_f16x3_t32_kernel<7>, grid, blk, 0, st, m->d, rb, logits, labels); break;
-        // accuracy experiments (ACC bits, rd_lstm_t32.hpp): id = 50 + ACC
-        case 50: hipLaunchKernelGGL((t32diag::rd_lstm_mfma_f16x3_t32_kernel<6, 0>), grid, blk, 0, st, m->d, rb, logits, labels); break;
-        case 51: hipLaunchKernelGGL((t32diag::rd_lstm_mfma_f16x3_t32_kernel<6, 1>), grid, blk, 0, st, m->d, rb, logits, labels); break;
-        case 52: hipLaunchKernelGGL((t32diag::rd_lstm_mfma_f16x3_t32_kernel<6, 2>), grid, blk, 0, st, m->d, rb, logits, labels); break;
-        case 54: hipLaunchKernelGGL((t32diag::rd_lstm_mfma_f16x3_t32_kernel<6, 4>), grid, blk, 0, st, m->d, rb, logits, labels); break;
-        case 58: hipLaunchKernelGGL((t32diag::rd_lstm_mfma_f16x3_t32_kernel<6, 8>), grid, blk, 0, st, m->d, rb, logits, labels); break;
-        case 65: hipLaunchKernelGGL((t32diag::rd_lstm_mfma_f16x3_t32_kernel<6, 15>), grid, blk, 0, st, m->d, rb, logits, labels); break;
-        case 66: hipLaunchKernelGGL((t32diag::rd_lstm_mfma_f16x3_t32_kernel<6, 16>), grid, blk, 0, st, m->d, rb, logits, labels); break;
-        case 82: hipLaunchKernelGGL((t32diag::rd_lstm_mfma_f16x3_t32_kernel<6, 32>), grid, blk, 0, st, m->d, rb, logits, labels); break;
-        case 98: hipLaunchKernelGGL((t32diag::rd_lstm_mfma_f16x3_t32_kernel<6, 48>), grid, blk, 0, st, m->d, rb, logits, labels); break;
-        case 162: hipLaunchKernelGGL((t32diag::rd_lstm_mfma_f16x3_t32_kernel<6, 48 + 64>), grid, blk, 0, st, m->d, rb, logits, labels); break;   // = the product
-        case 290: hipLaunchKernelGGL((t32diag::rd_lstm_mfma_f16x3_t32_kernel<6, 48 + 64 + 128>), grid, blk, 0, st, m->d, rb, logits, labels); break;
-        case 802: hipLaunchKernelGGL((t32diag::rd_lstm_mfma_f16x3_t32_kernel<6, 48 + 64 + 128 + 512>), grid, blk, 0, st, m->d, rb, logits, labels); break;
-        case 298: hipLaunchKernelGGL((t32diag::rd_lstm_mfma_f16x3_t32_kernel<6, 48 + 64 + 128 + 8>), grid, blk, 0, st, m->d, rb, logits, labels); break;
-        case 1314: hipLaunchKernelGGL((t32diag::rd_lstm_mfma_f16x3_t32_kernel<6, 48 + 64 + 128 + 1024>), grid, blk, 0, st, m->d, rb, logits, labels); break;   // wrong by design
-        case 418: hipLaunchKernelGGL((t32diag::rd_lstm_mfma_f16x3_t32_kernel<6, 48 + 64 + 256>), grid, blk, 0, st, m->d, rb, logits, labels); break;   // wrong by design
 #endif
         default: RD_FAIL(RD_E_UNSUPPORTED, "rd_classify: variant %d not available in this build", m->variant);
         }

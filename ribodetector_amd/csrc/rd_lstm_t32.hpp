@@ -137,7 +137,7 @@ struct PhaseCtx {       // per-lane constants of a phase
 // One stage of one cell (the gate math of DESIGN.md §3.1: shared reciprocals, 5 v_exp_f32 + 3 v_rcp_f32 + 20 plain VALU ops per
 // cell). NS = register slots of the cells in flight (slot = cell % NS); OWNROW: stage 0 fetches the cell's own table row (the
 // tail) instead of the next cell's (the phases, whose first row is fetched before the first unit).
-// The experiment switches this body carried in rounds 1-2 live in rd_lstm_t32_diag.hpp (diagnostic builds only).
+// (The experiment switches this body carried in rounds 1-2 - and their separate copy of round 3 - are gone: git history)
 template <int TP, int cell, int stage, int NS, bool OWNROW>
 __device__ __forceinline__ void rd_ew_cs(Lstm16bSmem &S, EwRegs &R, const f32x16 (&accP)[4], const PhaseCtx &c) {
     constexpr int a = cell >> 2, b = cell & 3, k = cell % NS, ap = a & 1;

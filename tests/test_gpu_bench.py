@@ -124,6 +124,39 @@ def test_bench_under_torchrun_two_ranks_one_gpu():
     assert j["n_gpus"] == 2 and j["value"] > 1e6
 
 
+def test_scale_sweep_script_on_one_gpu(tmp_path):
+    """tools/scale_sweep.sh - the N = 1, 2, 4, 8 sweep the first multi-GPU node will run - end to end on this box: the ranks of
+    every point share the one GPU and exchange labels over gloo. Every point passes bench.py's gather self-check (labels gathered on
+    rank 0 against each rank's own recomputation) and lists its ranks' devices; the JSON carries efficiency against N = 1 and the
+    agreement of the N = 1 rank-group run with the plain line."""
+    out = tmp_path / "sweep.json"
+    env = dict(os.environ, RD_DIST_BACKEND="gloo", RD_LOCAL_DEVICE="0", RD_PREFIX_K="8")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run(["bash", os.path.join(ROOT, "tools", "scale_sweep.sh"), str(out), "--pairs-per-step", "16384", "--steps", "2", "--warmup", "1"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    j = json.load(open(out))
+    pts = {p["n_gpus"]: p for p in j["points"]}
+    assert sorted(pts) == [1, 2, 4, 8] and not any(p.get("skipped") for p in j["points"]), j
+    for n, p in pts.items():
+        assert p["gather_self_check"] == "passed" and p["rccl_ranks"] == n and len(p["ranks"]) == n and p["reads_per_s"] > 1e5
+        assert all(rk["device"] == "cuda:0" and rk["first_gather_s"] >= 0 for rk in p["ranks"])
+        assert p["efficiency_vs_n1"] is not None
+    assert j["plain_line_reads_per_s"] > 1e5 and "n1_group_over_plain" in j
+
+
+def test_gather_self_check_catches_a_wrong_gather():
+    """bench.py --gpus N refuses to time a run whose gathered labels differ from the ranks' own: with RD_BENCH_CORRUPT_GATHER=1 rank 0
+    flips one gathered label of the check step and every rank must leave with exit code 4"""
+    env = dict(os.environ, RD_DIST_BACKEND="gloo", RD_LOCAL_DEVICE="0", RD_PREFIX_K="8", RD_BENCH_CORRUPT_GATHER="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0", "--pairs-per-step", "16384", "--no-alt",
+                        "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "label gather self-check FAILED" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
 def test_bench_needs_n_devices():
     """--gpus 2 on a box with one device (and no shared-GPU override) stops with a clear message, before any rank starts"""
     import torch
@@ -144,4 +177,26 @@ def test_two_gpu_rccl_when_available():
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     j = _line(r.stdout)
-    assert j["n_gpus"] == 2 and j["config"]["dist_backend"] == "nccl"
+    assert j["n_gpus"] == 2 and j["config"]["dist_backend"] == "nccl" and j["config"]["gather_self_check"] == "passed"
+    assert len({rk["device_uuid"] for rk in j["config"]["ranks"]}) == 2
+    # the CLI across the two devices: gz input (one decode per node through shared memory, label gather over RCCL) and plain input
+    # (sharded parse, device gzip of every rank's part) against the one-process run
+    import tempfile
+    sys.path.insert(0, ROOT)
+    from ribodetector_amd import synth
+    with tempfile.TemporaryDirectory() as d:
+        a, o, _ = synth.reads_numpy(200000, (40, 140), seed=5, rrna_frac=0.3)
+        for ext in (".fq.gz", ".fq"):
+            inp = os.path.join(d, "in" + ext)
+            synth.write_fastq(inp, a, o, 1)
+            got = {}
+            for tag, pre in (("one", [sys.executable, "-m", "ribodetector_amd.detect"]),
+                             ("two", [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                                      "127.0.0.1", "--master-port", "29731", "-m", "ribodetector_amd.detect"])):
+                out, rr = os.path.join(d, tag + ".non.fq.gz"), os.path.join(d, tag + ".rrna.fq")
+                r = subprocess.run(pre + ["-l", "100", "-i", inp, "-o", out, "-r", rr, "--chunk_size", "4", "-m", "3"], cwd=ROOT, env=env,
+                                   capture_output=True, text=True, timeout=900)
+                assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+                import gzip
+                got[tag] = (gzip.open(out, "rb").read(), open(rr, "rb").read())
+            assert got["one"] == got["two"] and len(got["one"][0]) > 0 and len(got["one"][1]) > 0

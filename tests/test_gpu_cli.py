@@ -100,6 +100,7 @@ def test_cli_gz_outputs_are_deflated_on_the_device(tmp_path, paired, monkeypatch
         files = outs + rrs + ([o + ".unclassified.gz" for o in outs] if paired else [])
         res[tag] = (files, (p.num_read, p.num_nonrrna, p.num_rrna, p.num_unknown))
     assert res["device"][1] == res["host"][1] and res["device"][1][0] == n and res["device"][1][2] > 0
+    sizes = []
     for fd, fh in zip(res["device"][0], res["host"][0]):
         text = _read(fd)
         assert text == _read(fh) and len(text) > 0
@@ -111,9 +112,12 @@ def test_cli_gz_outputs_are_deflated_on_the_device(tmp_path, paired, monkeypatch
             pos += struct.unpack("<H", raw[pos + 16:pos + 18])[0] + 1
             members += 1
         assert pos == len(raw) and members >= 2
-        assert len(raw) < 1.10 * os.path.getsize(fh)                   # (the host writes libdeflate level 5 in 4 MiB members)
+        import zlib
+        assert len(raw) < 1.10 * len(zlib.compress(text.encode(), 5))  # the reference's compressor: gzip.open(..., compresslevel=5)
+        sizes.append((os.path.basename(fd), len(raw), os.path.getsize(fh), len(zlib.compress(text.encode(), 5))))
         back = b"".join(c.buf[c.rec_start[0]:c.rec_start[-1]].tobytes() for c in fx.get_seq_chunks(fd, chunk_size=7777))
         assert back.decode() == text
+    print("device / host libdeflate-5 / zlib-5 bytes:", sizes)
 
 
 def test_cli_argument_errors(tmp_path):

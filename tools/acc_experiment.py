@@ -63,8 +63,7 @@ def main():
         ref = torch.from_numpy(ora.forward_packed(arena[: no * L].cpu().numpy(), off[: no + 1].cpu().numpy(), lens[:no].cpu().numpy(), L)).to(dev)
         out["oracle_s"] = time.time() - t0
         out["oracle_fp32_vs_f64"] = stats(ref.double() - truth[:no])
-    names = [v for v in a.variants.split(",") if v] or [v for v in ("auto", "mfma_f32", "t32_acc0", "t32_acc1_4prod", "t32_acc2_smallfirst",
-                                                                     "t32_acc4_exparg", "t32_acc8_newton", "t32_acc15_all") if v in N.VARIANTS]
+    names = [v for v in a.variants.split(",") if v] or [v for v in ("auto", "mfma_f32") if v in N.VARIANTS]
     for v in names:
         model.set_variant(v)
         model.classify_bytes(arena, offs, lens, L)

@@ -6,7 +6,7 @@ O=$R/gpurun_out/ab
 mkdir -p $O
 cd $R
 export RD_HIP_LIB=$R/ribodetector_amd/csrc/librd_hip_diag.so
-VARS=${@:-t32_acc48_ops24_creg}
+VARS=${@:-auto mfma_f32}
 (timeout 600 python tools/acc_experiment.py --reads 262144 --oracle-reads 0 --variants $(echo $VARS | tr ' ' ',')) > $O/acc.json 2> $O/acc.err
 python - <<PY
 import json

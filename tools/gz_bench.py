@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""gz_bench.py - the device gzip path (csrc/rd_deflate.hpp) on one chunk of FASTQ resident in HBM: the records of a 2^20-record chunk
+are split by label into two files' worth of gzip members. Reports, per FASTQ profile: compressed size against zlib level 5 (the
+reference's writer, detect.py:729-741), milliseconds and GB/s of uncompressed text per call, reads/s, and the time of each kernel
+(run it under `rocprofv3 --kernel-trace --stats` for the per-kernel table; tools/profile_round.sh does).
+
+    python tools/gz_bench.py [--records 1048576] [--out gpurun_out/gz_bench.json]"""
+import argparse
+import json
+import os
+import sys
+import zlib
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--records", type=int, default=1 << 20)
+    ap.add_argument("--out", default=None)
+    a = ap.parse_args()
+    import numpy as np
+    import torch
+    from ribodetector_amd import synth
+    from ribodetector_amd.gz import DeviceGzip
+    dev = torch.device("cuda", 0)
+    dg = DeviceGzip(dev)
+    n = a.records
+    arena, off, lens = synth.reads_torch(n, 100, seed=2000, device=dev)
+    rec = {"records": n}
+    # (1) the bench's own FASTQ (constant quality); (2) sequencer-like: Illumina headers + binned qualities, built on the host for 2^18
+    # records and tiled (the device path sees the same bytes a file would hold)
+    texts = {"bench_fastq": synth.fastq_image_torch(arena, off, lens, mate=1)}
+    m = min(n, 1 << 18)
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        a_np, o_np, _ = synth.reads_numpy(m, 100, seed=11)
+        p = os.path.join(d, "r.fq")
+        synth.write_fastq_realistic(p, a_np, o_np, mate=1, seed=1)
+        t = torch.from_numpy(np.fromfile(p, dtype=np.uint8)).to(dev)
+    texts["sequencer_like"] = t.repeat(max(1, n // m))
+    g = torch.Generator(device=dev)
+    g.manual_seed(1)
+    for name, text in texts.items():
+        nl = torch.nonzero(text == 10).flatten()
+        rs = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), nl[3::4] + 1])
+        nr = int(rs.numel()) - 1
+        labels = (torch.rand(nr, generator=g, device=dev) < 0.1).to(torch.int8)      # 10 % "rRNA"
+        outs = {}
+        for lab in (0, 1):
+            dg.compress_selected(text, rs, labels, lab, slot=lab)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 5
+        e0.record()
+        for _ in range(reps):
+            for lab in (0, 1):
+                outs[lab] = dg.compress_selected(text, rs, labels, lab, slot=lab)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        comp = sum(int(outs[lab][1][0]) for lab in (0, 1))
+        plain = sum(int(outs[lab][1][1]) for lab in (0, 1))
+        assert plain == int(text.numel())
+        # zlib level 5 on a 64 MB sample of the same text (one stream), scaled
+        sample = text[: min(int(text.numel()), 64 << 20)].cpu().numpy().tobytes()
+        z5 = len(zlib.compress(sample, 5)) * (int(text.numel()) / len(sample))
+        rec[name] = {"records": nr, "text_bytes": int(text.numel()), "device_gzip_bytes": comp, "ratio": int(text.numel()) / comp,
+                     "zlib5_bytes_est": z5, "size_vs_zlib5": comp / z5, "ms_per_chunk_both_labels": ms,
+                     "GB_per_s": int(text.numel()) / ms / 1e6, "reads_per_s": nr / ms * 1e3,
+                     "members": sum(int(outs[lab][1][2]) for lab in (0, 1))}
+    print(json.dumps(rec))
+    if a.out:
+        json.dump(rec, open(a.out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -6,7 +6,7 @@
 // header, BGZF framing) in a form that zlib's inflate checks on this machine. The kernel follows the same steps:
 //
 //   member  = 65,280 input bytes (BGZF's block size: the output is a valid BGZF file), one workgroup;
-//   quarter = 16,320 bytes, one wave: its own 4,096-entry hash table (8-byte hashes, nearest earlier occurrence; matches of 8+
+//   quarter = 16,320 bytes, one wave: its own 4,096-entry two-way hash table (8-byte hashes, the two nearest earlier occurrences; matches of 8+
 //             bytes only: on FASTQ the shorter ones cost more bits than the 2-bit literals they replace - measured here);
 //   strip   = 64 consecutive positions, one per lane: every lane hashes its position, looks its candidate up (positions before the
 //             strip), also tries distance 1 (runs), measures the match; then all 64 positions are inserted (the highest lane wins a
@@ -66,14 +66,14 @@ static int mlen(const uint8_t *m, int p, int c, int lim) {
     return l;
 }
 
-static int opt_dist1_min = 6, opt_lazy = 1, opt_two = 0;
+static int opt_dist1_min = 6, opt_lazy = 1, opt_two = 1, opt_rep = 0;
 
 // one quarter [q0, q1) of the member m; returns the number of tokens
 static int parse_quarter(const uint8_t *m, int q0, int q1, Tok *out) {
     static uint32_t tab[1 << HBITS], tab2[1 << HBITS];
     memset(tab, 0, sizeof(tab));
     memset(tab2, 0, sizeof(tab2));
-    int nt = 0, carry = 0;
+    int nt = 0, carry = 0, dlast = 0;
     for (int s0 = q0; s0 < q1; s0 += 64) {
         const int n = q1 - s0 < 64 ? q1 - s0 : 64;
         int L[64], D[64], H[64];
@@ -98,6 +98,10 @@ static int parse_quarter(const uint8_t *m, int q0, int q1, Tok *out) {
                     }
                 }
             }
+            if (opt_rep && carry < 64 && dlast > 1 && p - dlast >= q0) {   // the distance of the last match again (a substitution inside a repeat)
+                const int k = mlen(m, p, p - dlast, lim);
+                if (k >= opt_rep && k > L[l]) { L[l] = k; D[l] = dlast; }
+            }
             if (carry < 64 && p > q0) {
                 const int k = mlen(m, p, p - 1, lim);
                 if (k >= opt_dist1_min && k >= L[l]) { L[l] = k; D[l] = 1; }
@@ -115,6 +119,7 @@ static int parse_quarter(const uint8_t *m, int q0, int q1, Tok *out) {
             const int defer = opt_lazy && k > 0 && k < LAZY_MAX && pos + 1 < n && L[pos + 1] > k;
             if (k > 0 && !defer) {
                 out[nt].len = (uint16_t)k; out[nt].dist = (uint16_t)D[pos]; ++nt;
+                if (D[pos] > 1) dlast = D[pos];
                 pos += k;
             } else {
                 out[nt].len = 0; out[nt].dist = m[s0 + pos]; ++nt;
@@ -325,7 +330,8 @@ int main(int argc, char **argv) {
     for (int a = 1; a < argc; ++a) {
         if (!strncmp(argv[a], "--d1=", 5)) { opt_dist1_min = atoi(argv[a] + 5); continue; }
         if (!strcmp(argv[a], "--nolazy")) { opt_lazy = 0; continue; }
-        if (!strcmp(argv[a], "--two")) { opt_two = 1; continue; }
+        if (!strcmp(argv[a], "--one")) { opt_two = 0; continue; }
+        if (!strncmp(argv[a], "--rep=", 6)) { opt_rep = atoi(argv[a] + 6); continue; }
         FILE *f = fopen(argv[a], "rb");
         if (!f) { perror(argv[a]); return 1; }
         fseek(f, 0, SEEK_END);

@@ -1,13 +1,13 @@
 #!/bin/bash
 # Package power and shader clock (rocm-smi, 1 sample/s) while bench.py runs one kernel variant for ~20 s.
-#   tools/power_trace.sh [variant ...]      (default: auto mfma_f32 mfma_f16x3_t32_diag_mfmaonly)
+#   tools/power_trace.sh [variant ...]      (default: auto mfma_f32 mfma_f32_diag_mfmaonly)
 # Writes gpurun_out/power_trace.txt ; copy into profiles/ afterwards.
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 export RD_HIP_LIB=$R/ribodetector_amd/csrc/librd_hip_diag.so    # the *_diag_* variants exist only in the diagnostic build
 O=$R/gpurun_out/power_trace.txt
 mkdir -p $R/gpurun_out
-VARS=${@:-auto mfma_f32 mfma_f16x3_t32_diag_mfmaonly}
+VARS=${@:-auto mfma_f32 mfma_f32_diag_mfmaonly}
 : > $O
 for v in $VARS; do
   steps=300; [ "$v" = "mfma_f32" ] && steps=80

@@ -35,6 +35,9 @@ pmc pmc_lds SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_WAIT_INST_LD
 # 3. the HBM-bound kernels: standalone encoders, pair fusion, counters
 stats encoders python $R/tools/encoder_bench.py
 for c in FETCH_SIZE WRITE_SIZE; do pmc enc_pmc_$c $c -- python $R/tools/encoder_bench.py; done
+# 4. device gzip (round 4): kernel table of the rd_gz_* kernels on a 2^20-record chunk, and their HBM traffic
+stats gz python $R/tools/gz_bench.py --out $O/${TAG}_gz_bench.json
+for c in FETCH_SIZE WRITE_SIZE; do pmc gz_pmc_$c $c -- python $R/tools/gz_bench.py; done
 python $R/tools/prof_summarize.py --tag $TAG --out $O /tmp/p_$TAG > $O/${TAG}_summary.txt 2>&1
 cd $R
 T0=$(date +%s)

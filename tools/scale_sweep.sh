@@ -1,0 +1,57 @@
+#!/bin/bash
+# scale_sweep.sh - the metric's N > 1 points in one go: `python bench.py --gpus N` for N = 1, 2, 4, 8 back to back (each run
+# launches its own ranks, one per GPU over RCCL, and checks its label gather against a single-rank recomputation before timing),
+# plus the plain one-process line; writes ONE JSON with reads/s, efficiency against N = 1 and the agreement of the N = 1 rank-group
+# run with the plain line (must be within 2 %).
+#   tools/scale_sweep.sh [out.json] [extra bench.py flags ...]
+# On a box with fewer devices than N the point is skipped (bench.py exits 3) - or, for a functional run of the whole sweep on ONE
+# GPU (tests): RD_DIST_BACKEND=gloo RD_LOCAL_DEVICE=0 tools/scale_sweep.sh out.json --pairs-per-step 16384 --steps 2
+set -u
+R=$(cd "$(dirname "$0")/.." && pwd)
+OUT=${1:-$R/gpurun_out/scale_sweep.json}
+shift || true
+NS=${RD_SWEEP_NS:-"1 2 4 8"}
+FLAGS="--no-cpu-baseline --no-alt --no-encoder --no-e2e --traffic off $*"
+TMP=$(mktemp -d)
+cd "$R"
+# the plain line (no process group at all)
+env -u RD_FORCE_DIST -u WORLD_SIZE -u RANK -u LOCAL_RANK python bench.py --gpus 1 $FLAGS 2> $TMP/plain.err | grep '^{' > $TMP/plain.json
+for N in $NS; do
+  if [ "$N" = 1 ]; then   # one rank THROUGH the collectives (a one-rank group): what the N > 1 runs add to a rank, at N = 1
+    RD_FORCE_DIST=1 python bench.py --gpus 1 $FLAGS 2> $TMP/n1.err | grep '^{' > $TMP/n1.json; echo "N=1 rc=${PIPESTATUS[0]}" >> $TMP/rc
+  else
+    env -u RD_FORCE_DIST python bench.py --gpus $N $FLAGS 2> $TMP/n$N.err | grep '^{' > $TMP/n$N.json; echo "N=$N rc=${PIPESTATUS[0]}" >> $TMP/rc
+  fi
+done
+python - "$TMP" "$OUT" $NS <<'PY'
+import json, os, sys
+tmp, out, ns = sys.argv[1], sys.argv[2], [int(x) for x in sys.argv[3:]]
+def load(name):
+    try:
+        return json.loads(open(os.path.join(tmp, name)).read().strip().splitlines()[0])
+    except Exception:
+        return None
+plain = load("plain.json")
+rec = {"plain_line_reads_per_s": plain and plain["value"], "points": [], "rc": open(os.path.join(tmp, "rc")).read().split("\n")[:-1]}
+base = None
+for n in ns:
+    j = load("n%d.json" % n)
+    if j is None:
+        err = open(os.path.join(tmp, "n%d.err" % n)).read()[-400:]
+        rec["points"].append({"n_gpus": n, "skipped": True, "stderr_tail": err})
+        continue
+    if n == 1:
+        base = j["value"]
+    pt = {"n_gpus": n, "reads_per_s": j["value"], "ms_per_step": j["ms_per_step"], "dist_backend": j["config"]["dist_backend"],
+          "rccl_ranks": j["config"]["rccl_ranks"], "host_cores_busy": j["config"]["host_cores_busy"],
+          "gather_self_check": j["config"].get("gather_self_check"),
+          "ranks": [{k: r[k] for k in ("rank", "device", "device_uuid", "first_gather_s")} for r in (j["config"].get("ranks") or [])],
+          "efficiency_vs_n1": (j["value"] / (n * base)) if base else None}
+    rec["points"].append(pt)
+if plain and base:
+    rec["n1_group_over_plain"] = base / plain["value"]
+    rec["n1_agrees_with_plain_within_2pct"] = abs(base / plain["value"] - 1) <= 0.02
+json.dump(rec, open(out, "w"), indent=1)
+print(json.dumps(rec))
+PY
+rm -rf $TMP
