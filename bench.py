@@ -541,8 +541,7 @@ def main():
         ev.synchronize()
         mine = [int((keep["lab"] == v).sum()) for v in (0, 1, -1)]
         ev, f = compute(1, r1[0][0], r2[0][0] if paired else None, exchange)
-        if f:
-            f()
+        got_all = f() if f else None                        # rank 0: the [P * world] labels (host memory under gloo)
         sync()
         try:
             uuid = str(torch.cuda.get_device_properties(dev).uuid)
@@ -555,9 +554,9 @@ def main():
         if rank == 0:
             bad = []
             if os.environ.get("RD_BENCH_CORRUPT_GATHER") == "1":      # (tests: the check must catch a wrong gather)
-                gathered[P * world - 1] = 1 - gathered[P * world - 1]
+                got_all[P * world - 1] = 1 - got_all[P * world - 1]
             for r in range(world):
-                sl = gathered[r * P:(r + 1) * P]
+                sl = got_all[r * P:(r + 1) * P]
                 got = [int((sl == v).sum()) for v in (0, 1, -1)]
                 if got != infos[r]["step0_label_counts"]:
                     bad.append({"rank": r, "gathered": got, "local": infos[r]["step0_label_counts"]})
