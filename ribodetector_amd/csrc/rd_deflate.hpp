@@ -194,8 +194,7 @@ __device__ __forceinline__ uint32_t gz_ld32(const uint32_t *T, int i) {   // 4 b
     return __builtin_amdgcn_alignbyte(q[1], q[0], (uint32_t)(i & 3));
 }
 
-__device__ __forceinline__ int gz_mlen(const uint32_t *T, int p, int c, int lim) {
-    int k = 0;
+__device__ __forceinline__ int gz_mlen(const uint32_t *T, int p, int c, int lim, int k) {   // the first k bytes are known to agree
     while (k < lim) {
         const uint32_t x = gz_ld32(T, p + k) ^ gz_ld32(T, c + k);
         if (x) { k += __builtin_ctz(x) >> 3; break; }
@@ -355,6 +354,21 @@ __device__ void gz_huff(GzSmem &S, uint32_t *freq, uint8_t *lens, uint16_t *code
     __syncthreads();
 }
 
+#ifdef RD_DIAG
+// diagnostic build only: cycles per stage of the member loop, summed per workgroup (tools/gz_bench.py --stages)
+__device__ unsigned long long *g_gz_prof = nullptr;
+#define GZ_STAMP(k)                                                                                         \
+    do {                                                                                                    \
+        if (g_gz_prof && threadIdx.x == 0) {                                                                \
+            const unsigned long long now_ = clock64();                                                      \
+            atomicAdd(&g_gz_prof[k], now_ - stamp_);                                                        \
+            stamp_ = now_;                                                                                  \
+        }                                                                                                   \
+    } while (0)
+#else
+#define GZ_STAMP(k) do { } while (0)
+#endif
+
 // plain: the selected records of the chunk as one stream (info[1] bytes); member m = bytes [65280 m, ...). toks: 65,280 words of
 // scratch per workgroup. slots: GZ_SLOT bytes per member; msize[m] = the member's size.
 __global__ __launch_bounds__(256) void rd_gz_deflate_kernel(const uint8_t *__restrict__ plain, const int64_t *__restrict__ info,
@@ -383,6 +397,9 @@ __global__ __launch_bounds__(256) void rd_gz_deflate_kernel(const uint8_t *__res
     for (int64_t m = blockIdx.x; m < nmem; m += gridDim.x) {
         const int len = (int)(total - m * GZ_MEMBER < GZ_MEMBER ? total - m * GZ_MEMBER : GZ_MEMBER);
         __syncthreads();
+#ifdef RD_DIAG
+        unsigned long long stamp_ = clock64();
+#endif
         {   // member -> LDS (dword loads: plain is 256-byte aligned and GZ_MEMBER a multiple of 4), zero pad; tables cleared
             const uint32_t *src = reinterpret_cast<const uint32_t *>(plain + m * GZ_MEMBER);
             const int nw = (len + 3) >> 2;
@@ -399,6 +416,7 @@ __global__ __launch_bounds__(256) void rd_gz_deflate_kernel(const uint8_t *__res
             if (tid == 0) S.crc = 0;
         }
         __syncthreads();
+        GZ_STAMP(0);   // load
         // ---- CRC-32: thread t < 255 takes bytes [256 t, 256 t + 256), the pieces are combined with x^(8 bytes after) mod P ----------------
         if (tid < 255 && 256 * tid < len) {
             const int b0 = 256 * tid, b1 = b0 + 256 < len ? b0 + 256 : len;
@@ -412,6 +430,7 @@ __global__ __launch_bounds__(256) void rd_gz_deflate_kernel(const uint8_t *__res
             c = gz_multmodp(gz_x8n((uint32_t)(len - b1)), c);
             atomicXor(&S.crc, c);
         }
+        GZ_STAMP(1);   // crc (thread 0's share)
         // ---- parse: wave w, quarter w ---------------------------------------------------------------------------------------------------
         const int q0 = wave * GZ_QUARTER, q1 = len < q0 + GZ_QUARTER ? len : q0 + GZ_QUARTER;
         uint32_t *qt = mytoks + q0;
@@ -429,19 +448,23 @@ __global__ __launch_bounds__(256) void rd_gz_deflate_kernel(const uint8_t *__res
             int L = 0, D = 0;
             const uint32_t ent = hv ? S.tab[wave][h] : 0u;   // two ways: the nearest earlier position with this hash and the one before it
             if (carry < 64) {   // (else every position of the strip lies inside a match: nothing to find, only to insert)
-                if (ent & 0xffffu) {
-                    const int c = q0 + (int)(ent & 0xffffu) - 1;
-                    const int k = gz_mlen(S.text, p, c, lim);
-                    if (k >= GZ_MINM) { L = k; D = p - c; }
+                // The first 8 bytes of both candidates and the byte before the position are fetched TOGETHER (one LDS round trip;
+                // a candidate is only worth a match if all 8 agree - most are 12-bit hash collisions and end here), then the survivors
+                // are extended 4 bytes at a time.
+                const bool v1 = (ent & 0xffffu) != 0, v2 = (ent >> 16) != 0;
+                const int c1 = v1 ? q0 + (int)(ent & 0xffffu) - 1 : pl, c2 = v2 ? q0 + (int)(ent >> 16) - 1 : pl;
+                const uint32_t a0 = gz_ld32(S.text, c1), a1 = gz_ld32(S.text, c1 + 4);
+                const uint32_t b0 = gz_ld32(S.text, c2), b1 = gz_ld32(S.text, c2 + 4);
+                const uint32_t prevb = tb[pl > q0 ? pl - 1 : pl];
+                if (v1 && a0 == w0 && a1 == w1) { L = gz_mlen(S.text, p, c1, lim, 8); D = p - c1; }
+                if (v2 && b0 == w0 && b1 == w1) {
+                    const int k = gz_mlen(S.text, p, c2, lim, 8);
+                    if (k > L) { L = k; D = p - c2; }
                 }
-                if (ent >> 16) {
-                    const int c = q0 + (int)(ent >> 16) - 1;
-                    const int k = gz_mlen(S.text, p, c, lim);
-                    if (k >= GZ_MINM && k > L) { L = k; D = p - c; }
-                }
-                if (in && p > q0) {
-                    const int k = gz_mlen(S.text, p, p - 1, lim);
-                    if (k >= GZ_MINRUN && k >= L) { L = k; D = 1; }
+                const uint32_t splat = prevb * 0x01010101u;
+                if (in && p > q0 && lim >= GZ_MINRUN && w0 == splat && (w1 & 0xffffu) == (splat & 0xffffu)) {   // a run of 6+
+                    const int k = gz_mlen(S.text, p, p - 1, lim, 4);
+                    if (k >= L) { L = k; D = 1; }
                 }
             }
             // insert: the occupant from before this strip moves to the second way (lanes of this strip with the same hash: one of them
@@ -466,21 +489,32 @@ __global__ __launch_bounds__(256) void rd_gz_deflate_kernel(const uint8_t *__res
             carry = pos - n;
             const bool tk = (sel >> lane) & 1ull;
             const bool ismatch = tk && eff;
-            const uint32_t byte = tb[pl];
+            const uint32_t byte = w0 & 0xffu;
             if (tk) {
                 const int idx = __popcll(sel & ((1ull << lane) - 1));
                 qt[ntok + idx] = ismatch ? ((uint32_t)L << 16) | (uint32_t)D : byte;
                 if (ismatch) {
                     atomicAdd(&S.hist[wave][257 + S.lsym[L - 3]], 1u);
                     atomicAdd(&S.hist[wave][286 + S.dsym[D <= 256 ? D - 1 : 256 + ((D - 1) >> 7)]], 1u);
-                } else {
-                    atomicAdd(&S.hist[wave][byte], 1u);
                 }
+            }
+            // literal counts, aggregated over the wave: 64 lanes adding to the same few counters (A, C, G, T ...) would serialise in
+            // the LDS atomic unit; one plain add per DISTINCT byte value instead (the histogram is this wave's own)
+            const bool lit = tk && !ismatch;
+            uint64_t lm = __ballot(lit);
+            while (lm) {
+                const int f = __builtin_ctzll(lm);
+                const uint32_t bv = (uint32_t)__builtin_amdgcn_readlane((int)byte, f);
+                const uint64_t same = __ballot(lit && byte == bv);
+                if (lane == f) S.hist[wave][bv] += (uint32_t)__popcll(same);
+                lm &= ~same;
             }
             ntok += __popcll(sel);
         }
         if (lane == 0) S.qtok[wave] = (uint32_t)ntok;
+        GZ_STAMP(2);   // parse of wave 0
         __syncthreads();
+        GZ_STAMP(3);   // waiting for the slowest wave
         // ---- codes --------------------------------------------------------------------------------------------------------------------
         for (int s = tid; s < GZ_NSYM; s += 256) {
             uint32_t f = S.hist[0][s] + S.hist[1][s] + S.hist[2][s] + S.hist[3][s];
@@ -526,6 +560,7 @@ __global__ __launch_bounds__(256) void rd_gz_deflate_kernel(const uint8_t *__res
             if (lane == 0) S.qbits[wave] = b;
         }
         __syncthreads();
+        GZ_STAMP(4);   // codes
         const int hclen = S.hclen;
         const uint32_t c0 = sq[0] >= 0 ? S.cllen[sq[0]] : 0, c1 = sq[1] >= 0 ? S.cllen[sq[1]] : 0;
         uint32_t seqbits_lo, seqbits_total;
@@ -609,6 +644,7 @@ __global__ __launch_bounds__(256) void rd_gz_deflate_kernel(const uint8_t *__res
             }
         }
         __syncthreads();
+        GZ_STAMP(5);   // emission
         if (tid == 0) {   // trailer: CRC-32, ISIZE (byte-granular position)
             uint8_t *ob = reinterpret_cast<uint8_t *>(out) + GZ_HDR + cbytes_dyn;
             for (int k = 0; k < 4; ++k) { ob[k] = (uint8_t)(crc >> (8 * k)); ob[4 + k] = (uint8_t)((uint32_t)len >> (8 * k)); }
@@ -617,6 +653,7 @@ __global__ __launch_bounds__(256) void rd_gz_deflate_kernel(const uint8_t *__res
         __syncthreads();
         uint32_t *dst = reinterpret_cast<uint32_t *>(slot);
         for (int k = tid; k < (int)((tot + 3) >> 2); k += 256) dst[k] = out[k];
+        GZ_STAMP(6);   // copy to the slot
     }
 }
 

@@ -626,4 +626,12 @@ int rd_gz_compress_selected(const uint8_t *text, int64_t text_bytes, const int64
     return RD_OK;
 }
 
+#ifdef RD_DIAG
+// diagnostic build only (not in include/ribodetector_amd.h): [dev] uint64[8] that receives the cycles per stage of rd_gz_deflate_kernel
+int rd_gz_diag_set_profile(unsigned long long *dev_buf) {
+    RD_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_gz_prof), &dev_buf, sizeof(dev_buf)));
+    return RD_OK;
+}
+#endif
+
 }  // extern "C"

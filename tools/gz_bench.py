@@ -19,6 +19,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--records", type=int, default=1 << 20)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--stages", action="store_true", help="with RD_HIP_LIB=.../librd_hip_diag.so: cycles per stage of the deflate kernel")
     a = ap.parse_args()
     import numpy as np
     import torch
@@ -27,6 +28,12 @@ def main():
     dev = torch.device("cuda", 0)
     dg = DeviceGzip(dev)
     n = a.records
+    prof = None
+    if a.stages:
+        import ctypes as C
+        from ribodetector_amd import _native as N
+        prof = torch.zeros(8, dtype=torch.int64, device=dev)
+        N.check(N.lib().rd_gz_diag_set_profile(C.c_void_p(prof.data_ptr())), "rd_gz_diag_set_profile")
     arena, off, lens = synth.reads_torch(n, 100, seed=2000, device=dev)
     rec = {"records": n}
     # (1) the bench's own FASTQ (constant quality); (2) sequencer-like: Illumina headers + binned qualities, built on the host for 2^18
@@ -60,6 +67,12 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps
+        if prof is not None:
+            st = prof.cpu().tolist()
+            prof.zero_()
+            tot = float(sum(st)) or 1.0
+            rec.setdefault("stages", {})[name] = dict(zip(("load", "crc_thread0", "parse_wave0", "wait_slowest_wave", "codes", "emit", "copy"),
+                                                         [round(x / tot, 4) for x in st[:7]]))
         comp = sum(int(outs[lab][1][0]) for lab in (0, 1))
         plain = sum(int(outs[lab][1][1]) for lab in (0, 1))
         assert plain == int(text.numel())
