@@ -10,18 +10,19 @@
 //   rd_gz_sel_* / rd_gz_pack_kernel   selected records -> one contiguous byte stream (scan of the selected lengths + coalesced copy)
 //   rd_gz_deflate_kernel              one workgroup per member of 65,280 input bytes (BGZF's block size: the file is valid BGZF -
 //                                     bgzip / htslib index it, this build's reader inflates its members in parallel):
-//        wave w owns quarter w (16,320 bytes) and its own 4,096-entry, two-way hash table in LDS (8-byte hashes, the two nearest
-//        earlier occurrences); a STRIP of 64 consecutive positions is handled at once, one per lane: hash, candidate lookup (positions before
-//        the strip), distance-1 candidate (runs), match length by 4-byte compares in LDS; then the 64 positions are inserted; then the
-//        strip's parse is resolved from the ballot of match lanes (lazy rule: a match shorter than 32 yields to a longer one at the
-//        next position); tokens go to a scratch in HBM, symbol counts to per-wave LDS histograms;
+//        wave w owns quarter w (16,320 bytes) and its own hash table in LDS (1,024 buckets of the 8 nearest earlier positions with
+//        the same 8-byte hash); a STRIP of 64 consecutive positions is handled at once, one per lane: hash, the bucket's 8 candidates
+//        (positions before the strip) and distance 1 (runs) compared over the first 16 bytes; then the 64 positions are inserted; then
+//        the strip's parse is resolved from the ballot of match lanes (lazy rule: a match shorter than 16 yields to a longer one at
+//        the next position), and only the CHOSEN matches are measured exactly - by the whole wave, 8 lanes per candidate, 32 bytes
+//        per candidate and round; tokens go to a scratch in HBM, symbol counts to per-wave LDS histograms;
 //        ONE dynamic-Huffman block per member: lengths by two-queue merge over the rank-sorted used symbols, limited to 15 bits the
 //        way zlib's gen_bitlen does it, canonical codes; code lengths sent without the run-length symbols (+0.2 %); every wave emits
 //        its quarter's tokens with a prefix sum of bit lengths and LDS atomic-or; stored block if that is smaller; CRC-32 of the
 //        member from 255 per-thread CRCs combined with x^n mod P multiplications (zlib's crc32_combine identity).
 //   rd_gz_moff_kernel / rd_gz_compact_kernel   member sizes -> offsets, members -> one contiguous stream for the D2H copy
 // Matches of 8+ bytes only (runs: 6+): on FASTQ shorter matches cost more bits than the 2-bit literals they replace; measured with
-// the lane-for-lane CPU model tools/gzdev_model.c against zlib level 5: 1.00 / 1.05 / 0.94 of its size on three FASTQ profiles.
+// the lane-for-lane CPU model tools/gzdev_model.c against zlib level 5: 0.98 / 1.00 / 0.94 of its size on three FASTQ profiles (1.02-1.06 on files of reads that are all copies of ONE template).
 #pragma once
 #include "rd_common.hpp"
 
@@ -29,8 +30,8 @@ namespace {
 
 constexpr int GZ_MEMBER = 65280;                       // input bytes per member (BGZF_BLOCK_SIZE 0xff00)
 constexpr int GZ_NQ = 4, GZ_QUARTER = GZ_MEMBER / GZ_NQ;
-constexpr int GZ_HBITS = 12;
-constexpr int GZ_MINM = 8, GZ_MINRUN = 6, GZ_MAXM = 258, GZ_LAZY = 32;
+constexpr int GZ_HBITS = 10, GZ_WAYS = 8;               // 1,024 buckets of the 8 nearest earlier positions per wave
+constexpr int GZ_MINM = 8, GZ_MINRUN = 6, GZ_MAXM = 258, GZ_CAP = 16;
 constexpr int GZ_SLOT = 65536;                         // output bytes reserved per member (BGZF: total block size <= 65536)
 constexpr int GZ_HDR = 18, GZ_TRL = 8;
 constexpr int GZ_NSYM = 320;                           // 0..285 literal/length symbols, 286..315 distance symbols
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(256) void rd_gz_pack_kernel(const uint8_t *__restri
 // ------------------------------------------------------------------------------------------------
 struct __attribute__((aligned(16))) GzSmem {
     uint32_t text[(GZ_MEMBER + 16) / 4];      // the member's bytes (+ zero pad); after the parse: the output (header, deflate data, trailer)
-    uint32_t tab[GZ_NQ][1 << GZ_HBITS];       // per wave: hash -> two earlier positions in its quarter (+ 1): low half = the nearest
+    u32x4 tab[GZ_NQ][1 << GZ_HBITS];          // per wave: hash -> the 8 nearest earlier positions in its quarter (+ 1), 16 bits each, nearest first
     uint32_t hist[GZ_NQ][GZ_NSYM];            // per wave: symbol counts of its quarter
     uint32_t freq[GZ_NSYM];
     uint8_t lens[GZ_NSYM];
@@ -192,15 +193,6 @@ struct __attribute__((aligned(16))) GzSmem {
 __device__ __forceinline__ uint32_t gz_ld32(const uint32_t *T, int i) {   // 4 bytes at byte offset i (any alignment)
     const uint32_t *q = T + (i >> 2);
     return __builtin_amdgcn_alignbyte(q[1], q[0], (uint32_t)(i & 3));
-}
-
-__device__ __forceinline__ int gz_mlen(const uint32_t *T, int p, int c, int lim, int k) {   // the first k bytes are known to agree
-    while (k < lim) {
-        const uint32_t x = gz_ld32(T, p + k) ^ gz_ld32(T, c + k);
-        if (x) { k += __builtin_ctz(x) >> 3; break; }
-        k += 4;
-    }
-    return k < lim ? k : lim;
 }
 
 __device__ __forceinline__ uint32_t gz_multmodp(uint32_t a, uint32_t b) {   // zlib's multmodp: a(x) b(x) mod P, reflected
@@ -411,7 +403,7 @@ __global__ __launch_bounds__(256) void rd_gz_deflate_kernel(const uint8_t *__res
                 }
                 S.text[k] = v;
             }
-            for (int k = tid; k < GZ_NQ * (1 << GZ_HBITS); k += 256) (&S.tab[0][0])[k] = 0;
+            for (int k = tid; k < GZ_NQ * (1 << GZ_HBITS); k += 256) (&S.tab[0][0])[k] = u32x4{0u, 0u, 0u, 0u};
             for (int k = tid; k < GZ_NQ * GZ_NSYM; k += 256) (&S.hist[0][0])[k] = 0;
             if (tid == 0) S.crc = 0;
         }
@@ -445,46 +437,108 @@ __global__ __launch_bounds__(256) void rd_gz_deflate_kernel(const uint8_t *__res
             const int pl = in ? p : s0;                 // (lanes past the quarter's end load somewhere harmless)
             const uint32_t w0 = gz_ld32(S.text, pl), w1 = gz_ld32(S.text, pl + 4);
             const uint32_t h = (((w0 * 0x9E3779B1u) ^ (w1 * 0x85EBCA77u)) * 0xC2B2AE3Du) >> (32 - GZ_HBITS);
-            int L = 0, D = 0;
-            const uint32_t ent = hv ? S.tab[wave][h] : 0u;   // two ways: the nearest earlier position with this hash and the one before it
-            if (carry < 64) {   // (else every position of the strip lies inside a match: nothing to find, only to insert)
-                // The first 8 bytes of both candidates and the byte before the position are fetched TOGETHER (one LDS round trip;
-                // a candidate is only worth a match if all 8 agree - most are 12-bit hash collisions and end here), then the survivors
-                // are extended 4 bytes at a time.
-                const bool v1 = (ent & 0xffffu) != 0, v2 = (ent >> 16) != 0;
-                const int c1 = v1 ? q0 + (int)(ent & 0xffffu) - 1 : pl, c2 = v2 ? q0 + (int)(ent >> 16) - 1 : pl;
-                const uint32_t a0 = gz_ld32(S.text, c1), a1 = gz_ld32(S.text, c1 + 4);
-                const uint32_t b0 = gz_ld32(S.text, c2), b1 = gz_ld32(S.text, c2 + 4);
-                const uint32_t prevb = tb[pl > q0 ? pl - 1 : pl];
-                if (v1 && a0 == w0 && a1 == w1) { L = gz_mlen(S.text, p, c1, lim, 8); D = p - c1; }
-                if (v2 && b0 == w0 && b1 == w1) {
-                    const int k = gz_mlen(S.text, p, c2, lim, 8);
-                    if (k > L) { L = k; D = p - c2; }
+            // Per lane: the bucket's 8 candidates (the 8 nearest earlier positions with this hash, nearest first), the first 8 bytes of
+            // all of them and the byte before the position fetched TOGETHER (one LDS round trip; most candidates are hash collisions and
+            // end there), the survivors compared over 8 more bytes: a length CAPPED at 16 per lane - all the lazy rule needs (zlib level
+            // 5 does not look for a better match behind one of 16+ either). Exact lengths are found later, for the CHOSEN matches only.
+            const u32x4 ent = hv ? S.tab[wave][h] : u32x4{0u, 0u, 0u, 0u};
+            int Lc = 0, Dc = 0;        // capped length and distance of the lane's best candidate
+            uint32_t full = 0;         // ways whose first 16 bytes agree (bit 8: the run candidate): their exact length is still open
+            if (carry < 64) {          // (else every position of the strip lies inside a match: nothing to find, only to insert)
+                const uint32_t w2 = gz_ld32(S.text, pl + 8), w3 = gz_ld32(S.text, pl + 12);
+#pragma unroll
+                for (int wy = 0; wy < GZ_WAYS; ++wy) {
+                    const uint32_t c16 = (ent[wy >> 1] >> (16 * (wy & 1))) & 0xffffu;
+                    const int c = c16 ? q0 + (int)c16 - 1 : pl;
+                    const uint32_t a0 = gz_ld32(S.text, c), a1 = gz_ld32(S.text, c + 4);
+                    if (c16 && a0 == w0 && a1 == w1) {
+                        const uint32_t x2 = gz_ld32(S.text, c + 8) ^ w2, x3 = gz_ld32(S.text, c + 12) ^ w3;
+                        const int k = x2 ? 8 + (__builtin_ctz(x2) >> 3) : x3 ? 12 + (__builtin_ctz(x3) >> 3) : GZ_CAP;
+                        if (k == GZ_CAP) full |= 1u << wy;
+                        if (k > Lc) { Lc = k; Dc = p - c; }
+                    }
                 }
-                const uint32_t splat = prevb * 0x01010101u;
+                const uint32_t splat = (uint32_t)tb[pl > q0 ? pl - 1 : pl] * 0x01010101u;
                 if (in && p > q0 && lim >= GZ_MINRUN && w0 == splat && (w1 & 0xffffu) == (splat & 0xffffu)) {   // a run of 6+
-                    const int k = gz_mlen(S.text, p, p - 1, lim, 4);
-                    if (k >= L) { L = k; D = 1; }
+                    const uint32_t y1 = w1 ^ splat, y2 = w2 ^ splat, y3 = w3 ^ splat;
+                    const int k = y1 ? 4 + (__builtin_ctz(y1) >> 3) : y2 ? 8 + (__builtin_ctz(y2) >> 3) : y3 ? 12 + (__builtin_ctz(y3) >> 3) : GZ_CAP;
+                    if (k == GZ_CAP) full |= 1u << 8;
+                    if (k >= Lc) { Lc = k; Dc = 1; }
                 }
+                if (Lc > lim) Lc = lim;
             }
-            // insert: the occupant from before this strip moves to the second way (lanes of this strip with the same hash: one of them
-            // wins the store - any of them is a valid earlier position for the strips that follow)
-            if (hv) S.tab[wave][h] = (ent << 16) | (uint32_t)(p - q0 + 1);
+            // insert: the occupants from before this strip move one way down (lanes of this strip with the same hash differ only in the
+            // low half of .x: whichever of them wins the store leaves a valid bucket)
+            if (hv) S.tab[wave][h] = u32x4{(ent.x << 16) | (uint32_t)(p - q0 + 1), (ent.y << 16) | (ent.x >> 16), (ent.z << 16) | (ent.y >> 16),
+                                           (ent.w << 16) | (ent.z >> 16)};
             if (carry >= n) { carry -= n; continue; }
-            const int Ln = __shfl_down(L, 1);
-            const bool defer = L > 0 && L < GZ_LAZY && lane + 1 < n && Ln > L;
-            const bool eff = in && L > 0 && !defer;
+            const int Ln = __shfl_down(Lc, 1);
+            const bool defer = Lc > 0 && Lc < GZ_CAP && lane + 1 < n && Ln > Lc;
+            const bool eff = in && Lc > 0 && !defer;
             const uint64_t mm = __ballot(eff);
             const uint64_t all = n == 64 ? ~0ull : ((1ull << n) - 1);
             uint64_t sel = 0;
-            int pos = carry;
-            while (pos < n) {
+            int pos = carry, L = 0, D = 0;
+            while (pos < n) {   // from chosen match to chosen match (uniform: everything below is wave-wide)
                 const uint64_t from = ~0ull << pos;
                 const uint64_t m2 = mm & from;
                 if (!m2) { sel |= all & from; pos = n; break; }
                 const int f = __builtin_ctzll(m2);
                 sel |= (f == 63 ? ~0ull : ((2ull << f) - 1)) & from;
-                pos = f + __builtin_amdgcn_readlane(L, f);
+                int bestL = __builtin_amdgcn_readlane(Lc, f), bestD = __builtin_amdgcn_readlane(Dc, f);
+                const uint32_t fullf = (uint32_t)__builtin_amdgcn_readlane((int)full, f);
+                if (fullf) {
+                    // the exact length of lane f's match, by the whole wave: 8 lanes per way, each comparing 4 bytes - 32 bytes per way
+                    // and round (a match of 258 in eight rounds, the common ones in one or two)
+                    const int pf = s0 + f, limf = q1 - pf < GZ_MAXM ? q1 - pf : GZ_MAXM;
+                    const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)ent.x, f), e1 = (uint32_t)__builtin_amdgcn_readlane((int)ent.y, f);
+                    const uint32_t e2 = (uint32_t)__builtin_amdgcn_readlane((int)ent.z, f), e3 = (uint32_t)__builtin_amdgcn_readlane((int)ent.w, f);
+                    bestL = 0;
+                    if (fullf & 0xffu) {
+                        const int way = lane >> 3, sub = lane & 7;
+                        const uint32_t ew = way < 2 ? e0 : way < 4 ? e1 : way < 6 ? e2 : e3;
+                        const bool act = (fullf >> way) & 1u;
+                        const int c = act ? q0 + (int)((ew >> (16 * (way & 1))) & 0xffffu) - 1 : pf;
+                        int glen = act ? limf : 0;
+                        bool open = act;
+                        for (int base = GZ_CAP; base < limf; base += 32) {
+                            if (!__ballot(open)) break;
+                            const int o = base + 4 * sub;
+                            uint32_t x = 0;
+                            if (open && o < limf) x = gz_ld32(S.text, pf + o) ^ gz_ld32(S.text, c + o);
+                            int cand = x ? o + (__builtin_ctz(x) >> 3) : 0x7fffffff;
+                            cand = min(cand, __shfl_xor(cand, 1));
+                            cand = min(cand, __shfl_xor(cand, 2));
+                            cand = min(cand, __shfl_xor(cand, 4));
+                            if (open && cand != 0x7fffffff) { glen = cand < limf ? cand : limf; open = false; }
+                        }
+                        int key = (glen << 3) | (7 - way);   // longest; the nearest on ties
+#pragma unroll
+                        for (int o = 8; o < 64; o <<= 1) key = max(key, __shfl_xor(key, o));
+                        key = __builtin_amdgcn_readfirstlane(key);
+                        const int bw = 7 - (key & 7);
+                        const uint32_t eb = bw < 2 ? e0 : bw < 4 ? e1 : bw < 6 ? e2 : e3;
+                        bestL = key >> 3;
+                        bestD = pf - (q0 + (int)((eb >> (16 * (bw & 1))) & 0xffffu) - 1);
+                    }
+                    if (fullf >> 8) {   // the run: the first byte from pf + 16 on that differs from the byte before pf
+                        const uint32_t sp = (uint32_t)tb[pf - 1] * 0x01010101u;
+                        int r = limf;
+                        for (int base = GZ_CAP; base < limf; base += 256) {
+                            const int o = base + 4 * lane;
+                            const uint32_t x = o < limf ? gz_ld32(S.text, pf + o) ^ sp : 0u;
+                            int cand = x ? o + (__builtin_ctz(x) >> 3) : 0x7fffffff;
+#pragma unroll
+                            for (int k = 1; k < 64; k <<= 1) cand = min(cand, __shfl_xor(cand, k));
+                            cand = __builtin_amdgcn_readfirstlane(cand);
+                            if (cand != 0x7fffffff) { r = cand < limf ? cand : limf; break; }
+                        }
+                        if (r >= bestL) { bestL = r; bestD = 1; }
+                    }
+                    // (a lane's capped candidates of fewer than 16 bytes cannot beat one of 16+)
+                }
+                if (lane == f) { L = bestL; D = bestD; }
+                pos = f + bestL;
             }
             carry = pos - n;
             const bool tk = (sel >> lane) & 1ull;

@@ -6,11 +6,11 @@
 // header, BGZF framing) in a form that zlib's inflate checks on this machine. The kernel follows the same steps:
 //
 //   member  = 65,280 input bytes (BGZF's block size: the output is a valid BGZF file), one workgroup;
-//   quarter = 16,320 bytes, one wave: its own 4,096-entry two-way hash table (8-byte hashes, the two nearest earlier occurrences; matches of 8+
-//             bytes only: on FASTQ the shorter ones cost more bits than the 2-bit literals they replace - measured here);
+//   quarter = 16,320 bytes, one wave: its own hash table of 1,024 buckets x the 8 nearest earlier positions (8-byte hashes; matches
+//             of 8+ bytes only: on FASTQ the shorter ones cost more bits than the 2-bit literals they replace - measured here);
 //   strip   = 64 consecutive positions, one per lane: every lane hashes its position, looks its candidate up (positions before the
 //             strip), also tries distance 1 (runs), measures the match; then all 64 positions are inserted (the highest lane wins a
-//             slot); then the parse of the strip is resolved left to right: lazy rule (a match shorter than 32 is dropped for a
+//             slot); then the parse of the strip is resolved left to right: lazy rule (a match shorter than 16 is dropped for a
 //             literal when the next position holds a longer one), matches may run over the following strips;
 //   one dynamic-Huffman block per member (stored blocks if that is not smaller), codes limited to 15 bits the way zlib does it.
 //
@@ -22,7 +22,7 @@
 #include <zlib.h>
 
 #ifndef HBITS
-#define HBITS 12
+#define HBITS 10
 #endif
 #ifndef HBYTES
 #define HBYTES 8
@@ -33,7 +33,13 @@
 #ifndef NQ
 #define NQ 4
 #endif
-enum { MEMBER = 65280, QUARTER = MEMBER / NQ, MAXM = 258, LAZY_MAX = 32 };
+#ifndef NWAYS
+#define NWAYS 8
+#endif
+#ifndef LAZY_MAX
+#define LAZY_MAX 16
+#endif
+enum { MEMBER = 65280, QUARTER = MEMBER / NQ, MAXM = 258 };
 
 typedef struct { uint16_t len, dist; } Tok;   // len == 0: literal byte in dist
 
@@ -70,9 +76,8 @@ static int opt_dist1_min = 6, opt_lazy = 1, opt_two = 1, opt_rep = 0;
 
 // one quarter [q0, q1) of the member m; returns the number of tokens
 static int parse_quarter(const uint8_t *m, int q0, int q1, Tok *out) {
-    static uint32_t tab[1 << HBITS], tab2[1 << HBITS];
+    static uint32_t tab[1 << HBITS][NWAYS];
     memset(tab, 0, sizeof(tab));
-    memset(tab2, 0, sizeof(tab2));
     int nt = 0, carry = 0, dlast = 0;
     for (int s0 = q0; s0 < q1; s0 += 64) {
         const int n = q1 - s0 < 64 ? q1 - s0 : 64;
@@ -84,16 +89,11 @@ static int parse_quarter(const uint8_t *m, int q0, int q1, Tok *out) {
             if (p + HBYTES <= q1) {
                 H[l] = HBYTES == 4 ? hash4(load32(m + p)) : hashn(m + p);
                 if (carry < 64) {
-                    const int c = (int)tab[H[l]] - 1;
-                    if (c >= 0) {
-                        const int k = mlen(m, p, c, lim);
-                        if (k >= MINM) { L[l] = k; D[l] = p - c; }
-                    }
-                    if (opt_two) {
-                        const int c2 = (int)tab2[H[l]] - 1;
-                        if (c2 >= 0) {
-                            const int k = mlen(m, p, c2, lim);
-                            if (k >= MINM && k > L[l]) { L[l] = k; D[l] = p - c2; }
+                    for (int wy = 0; wy < (opt_two ? NWAYS : 1); ++wy) {
+                        const int c = (int)tab[H[l]][wy] - 1;
+                        if (c >= 0) {
+                            const int k = mlen(m, p, c, lim);
+                            if (k >= MINM && k > L[l]) { L[l] = k; D[l] = p - c; }
                         }
                     }
                 }
@@ -109,8 +109,9 @@ static int parse_quarter(const uint8_t *m, int q0, int q1, Tok *out) {
         }
         for (int l = 0; l < n; ++l)
             if (H[l] >= 0) {
-                if (opt_two && tab[H[l]] && (int)tab[H[l]] - 1 < s0) tab2[H[l]] = tab[H[l]];   // the pre-strip occupant moves to the second way
-                tab[H[l]] = (uint32_t)(s0 + l + 1);
+                if (tab[H[l]][0] && (int)tab[H[l]][0] - 1 < s0)      // the occupants from before the strip move one way down
+                    for (int wy = NWAYS - 1; wy > 0; --wy) tab[H[l]][wy] = tab[H[l]][wy - 1];
+                tab[H[l]][0] = (uint32_t)(s0 + l + 1);
             }
         if (carry >= n) { carry -= n; continue; }
         int pos = carry;
