@@ -260,10 +260,11 @@ def e2e_record(torch, synth, arenas, offsets, lens, L, ensure, timed_calls=1, gz
             for q in outs + rrs:                      # every call writes NEW files (truncating GBs of tmpfs pages is not the CLI's work)
                 if os.path.exists(q):
                     os.remove(q)
-            t0 = time.perf_counter()
+            t0, c0 = time.perf_counter(), time.process_time()
             pr = detect.main(argv)
-            dt = time.perf_counter() - t0
+            dt, cpu = time.perf_counter() - t0, time.process_time() - c0
             calls.append({"seconds": dt, "reads_per_s": len(ins) * n / dt, "main_thread_s": {k: round(v, 4) for k, v in pr._stage_s.items()},
+                          "host_cores_busy": round(cpu / dt, 2),      # CPU seconds of ALL threads of the process / wall seconds
                           "load_model_s": round(pr.timing["load_model_s"], 4), "detect_s": round(pr.timing["detect_s"], 4),
                           "prefix_k": pr.timing["prefix_k"], "reads_per_s_after_model_load": len(ins) * n / pr.timing["detect_s"]})
             del pr
@@ -272,6 +273,7 @@ def e2e_record(torch, synth, arenas, offsets, lens, L, ensure, timed_calls=1, gz
         out_bytes = sum(os.path.getsize(p) for p in outs + rrs)
         return {"reads_per_s": med["reads_per_s"], "seconds": med["seconds"], "files": len(ins),
                 "reads_per_s_after_model_load": med["reads_per_s_after_model_load"], "timed_calls": timed_calls,
+                "host_cores_busy": med["host_cores_busy"],
                 "spread": (timed[-1]["seconds"] - timed[0]["seconds"]) / med["seconds"],
                 "records_per_file": n, "input_bytes": sum(os.path.getsize(p) for p in ins), "plain_input_bytes": plain_bytes,
                 "output_bytes": out_bytes, "input_compressor": how,
@@ -336,6 +338,9 @@ def main():
     ap.add_argument("--inline-refine", action="store_true",
                     help="leave the float64 refine pass inside rd_classify (on the main stream) instead of overlapping it with the next "
                          "step's recurrences on a side stream")
+    ap.add_argument("--refine-scan", action="store_true",
+                    help="A/B only: the round-3 placement of the float64 pass - rd_refine (a scan of all logits) issued by this script on the "
+                         "side stream - instead of the deferred pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the short extra measurement of the exact-fp32 MFMA kernel")
     ap.add_argument("--no-encoder", action="store_true", help="skip the standalone encoder kernels")
@@ -422,7 +427,9 @@ def main():
     cur = torch.cuda.current_stream(dev)
     side = torch.cuda.Stream(dev)
     pipelined = not (args.inline_refine or args.pmc_child)   # counter passes: one stream, so that no other kernel runs beside the one counted
-    if pipelined:
+    if pipelined and args.refine_scan:
+        model.set_refine(0.0)
+    elif pipelined:
         # deferred float64 pass (C ABI rd_set_refine_async): the recurrence kernel's epilogue records the reads inside the noise band;
         # rd_sync_results - called on the SIDE stream, in the step's post-pass - evaluates them, one workgroup each, on the model's
         # stream beside the next step's recurrences. No scan launch over the logits (rounds 2-3 issued rd_refine here: 1.4 ms each).
@@ -445,8 +452,12 @@ def main():
         post = side if pipelined else cur
         with torch.cuda.stream(post):
             post.wait_event(ev_main)
-            if pipelined:
+            if pipelined and not args.refine_scan:
                 model.sync_results()                       # (current stream = the side stream: the main stream never waits)
+            if args.refine_scan and pipelined and not (paired and args.ensure == "none"):
+                model.refine(a1, offs, lens, MAXLEN, lg[0], None if paired else lab8)
+                if paired:
+                    model.refine(a2, offs, lens, MAXLEN, lg[1], None)
             if paired:
                 if args.ensure == "none":                  # pair margin decides (reference detect.py:657): the scan form, with the mate
                     model.refine(a1, offs, lens, MAXLEN, lg[0], None, lg[1])
@@ -675,7 +686,8 @@ def main():
                                                 "tests/test_gpu_prefix.py); alt_no_prefix_table = the same steps with k = 0"},
                        "refine": {"band": module_arch.SeqModel.REFINE_DEFAULT, "what": "reads whose margin is inside the band are "
                                   "re-evaluated in float64 (labels of the exact function); inside the timed region",
-                                  "placement": ("deferred (rd_set_refine_async): candidates recorded by the recurrence kernel's epilogue, "
+                                  "placement": ("rd_refine scan on the side stream (round-3 form, --refine-scan)" if (pipelined and args.refine_scan) else
+                                                "deferred (rd_set_refine_async): candidates recorded by the recurrence kernel's epilogue, "
                                                 "evaluated by rd_sync_results on the post-pass stream beside the next step's recurrences")
                                   if pipelined else "inline in rd_classify"},
                        "label_counts": {"non_rrna": c[0], "rrna": c[1], "unclassified": c[2]},
