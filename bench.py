@@ -218,7 +218,7 @@ def gzip_file(src, dst, level=4):
         return "zlib level 1"
 
 
-def e2e_record(torch, synth, arenas, offsets, lens, L, ensure, timed_calls=1, gz=False):
+def e2e_record(torch, synth, arenas, offsets, lens, L, ensure, timed_calls=1, gz=False, threads=None):
     """Timed region (iii) of SURVEY §8d: the whole `ribodetector` CLI - detect.main(): model load (incl. building the prefix-state
     table), native FASTQ parse, H2D, kernels, label D2H, output write - on a FASTQ file (pair) built from the rank-0 stream of this
     run in tmpfs (the reference flow: detect.py:464-499). One warm call (it pays one-off costs of the process: first pinned
@@ -254,7 +254,7 @@ def e2e_record(torch, synth, arenas, offsets, lens, L, ensure, timed_calls=1, gz
         ext = ".fq.gz" if gz else ".fq"
         outs = [os.path.join(d, "non_%d%s" % (m + 1, ext)) for m in range(len(ins))]
         rrs = [os.path.join(d, "rrna_%d%s" % (m + 1, ext)) for m in range(len(ins))]
-        argv = ["-l", str(L), "-i", *ins, "-o", *outs, "-r", *rrs] + (["-e", ensure] if len(ins) == 2 else [])
+        argv = ["-l", str(L), "-i", *ins, "-o", *outs, "-r", *rrs] + (["-e", ensure] if len(ins) == 2 else []) + (["-t", str(threads)] if threads else [])
         calls = []
         for call in range(1 + timed_calls):
             for q in outs + rrs:                      # every call writes NEW files (truncating GBs of tmpfs pages is not the CLI's work)
@@ -277,8 +277,10 @@ def e2e_record(torch, synth, arenas, offsets, lens, L, ensure, timed_calls=1, gz
                 "spread": (timed[-1]["seconds"] - timed[0]["seconds"]) / med["seconds"],
                 "records_per_file": n, "input_bytes": sum(os.path.getsize(p) for p in ins), "plain_input_bytes": plain_bytes,
                 "output_bytes": out_bytes, "input_compressor": how,
-                "what": "whole detect.main() call on FASTQ in tmpfs, %s, default -t 10: model load + prefix table build + parse + H2D + "
-                        "kernels + D2H + write; median of %d call(s) after one warm call" % ("gz -> gz" if gz else "plain -> plain", timed_calls),
+                "threads_flag": threads or 10,
+                "what": "whole detect.main() call on FASTQ in tmpfs, %s, -t %d%s: model load + prefix table build + parse + H2D + "
+                        "kernels + D2H + write; median of %d call(s) after one warm call"
+                        % ("gz -> gz" if gz else "plain -> plain", threads or 10, "" if threads else " (the CLI's default)", timed_calls),
                 "warm_call": calls[0], "calls": calls[1:]}
     finally:
         shutil.rmtree(d, ignore_errors=True)
@@ -794,6 +796,11 @@ def main():
                         out["e2e_cli"]["gz_to_gz"] = gzr
                         out["e2e_cli"]["gz_to_gz_reads_per_s"] = gzr["reads_per_s"]
                         out["config"]["e2e_cli_gz_to_gz_reads_per_s"] = gzr["reads_per_s"]
+                        # the same with -t = the usable host cores: with the deflate on the GPU every core can inflate the inputs
+                        gza = e2e_record(torch, synth, [torch.cat([t[0] for t in r1])] + ([torch.cat([t[0] for t in r2])] if paired else []),
+                                         offs_l[: ng + 1], lens.repeat(nslices), MAXLEN, args.ensure, timed_calls=2, gz=True, threads=usable_cores())
+                        out["e2e_cli"]["gz_to_gz_all_cores"] = gza
+                        out["config"]["e2e_cli_gz_to_gz_all_cores_reads_per_s"] = gza["reads_per_s"]
                 if "reads_per_s" not in out["e2e_cli"]:
                     out["e2e_cli"].update({k: e2e[k] for k in ("reads_per_s", "seconds", "records_per_file", "files", "spread", "what")})
                     out["config"]["e2e_cli_reads_per_s"] = e2e["reads_per_s"]

@@ -190,6 +190,44 @@ struct __attribute__((aligned(16))) GzSmem {
     int used, hlit, hdist, hclen;
 };
 
+// Cross-lane steps as DPP modifiers of VALU instructions (a few cycles each) instead of ds_bpermute round trips (__shfl_*: the LDS
+// crossbar, ~100 cycles when the next step depends on it - a strip resolves several matches, each with two reductions).
+template <int CTRL>
+__device__ __forceinline__ int gz_dpp(int v) {   // every lane has a valid source for the controls used with this form
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false);
+}
+template <int CTRL>
+__device__ __forceinline__ uint32_t gz_dpp0(uint32_t v) {   // lanes without a source read 0 (row_shr / wave_shl shift zeros in)
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
+}
+constexpr int DPP_QUAD_1032 = 0xB1, DPP_QUAD_2301 = 0x4E, DPP_ROW_MIRROR = 0x140, DPP_ROW_HALF_MIRROR = 0x141, DPP_WAVE_SHL1 = 0x130;
+constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118;
+__device__ __forceinline__ int gz_min8(int v) {    // minimum over each group of 8 consecutive lanes, in all of them
+    v = min(v, gz_dpp<DPP_QUAD_1032>(v));
+    v = min(v, gz_dpp<DPP_QUAD_2301>(v));
+    return min(v, gz_dpp<DPP_ROW_HALF_MIRROR>(v));
+}
+__device__ __forceinline__ int gz_min64(int v) {   // wave minimum (uniform)
+    v = gz_min8(v);
+    v = min(v, gz_dpp<DPP_ROW_MIRROR>(v));
+    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+__device__ __forceinline__ int gz_max64_of_groups(int v) {   // wave maximum of a value that is already uniform within groups of 8
+    v = max(v, gz_dpp<DPP_ROW_MIRROR>(v));
+    return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+__device__ __forceinline__ uint32_t gz_wave_scan(uint32_t x) {   // inclusive prefix sum over the 64 lanes
+    uint32_t t = x;
+    t += gz_dpp0<DPP_ROW_SHR1>(t);
+    t += gz_dpp0<DPP_ROW_SHR2>(t);
+    t += gz_dpp0<DPP_ROW_SHR4>(t);
+    t += gz_dpp0<DPP_ROW_SHR8>(t);                              // inclusive within each row of 16
+    const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)t, 15), r1 = (uint32_t)__builtin_amdgcn_readlane((int)t, 31),
+                   r2 = (uint32_t)__builtin_amdgcn_readlane((int)t, 47);
+    const int row = (int)(threadIdx.x & 63) >> 4;
+    return t + (row == 0 ? 0u : row == 1 ? r0 : row == 2 ? r0 + r1 : r0 + r1 + r2);
+}
+
 __device__ __forceinline__ uint32_t gz_ld32(const uint32_t *T, int i) {   // 4 bytes at byte offset i (any alignment)
     const uint32_t *q = T + (i >> 2);
     return __builtin_amdgcn_alignbyte(q[1], q[0], (uint32_t)(i & 3));
@@ -216,12 +254,7 @@ __device__ __forceinline__ uint32_t gz_x8n(uint32_t nbytes) {   // x^(8 nbytes) 
 
 __device__ __forceinline__ uint32_t gz_scan256(uint32_t v, uint32_t *sh, uint32_t &total) {   // exclusive, 256 threads
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    uint32_t inc = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t t = __shfl_up(inc, o);
-        if (lane >= o) inc += t;
-    }
+    const uint32_t inc = gz_wave_scan(v);
     if (lane == 63) sh[wave] = inc;
     __syncthreads();
     uint32_t base = 0;
@@ -471,8 +504,9 @@ __global__ __launch_bounds__(256) void rd_gz_deflate_kernel(const uint8_t *__res
             // low half of .x: whichever of them wins the store leaves a valid bucket)
             if (hv) S.tab[wave][h] = u32x4{(ent.x << 16) | (uint32_t)(p - q0 + 1), (ent.y << 16) | (ent.x >> 16), (ent.z << 16) | (ent.y >> 16),
                                            (ent.w << 16) | (ent.z >> 16)};
+            GZ_STAMP(8);    // strip: per-lane candidates + insert
             if (carry >= n) { carry -= n; continue; }
-            const int Ln = __shfl_down(Lc, 1);
+            const int Ln = (int)gz_dpp0<DPP_WAVE_SHL1>((uint32_t)Lc);   // lane + 1's (lane 63: 0)
             const bool defer = Lc > 0 && Lc < GZ_CAP && lane + 1 < n && Ln > Lc;
             const bool eff = in && Lc > 0 && !defer;
             const uint64_t mm = __ballot(eff);
@@ -506,16 +540,10 @@ __global__ __launch_bounds__(256) void rd_gz_deflate_kernel(const uint8_t *__res
                             const int o = base + 4 * sub;
                             uint32_t x = 0;
                             if (open && o < limf) x = gz_ld32(S.text, pf + o) ^ gz_ld32(S.text, c + o);
-                            int cand = x ? o + (__builtin_ctz(x) >> 3) : 0x7fffffff;
-                            cand = min(cand, __shfl_xor(cand, 1));
-                            cand = min(cand, __shfl_xor(cand, 2));
-                            cand = min(cand, __shfl_xor(cand, 4));
+                            const int cand = gz_min8(x ? o + (__builtin_ctz(x) >> 3) : 0x7fffffff);
                             if (open && cand != 0x7fffffff) { glen = cand < limf ? cand : limf; open = false; }
                         }
-                        int key = (glen << 3) | (7 - way);   // longest; the nearest on ties
-#pragma unroll
-                        for (int o = 8; o < 64; o <<= 1) key = max(key, __shfl_xor(key, o));
-                        key = __builtin_amdgcn_readfirstlane(key);
+                        const int key = gz_max64_of_groups((glen << 3) | (7 - way));   // longest; the nearest on ties
                         const int bw = 7 - (key & 7);
                         const uint32_t eb = bw < 2 ? e0 : bw < 4 ? e1 : bw < 6 ? e2 : e3;
                         bestL = key >> 3;
@@ -527,10 +555,7 @@ __global__ __launch_bounds__(256) void rd_gz_deflate_kernel(const uint8_t *__res
                         for (int base = GZ_CAP; base < limf; base += 256) {
                             const int o = base + 4 * lane;
                             const uint32_t x = o < limf ? gz_ld32(S.text, pf + o) ^ sp : 0u;
-                            int cand = x ? o + (__builtin_ctz(x) >> 3) : 0x7fffffff;
-#pragma unroll
-                            for (int k = 1; k < 64; k <<= 1) cand = min(cand, __shfl_xor(cand, k));
-                            cand = __builtin_amdgcn_readfirstlane(cand);
+                            const int cand = gz_min64(x ? o + (__builtin_ctz(x) >> 3) : 0x7fffffff);
                             if (cand != 0x7fffffff) { r = cand < limf ? cand : limf; break; }
                         }
                         if (r >= bestL) { bestL = r; bestD = 1; }
@@ -541,6 +566,7 @@ __global__ __launch_bounds__(256) void rd_gz_deflate_kernel(const uint8_t *__res
                 pos = f + bestL;
             }
             carry = pos - n;
+            GZ_STAMP(9);    // strip: walk over the chosen matches
             const bool tk = (sel >> lane) & 1ull;
             const bool ismatch = tk && eff;
             const uint32_t byte = w0 & 0xffu;
@@ -560,10 +586,11 @@ __global__ __launch_bounds__(256) void rd_gz_deflate_kernel(const uint8_t *__res
                 const int f = __builtin_ctzll(lm);
                 const uint32_t bv = (uint32_t)__builtin_amdgcn_readlane((int)byte, f);
                 const uint64_t same = __ballot(lit && byte == bv);
-                if (lane == f) S.hist[wave][bv] += (uint32_t)__popcll(same);
+                if (lane == f) atomicAdd(&S.hist[wave][bv], (uint32_t)__popcll(same));   // (ds_add without return: nothing to wait for)
                 lm &= ~same;
             }
             ntok += __popcll(sel);
+            GZ_STAMP(10);   // strip: tokens + counts
         }
         if (lane == 0) S.qtok[wave] = (uint32_t)ntok;
         GZ_STAMP(2);   // parse of wave 0
@@ -609,9 +636,8 @@ __global__ __launch_bounds__(256) void rd_gz_deflate_kernel(const uint8_t *__res
                 const uint32_t extra = s >= 286 ? GZ_DEXTRA[s - 286 < 30 ? s - 286 : 0] : s >= 257 ? GZ_LEXTRA[s - 257] : 0;
                 if (s < 316) b += S.hist[wave][s] * (S.lens[s] + extra);
             }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) b += __shfl_xor(b, o);
-            if (lane == 0) S.qbits[wave] = b;
+            b = gz_wave_scan(b);
+            if (lane == 63) S.qbits[wave] = b;
         }
         __syncthreads();
         GZ_STAMP(4);   // codes
@@ -687,14 +713,9 @@ __global__ __launch_bounds__(256) void rd_gz_deflate_kernel(const uint8_t *__res
                         nb = S.lens[tv];
                     }
                 }
-                uint32_t inc = (uint32_t)nb;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    const uint32_t u = __shfl_up(inc, o);
-                    if (lane >= o) inc += u;
-                }
+                const uint32_t inc = gz_wave_scan((uint32_t)nb);
                 gz_or_bits(out, bit + inc - (uint32_t)nb, bits, nb);
-                bit += __shfl(inc, 63);
+                bit += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
             }
         }
         __syncthreads();

@@ -25,6 +25,7 @@
 //   rd_encode_* / rd_pack_onehot       standalone encoder kernels (reference tensor layouts), HBM-bound
 //   rd_pair_fuse_kernel, rd_count_kernel
 //   rd_gz_*                            records of one label -> gzip (BGZF) members on the device (rd_deflate.hpp)
+#include <stdlib.h>
 #include "rd_common.hpp"
 #include "rd_prep.hpp"
 #include "rd_recurrence.hpp"
@@ -165,7 +166,8 @@ static int rd_async_flush(rd_model *m, hipStream_t st, int x) {
         const auto &pd = m->q_pend[x][k];
         ReadBatch rb{(const uint8_t *)pd.p[0], (const int64_t *)pd.p[1], (const int32_t *)pd.p[2], nullptr, nullptr, pd.n, pd.max_len, pd.sem,
                      m->d.rev_tab, nullptr, nullptr, 0, RefineQueue{nullptr, nullptr, 0}, 0.0f};
-        const int64_t nb = (pd.n + REFINE_SLICE - 1) / REFINE_SLICE;
+        int64_t nb = (pd.n + REFINE_SLICE - 1) / REFINE_SLICE;
+        if (nb > 16) nb = 16;   // the workgroups walk the slices (gate closed: sixteen workgroups look at it and leave)
         hipLaunchKernelGGL(rd_refine_kernel, dim3((unsigned)nb), dim3(1024), 0, m->side, m->d, rb, (const float2 *)nullptr, pd.thresh,
                            (float *)pd.p[3], (uint8_t *)pd.p[4], rd_queue(m, x), (const uint32_t *)m->q_count[x]);
     }
@@ -224,7 +226,9 @@ int rd_set_refine_async(rd_model *m, int calls) {
         // threads), and so does every workgroup of the recurrence kernel that the pass is meant to run beside
         int lo = 0, hi = 0;
         RD_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        RD_HIP(hipStreamCreateWithPriority(&m->side, hipStreamNonBlocking, hi));
+        const char *pr = getenv("RD_REFINE_STREAM_PRIORITY");   // (A/B knob: "low" / "normal"; default high)
+        const int prio = pr && !strcmp(pr, "low") ? lo : pr && !strcmp(pr, "normal") ? (lo + hi) / 2 : hi;
+        RD_HIP(hipStreamCreateWithPriority(&m->side, hipStreamNonBlocking, prio));
         RD_HIP(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
         for (int x = 0; x < 2; ++x) {
             RD_HIP(hipEventCreateWithFlags(&m->ev_join[x], hipEventDisableTiming));

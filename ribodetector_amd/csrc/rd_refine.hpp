@@ -143,36 +143,42 @@ __global__ __launch_bounds__(1024) void rd_refine_kernel(DevModel d, ReadBatch r
     __shared__ int cand[REFINE_SLICE];
     __shared__ int ncand;
     const int tid = threadIdx.x;
-    const int64_t s0 = (int64_t)blockIdx.x * REFINE_SLICE;
-    const int64_t s1 = s0 + REFINE_SLICE < rb.n ? s0 + REFINE_SLICE : rb.n;
-    if (tid == 0) ncand = 0;
-    __syncthreads();
-    for (int64_t i = s0 + tid; i < s1; i += 1024) {
-        const float2 a = reinterpret_cast<const float2 *>(logits)[i];
-        bool hit = fabsf(a.y - a.x) < thresh;
-        if (mate) {
-            const float2 m = mate[i];
-            hit = hit || fabsf((a.y + m.y) - (a.x + m.x)) < 2.0f * thresh;
-        }
-        if (hit && q.e) {   // record it; evaluated by the flush
-            const uint32_t slot = atomicAdd(q.count, 1u);
-            if (slot < q.cap) {
-                q.e[slot] = RefineEntry{rb.arena + rb.off[i], logits + 2 * i, labels ? labels + i : nullptr, rd_T(rb.len, i, rb.max_len),
-                                        rb.max_len, rb.sem, 0};
-                hit = false;
-            }
-        }
-        if (hit) cand[atomicAdd(&ncand, 1)] = (int)(i - s0);
-    }
-    __syncthreads();
-    const int total = ncand;
-    if (total == 0) return;
+    bool loaded = false;
     RefineWeights W;
-    rd_refine_load(d, W);
-    for (int k = 0; k < total; ++k) {
-        const int64_t i = s0 + cand[k];
-        rd_refine_eval(d, S, W, rb.arena + rb.off[i], rd_T(rb.len, i, rb.max_len), rb.sem, rb.max_len, rb.rev_tab, logits + 2 * i,
-                       labels ? labels + i : nullptr);
+    // (the second tier is launched with a handful of workgroups that walk the slices: when its gate is closed - always, unless a queue
+    // overflowed - it must cost nothing, and 2,048 workgroups of 1,024 threads that each need a whole CU do not cost nothing)
+    for (int64_t slice = blockIdx.x; slice * REFINE_SLICE < rb.n; slice += gridDim.x) {
+        const int64_t s0 = slice * REFINE_SLICE;
+        const int64_t s1 = s0 + REFINE_SLICE < rb.n ? s0 + REFINE_SLICE : rb.n;
+        __syncthreads();
+        if (tid == 0) ncand = 0;
+        __syncthreads();
+        for (int64_t i = s0 + tid; i < s1; i += 1024) {
+            const float2 a = reinterpret_cast<const float2 *>(logits)[i];
+            bool hit = fabsf(a.y - a.x) < thresh;
+            if (mate) {
+                const float2 m = mate[i];
+                hit = hit || fabsf((a.y + m.y) - (a.x + m.x)) < 2.0f * thresh;
+            }
+            if (hit && q.e) {   // record it; evaluated by the flush
+                const uint32_t slot = atomicAdd(q.count, 1u);
+                if (slot < q.cap) {
+                    q.e[slot] = RefineEntry{rb.arena + rb.off[i], logits + 2 * i, labels ? labels + i : nullptr, rd_T(rb.len, i, rb.max_len),
+                                            rb.max_len, rb.sem, 0};
+                    hit = false;
+                }
+            }
+            if (hit) cand[atomicAdd(&ncand, 1)] = (int)(i - s0);
+        }
+        __syncthreads();
+        const int total = ncand;
+        if (total == 0) continue;
+        if (!loaded) { rd_refine_load(d, W); loaded = true; }
+        for (int k = 0; k < total; ++k) {
+            const int64_t i = s0 + cand[k];
+            rd_refine_eval(d, S, W, rb.arena + rb.off[i], rd_T(rb.len, i, rb.max_len), rb.sem, rb.max_len, rb.rev_tab, logits + 2 * i,
+                           labels ? labels + i : nullptr);
+        }
     }
 }
 

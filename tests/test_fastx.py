@@ -181,6 +181,52 @@ def test_gzip_writer_members(tmp_path):
         assert fh.read() == b""
 
 
+def test_writer_appends_members_made_elsewhere(tmp_path):
+    """rd_writer_write_members: complete gzip members made elsewhere (the GPU's BGZF blocks; here: Python's zlib) are appended as they
+    are, in order with what the host path wrote before and after; the file is closed with BGZF's end-of-file marker; a plain
+    output refuses them."""
+    import ctypes as C
+    import zlib
+    arena, off, lens = synth.reads_numpy(4000, 100, seed=9)
+    p = str(tmp_path / "in.fq")
+    synth.write_fastq(p, arena, off, mate=1)
+    c = next(fx.get_seq_chunks(p, chunk_size=4000))
+    all1 = np.ones(len(c.seq_len), np.int8)
+    text = fx.select_records(c, all1 == 1)
+
+    def member(b):   # what a BGZF writer emits for one block of bytes
+        co = zlib.compressobj(5, zlib.DEFLATED, -15)
+        d = co.compress(b) + co.flush()
+        n = 18 + len(d) + 8
+        return (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + (n - 1).to_bytes(2, "little") + d +
+                (zlib.crc32(b) & 0xffffffff).to_bytes(4, "little") + len(b).to_bytes(4, "little"))
+    eof = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+    out = str(tmp_path / "mixed.fq.gz")
+    w = fx.open_for_write(out)
+    w.write_selected(c, all1, 1)                          # host path first (buffered: less than a 4 MiB member) ...
+    mem = b"".join(member(text[i:i + 60000]) for i in range(0, len(text), 60000))
+    buf = C.create_string_buffer(mem, len(mem))
+    w.write_members(C.addressof(buf), len(mem))           # ... then members made elsewhere: the buffered records come first
+    w.write_members(None, 0)                              # (nothing to append is fine)
+    w.write_selected(c, all1, 1)
+    w.close()
+    raw = open(out, "rb").read()
+    assert raw.endswith(eof) and raw.count(mem) == 1
+    with gzip.open(out, "rb") as fh:
+        assert fh.read() == text * 3
+    back = b"".join(ch.buf[ch.rec_start[0]:ch.rec_start[-1]].tobytes() for ch in fx.get_seq_chunks(out, chunk_size=3000))
+    assert back == text * 3                               # this build's reader walks the mixed member kinds
+    only = str(tmp_path / "only.fq.gz")
+    w = fx.open_for_write(only)
+    w.write_members(None, 0)
+    w.close()
+    assert open(only, "rb").read() == eof and gzip.open(only, "rb").read() == b""
+    plain = fx.open_for_write(str(tmp_path / "plain.fq"))
+    with pytest.raises(ValueError, match="not a gzip output"):
+        plain.write_members(C.addressof(buf), len(mem))
+    plain.close()
+
+
 def test_gzip_writer_zlib_fallback(tmp_path):
     """RD_HOST_ZLIB=1 (or a machine without libdeflate.so.0) takes the zlib path: same decompressed bytes, and the
     library's own reader/decoder reads both back."""

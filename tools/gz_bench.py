@@ -32,7 +32,7 @@ def main():
     if a.stages:
         import ctypes as C
         from ribodetector_amd import _native as N
-        prof = torch.zeros(8, dtype=torch.int64, device=dev)
+        prof = torch.zeros(16, dtype=torch.int64, device=dev)
         N.check(N.lib().rd_gz_diag_set_profile(C.c_void_p(prof.data_ptr())), "rd_gz_diag_set_profile")
     arena, off, lens = synth.reads_torch(n, 100, seed=2000, device=dev)
     rec = {"records": n}
@@ -71,8 +71,8 @@ def main():
             st = prof.cpu().tolist()
             prof.zero_()
             tot = float(sum(st)) or 1.0
-            rec.setdefault("stages", {})[name] = dict(zip(("load", "crc_thread0", "parse_wave0", "wait_slowest_wave", "codes", "emit", "copy"),
-                                                         [round(x / tot, 4) for x in st[:7]]))
+            names = ("load", "crc_thread0", "parse_rest", "wait_slowest_wave", "codes", "emit", "copy", "-", "strip_candidates", "strip_walk", "strip_tokens")
+            rec.setdefault("stages", {})[name] = {k: round(x / tot, 4) for k, x in zip(names, st[:11]) if k != "-"}
         comp = sum(int(outs[lab][1][0]) for lab in (0, 1))
         plain = sum(int(outs[lab][1][1]) for lab in (0, 1))
         assert plain == int(text.numel())

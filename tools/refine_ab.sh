@@ -5,9 +5,10 @@
 R=$(cd "$(dirname "$0")/.." && pwd); cd "$R"
 F="--steps 20 --warmup 3 --no-cpu-baseline --no-alt --no-encoder --no-e2e --traffic off"
 for i in 1 2 3; do
-  for mode in deferred scan; do
+  for mode in deferred deferred_normal_prio scan; do
     X=""; [ $mode = scan ] && X="--refine-scan"
-    python bench.py $F $X 2>/dev/null | grep '^{' | python -c "
+    P=high; [ $mode = deferred_normal_prio ] && P=normal
+    RD_REFINE_STREAM_PRIORITY=$P python bench.py $F $X 2>/dev/null | grep '^{' | python -c "
 import json,sys; j=json.loads(sys.stdin.read()); print('$mode', 'run $i', 'reads/s %.0f' % j['value'], 'ms_per_step %.3f' % j['ms_per_step'], 'launch_ms %.3f' % j['roofline']['avg_launch_ms'], 'kernel_only %.0f' % j['config']['kernel_only_reads_per_s'])"
   done
 done
