@@ -184,6 +184,7 @@ struct __attribute__((aligned(16))) GzSmem {
     uint32_t crc_tab[256];
     uint8_t lsym[256];                        // match length - 3 -> length symbol - 257
     uint8_t dsym[512];                        // zlib's _dist_code
+    uint64_t litmask[GZ_NQ][(GZ_QUARTER + 63) / 64];   // per strip: which positions became literals
     uint32_t scan[4];
     uint32_t qbits[GZ_NQ], qtok[GZ_NQ];
     uint32_t crc;
@@ -469,7 +470,10 @@ __global__ __launch_bounds__(256) void rd_gz_deflate_kernel(const uint8_t *__res
             const bool hv = in && p + 8 <= q1;
             const int pl = in ? p : s0;                 // (lanes past the quarter's end load somewhere harmless)
             const uint32_t w0 = gz_ld32(S.text, pl), w1 = gz_ld32(S.text, pl + 4);
-            const uint32_t h = (((w0 * 0x9E3779B1u) ^ (w1 * 0x85EBCA77u)) * 0xC2B2AE3Du) >> (32 - GZ_HBITS);
+            const uint32_t hh = ((w0 * 0x9E3779B1u) ^ (w1 * 0x85EBCA77u)) * 0xC2B2AE3Du;
+            const uint32_t h = hh >> (32 - GZ_HBITS);
+            const uint32_t tag = ((hh >> (30 - GZ_HBITS)) & 3u) << 14;   // two more hash bits ride in the entry (a position needs 14 bits):
+                                                                        // three of four hash collisions are rejected without touching the text
             // Per lane: the bucket's 8 candidates (the 8 nearest earlier positions with this hash, nearest first), the first 8 bytes of
             // all of them and the byte before the position fetched TOGETHER (one LDS round trip; most candidates are hash collisions and
             // end there), the survivors compared over 8 more bytes: a length CAPPED at 16 per lane - all the lazy rule needs (zlib level
@@ -479,17 +483,25 @@ __global__ __launch_bounds__(256) void rd_gz_deflate_kernel(const uint8_t *__res
             uint32_t full = 0;         // ways whose first 16 bytes agree (bit 8: the run candidate): their exact length is still open
             if (carry < 64) {          // (else every position of the strip lies inside a match: nothing to find, only to insert)
                 const uint32_t w2 = gz_ld32(S.text, pl + 8), w3 = gz_ld32(S.text, pl + 12);
+                // straight-line on purpose: a branch per way would serialise eight LDS round trips; every way loads 16 bytes (five dwords)
+                // from its candidate - or, when the way is empty or its tag differs, from the lane's own position (consecutive lanes,
+                // consecutive addresses: no bank conflicts) - and the outcome is folded in with selects
 #pragma unroll
                 for (int wy = 0; wy < GZ_WAYS; ++wy) {
-                    const uint32_t c16 = (ent[wy >> 1] >> (16 * (wy & 1))) & 0xffffu;
-                    const int c = c16 ? q0 + (int)c16 - 1 : pl;
-                    const uint32_t a0 = gz_ld32(S.text, c), a1 = gz_ld32(S.text, c + 4);
-                    if (c16 && a0 == w0 && a1 == w1) {
-                        const uint32_t x2 = gz_ld32(S.text, c + 8) ^ w2, x3 = gz_ld32(S.text, c + 12) ^ w3;
-                        const int k = x2 ? 8 + (__builtin_ctz(x2) >> 3) : x3 ? 12 + (__builtin_ctz(x3) >> 3) : GZ_CAP;
-                        if (k == GZ_CAP) full |= 1u << wy;
-                        if (k > Lc) { Lc = k; Dc = p - c; }
-                    }
+                    const uint32_t e16 = (ent[wy >> 1] >> (16 * (wy & 1))) & 0xffffu;
+                    const uint32_t c16 = e16 & 0x3fffu;
+                    const bool ok = c16 != 0 && (e16 & 0xc000u) == tag;
+                    const int c = ok ? q0 + (int)c16 - 1 : pl;
+                    const uint32_t *cq = S.text + (c >> 2);
+                    const uint32_t sh = (uint32_t)(c & 3);
+                    const uint32_t d0 = cq[0], d1 = cq[1], d2 = cq[2], d3 = cq[3], d4 = cq[4];
+                    const uint32_t x0 = __builtin_amdgcn_alignbyte(d1, d0, sh) ^ w0, x1 = __builtin_amdgcn_alignbyte(d2, d1, sh) ^ w1;
+                    const uint32_t x2 = __builtin_amdgcn_alignbyte(d3, d2, sh) ^ w2, x3 = __builtin_amdgcn_alignbyte(d4, d3, sh) ^ w3;
+                    const int k = (!ok || (x0 | x1)) ? 0 : x2 ? 8 + (__builtin_ctz(x2) >> 3) : x3 ? 12 + (__builtin_ctz(x3) >> 3) : GZ_CAP;
+                    full |= (k == GZ_CAP ? 1u : 0u) << wy;
+                    const bool better = k > Lc;
+                    Dc = better ? p - c : Dc;
+                    Lc = better ? k : Lc;
                 }
                 const uint32_t splat = (uint32_t)tb[pl > q0 ? pl - 1 : pl] * 0x01010101u;
                 if (in && p > q0 && lim >= GZ_MINRUN && w0 == splat && (w1 & 0xffffu) == (splat & 0xffffu)) {   // a run of 6+
@@ -502,10 +514,14 @@ __global__ __launch_bounds__(256) void rd_gz_deflate_kernel(const uint8_t *__res
             }
             // insert: the occupants from before this strip move one way down (lanes of this strip with the same hash differ only in the
             // low half of .x: whichever of them wins the store leaves a valid bucket)
-            if (hv) S.tab[wave][h] = u32x4{(ent.x << 16) | (uint32_t)(p - q0 + 1), (ent.y << 16) | (ent.x >> 16), (ent.z << 16) | (ent.y >> 16),
+            if (hv) S.tab[wave][h] = u32x4{(ent.x << 16) | tag | (uint32_t)(p - q0 + 1), (ent.y << 16) | (ent.x >> 16), (ent.z << 16) | (ent.y >> 16),
                                            (ent.w << 16) | (ent.z >> 16)};
             GZ_STAMP(8);    // strip: per-lane candidates + insert
-            if (carry >= n) { carry -= n; continue; }
+            if (carry >= n) {
+                if (lane == 0) S.litmask[wave][(s0 - q0) >> 6] = 0;
+                carry -= n;
+                continue;
+            }
             const int Ln = (int)gz_dpp0<DPP_WAVE_SHL1>((uint32_t)Lc);   // lane + 1's (lane 63: 0)
             const bool defer = Lc > 0 && Lc < GZ_CAP && lane + 1 < n && Ln > Lc;
             const bool eff = in && Lc > 0 && !defer;
@@ -532,7 +548,7 @@ __global__ __launch_bounds__(256) void rd_gz_deflate_kernel(const uint8_t *__res
                         const int way = lane >> 3, sub = lane & 7;
                         const uint32_t ew = way < 2 ? e0 : way < 4 ? e1 : way < 6 ? e2 : e3;
                         const bool act = (fullf >> way) & 1u;
-                        const int c = act ? q0 + (int)((ew >> (16 * (way & 1))) & 0xffffu) - 1 : pf;
+                        const int c = act ? q0 + (int)((ew >> (16 * (way & 1))) & 0x3fffu) - 1 : pf;
                         int glen = act ? limf : 0;
                         bool open = act;
                         for (int base = GZ_CAP; base < limf; base += 32) {
@@ -547,7 +563,7 @@ __global__ __launch_bounds__(256) void rd_gz_deflate_kernel(const uint8_t *__res
                         const int bw = 7 - (key & 7);
                         const uint32_t eb = bw < 2 ? e0 : bw < 4 ? e1 : bw < 6 ? e2 : e3;
                         bestL = key >> 3;
-                        bestD = pf - (q0 + (int)((eb >> (16 * (bw & 1))) & 0xffffu) - 1);
+                        bestD = pf - (q0 + (int)((eb >> (16 * (bw & 1))) & 0x3fffu) - 1);
                     }
                     if (fullf >> 8) {   // the run: the first byte from pf + 16 on that differs from the byte before pf
                         const uint32_t sp = (uint32_t)tb[pf - 1] * 0x01010101u;
@@ -578,19 +594,24 @@ __global__ __launch_bounds__(256) void rd_gz_deflate_kernel(const uint8_t *__res
                     atomicAdd(&S.hist[wave][286 + S.dsym[D <= 256 ? D - 1 : 256 + ((D - 1) >> 7)]], 1u);
                 }
             }
-            // literal counts, aggregated over the wave: 64 lanes adding to the same few counters (A, C, G, T ...) would serialise in
-            // the LDS atomic unit; one plain add per DISTINCT byte value instead (the histogram is this wave's own)
-            const bool lit = tk && !ismatch;
-            uint64_t lm = __ballot(lit);
-            while (lm) {
-                const int f = __builtin_ctzll(lm);
-                const uint32_t bv = (uint32_t)__builtin_amdgcn_readlane((int)byte, f);
-                const uint64_t same = __ballot(lit && byte == bv);
-                if (lane == f) atomicAdd(&S.hist[wave][bv], (uint32_t)__popcll(same));   // (ds_add without return: nothing to wait for)
-                lm &= ~same;
-            }
+            // literal counts: not here (64 lanes adding to the same few counters - A, C, G, T ... - every strip); the strip leaves the mask
+            // of its literal positions and the quarter is counted in one pass after the loop
+            const uint64_t lm = __ballot(tk && !ismatch);
+            if (lane == 0) S.litmask[wave][(s0 - q0) >> 6] = lm;
             ntok += __popcll(sel);
             GZ_STAMP(10);   // strip: tokens + counts
+        }
+        {   // literal counts of the quarter: lane l walks the literal positions of strips l, l + 64, ... (ds_add without return)
+            const int nstrip = q1 > q0 ? (q1 - q0 + 63) >> 6 : 0;
+            for (int st = lane; st < nstrip; st += 64) {
+                uint64_t lm = S.litmask[wave][st];
+                const uint8_t *sb = tb + q0 + 64 * st;
+                while (lm) {
+                    const int b = __builtin_ctzll(lm);
+                    lm &= lm - 1;
+                    atomicAdd(&S.hist[wave][sb[b]], 1u);
+                }
+            }
         }
         if (lane == 0) S.qtok[wave] = (uint32_t)ntok;
         GZ_STAMP(2);   // parse of wave 0

@@ -45,6 +45,24 @@ def main():
     run("pe_plain_to_plain", [files[1], files[2]], [o("d1.fq"), o("d2.fq")], ["-e", "rrna"])
     run("pe_gz_to_plain", [files[1] + ".gz", files[2] + ".gz"], [o("e1.fq"), o("e2.fq")], ["-e", "rrna"])
     run("pe_gz_to_gz", [files[1] + ".gz", files[2] + ".gz"], [o("f1.fq.gz"), o("f2.fq.gz")], ["-e", "rrna"])
+    # round 4: .gz outputs are deflated on the GPU by default; the host's libdeflate writer for comparison, plain -> gz (GPU-bound:
+    # recurrence + deflate), and gz -> gz with every usable core given to the inflate of the inputs (-t)
+    run("se_plain_to_gz", [files[1]], [o("g.fq.gz")])
+    run("pe_plain_to_gz", [files[1], files[2]], [o("h1.fq.gz"), o("h2.fq.gz")], ["-e", "rrna"])
+    cores = len(os.sched_getaffinity(0))
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            cores = min(cores, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    run("pe_gz_to_gz_t%d" % cores, [files[1] + ".gz", files[2] + ".gz"], [o("i1.fq.gz"), o("i2.fq.gz")], ["-e", "rrna", "-t", str(cores)])
+    os.environ["RD_DEVICE_GZIP"] = "0"
+    run("se_gz_to_gz_host_deflate", [files[1] + ".gz"], [o("j.fq.gz")])
+    run("pe_gz_to_gz_host_deflate", [files[1] + ".gz", files[2] + ".gz"], [o("k1.fq.gz"), o("k2.fq.gz")], ["-e", "rrna"])
+    run("pe_plain_to_gz_host_deflate", [files[1], files[2]], [o("l1.fq.gz"), o("l2.fq.gz")], ["-e", "rrna"])
+    del os.environ["RD_DEVICE_GZIP"]
+    out["output_bytes"] = {n: os.path.getsize(o(n)) for n in ("f1.fq.gz", "k1.fq.gz", "d1.fq") if os.path.exists(o(n))}
     shutil.rmtree(d, ignore_errors=True)
     print(json.dumps(out))
 
