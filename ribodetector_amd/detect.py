@@ -254,21 +254,22 @@ class Predictor:
             if not self.multi or self.sharded_parse:
                 host = torch.empty(labels.shape, dtype=torch.int8, pin_memory=True)
                 host.copy_(labels, non_blocking=True)
-                # .gz outputs: the records of every label file of this chunk are deflated here, where the chunk's text already is
-                # (BGZF members, csrc/rd_deflate.hpp), beside the next chunk's recurrences; the writer threads fetch the compressed
-                # bytes and append them (reference: gzip.open(..., compresslevel=5) on the host, detect.py:729-741)
-                if self._gz_files and all(c.tensors is not None and len(c.tensors) > 3 and c.verbatim for c in chunks):
-                    ring = self._gz_seq % self.GZ_RING
-                    self._gz_seq += 1
-                    for e, lab in self._gz_files:
-                        c = chunks[e]
-                        b0 = int(c.rec_start[lo])
-                        rs = c.tensors[3][lo:hi + 1].to(self.device, non_blocking=True) - b0
-                        out, info = self._gz.compress_selected(dev_in[e][0], rs, labels.view(torch.int8), lab, slot=(e, lab, ring))
-                        ih = torch.empty(4, dtype=torch.int64, pin_memory=True)
-                        ih.copy_(info, non_blocking=True)
-                        gzparts[(e, lab)] = (out, ih)
-            else:                                    # label gather (1 B per read) queued behind the kernels, collected later
+            # .gz outputs: the records of every label file of this chunk - under the label gather: of this rank's shard of it - are
+            # deflated here, where the text already is (BGZF members, csrc/rd_deflate.hpp), beside the next chunk's recurrences; the
+            # writer threads fetch the compressed bytes and append them (reference: gzip.open(..., compresslevel=5) on the host,
+            # detect.py:729-741). Every rank takes the same decision (the chunks of a shared decode are the same chunks).
+            if self._gz_files and all(c.tensors is not None and len(c.tensors) > 3 and c.verbatim for c in chunks):
+                ring = self._gz_seq % self.GZ_RING
+                self._gz_seq += 1
+                for e, lab in self._gz_files:
+                    c = chunks[e]
+                    b0 = int(c.rec_start[lo])
+                    rs = c.tensors[3][lo:hi + 1].to(self.device, non_blocking=True) - b0
+                    out, info = self._gz.compress_selected(dev_in[e][0], rs, labels.view(torch.int8), lab, slot=(e, lab, ring))
+                    ih = torch.empty(4, dtype=torch.int64, pin_memory=True)
+                    ih.copy_(info, non_blocking=True)
+                    gzparts[(e, lab)] = [(out, ih)]
+            if self.multi and not self.sharded_parse:   # label gather (1 B per read) queued behind the kernels, collected later
                 _, finish = rdist.gather_labels(labels, n, dst=0, bounds=bounds, async_op=True)
             done = torch.cuda.Event()
             done.record(post)
@@ -279,6 +280,22 @@ class Predictor:
         """Labels of a submitted chunk: int8 numpy on rank 0 (whole chunk, input order), None elsewhere."""
         if self.multi and not self.sharded_parse:
             labels = tk["finish"]()
+            if tk.get("gz"):
+                # the members every rank made of its shard travel to rank 0, which appends them in rank order = input order (sizes
+                # first: one small all-gather per chunk; then one padded gather per output file)
+                while not tk["done"].query():
+                    time.sleep(2e-4)
+                mine = [int(tk["gz"][key][0][1][0]) for key in self._gz_files]
+                sizes = rdist.all_gather_sizes(mine)
+                gathered = {}
+                for f, key in enumerate(self._gz_files):
+                    out, _ = tk["gz"][key][0]
+                    if mine[f] > out.numel():
+                        raise RuntimeError("device gzip: output buffer too small (%d > %d)" % (mine[f], out.numel()))
+                    parts = rdist.gather_var_bytes(out, mine[f], sizes[:, f].tolist(), dst=0)
+                    if self.rank == 0:
+                        gathered[key] = [(t, None) for t in parts]
+                tk["gz"] = gathered
             return None if self.rank != 0 else labels.cpu().numpy()
         while not tk["done"].query():              # sleep-poll instead of hipEventSynchronize: that one spins a host core for the
             time.sleep(2e-4)                       # whole run, and the ranks of a node share their cores with readers and writers
@@ -444,14 +461,14 @@ class Predictor:
         self._stage_s = {"wait_reader": 0.0, "classify": 0.0, "wait_writer": 0.0}   # main-thread seconds per pipeline stage
         self._copy_stream = torch.cuda.Stream(self.device)
         self._post_stream = torch.cuda.Stream(self.device)
-        # which (mate, label) files are gzip outputs deflated on the device: every rank writes its own records there (one rank, or
-        # the sharded parse of plain inputs); under the label gather rank 0 holds only its shard of the text, so the host compresses
+        # which (mate, label) files are gzip outputs deflated on the device: every rank deflates the records it classified - and writes
+        # them itself (one rank, or the sharded parse of plain inputs) or, under the label gather, sends the members to rank 0
         self._gz_files, self._gz_seq = [], 0
-        if writer and self.gzip_on_device and (not self.multi or self.sharded_parse):
+        if self.gzip_on_device:                    # (the same list on every rank: it is derived from the arguments)
             from .gz import DeviceGzip
             self._gz_files = [(e, lab) for lab, names in ((1, self.rrna), (0, self.output)) if names is not None for e in ends
                               if names[e].endswith('gz')]
-            if -1 in fhs:
+            if self.is_paired and self.args.ensure == 'both':
                 self._gz_files += [(e, -1) for e in ends]
             if self._gz_files:
                 self._gz = DeviceGzip(self.device)
@@ -473,17 +490,19 @@ class Predictor:
                             if part is None:
                                 handles[e].write_selected(chunk, labels, lab)
                                 continue
-                            out, info = part            # members made on the GPU: fetch the compressed bytes, append them
-                            nb = int(info[0])
-                            if nb > out.numel():
-                                raise RuntimeError("device gzip: output buffer too small (%d > %d)" % (nb, out.numel()))
-                            if nb:
-                                if stage[0] is None or stage[0].numel() < nb:
-                                    stage[0] = torch.empty(max(nb, 1 << 24) * 5 // 4, dtype=torch.uint8, pin_memory=True)
-                                with torch.cuda.stream(gz_copy):
-                                    stage[0][:nb].copy_(out[:nb], non_blocking=True)
-                                gz_copy.synchronize()
-                                handles[e].write_members(stage[0].data_ptr(), nb)
+                            for out, info in part:      # members made on the GPU (one piece per rank under the label gather): fetch, append
+                                nb = int(info[0]) if info is not None else int(out.numel())
+                                if nb > out.numel():
+                                    raise RuntimeError("device gzip: output buffer too small (%d > %d)" % (nb, out.numel()))
+                                if nb and not out.is_cuda:
+                                    handles[e].write_members(out.data_ptr(), nb)
+                                elif nb:
+                                    if stage[0] is None or stage[0].numel() < nb:
+                                        stage[0] = torch.empty(max(nb, 1 << 24) * 5 // 4, dtype=torch.uint8, pin_memory=True)
+                                    with torch.cuda.stream(gz_copy):
+                                        stage[0][:nb].copy_(out[:nb], non_blocking=True)
+                                    gz_copy.synchronize()
+                                    handles[e].write_members(stage[0].data_ptr(), nb)
                         if chunk.release is not None:   # a shared-memory slot: free for the next chunk once its text is written
                             chunk.release()
                 except BaseException as ex:

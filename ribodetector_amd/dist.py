@@ -111,6 +111,43 @@ def gather_labels(local_labels, n_total, dst=0, group=None, async_op=False, out=
     return finish()
 
 
+def gather_var_bytes(buf, nbytes, sizes, dst=0, group=None):
+    """Gather byte strings of different lengths (the gzip members every rank made of its shard of a chunk, ribodetector_amd/gz.py) to
+    rank `dst`: `buf` uint8 tensor (device or host) whose first `nbytes` bytes are this rank's, `sizes` the byte counts of all ranks
+    (every rank knows them: all_gather_sizes). Returns on `dst` a list of W uint8 tensors (views of one receive buffer: device
+    memory under nccl, host memory under gloo), None elsewhere. One collective, padded to the largest string (compressed data:
+    tens of MB per chunk at most)."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    sizes = [int(x) for x in sizes]
+    assert len(sizes) == world and sizes[rank] == int(nbytes)
+    mx = max(sizes)
+    if mx == 0:
+        return [torch.empty(0, dtype=torch.uint8) for _ in range(world)] if rank == dst else None
+    on_host = dist.get_backend(group) == "gloo"
+    dev = "cpu" if on_host else buf.device
+    send = torch.zeros(mx, dtype=torch.uint8, device=dev)
+    if nbytes:
+        send[:nbytes] = buf[:nbytes].cpu() if on_host else buf[:nbytes]
+    recv = None
+    if rank == dst:
+        big = torch.empty(mx * world, dtype=torch.uint8, device=dev)
+        recv = list(big.view(world, mx).unbind(0))
+    dist.gather(send, recv, dst=dst, group=group)
+    return [recv[r][: sizes[r]] for r in range(world)] if rank == dst else None
+
+
+def all_gather_sizes(values, group=None):
+    """every rank's list of integers -> int64 tensor [W, len(values)] on every rank (host memory)"""
+    world = dist.get_world_size(group)
+    on_host = dist.get_backend(group) == "gloo"
+    t = torch.tensor(list(values), dtype=torch.int64)
+    if not on_host:
+        t = t.cuda()
+    out = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(out, t, group=group)
+    return torch.stack(out).cpu()
+
+
 def reduce_counts(counts, group=None):
     """all-reduce(SUM) of the int64[3] counters; every rank gets the totals."""
     if active(group):

@@ -87,10 +87,12 @@ def test_cli_modes_over_one_rank_rccl(tmp_path, ext):
     synth.write_fastq(inp, a, o, 1)
     outs = {}
     for name, env in (("forced", _env()), ("plain", {k: v for k, v in _env().items() if k != "RD_FORCE_DIST"})):
-        out, rr = str(tmp_path / (name + ".non.fq")), str(tmp_path / (name + ".rrna.fq"))
+        out, rr = str(tmp_path / (name + ".non.fq")), str(tmp_path / (name + ".rrna.fq.gz"))   # (.gz: deflated on the device, and under the
+                                                                                                # label gather sent to rank 0 over RCCL)
         r = subprocess.run([sys.executable, "-m", "ribodetector_amd.detect", "-l", "100", "-i", inp, "-o", out, "-r", rr, "--chunk_size", "1", "-m", "3"],
                            cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
-        outs[name] = (open(out, "rb").read(), open(rr, "rb").read())
+        import gzip
+        outs[name] = (open(out, "rb").read(), gzip.open(rr, "rb").read())
     assert outs["forced"] == outs["plain"] and len(outs["plain"][0]) > 0 and len(outs["plain"][1]) > 0
-    assert sorted(os.listdir(tmp_path)) == sorted(["in" + ext, "forced.non.fq", "forced.rrna.fq", "plain.non.fq", "plain.rrna.fq"])
+    assert sorted(os.listdir(tmp_path)) == sorted(["in" + ext, "forced.non.fq", "forced.rrna.fq.gz", "plain.non.fq", "plain.rrna.fq.gz"])
