@@ -71,6 +71,44 @@ def test_two_rank_gather_matches_single(tmp_path, oracle, n, ensure, weighted):
         assert np.load(str(tmp_path / ("counts%d.npy" % r))).tolist() == c
 
 
+def _var_worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from ribodetector_amd import dist as rdist
+    rdist.init_from_env(backend="gloo")
+    rng = np.random.default_rng(100 + rank)
+    # three "files" per chunk with sizes that differ per rank, one of them empty on some ranks, one empty everywhere
+    for chunk in range(3):
+        mine = [int(rng.integers(0, 5000)) if (rank + chunk) % 2 else 0, int(rng.integers(1, 70000)), 0]
+        bufs = [torch.from_numpy(rng.integers(0, 256, max(m, 1) + 17, dtype=np.uint8)) for m in mine]   # (longer than the payload, like the device buffers)
+        sizes = rdist.all_gather_sizes(mine)
+        assert sizes.shape == (world, 3) and sizes[rank].tolist() == mine
+        for f in range(3):
+            got = rdist.gather_var_bytes(bufs[f], mine[f], sizes[:, f].tolist(), dst=0)
+            np.save(os.path.join(tmp, "sent_%d_%d_%d.npy" % (chunk, f, rank)), bufs[f][: mine[f]].numpy())
+            if rank == 0:
+                assert len(got) == world
+                for r in range(world):
+                    np.save(os.path.join(tmp, "got_%d_%d_%d.npy" % (chunk, f, r)), got[r].numpy())
+            else:
+                assert got is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_variable_size_byte_gather(tmp_path, world):
+    """gather_var_bytes / all_gather_sizes: the compressed members every rank makes of its shard of a chunk reach rank 0 byte for byte,
+    whatever their sizes (empty ones included), in rank order"""
+    mp.spawn(_var_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for chunk in range(3):
+        for f in range(3):
+            for r in range(world):
+                sent = np.load(str(tmp_path / ("sent_%d_%d_%d.npy" % (chunk, f, r))))
+                got = np.load(str(tmp_path / ("got_%d_%d_%d.npy" % (chunk, f, r))))
+                assert sent.dtype == np.uint8 and np.array_equal(sent, got)
+
+
 def test_shard_ranges_cover_and_order():
     from ribodetector_amd import dist as rdist
     for n in (0, 1, 7, 64, 1000003):
