@@ -119,3 +119,103 @@ def test_part_files_of_the_sharded_cli(tmp_path):
     open(pp[1], "wb").write(b"y" * 3)
     fx.concatenate_parts(plain, pp)
     assert open(plain, "rb").read() == b"xxxxxyyy"
+
+
+# ---- round 4: advisor findings of round 3 (shared-memory chunk slots, cleanup on SIGTERM, LOCAL_WORLD_SIZE) ----------------------------
+
+def _predictor(tmp_path=None):
+    import argparse
+    from ribodetector_amd import detect
+    from ribodetector_amd.parse_config import ConfigParser
+    args = argparse.Namespace(log=None, chunk_size=None, len=100, ensure="none", deviceid=None, semantics=None)
+    return detect.Predictor(ConfigParser.from_json(os.path.join(ROOT, "ribodetector_amd", "config.json")), args)
+
+
+def test_shm_slot_is_reserved_not_sparse(tmp_path, monkeypatch):
+    """a chunk slot in /dev/shm is posix_fallocate'd: where the space is missing the reader gets an OSError with a hint (which travels
+    the parser-error path to the other ranks) instead of a SIGBUS at the first store; nothing is left behind"""
+    import errno
+    from ribodetector_amd.data_loader import fastx_parser as fx
+    a = fx.ShmArena("rd_0_%d_f0" % os.getpid())
+    views, sl = a.alloc(1 << 16, 100)
+    assert os.path.getsize(sl["path"]) >= (1 << 16) and os.stat(sl["path"]).st_blocks * 512 >= (1 << 16)   # pages are reserved
+    a.close()
+    assert not os.path.exists(sl["path"])
+
+    def no_space(fd, off, n):
+        raise OSError(errno.ENOSPC, "No space left on device")
+    monkeypatch.setattr(os, "posix_fallocate", no_space)
+    b = fx.ShmArena("rd_0_%d_f1" % os.getpid())
+    with pytest.raises(OSError, match="RD_SHARED_DECODE=0"):
+        b.alloc(1 << 16, 100)
+    assert not [f for f in os.listdir(b.dir) if f.startswith("rd_0_%d_f1" % os.getpid())]
+    ok, need = fx.ShmArena.fits(2, 1 << 20, 280)
+    assert need > 2 * 6 * (1 << 20) * 280 and isinstance(ok, bool)
+    assert fx.ShmArena.fits(2, 1 << 40, 280)[0] is False                       # more than any /dev/shm holds
+
+
+def test_stale_shm_slots_of_dead_processes_are_swept(tmp_path):
+    import subprocess
+    import sys
+    from ribodetector_amd.data_loader import fastx_parser as fx
+    d = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
+    p = subprocess.Popen([sys.executable, "-c", "pass"])
+    p.wait()
+    dead = os.path.join(d, "rd_12345_%d_f0.0" % p.pid)                         # a slot of a process that is gone
+    alive = os.path.join(d, "rd_12345_%d_f0.0" % os.getpid())                  # ... and of one that is not
+    for f in (dead, alive):
+        open(f, "wb").write(b"x")
+    try:
+        assert fx.ShmArena.sweep_stale() >= 1
+        assert not os.path.exists(dead) and os.path.exists(alive)
+    finally:
+        for f in (dead, alive):
+            if os.path.exists(f):
+                os.remove(f)
+
+
+def test_sigterm_removes_slots_and_part_files(tmp_path):
+    """when ANOTHER rank fails, torch.distributed.run sends this one SIGTERM: the handler Predictor installs removes the shared-memory
+    slots and this rank's part files before the process goes"""
+    import signal
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, signal, argparse
+sys.path.insert(0, %r)
+from ribodetector_amd import detect
+from ribodetector_amd.data_loader import fastx_parser as fx
+from ribodetector_amd.parse_config import ConfigParser
+args = argparse.Namespace(log=None, chunk_size=None, len=100, ensure="none", deviceid=None, semantics=None)
+p = detect.Predictor(ConfigParser.from_json(os.path.join(%r, "ribodetector_amd", "config.json")), args)
+a = fx.ShmArena("rd_0_%%d_f0" %% os.getpid())
+views, sl = a.alloc(1 << 16, 100)
+p._arenas.append(a)
+part = os.path.join(%r, "out.fq.part1")
+open(part, "w").write("x")
+p._part_files.append(part)
+print(sl["path"], flush=True)
+os.kill(os.getpid(), signal.SIGTERM)
+import time; time.sleep(30)
+''' % (ROOT, ROOT, str(tmp_path))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == -signal.SIGTERM, (r.returncode, r.stderr[-1500:])
+    slot = r.stdout.strip().splitlines()[-1]
+    assert slot and not os.path.exists(slot) and not os.path.exists(str(tmp_path / "out.fq.part1"))
+
+
+def test_shared_decode_needs_local_world_size(monkeypatch):
+    """one decode per node only when the launcher says the ranks ARE on one node: LOCAL_WORLD_SIZE set and equal to the world size
+    (a launcher that sets only RANK / WORLD_SIZE may have spread the ranks over hosts, whose /dev/shm are different memories)"""
+    p = _predictor()
+    p.multi, p.world, p.rank, p.sharded_parse = True, 2, 1, False
+    p.input = ["x.fq.gz"]
+    monkeypatch.delenv("LOCAL_WORLD_SIZE", raising=False)
+    assert p._shared_decode() is False                                        # (no collective is entered for the answer)
+    p._shared = None
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "1")
+    assert p._shared_decode() is False
+    p._shared = None
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "2")
+    monkeypatch.setenv("RD_SHARED_DECODE", "0")
+    assert p._shared_decode() is False
