@@ -36,6 +36,15 @@ def _records(rng, n, kind):
             recs.append(bytes(rng.choice(list(b"AC\n"), int(rng.integers(1, 4))).astype(np.uint8)))
         elif kind == "huge":
             recs.append(bytes(rng.choice(list(b"ACGT"), int(rng.integers(60000, 200000))).astype(np.uint8)) + b"\n")
+        elif kind == "fib":
+            # 23 byte values with Fibonacci frequencies, shuffled: the optimal Huffman code of a member is deeper than DEFLATE's 15
+            # bits, so the length-limiting repair (zlib's gen_bitlen step) is what makes the block decodable
+            fib = [1, 1]
+            while len(fib) < 23:
+                fib.append(fib[-1] + fib[-2])
+            data = np.concatenate([np.full(f, 33 + j, dtype=np.uint8) for j, f in enumerate(fib)])
+            rng.shuffle(data)
+            recs.append(data.tobytes())
     return recs
 
 
@@ -68,12 +77,12 @@ def _check_members(comp, members, plain):
     assert p == len(comp) and k == members and total == plain
 
 
-@pytest.mark.parametrize("kind", ["fastq", "random", "runs", "tiny", "huge"])
+@pytest.mark.parametrize("kind", ["fastq", "random", "runs", "tiny", "huge", "fib"])
 def test_round_trip_and_framing(kind):
     from ribodetector_amd.gz import DeviceGzip
     rng = np.random.default_rng(hash(kind) % 1000)
     dg = DeviceGzip(DEV)
-    n = {"fastq": 5000, "random": 400, "runs": 300, "tiny": 20000, "huge": 9}[kind]
+    n = {"fastq": 5000, "random": 400, "runs": 300, "tiny": 20000, "huge": 9, "fib": 6}[kind]
     recs = _records(rng, n, kind)
     labels = rng.choice(np.array([0, 1, -1], dtype=np.int8), n, p=[0.6, 0.3, 0.1])
     for label in (0, 1, -1, 5):
@@ -100,6 +109,36 @@ def test_sizes_around_the_member_boundary_and_empty_inputs():
                                      torch.zeros(0, dtype=torch.int8, device=DEV), 0)
     torch.cuda.synchronize()
     assert info.cpu().tolist()[:3] == [0, 0, 0]
+
+
+def test_fuzz_small_inputs_of_every_alphabet():
+    """300 small chunks: alphabets of 1 ... 256 symbols, skewed and flat, with planted repeats at every distance class, uint8 labels -
+    each must inflate (zlib checks every code, CRC-32 and ISIZE) to exactly the selected records"""
+    from ribodetector_amd.gz import DeviceGzip
+    dg = DeviceGzip(DEV)
+    rng = np.random.default_rng(2026)
+    for case in range(300):
+        k = int(rng.choice([1, 2, 3, 4, 5, 16, 64, 256]))
+        nrec = int(rng.integers(1, 60))
+        recs = []
+        for _ in range(nrec):
+            L = int(rng.integers(0, 4000))
+            p = rng.dirichlet(np.full(k, float(rng.choice([0.05, 0.5, 5.0]))))
+            b = bytearray(rng.choice(k, L, p=p).astype(np.uint8) + int(rng.integers(0, 256 - k + 1)))
+            for _ in range(int(rng.integers(0, 6))):                       # plant repeats: distance 1 ... 20000, length 3 ... 400
+                if len(b) > 16 and recs:
+                    src = recs[int(rng.integers(0, len(recs)))]
+                    if len(src) > 8:
+                        a0 = int(rng.integers(0, len(src) - 4))
+                        piece = src[a0:a0 + int(rng.integers(3, 400))]
+                        at = int(rng.integers(0, len(b)))
+                        b[at:at + len(piece)] = piece
+            recs.append(bytes(b))
+        labels = rng.integers(0, 2, nrec).astype(np.uint8)                 # rd_classify's label type
+        for label in (0, 1):
+            comp, want, plain, members = _run(dg, recs, labels, label)
+            assert (gzip.decompress(comp) if comp else b"") == want, case
+            _check_members(comp, members, plain)
 
 
 def test_the_eof_block_is_an_empty_member():
