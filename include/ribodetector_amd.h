@@ -201,7 +201,8 @@ int rd_pack_onehot(const uint8_t *arena, const int64_t *seq_off, const int32_t *
  *   newline); labels [dev] int8[n] (rd_pair_fuse's pair labels, or rd_classify's uint8 labels); label: the value to select.
  *   out [dev] >= rd_gz_out_bound(text_bytes) bytes is always enough (256-byte aligned); info [dev] int64[4]:
  *     info[0] = bytes written to out (if > out_cap: out was too small and is incomplete), info[1] = uncompressed bytes,
- *     info[2] = members. Asynchronous on `stream`; the caller copies info and out[0, info[0]) to the host afterwards.
+ *     info[2] = members, info[3] != 0: rec_start does not describe `text` (the selected records hold more bytes than the text:
+ *     nothing was compressed). Asynchronous on `stream`; the caller copies info and out[0, info[0]) to the host afterwards.
  *   rd_gz_eof_block: [host] BGZF's 28-byte end-of-file marker (an empty member), to be appended once when the file is closed. */
 size_t rd_gz_workspace_bytes(int64_t n, int64_t text_bytes);
 size_t rd_gz_out_bound(int64_t text_bytes);

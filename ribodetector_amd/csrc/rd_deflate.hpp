@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void rd_gz_sel_sum_kernel(const int64_t *__res
 }
 
 // one workgroup: bsum[] -> exclusive bases in place; info = {compressed bytes (filled later), plain bytes, members}
-__global__ __launch_bounds__(256) void rd_gz_sel_base_kernel(int64_t *__restrict__ bsum, int nb, int64_t *__restrict__ info) {
+__global__ __launch_bounds__(256) void rd_gz_sel_base_kernel(int64_t *__restrict__ bsum, int nb, int64_t *__restrict__ info, int64_t text_bytes) {
     __shared__ int64_t sh[4];
     __shared__ int64_t run_s;
     if (threadIdx.x == 0) run_s = 0;
@@ -104,9 +104,13 @@ __global__ __launch_bounds__(256) void rd_gz_sel_base_kernel(int64_t *__restrict
         __syncthreads();
     }
     if (threadIdx.x == 0) {
+        // info[3] != 0: the record table does not describe the text (selected bytes > text bytes: overlapping or stray records) - the
+        // workspace is sized by the text, so nothing is packed or compressed and the caller is told
+        const bool bad = run_s > text_bytes || run_s < 0;
         info[0] = 0;
-        info[1] = run_s;
-        info[2] = (run_s + GZ_MEMBER - 1) / GZ_MEMBER;
+        info[1] = bad ? 0 : run_s;
+        info[2] = bad ? 0 : (run_s + GZ_MEMBER - 1) / GZ_MEMBER;
+        info[3] = bad ? 1 : 0;
     }
 }
 
@@ -131,9 +135,11 @@ __global__ __launch_bounds__(256) void rd_gz_sel_off_kernel(const int64_t *__res
 // threads take 16-byte pieces of that range (a piece finds its record by bisection over the 257 staged offsets)
 constexpr int GZ_PACK_RECS = 256;
 __global__ __launch_bounds__(256) void rd_gz_pack_kernel(const uint8_t *__restrict__ text, const int64_t *__restrict__ rec_start,
-                                                        const int64_t *__restrict__ out_off, int64_t n, uint8_t *__restrict__ plain) {
+                                                        const int64_t *__restrict__ out_off, int64_t n, uint8_t *__restrict__ plain,
+                                                        const int64_t *__restrict__ info) {
     __shared__ int64_t offs[GZ_PACK_RECS + 1];
     __shared__ int64_t srcs[GZ_PACK_RECS];
+    if (info[3]) return;
     const int64_t r0 = (int64_t)blockIdx.x * GZ_PACK_RECS;
     const int nr = (int)(n - r0 < GZ_PACK_RECS ? n - r0 : GZ_PACK_RECS);
     for (int k = threadIdx.x; k <= nr; k += 256) offs[k] = out_off[r0 + k];

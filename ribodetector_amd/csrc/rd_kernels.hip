@@ -620,9 +620,9 @@ int rd_gz_compress_selected(const uint8_t *text, int64_t text_bytes, const int64
     uint32_t *msize = (uint32_t *)w; w += p.msize_bytes;
     int64_t *moff = (int64_t *)w;
     hipLaunchKernelGGL(rd_gz_sel_sum_kernel, dim3(p.nb), dim3(256), 0, st, rec_start, labels, n, label, bsum);
-    hipLaunchKernelGGL(rd_gz_sel_base_kernel, dim3(1), dim3(256), 0, st, bsum, p.nb, info);
+    hipLaunchKernelGGL(rd_gz_sel_base_kernel, dim3(1), dim3(256), 0, st, bsum, p.nb, info, text_bytes);
     hipLaunchKernelGGL(rd_gz_sel_off_kernel, dim3(p.nb), dim3(256), 0, st, rec_start, labels, n, label, bsum, out_off);
-    hipLaunchKernelGGL(rd_gz_pack_kernel, dim3((unsigned)((n + GZ_PACK_RECS - 1) / GZ_PACK_RECS)), dim3(256), 0, st, text, rec_start, out_off, n, plain);
+    hipLaunchKernelGGL(rd_gz_pack_kernel, dim3((unsigned)((n + GZ_PACK_RECS - 1) / GZ_PACK_RECS)), dim3(256), 0, st, text, rec_start, out_off, n, plain, info);
     hipLaunchKernelGGL(rd_gz_deflate_kernel, dim3(p.grid), dim3(256), 0, st, plain, info, toks, slots, msize);
     hipLaunchKernelGGL(rd_gz_moff_kernel, dim3(1), dim3(256), 0, st, msize, moff, info);
     hipLaunchKernelGGL(rd_gz_compact_kernel, dim3(p.grid), dim3(256), 0, st, slots, msize, moff, info, out, (int64_t)out_cap);

@@ -492,6 +492,8 @@ class Predictor:
                                 continue
                             for out, info in part:      # members made on the GPU (one piece per rank under the label gather): fetch, append
                                 nb = int(info[0]) if info is not None else int(out.numel())
+                                if info is not None and int(info[3]):
+                                    raise RuntimeError("device gzip: the chunk's record table does not describe its text")
                                 if nb > out.numel():
                                     raise RuntimeError("device gzip: output buffer too small (%d > %d)" % (nb, out.numel()))
                                 if nb and not out.is_cuda:

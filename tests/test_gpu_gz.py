@@ -108,7 +108,13 @@ def test_sizes_around_the_member_boundary_and_empty_inputs():
     out, info = dg.compress_selected(torch.zeros(0, dtype=torch.uint8, device=DEV), torch.zeros(1, dtype=torch.int64, device=DEV),
                                      torch.zeros(0, dtype=torch.int8, device=DEV), 0)
     torch.cuda.synchronize()
-    assert info.cpu().tolist()[:3] == [0, 0, 0]
+    assert info.cpu().tolist() == [0, 0, 0, 0]
+    # a record table that does not describe the text (records past its end): flagged, nothing compressed, nothing overrun
+    t = torch.from_numpy(np.frombuffer(b"ACGT\n" * 100, dtype=np.uint8).copy()).to(DEV)
+    rs = torch.tensor([0, 400, 900, 5000], dtype=torch.int64, device=DEV)
+    out, info = dg.compress_selected(t, rs, torch.ones(3, dtype=torch.int8, device=DEV), 1)
+    torch.cuda.synchronize()
+    assert info.cpu().tolist() == [0, 0, 0, 1]
 
 
 def test_fuzz_small_inputs_of_every_alphabet():
