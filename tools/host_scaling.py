@@ -6,7 +6,7 @@ The 8-GPU node of the scaling run gives every rank its own GPU but the same cgro
 over gloo - and records the host side of it: CPU seconds per rank inside the timed region, cores busy, and the ratio device
 path / kernel-only, for bench.py at W = 1, 2, 4, 8 and for the CLI (plain and gz input) at W = 1 and 8. The GPU is shared, so
 reads/s do NOT scale here; what the numbers show is that W x (launch thread + reader + writers) stay below the core budget.
-Writes gpurun_out/r03_host_scaling.json.      python tools/host_scaling.py [--reads 4000000]"""
+Writes gpurun_out/r04_host_scaling.json.      python tools/host_scaling.py [--reads 4000000]"""
 import argparse
 import json
 import os
@@ -114,7 +114,7 @@ def main():
     finally:
         shutil.rmtree(d, ignore_errors=True)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "r03_host_scaling.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "r04_host_scaling.json"), "w"), indent=1)
     print(json.dumps(out))
 
 

@@ -14,6 +14,8 @@ NS=${RD_SWEEP_NS:-"1 2 4 8"}
 FLAGS="--no-cpu-baseline --no-alt --no-encoder --no-e2e --traffic off $*"
 TMP=$(mktemp -d)
 cd "$R"
+# a throw-away run first: the first process on a box pays cold caches and clocks, and the plain line is compared with the N = 1 group
+env -u RD_FORCE_DIST -u WORLD_SIZE -u RANK -u LOCAL_RANK python bench.py --gpus 1 $FLAGS --steps 2 > /dev/null 2>&1
 # the plain line (no process group at all)
 env -u RD_FORCE_DIST -u WORLD_SIZE -u RANK -u LOCAL_RANK python bench.py --gpus 1 $FLAGS 2> $TMP/plain.err | grep '^{' > $TMP/plain.json
 for N in $NS; do
