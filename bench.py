@@ -286,6 +286,42 @@ def e2e_record(torch, synth, arenas, offsets, lens, L, ensure, timed_calls=1, gz
         shutil.rmtree(d, ignore_errors=True)
 
 
+def gzip_record(torch, synth, dev, arena, offsets, lens, labels):
+    """device gzip (csrc/rd_deflate.hpp) on the FASTQ text of one step's first mate, partitioned by the step's own labels into the two
+    files a CLI run writes: compressed size against zlib level 5 (the reference's writer, on a 32 MB sample), time per chunk by events"""
+    import zlib
+    from ribodetector_amd.gz import DeviceGzip
+    text = synth.fastq_image_torch(arena, offsets, lens, mate=1)
+    n = int(lens.numel())
+    rs = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(18 + 2 * lens.to(torch.int64), 0, out=rs[1:])
+    lab = labels.view(torch.int8).contiguous()
+    dg = DeviceGzip(dev)
+    outs = {}
+    for v in (0, 1):
+        outs[v] = dg.compress_selected(text, rs, lab, v, slot=v)
+    torch.cuda.synchronize(dev)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 5
+    a.record()
+    for _ in range(reps):
+        for v in (0, 1):
+            outs[v] = dg.compress_selected(text, rs, lab, v, slot=v)
+    b.record()
+    torch.cuda.synchronize(dev)
+    ms = a.elapsed_time(b) / reps
+    comp = sum(int(outs[v][1][0]) for v in (0, 1))
+    plain = sum(int(outs[v][1][1]) for v in (0, 1))
+    sample = text[: min(int(text.numel()), 32 << 20)].cpu().numpy().tobytes()
+    z5 = len(zlib.compress(sample, 5)) / len(sample)
+    return {"kernel": "rd_gz_deflate_kernel (+ select, pack, compact)", "records": n, "text_bytes": plain, "compressed_bytes": comp,
+            "ratio": plain / max(comp, 1), "size_vs_zlib_level_5": (comp / max(plain, 1)) / z5, "ms_per_chunk_both_label_files": ms,
+            "GB_per_s_of_text": plain / ms / 1e6, "reads_per_s": n / ms * 1e3, "members": sum(int(outs[v][1][2]) for v in (0, 1)),
+            "bound": "VALU issue with one wave per SIMD (152 KB of LDS per workgroup); HBM: %.3f of 8 TB/s" % (plain / ms / 1e6 / HBM_PEAK_GBPS),
+            "what": "the FASTQ text of one step's first mate (constant quality, 218 B per record) split by the step's labels into the two "
+                    "gzip (BGZF) streams the CLI appends to its .gz outputs; zlib level 5 = the reference's gzip.open(..., compresslevel=5)"}
+
+
 def encoder_record(torch, N, dev, arena, offs, lens, n, L):
     """standalone encoder kernels on the first n reads: algorithmic bytes / kernel time (events on the launch stream)"""
     lib, st = N.lib(), N.stream_ptr(dev)
@@ -767,6 +803,13 @@ def main():
                 out["encoder"] = encoder_record(torch, N, dev, r1[0][0], offs, lens, P, MAXLEN)
             except Exception as e:
                 out["encoder"] = {"error": repr(e)}
+        if world == 1 and not args.no_encoder and args.workload != "var300":
+            try:
+                lab_now = (host_lab[(args.steps - 1) & 1].to(dev) if not args.resident_only and args.steps > 0 else
+                           torch.zeros(P, dtype=torch.int8, device=dev))
+                out["device_gzip"] = gzip_record(torch, synth, dev, r1[(args.steps - 1) % nslices][0], r1[0][1], lens, lab_now)
+            except Exception as e:
+                out["device_gzip"] = {"error": repr(e)}
         if world == 1 and not args.no_e2e and not multi:
             try:
                 # the batch of one step: the pipeline-fill-bound point (a 2 M-read input is 0.15 s of CLI)

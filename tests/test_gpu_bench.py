@@ -57,6 +57,9 @@ def test_bench_single_gpu_contract():
     enc = j["encoder"]["kernels"]
     assert set(enc) == {"rd_encode_codes_kernel", "rd_encode_onehot_padded_kernel", "rd_pack_onehot_kernel"}
     assert all(v["achieved"] > 50 for v in enc.values())
+    gz = j["device_gzip"]                                               # round 4: the .gz outputs' deflate runs on the device
+    assert gz["records"] == 65536 and gz["text_bytes"] == 65536 * 218 and gz["members"] >= 218
+    assert gz["size_vs_zlib_level_5"] < 1.10 and gz["ratio"] > 4 and gz["GB_per_s_of_text"] > 1
 
 
 def test_bench_reports_the_rate_without_the_prefix_table():
