@@ -265,7 +265,10 @@ class Predictor:
                     c = chunks[e]
                     b0 = int(c.rec_start[lo])
                     rs = c.tensors[3][lo:hi + 1].to(self.device, non_blocking=True) - b0
-                    out, info = self._gz.compress_selected(dev_in[e][0], rs, labels.view(torch.int8), lab, slot=(e, lab, ring))
+                    # (own writer: half of the worst-case output size is reserved - an incompressible chunk falls back to the host's
+                    # deflate; under the label gather the full bound, every rank must take the same path)
+                    out, info = self._gz.compress_selected(dev_in[e][0], rs, labels.view(torch.int8), lab, slot=(e, lab, ring),
+                                                           out_frac=1.0 if (self.multi and not self.sharded_parse) else 0.5)
                     ih = torch.empty(4, dtype=torch.int64, pin_memory=True)
                     ih.copy_(info, non_blocking=True)
                     gzparts[(e, lab)] = [(out, ih)]
@@ -494,8 +497,9 @@ class Predictor:
                                 nb = int(info[0]) if info is not None else int(out.numel())
                                 if info is not None and int(info[3]):
                                     raise RuntimeError("device gzip: the chunk's record table does not describe its text")
-                                if nb > out.numel():
-                                    raise RuntimeError("device gzip: output buffer too small (%d > %d)" % (nb, out.numel()))
+                                if nb > out.numel():        # text that does not compress into the reserved half: the host deflates this piece
+                                    handles[e].write_selected(chunk, labels, lab)
+                                    continue
                                 if nb and not out.is_cuda:
                                     handles[e].write_members(out.data_ptr(), nb)
                                 elif nb:

@@ -33,7 +33,7 @@ class DeviceGzip:
         self._ws = None
         self._out = {}
 
-    def compress_selected(self, text, rec_start, labels, label, slot=0):
+    def compress_selected(self, text, rec_start, labels, label, slot=0, out_frac=1.0):
         lib = N.lib()
         n = int(labels.numel())
         tb = int(text.numel())
@@ -45,7 +45,9 @@ class DeviceGzip:
         if self._ws is None or self._ws.numel() < need:
             self._ws = None
             self._ws = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=self.device)
-        cap = max(int(lib.rd_gz_out_bound(tb)), 256)
+        # out_frac < 1: a smaller output buffer than the worst case (every member stored). FASTQ shrinks 4-6x, so half the bound is
+        # plenty; if a chunk does not fit (info[0] > out.numel()) the stream in `out` is incomplete and the caller falls back
+        cap = max(int(int(lib.rd_gz_out_bound(tb)) * float(out_frac)) + (1 << 20), 256) if out_frac < 1.0 else max(int(lib.rd_gz_out_bound(tb)), 256)
         out = self._out.get(slot)
         if out is None or out.numel() < cap:
             self._out[slot] = None

@@ -122,6 +122,32 @@ def test_cli_gz_outputs_are_deflated_on_the_device(tmp_path, paired, chunk, monk
     print("device / host libdeflate-5 / zlib-5 bytes:", sizes)
 
 
+def test_cli_gz_output_of_text_that_does_not_compress(tmp_path, monkeypatch):
+    """the device path reserves half of the worst-case output size per chunk and file; records that do not shrink into it (IUPAC
+    letters, full-range qualities: ~0.6 of their size) are deflated by the host for that chunk - same file contents, valid gzip"""
+    from ribodetector_amd import detect
+    rng = np.random.default_rng(5)
+    n = 30000
+    iupac, quals = np.frombuffer(b"ACGTRYKMSWBDHVN-", np.uint8), np.arange(33, 127, dtype=np.uint8)
+    inp = str(tmp_path / "noisy.fq")
+    with open(inp, "wb") as fh:
+        for i in range(n):
+            L = int(rng.integers(80, 151))
+            fh.write(b"@r%d\n%s\n+\n%s\n" % (i, iupac[rng.integers(0, 16, L)].tobytes(), quals[rng.integers(0, 94, L)].tobytes()))
+    res = {}
+    for tag, env in (("device", None), ("host", "0")):
+        if env is None:
+            monkeypatch.delenv("RD_DEVICE_GZIP", raising=False)
+        else:
+            monkeypatch.setenv("RD_DEVICE_GZIP", env)
+        out = str(tmp_path / (tag + ".fq.gz"))
+        p = detect.main(["-l", "100", "-i", inp, "-o", out, "--chunk_size", "64", "-m", "3"])
+        res[tag] = (_read(out), p.num_read)
+    assert res["device"] == res["host"] and res["device"][1] == n and len(res["device"][0]) > 0
+    raw = open(str(tmp_path / "device.fq.gz"), "rb").read()
+    assert b"RD\x04\x00" in raw[:64]                                    # the first member is the host writer's ('R','D' subfield), not a BGZF block
+
+
 def test_cli_argument_errors(tmp_path):
     from ribodetector_amd import detect
     with pytest.raises(RuntimeError):
