@@ -16,8 +16,9 @@ for m, seed in ((1, 2000), (2, 7000)):
     a, o, l = synth.reads_torch(n, 100, seed=seed, device="cuda:0")
     synth.fastq_image_torch(a, o, l, mate=m).cpu().numpy().tofile(os.path.join(d, "r_%d.fq" % m))
 PY
-cd /tmp && export TMPDIR=/tmp
+cd /tmp && export TMPDIR=/tmp PYTHONPATH=$R
 rocprofv3 --kernel-trace --output-format csv -d $D/tr -o x -- python -m ribodetector_amd.detect -l 100 -i $D/r_1.fq $D/r_2.fq -o $D/o1.fq.gz $D/o2.fq.gz -r $D/q1.fq.gz $D/q2.fq.gz -e rrna > $D/run.log 2>&1
+tail -2 $D/run.log | cut -c1-200 1>&2
 cd "$R"
 echo "# CLI, paired-end plain -> gz, 3 Mi pairs (three chunks): kernel trace around a device-deflate launch (tools/trace_window.py)."
 echo "# q = HSA queue: the recurrence kernels run on the main stream's queue, rd_gz_* on the post stream's - beside the next chunk's recurrences."
