@@ -218,7 +218,7 @@ def gzip_file(src, dst, level=4):
         return "zlib level 1"
 
 
-def e2e_record(torch, synth, arenas, offsets, lens, L, ensure, timed_calls=1, gz=False, threads=None):
+def e2e_record(torch, synth, arenas, offsets, lens, L, ensure, timed_calls=1, gz=False, threads=None, gz_in=None):
     """Timed region (iii) of SURVEY §8d: the whole `ribodetector` CLI - detect.main(): model load (incl. building the prefix-state
     table), native FASTQ parse, H2D, kernels, label D2H, output write - on a FASTQ file (pair) built from the rank-0 stream of this
     run in tmpfs (the reference flow: detect.py:464-499). One warm call (it pays one-off costs of the process: first pinned
@@ -238,7 +238,7 @@ def e2e_record(torch, synth, arenas, offsets, lens, L, ensure, timed_calls=1, gz
             synth.fastq_image_torch(a, offsets, lens, mate=m + 1).cpu().numpy().tofile(p)
             ins.append(p)
         plain_bytes = sum(os.path.getsize(p) for p in ins)
-        if gz:
+        if gz and gz_in is not False:
             res = [None] * len(ins)
 
             def comp(i):
@@ -280,7 +280,8 @@ def e2e_record(torch, synth, arenas, offsets, lens, L, ensure, timed_calls=1, gz
                 "threads_flag": threads or 10,
                 "what": "whole detect.main() call on FASTQ in tmpfs, %s, -t %d%s: model load + prefix table build + parse + H2D + "
                         "kernels + D2H + write; median of %d call(s) after one warm call"
-                        % ("gz -> gz" if gz else "plain -> plain", threads or 10, "" if threads else " (the CLI's default)", timed_calls),
+                        % (("gz -> gz" if gz_in is not False else "plain -> gz") if gz else "plain -> plain", threads or 10,
+                           "" if threads else " (the CLI's default)", timed_calls),
                 "warm_call": calls[0], "calls": calls[1:]}
     finally:
         shutil.rmtree(d, ignore_errors=True)
@@ -844,6 +845,11 @@ def main():
                                          offs_l[: ng + 1], lens.repeat(nslices), MAXLEN, args.ensure, timed_calls=2, gz=True, threads=usable_cores())
                         out["e2e_cli"]["gz_to_gz_all_cores"] = gza
                         out["config"]["e2e_cli_gz_to_gz_all_cores_reads_per_s"] = gza["reads_per_s"]
+                        # plain -> gz: no inflate, so the GPU is the bound - recurrences plus the deflate of every chunk
+                        p2g = e2e_record(torch, synth, [torch.cat([t[0] for t in r1])] + ([torch.cat([t[0] for t in r2])] if paired else []),
+                                         offs_l[: ng + 1], lens.repeat(nslices), MAXLEN, args.ensure, timed_calls=2, gz=True, gz_in=False)
+                        out["e2e_cli"]["plain_to_gz"] = p2g
+                        out["config"]["e2e_cli_plain_to_gz_reads_per_s"] = p2g["reads_per_s"]
                 if "reads_per_s" not in out["e2e_cli"]:
                     out["e2e_cli"].update({k: e2e[k] for k in ("reads_per_s", "seconds", "records_per_file", "files", "spread", "what")})
                     out["config"]["e2e_cli_reads_per_s"] = e2e["reads_per_s"]

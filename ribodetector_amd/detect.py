@@ -469,10 +469,7 @@ class Predictor:
         self._gz_files, self._gz_seq = [], 0
         if self.gzip_on_device:                    # (the same list on every rank: it is derived from the arguments)
             from .gz import DeviceGzip
-            self._gz_files = [(e, lab) for lab, names in ((1, self.rrna), (0, self.output)) if names is not None for e in ends
-                              if names[e].endswith('gz')]
-            if self.is_paired and self.args.ensure == 'both':
-                self._gz_files += [(e, -1) for e in ends]
+            self._gz_files = self.gz_output_files(self.output, self.rrna, self.is_paired, self.args.ensure)
             if self._gz_files:
                 self._gz = DeviceGzip(self.device)
 
@@ -597,6 +594,17 @@ class Predictor:
                 self.logger.info('Discarded {}{}{}{} unclassified sequences'.format(
                     colors.BOLD, colors.OKCYAN, num_unknown, colors.ENDC))
         self.num_read, self.num_nonrrna, self.num_rrna, self.num_unknown = num_read, num_nonrrna, num_rrna, num_unknown
+
+    @staticmethod
+    def gz_output_files(output, rrna, is_paired, ensure):
+        """(mate, label) of every output file that is written gzip-compressed - by name, like the reference's writer
+        (detect.py:738: read_file.endswith('gz')); the '<out>.unclassified.gz' files of --ensure both (detect.py:390-400) always are.
+        The same list on every rank (it depends on the arguments only): the files whose records are deflated on the device."""
+        ends = (0, 1) if is_paired else (0,)
+        files = [(e, lab) for lab, names in ((1, rrna), (0, output)) if names is not None for e in ends if names[e].endswith('gz')]
+        if is_paired and ensure == 'both':
+            files += [(e, -1) for e in ends]
+        return files
 
     def _close_arenas(self):
         for a in self._arenas:

@@ -219,3 +219,15 @@ def test_shared_decode_needs_local_world_size(monkeypatch):
     monkeypatch.setenv("LOCAL_WORLD_SIZE", "2")
     monkeypatch.setenv("RD_SHARED_DECODE", "0")
     assert p._shared_decode() is False
+
+
+def test_which_output_files_are_gzip(tmp_path):
+    """by name, like the reference's writer (detect.py:738); --ensure both adds the two '.unclassified.gz' files (detect.py:390-400)"""
+    from ribodetector_amd.detect import Predictor
+    f = Predictor.gz_output_files
+    assert f(["o.fq"], None, False, "none") == []
+    assert f(["o.fq.gz"], None, False, "none") == [(0, 0)]
+    assert f(["o.fq"], ["r.fq.gz"], False, "none") == [(0, 1)]
+    assert f(["o1.fq.gz", "o2.fq"], ["r1.fq", "r2.fastq.gz"], True, "rrna") == [(1, 1), (0, 0)]
+    assert f(["o1.fq", "o2.fq"], None, True, "both") == [(0, -1), (1, -1)]
+    assert f(["o1.fqgz", "o2.fq"], None, True, "none") == [(0, 0)]            # ends with 'gz', as the reference tests it
