@@ -211,6 +211,33 @@ int rd_gz_compress_selected(const uint8_t *text, int64_t text_bytes, const int64
                             void *stream);
 int rd_gz_eof_block(uint8_t *dst, size_t cap);
 
+/* The input side of the same idea (round 4): a .gz whose members say how long they are - BGZF (bgzip / htslib, and every .gz this
+ * build's CLI writes) - is a list of independent DEFLATE streams, and they are inflated on the device, one wave per member
+ * (replaces, for such files: gzip.open(path, 'rt') in reference data_loader/seq_encoder.py:21-39 / fastx_parser.py:15-55). The host
+ * walks the member headers (no decoding needed: the size is in the 'B','C' subfield, ISIZE in the trailer) and fills one rd_gz_member
+ * per member; every DEFLATE block type is handled; each member's CRC-32 and ISIZE are checked on the device.
+ *   comp [dev] the compressed bytes (at least 8 readable bytes behind the last member's data: its trailer);
+ *   members [dev] rd_gz_member[n]; text [dev] receives member i's out_len bytes at out_off;
+ *   status [dev] uint32[n]: 0 = ok, else RD_GZI_* (the member's output is then undefined). Asynchronous on `stream`. */
+typedef struct rd_gz_member {
+    int64_t in_off;   /* first byte of the member's raw DEFLATE data in comp (behind the gzip header) */
+    int64_t out_off;  /* where its bytes go in text */
+    int32_t in_len;   /* bytes of raw DEFLATE data; the 8-byte trailer (CRC-32, ISIZE) follows them */
+    int32_t out_len;  /* ISIZE */
+} rd_gz_member;
+#define RD_GZI_OK 0
+#define RD_GZI_BAD_BLOCK 1
+#define RD_GZI_BAD_CODE 2
+#define RD_GZI_BAD_LENGTHS 3
+#define RD_GZI_OVERRUN 4
+#define RD_GZI_BAD_DISTANCE 5
+#define RD_GZI_TRUNCATED 6
+#define RD_GZI_SIZE 7
+#define RD_GZI_CRC 8
+#define RD_GZI_STORED 9
+int rd_gz_inflate_members(const uint8_t *comp, int64_t comp_bytes, const rd_gz_member *members, int64_t n, uint8_t *text, int64_t text_bytes,
+                          uint32_t *status, void *stream);
+
 /* Timing of the dominant kernel, for bench.py's roofline: rd_classify records hipEvents around the recurrence
  * kernel on the launch stream when enabled. rd_profile_read synchronises those events and returns the number of
  * recorded launches and their total duration. */

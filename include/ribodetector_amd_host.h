@@ -81,6 +81,26 @@ int rd_host_set_threads(int threads);
  * The CLI divides its -t value among its input files. */
 int rd_host_set_gz_threads(int threads);
 
+/* A reader whose bytes are fed by the caller instead of read from a file: the decompressed text of gzip members inflated elsewhere
+ * (on the GPU: librd_hip.so rd_gz_inflate_members). Records come out of rd_reader_next exactly as from a file of those bytes.
+ *   rd_reader_open_feed(format: 0 FASTQ / 1 FASTA); rd_reader_feed: hands `len` bytes over and returns when the reader has copied
+ *   them (call it from a thread other than the one in rd_reader_next); rd_reader_feed_end: end of the stream (error non-empty: the
+ *   stream is damaged - rd_reader_next fails with that text after the records before it). */
+int rd_reader_open_feed(int format, rd_reader **out);
+int rd_reader_feed(rd_reader *r, const uint8_t *bytes, int64_t len);
+int rd_reader_feed_end(rd_reader *r, const char *error);
+
+/* Walk gzip members that carry their own size - BGZF ('B','C') and this library's writer ('R','D') - without decoding them: one
+ * entry per non-empty member (layout = rd_gz_member of include/ribodetector_amd.h), offsets relative to in_base / out_base.
+ * Stops at an incomplete member or after `cap` entries (*consumed = bytes walked; call again with more bytes); returns 1 when it
+ * meets a member without a size subfield (*consumed points at it: the rest is for the streaming decoder), < 0 on damage. */
+typedef struct rd_host_gz_member {
+    int64_t in_off, out_off;
+    int32_t in_len, out_len;
+} rd_host_gz_member;
+int rd_host_gz_index(const uint8_t *buf, int64_t len, int64_t in_base, int64_t out_base, rd_host_gz_member *out, int64_t cap, int64_t *n,
+                     int64_t *consumed, int64_t *out_bytes);
+
 int rd_writer_open(const char *path, rd_writer **out);
 /* compressor threads this writer was opened with (= the rd_host_set_threads value in force at rd_writer_open) */
 int rd_writer_threads(const rd_writer *w);

@@ -24,7 +24,7 @@ SYMBOLS = [
     "rd_model_create", "rd_model_destroy", "rd_set_variant", "rd_variant_available", "rd_set_semantics", "rd_set_refine", "rd_set_refine_async", "rd_sync_results", "rd_refine", "rd_prefix_table_bytes", "rd_prefix_scratch_bytes", "rd_set_prefix_table", "rd_prefix_k", "rd_classify_workspace_bytes", "rd_classify",
     "rd_pair_fuse", "rd_count_labels", "rd_encode_codes", "rd_encode_onehot_padded", "rd_pack_plan",
     "rd_pack_onehot", "rd_profile_enable", "rd_profile_read", "rd_last_error", "rd_version",
-    "rd_gz_workspace_bytes", "rd_gz_out_bound", "rd_gz_compress_selected", "rd_gz_eof_block",
+    "rd_gz_workspace_bytes", "rd_gz_out_bound", "rd_gz_compress_selected", "rd_gz_eof_block", "rd_gz_inflate_members",
 ]
 
 
@@ -83,6 +83,7 @@ def lib():
     L.rd_gz_out_bound.restype = sz
     L.rd_gz_compress_selected.argtypes = [vp, i64, vp, vp, i64, i32, vp, sz, vp, vp, sz, vp]
     L.rd_gz_eof_block.argtypes = [vp, sz]
+    L.rd_gz_inflate_members.argtypes = [vp, i64, vp, i64, vp, i64, vp, vp]
     L.rd_profile_enable.argtypes = [vp, C.c_int]
     L.rd_profile_read.argtypes = [vp, C.POINTER(i64), C.POINTER(C.c_double)]
     L.rd_last_error.restype = C.c_char_p
@@ -112,7 +113,7 @@ def ptr(t):
 HOST_LIB_PATH = os.path.join(_HERE, "csrc", "librd_host.so")
 HOST_SYMBOLS = ["rd_reader_open", "rd_reader_close", "rd_reader_next", "rd_host_file_info", "rd_host_find_record_start",
                 "rd_host_count_records", "rd_host_skip_records", "rd_reader_open_range", "rd_writer_open", "rd_writer_write_selected",
-                "rd_writer_write_members", "rd_writer_close", "rd_writer_threads", "rd_host_last_error", "rd_host_set_threads", "rd_host_set_gz_threads", "rd_host_gunzip", "rd_host_gunzip_parallel"]
+                "rd_writer_write_members", "rd_writer_close", "rd_reader_open_feed", "rd_reader_feed", "rd_reader_feed_end", "rd_host_gz_index", "rd_writer_threads", "rd_host_last_error", "rd_host_set_threads", "rd_host_set_gz_threads", "rd_host_gunzip", "rd_host_gunzip_parallel"]
 _host = None
 
 
@@ -134,6 +135,10 @@ def host_lib():
     L.rd_reader_open_range.argtypes = [C.c_char_p, C.c_int, i64, i64, C.POINTER(vp)]
     L.rd_reader_close.restype = None
     L.rd_reader_next.argtypes = [vp, i64, vp, i64, vp, vp, vp, C.POINTER(i64), C.POINTER(i64)]
+    L.rd_reader_open_feed.argtypes = [C.c_int, C.POINTER(vp)]
+    L.rd_reader_feed.argtypes = [vp, vp, i64]
+    L.rd_reader_feed_end.argtypes = [vp, C.c_char_p]
+    L.rd_host_gz_index.argtypes = [vp, i64, i64, i64, vp, i64, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
     L.rd_writer_open.argtypes = [C.c_char_p, C.POINTER(vp)]
     L.rd_writer_write_selected.argtypes = [vp, vp, vp, i64, vp, C.c_int32]
     L.rd_writer_write_members.argtypes = [vp, vp, i64]

@@ -112,8 +112,21 @@ struct rd_prefetch {
     }
 };
 
+// a reader whose bytes are FED by the caller (rd_reader_open_feed): the decompressed text of gzip members inflated elsewhere - on the
+// GPU, librd_hip.so rd_gz_inflate_members. rd_reader_feed hands a span over and returns when the reader's prefetch thread has copied
+// all of it (a synchronous hand-over: the caller may reuse the buffer at once, no second copy, no queue of buffers to own).
+struct rd_feed {
+    std::mutex m;
+    std::condition_variable cv;
+    const uint8_t *p = nullptr;
+    size_t left = 0;
+    bool eof = false, aborted = false;
+    std::string err;
+};
+
 struct rd_reader {
     FILE *fp = nullptr;
+    rd_feed *feed = nullptr;
     rdz::GzipStream *gz = nullptr;   // set when the file starts with the gzip magic; plain bytes otherwise
     rdz::ParallelGzip *pgz = nullptr;   // ... and is large: sections of the DEFLATE stream decoded in parallel (rd_pgzip.h)
     rd_prefetch *pf = nullptr;
@@ -609,11 +622,116 @@ int rd_reader_open_range(const char *path, int format, int64_t start, int64_t en
 
 void rd_reader_close(rd_reader *r) {
     if (!r) return;
+    if (r->feed) {   // a feeder that still waits must not wait forever, and the prefetch thread must not wait for a feeder that is gone
+        std::lock_guard<std::mutex> lk(r->feed->m);
+        r->feed->aborted = true;
+        r->feed->eof = true;
+        r->feed->cv.notify_all();
+    }
     delete r->pf;   // joins the decompression thread first
     delete r->gz;
     delete r->pgz;
-    fclose(r->fp);
+    if (r->fp) fclose(r->fp);
+    delete r->feed;
     delete r;
+}
+
+int rd_reader_open_feed(int format, rd_reader **out) {
+    if (!out || (format != 0 && format != 1)) RDH_FAIL("rd_reader_open_feed: format must be 0 (FASTQ) or 1 (FASTA)");
+    rd_reader *r = new rd_reader();
+    r->fasta = format;
+    r->in.resize(8 << 20);
+    r->pos = r->end = 0;
+    rd_feed *f = r->feed = new rd_feed();
+    r->pf = new rd_prefetch(
+        [f](uint8_t *dst, size_t cap) -> long {
+            std::unique_lock<std::mutex> lk(f->m);
+            f->cv.wait(lk, [f]() { return f->left > 0 || f->eof; });
+            if (f->left == 0) return f->err.empty() ? 0L : -1L;   // (what was fed before the end is delivered first)
+            const size_t k = std::min(cap, f->left);
+            memcpy(dst, f->p, k);
+            f->p += k;
+            f->left -= k;
+            if (f->left == 0) f->cv.notify_all();
+            return (long)k;
+        },
+        [f]() { return f->err; });
+    r->eof = false;
+    r->scan_next = 0;
+    *out = r;
+    return 0;
+}
+
+int rd_reader_feed(rd_reader *r, const uint8_t *bytes, int64_t len) {
+    if (!r || !r->feed || len < 0 || (!bytes && len)) RDH_FAIL("rd_reader_feed: not a feed reader, or bad argument");
+    rd_feed *f = r->feed;
+    std::unique_lock<std::mutex> lk(f->m);
+    if (f->eof) RDH_FAIL("rd_reader_feed: the stream was closed");
+    if (len == 0) return 0;
+    f->p = bytes;
+    f->left = (size_t)len;
+    f->cv.notify_all();
+    f->cv.wait(lk, [f]() { return f->left == 0 || f->aborted; });
+    if (f->aborted) RDH_FAIL("rd_reader_feed: the reader was closed");
+    return 0;
+}
+
+int rd_reader_feed_end(rd_reader *r, const char *error) {
+    if (!r || !r->feed) RDH_FAIL("rd_reader_feed_end: not a feed reader");
+    rd_feed *f = r->feed;
+    std::lock_guard<std::mutex> lk(f->m);
+    if (error && error[0]) f->err = error;    // the records parsed so far are delivered, then rd_reader_next fails with this text
+    f->eof = true;
+    f->cv.notify_all();
+    return 0;
+}
+
+// Walk gzip members that say how long they are: BGZF ('B','C' subfield: 16-bit size - 1) and this build's host writer ('R','D':
+// 32-bit size - 1). No decoding: header, size subfield, trailer. Fills one entry per member; stops at the end of the bytes, at an
+// incomplete member (the caller reads more and walks on from *consumed), at `cap` entries, or at a member without a size subfield
+// (*consumed then points at it and the return value is 1: the caller hands the rest to the streaming decoder). Empty members (BGZF's
+// end-of-file marker) are skipped.
+int rd_host_gz_index(const uint8_t *buf, int64_t len, int64_t in_base, int64_t out_base, rd_host_gz_member *out, int64_t cap, int64_t *n_out,
+                     int64_t *consumed, int64_t *out_bytes) {
+    if (!buf || !out || !n_out || !consumed || !out_bytes || len < 0 || cap < 0) RDH_FAIL("rd_host_gz_index: bad argument");
+    int64_t p = 0, n = 0, ob = 0;
+    int rc = 0;
+    while (p < len && n < cap) {
+        if (len - p < 18) break;
+        const uint8_t *h = buf + p;
+        if (h[0] != 0x1f || h[1] != 0x8b) { snprintf(g_err, sizeof(g_err), "rd_host_gz_index: not a gzip member at byte %lld", (long long)(in_base + p)); return -1; }
+        if (h[2] != 8 || !(h[3] & 4) || (h[3] & ~4)) { rc = 1; break; }   // only FEXTRA: anything else is for the streaming decoder
+        const size_t xlen = h[10] | ((size_t)h[11] << 8);
+        if ((int64_t)(12 + xlen) > len - p) break;
+        int64_t msize = 0;
+        for (size_t q = 12; q + 4 <= 12 + xlen;) {
+            const size_t sl = h[q + 2] | ((size_t)h[q + 3] << 8);
+            if (q + 4 + sl > 12 + xlen) break;
+            if (h[q] == 'B' && h[q + 1] == 'C' && sl == 2) msize = (int64_t)(h[q + 4] | ((uint32_t)h[q + 5] << 8)) + 1;
+            if (h[q] == 'R' && h[q + 1] == 'D' && sl == 4)
+                msize = (int64_t)(h[q + 4] | ((uint32_t)h[q + 5] << 8) | ((uint32_t)h[q + 6] << 16) | ((uint32_t)h[q + 7] << 24)) + 1;
+            q += 4 + sl;
+        }
+        if (msize == 0) { rc = 1; break; }
+        if (msize < (int64_t)(12 + xlen + 8)) { snprintf(g_err, sizeof(g_err), "rd_host_gz_index: member size %lld too small at byte %lld", (long long)msize, (long long)(in_base + p)); return -1; }
+        if (msize > len - p) break;                                        // incomplete: more bytes needed
+        const uint8_t *t = h + msize - 8;
+        const uint32_t isize = t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
+        if (isize > 0x7fffffffu) { rc = 1; break; }
+        if (isize) {
+            out[n].in_off = in_base + p + 12 + (int64_t)xlen;
+            out[n].out_off = out_base + ob;
+            out[n].in_len = (int32_t)(msize - 12 - (int64_t)xlen - 8);
+            out[n].out_len = (int32_t)isize;
+            ++n;
+            ob += isize;
+        }
+        p += msize;
+    }
+    *n_out = n;
+    *consumed = p;
+    *out_bytes = ob;
+    return rc;
 }
 
 int rd_reader_next(rd_reader *r, int64_t max_records, uint8_t *buf, int64_t buf_cap, int64_t *rec_start, int64_t *seq_off,

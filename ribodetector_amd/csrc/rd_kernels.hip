@@ -35,6 +35,7 @@
 #include "rd_refine.hpp"
 #include "rd_encode.hpp"
 #include "rd_deflate.hpp"
+#include "rd_inflate_dev.hpp"
 
 // ================================================================================================
 // C ABI
@@ -626,6 +627,18 @@ int rd_gz_compress_selected(const uint8_t *text, int64_t text_bytes, const int64
     hipLaunchKernelGGL(rd_gz_deflate_kernel, dim3(p.grid), dim3(256), 0, st, plain, info, toks, slots, msize);
     hipLaunchKernelGGL(rd_gz_moff_kernel, dim3(1), dim3(256), 0, st, msize, moff, info);
     hipLaunchKernelGGL(rd_gz_compact_kernel, dim3(p.grid), dim3(256), 0, st, slots, msize, moff, info, out, (int64_t)out_cap);
+    RD_HIP(hipGetLastError());
+    return RD_OK;
+}
+
+int rd_gz_inflate_members(const uint8_t *comp, int64_t comp_bytes, const rd_gz_member *members, int64_t n, uint8_t *text, int64_t text_bytes,
+                          uint32_t *status, void *stream) {
+    static_assert(sizeof(rd_gz_member) == sizeof(GzMemberIn), "rd_gz_member layout");
+    if (n < 0 || comp_bytes < 0 || text_bytes < 0) RD_FAIL(RD_E_INVALID, "rd_gz_inflate_members: bad size");
+    if (n == 0) return RD_OK;
+    if (!comp || !members || !status || (!text && text_bytes > 0)) RD_FAIL(RD_E_INVALID, "rd_gz_inflate_members: null pointer");
+    int64_t grid = n < 65536 ? n : 65536;
+    hipLaunchKernelGGL(rd_gz_inflate_kernel, dim3((unsigned)grid), dim3(64), 0, (hipStream_t)stream, comp, (const GzMemberIn *)members, n, text, status);
     RD_HIP(hipGetLastError());
     return RD_OK;
 }

@@ -310,6 +310,86 @@ class ShmArena:
         return Chunk(buf[:nb].numpy(), rs[:n + 1].numpy(), so[:n].numpy(), sl[:n].numpy(), True, None, (buf[:nb], so[:n], sl[:n], rs[:n + 1]))
 
 
+def device_inflate_wanted(path):
+    """RD_DEVICE_INFLATE=1 and a GPU and a .gz whose first member carries its size (BGZF / this build's writer)"""
+    import os
+    if os.environ.get("RD_DEVICE_INFLATE", "0") != "1":
+        return False
+    import torch
+    if not torch.cuda.is_available():
+        return False
+    from .. import gz
+    return gz.is_member_indexed(path)
+
+
+class _DeviceInflateFeeder:
+    """thread: compressed file -> batches of whole members -> GPU (one wave per member) -> pinned host text -> rd_reader_feed.
+    Members without a size subfield (a plain gzip member concatenated behind BGZF blocks) cannot be handed to the device: that is an
+    error of this path (the caller chose it for a file that starts as BGZF), reported through the reader like a damaged file."""
+
+    BATCH = 48 << 20        # compressed bytes per launch (~200 MB of text, ~3,500 BGZF blocks)
+
+    def __init__(self, path, handle):
+        import threading
+        self.path, self.h = path, handle
+        self._stop = False
+        self.th = threading.Thread(target=self._run, daemon=True)
+        self.th.start()
+
+    def stop(self):
+        self._stop = True
+
+    def join(self):
+        self.th.join()
+
+    def _run(self):
+        import numpy as np
+        import torch
+        from .. import gz
+        L = N.host_lib()
+        err = b""
+        try:
+            dg = gz.DeviceGunzip(torch.device("cuda", torch.cuda.current_device()))
+            pinned = torch.empty(self.BATCH + (1 << 20), dtype=torch.uint8, pin_memory=True)
+            buf = pinned.numpy()
+            host_text = None
+            have = 0
+            with open(self.path, "rb", buffering=0) as fh:
+                eof = False
+                while not self._stop:
+                    while have < self.BATCH and not eof:
+                        k = fh.readinto(memoryview(buf)[have:self.BATCH + (1 << 20)])
+                        if not k:
+                            eof = True
+                        else:
+                            have += k
+                    if have == 0:
+                        break
+                    n, consumed, out_bytes, streaming = dg.index(buf, have)
+                    if streaming and n == 0:
+                        raise ValueError("a gzip member without a size subfield follows the indexed members: not a BGZF file throughout")
+                    if n == 0 and eof:
+                        if consumed < have:
+                            raise ValueError("Compressed file ended before the end-of-stream marker was reached")
+                        break
+                    if n:
+                        text = dg.inflate(buf, consumed, n, out_bytes)
+                        if host_text is None or host_text.numel() < out_bytes:
+                            host_text = torch.empty(int(out_bytes * 1.25) + 4096, dtype=torch.uint8, pin_memory=True)
+                        with torch.cuda.stream(dg.stream):
+                            host_text[:out_bytes].copy_(text, non_blocking=True)
+                        dg.stream.synchronize()
+                        if L.rd_reader_feed(self.h, host_text.data_ptr(), out_bytes) != 0:
+                            return                      # the reader was closed
+                    buf[: have - consumed] = buf[consumed:have].copy()
+                    have -= consumed
+                    if consumed == 0 and eof:
+                        raise ValueError("Compressed file ended before the end-of-stream marker was reached")
+        except BaseException as e:      # reported by rd_reader_next on the consumer's thread
+            err = (str(e) or repr(e)).encode()[:400]
+        L.rd_reader_feed_end(self.h, err)
+
+
 class NativeReader:
     """librd_host.so reader: records are parsed in C++ straight into (pinned) buffers that go to the GPU as they are."""
 
@@ -322,8 +402,14 @@ class NativeReader:
         self._pin = torch.cuda.is_available()
         fmt = get_seq_format(path)                  # raises ValueError like the reference for unknown extensions
         self.h = C.c_void_p()
+        self._feeder = None
         f = 1 if fmt.startswith("fa") else 0
-        if byte_range is None:
+        if byte_range is None and fmt.endswith("gz") and device_inflate_wanted(path):
+            # a .gz whose members say how long they are (BGZF; this build's own outputs): the members are inflated on the GPU and the
+            # text is FED to the parser (ribodetector_amd/gz.py:DeviceGunzip, csrc/rd_inflate_dev.hpp) - no host inflate thread at all
+            N.host_check(N.host_lib().rd_reader_open_feed(f, C.byref(self.h)), "rd_reader_open_feed")
+            self._feeder = _DeviceInflateFeeder(path, self.h)
+        elif byte_range is None:
             N.host_check(N.host_lib().rd_reader_open(str(path).encode(), f, C.byref(self.h)), "rd_reader_open")
         else:
             N.host_check(N.host_lib().rd_reader_open_range(str(path).encode(), f, int(byte_range[0]), int(byte_range[1]), C.byref(self.h)),
@@ -334,7 +420,12 @@ class NativeReader:
 
     def close(self):
         if self.h:
+            if self._feeder is not None:
+                self._feeder.stop()
             N.host_lib().rd_reader_close(self.h)
+            if self._feeder is not None:
+                self._feeder.join()
+                self._feeder = None
             self.h = None
 
     def __del__(self):

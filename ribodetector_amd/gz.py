@@ -58,3 +58,80 @@ class DeviceGzip:
                                                 N.ptr(info), N.ptr(self._ws), self._ws.numel(), N.stream_ptr(self.device)),
                     "rd_gz_compress_selected")
         return out, info
+
+
+# ---- the input side: gzip members inflated on the device (csrc/rd_inflate_dev.hpp) ---------------------------------------------------------
+
+GZI_ERRORS = {1: "invalid block type", 2: "invalid Huffman code", 3: "invalid code lengths set", 4: "more data than the member's ISIZE says",
+              5: "invalid distance too far back", 6: "Compressed file ended before the end-of-stream marker was reached",
+              7: "Incorrect length of data produced", 8: "CRC check failed", 9: "invalid stored block lengths"}
+
+
+def is_member_indexed(path):
+    """does the file start with a gzip member that says how long it is (BGZF 'B','C' / this build's 'R','D' subfield)?"""
+    try:
+        with open(path, "rb") as fh:
+            h = fh.read(64)
+    except OSError:
+        return False
+    if len(h) < 18 or h[:3] != b"\x1f\x8b\x08" or h[3] != 4:
+        return False
+    xlen = h[10] | (h[11] << 8)
+    q = 12
+    while q + 4 <= min(12 + xlen, len(h)):
+        sl = h[q + 2] | (h[q + 3] << 8)
+        if (h[q:q + 2] == b"BC" and sl == 2) or (h[q:q + 2] == b"RD" and sl == 4):
+            return True
+        q += 4 + sl
+    return False
+
+
+class DeviceGunzip:
+    """inflate(comp_host uint8 numpy/tensor (pinned or not) holding whole members): returns (text device tensor, nbytes) for the members
+    indexed in it. One call = H2D of the compressed bytes + one kernel launch (one wave per member); synchronises on its own stream
+    before returning so that the caller may copy the text out."""
+
+    def __init__(self, device):
+        import numpy as np
+        self.device = torch.device(device)
+        self.stream = torch.cuda.Stream(self.device)
+        self._np = np
+        self._cap_members = 0
+        self._mem_host = self._mem_dev = self._status = None
+        self._comp_dev = self._text_dev = None
+
+    def index(self, buf, nbytes):
+        """walk the members in buf[:nbytes] (host numpy uint8): (n, consumed, out_bytes, streaming_needed)"""
+        np = self._np
+        cap = max(1024, nbytes // 64 + 16)
+        if self._mem_host is None or self._cap_members < cap:
+            self._cap_members = cap
+            self._mem_host = torch.empty(cap * 24, dtype=torch.uint8, pin_memory=True)
+        n, consumed, ob = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        rc = N.host_lib().rd_host_gz_index(buf.ctypes.data, int(nbytes), 0, 0, self._mem_host.data_ptr(), cap, C.byref(n), C.byref(consumed), C.byref(ob))
+        if rc < 0:
+            raise ValueError(N.host_lib().rd_host_last_error().decode())
+        return int(n.value), int(consumed.value), int(ob.value), rc == 1
+
+    def inflate(self, buf, nbytes, n, out_bytes):
+        """the n members indexed by the last index() call over buf[:nbytes] -> device tensor of out_bytes bytes"""
+        lib = N.lib()
+        with torch.cuda.device(self.device), torch.cuda.stream(self.stream):
+            if self._comp_dev is None or self._comp_dev.numel() < nbytes + 16:
+                self._comp_dev = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=self.device)
+            if self._text_dev is None or self._text_dev.numel() < out_bytes:
+                self._text_dev = None
+                self._text_dev = torch.empty(int(out_bytes * 1.25) + 4096, dtype=torch.uint8, device=self.device)
+            if self._status is None or self._status.numel() < n:
+                self._status = torch.empty(max(n, 1024) * 2, dtype=torch.int32, device=self.device)
+                self._mem_dev = torch.empty(max(n, 1024) * 2 * 24, dtype=torch.uint8, device=self.device)
+            self._comp_dev[:nbytes].copy_(torch.from_numpy(buf[:nbytes]), non_blocking=True)
+            self._mem_dev[: n * 24].copy_(self._mem_host[: n * 24], non_blocking=True)
+            N.check(lib.rd_gz_inflate_members(N.ptr(self._comp_dev), int(nbytes), N.ptr(self._mem_dev), n, N.ptr(self._text_dev), int(out_bytes),
+                                              N.ptr(self._status), C.c_void_p(self.stream.cuda_stream)), "rd_gz_inflate_members")
+            bad = torch.nonzero(self._status[:n]).flatten()[:1]
+            self.stream.synchronize()
+            if bad.numel():
+                i = int(bad[0])
+                raise ValueError("gzip member %d: %s" % (i, GZI_ERRORS.get(int(self._status[i]), "error %d" % int(self._status[i]))))
+        return self._text_dev[:out_bytes]
