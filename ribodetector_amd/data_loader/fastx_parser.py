@@ -311,19 +311,23 @@ class ShmArena:
 
 
 def device_inflate_wanted(path):
-    """RD_DEVICE_INFLATE=1 and a GPU and a .gz whose first member carries its size (BGZF / this build's writer)"""
+    """a GPU, and a .gz that starts with BGZF blocks (bgzip / htslib output, and every .gz the CLI writes with its device deflate):
+    its members are inflated on the device. RD_DEVICE_INFLATE=0 keeps the host's decoders; =1 also takes files of this build's host
+    writer (4 MiB members: a wave per member is a long time per member - the host's parallel member decoder suits them better)."""
     import os
-    if os.environ.get("RD_DEVICE_INFLATE", "0") != "1":
+    mode = os.environ.get("RD_DEVICE_INFLATE", "auto")
+    if mode == "0":
         return False
     import torch
     if not torch.cuda.is_available():
         return False
     from .. import gz
-    return gz.is_member_indexed(path)
+    kind = gz.is_member_indexed(path)
+    return kind == "BC" or (kind == "RD" and mode == "1")
 
 
 class _DeviceInflateFeeder:
-    """thread: compressed file -> batches of whole members -> GPU (one wave per member) -> pinned host text -> rd_reader_feed.
+    """threads: compressed file -> batches of whole members -> GPU (one wave per member) -> pinned host text -> rd_reader_feed.
     Members without a size subfield (a plain gzip member concatenated behind BGZF blocks) cannot be handed to the device: that is an
     error of this path (the caller chose it for a file that starts as BGZF), reported through the reader like a damaged file."""
 
@@ -343,16 +347,37 @@ class _DeviceInflateFeeder:
         self.th.join()
 
     def _run(self):
-        import numpy as np
+        """two stages, two threads, two pinned text buffers: this thread reads the file, walks the member headers, ships the members to
+        the GPU and fetches their text; the second one hands the text to the parser (rd_reader_feed copies it into the reader's
+        blocks: the slowest step) - so batch k + 1 is inflated while batch k is parsed"""
+        import queue
+        import threading
         import torch
         from .. import gz
         L = N.host_lib()
-        err = b""
+        full, free = queue.Queue(), queue.Queue()
+        texts = [None, None]
+        for i in range(2):
+            free.put(i)
+        state = {"err": b"", "closed": False}
+
+        def feed():
+            while True:
+                item = full.get()
+                if item is None:
+                    break
+                i, nbytes = item
+                if not state["closed"] and L.rd_reader_feed(self.h, texts[i].data_ptr(), nbytes) != 0:
+                    state["closed"] = True          # the reader was closed: drain the queue, stop the producer
+                    self._stop = True
+                free.put(i)
+            L.rd_reader_feed_end(self.h, state["err"])
+        ft = threading.Thread(target=feed, daemon=True)
+        ft.start()
         try:
             dg = gz.DeviceGunzip(torch.device("cuda", torch.cuda.current_device()))
             pinned = torch.empty(self.BATCH + (1 << 20), dtype=torch.uint8, pin_memory=True)
             buf = pinned.numpy()
-            host_text = None
             have = 0
             with open(self.path, "rb", buffering=0) as fh:
                 eof = False
@@ -367,27 +392,29 @@ class _DeviceInflateFeeder:
                         break
                     n, consumed, out_bytes, streaming = dg.index(buf, have)
                     if streaming and n == 0:
-                        raise ValueError("a gzip member without a size subfield follows the indexed members: not a BGZF file throughout")
+                        raise ValueError("a gzip member without a size subfield follows the BGZF blocks of %s: set RD_DEVICE_INFLATE=0 (the host's "
+                                         "decoders take mixed files)" % self.path)
                     if n == 0 and eof:
                         if consumed < have:
                             raise ValueError("Compressed file ended before the end-of-stream marker was reached")
                         break
                     if n:
                         text = dg.inflate(buf, consumed, n, out_bytes)
-                        if host_text is None or host_text.numel() < out_bytes:
-                            host_text = torch.empty(int(out_bytes * 1.25) + 4096, dtype=torch.uint8, pin_memory=True)
+                        i = free.get()
+                        if texts[i] is None or texts[i].numel() < out_bytes:
+                            texts[i] = torch.empty(int(out_bytes * 1.25) + 4096, dtype=torch.uint8, pin_memory=True)
                         with torch.cuda.stream(dg.stream):
-                            host_text[:out_bytes].copy_(text, non_blocking=True)
+                            texts[i][:out_bytes].copy_(text, non_blocking=True)
                         dg.stream.synchronize()
-                        if L.rd_reader_feed(self.h, host_text.data_ptr(), out_bytes) != 0:
-                            return                      # the reader was closed
+                        full.put((i, out_bytes))
                     buf[: have - consumed] = buf[consumed:have].copy()
                     have -= consumed
                     if consumed == 0 and eof:
                         raise ValueError("Compressed file ended before the end-of-stream marker was reached")
-        except BaseException as e:      # reported by rd_reader_next on the consumer's thread
-            err = (str(e) or repr(e)).encode()[:400]
-        L.rd_reader_feed_end(self.h, err)
+        except BaseException as e:      # reported by rd_reader_next on the consumer's thread, after the records before the damage
+            state["err"] = (str(e) or repr(e)).encode()[:400]
+        full.put(None)
+        ft.join()
 
 
 class NativeReader:

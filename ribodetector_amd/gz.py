@@ -68,22 +68,25 @@ GZI_ERRORS = {1: "invalid block type", 2: "invalid Huffman code", 3: "invalid co
 
 
 def is_member_indexed(path):
-    """does the file start with a gzip member that says how long it is (BGZF 'B','C' / this build's 'R','D' subfield)?"""
+    """does the file start with a gzip member that says how long it is? "BC" (BGZF: bgzip, htslib, this build's device writer),
+    "RD" (this build's host writer: 4 MiB members) or None"""
     try:
         with open(path, "rb") as fh:
             h = fh.read(64)
     except OSError:
-        return False
+        return None
     if len(h) < 18 or h[:3] != b"\x1f\x8b\x08" or h[3] != 4:
-        return False
+        return None
     xlen = h[10] | (h[11] << 8)
     q = 12
     while q + 4 <= min(12 + xlen, len(h)):
         sl = h[q + 2] | (h[q + 3] << 8)
-        if (h[q:q + 2] == b"BC" and sl == 2) or (h[q:q + 2] == b"RD" and sl == 4):
-            return True
+        if h[q:q + 2] == b"BC" and sl == 2:
+            return "BC"
+        if h[q:q + 2] == b"RD" and sl == 4:
+            return "RD"
         q += 4 + sl
-    return False
+    return None
 
 
 class DeviceGunzip:

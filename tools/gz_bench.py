@@ -79,7 +79,32 @@ def main():
         # zlib level 5 on a 64 MB sample of the same text (one stream), scaled
         sample = text[: min(int(text.numel()), 64 << 20)].cpu().numpy().tobytes()
         z5 = len(zlib.compress(sample, 5)) * (int(text.numel()) / len(sample))
-        rec[name] = {"records": nr, "text_bytes": int(text.numel()), "device_gzip_bytes": comp, "ratio": int(text.numel()) / comp,
+        # the way back: the members just made (label-0 file), inflated on the device (one wave per member)
+        inf = {}
+        try:
+            from ribodetector_amd.gz import DeviceGunzip
+            du = DeviceGunzip(dev)
+            nb0 = int(outs[0][1][0])
+            cbuf = outs[0][0][:nb0].cpu().numpy()
+            nm, consumed, ob, _ = du.index(cbuf, nb0)
+            du.inflate(cbuf, consumed, nm, ob)
+            lib = __import__("ribodetector_amd._native", fromlist=["lib"]).lib()
+            import ctypes as C
+            from ribodetector_amd import _native as N
+            st = torch.cuda.current_stream(dev)
+            a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a0.record()
+            for _ in range(5):
+                N.check(lib.rd_gz_inflate_members(N.ptr(du._comp_dev), consumed, N.ptr(du._mem_dev), nm, N.ptr(du._text_dev), ob, N.ptr(du._status),
+                                                  C.c_void_p(st.cuda_stream)), "rd_gz_inflate_members")
+            a1.record()
+            torch.cuda.synchronize()
+            ims = a0.elapsed_time(a1) / 5
+            ok = bool((du._status[:nm] == 0).all())
+            inf = {"members": nm, "compressed_bytes": consumed, "text_bytes": ob, "ms": ims, "GB_per_s_of_text": ob / ims / 1e6, "all_members_ok": ok}
+        except Exception as e:      # noqa: BLE001
+            inf = {"error": repr(e)}
+        rec[name] = {"records": nr, "text_bytes": int(text.numel()), "device_gzip_bytes": comp, "ratio": int(text.numel()) / comp, "device_inflate": inf,
                      "zlib5_bytes_est": z5, "size_vs_zlib5": comp / z5, "ms_per_chunk_both_labels": ms,
                      "GB_per_s": int(text.numel()) / ms / 1e6, "reads_per_s": nr / ms * 1e3,
                      "members": sum(int(outs[lab][1][2]) for lab in (0, 1))}
