@@ -238,7 +238,25 @@ def e2e_record(torch, synth, arenas, offsets, lens, L, ensure, timed_calls=1, gz
             synth.fastq_image_torch(a, offsets, lens, mate=m + 1).cpu().numpy().tofile(p)
             ins.append(p)
         plain_bytes = sum(os.path.getsize(p) for p in ins)
-        if gz and gz_in is not False:
+        if gz and gz_in == "bgzf":
+            # BGZF inputs (what bgzip and this build's own writer produce): framed by the device writer, outside every timed region
+            from ribodetector_amd.gz import DeviceGzip, eof_block
+            dg = DeviceGzip(arenas[0].device)
+            for p in ins:
+                import numpy as np
+                t = torch.from_numpy(np.fromfile(p, dtype=np.uint8)).to(arenas[0].device)
+                rs = torch.zeros(n + 1, dtype=torch.int64, device=t.device)
+                torch.cumsum(18 + 2 * lens.to(torch.int64), 0, out=rs[1:])
+                o, info = dg.compress_selected(t, rs, torch.zeros(n, dtype=torch.int8, device=t.device), 0)
+                torch.cuda.synchronize(t.device)
+                with open(p + ".gz", "wb") as fh:
+                    fh.write(o[: int(info[0])].cpu().numpy().tobytes())
+                    fh.write(eof_block())
+                os.remove(p)
+                del t, o
+            del dg
+            ins, how = [p + ".gz" for p in ins], "BGZF members of 65,280 bytes (device writer)"
+        elif gz and gz_in is not False:
             res = [None] * len(ins)
 
             def comp(i):
@@ -280,7 +298,8 @@ def e2e_record(torch, synth, arenas, offsets, lens, L, ensure, timed_calls=1, gz
                 "threads_flag": threads or 10,
                 "what": "whole detect.main() call on FASTQ in tmpfs, %s, -t %d%s: model load + prefix table build + parse + H2D + "
                         "kernels + D2H + write; median of %d call(s) after one warm call"
-                        % (("gz -> gz" if gz_in is not False else "plain -> gz") if gz else "plain -> plain", threads or 10,
+                        % (("BGZF -> gz (RD_DEVICE_INFLATE=%s)" % os.environ.get("RD_DEVICE_INFLATE", "auto") if gz_in == "bgzf" else
+                            "gz -> gz" if gz_in is not False else "plain -> gz") if gz else "plain -> plain", threads or 10,
                            "" if threads else " (the CLI's default)", timed_calls),
                 "warm_call": calls[0], "calls": calls[1:]}
     finally:
@@ -850,6 +869,21 @@ def main():
                                          offs_l[: ng + 1], lens.repeat(nslices), MAXLEN, args.ensure, timed_calls=2, gz=True, gz_in=False)
                         out["e2e_cli"]["plain_to_gz"] = p2g
                         out["config"]["e2e_cli_plain_to_gz_reads_per_s"] = p2g["reads_per_s"]
+                        # BGZF -> gz: the members of the inputs inflated on the GPU (the default for such files), then by the host's
+                        # member decoder on the same files
+                        old = os.environ.get("RD_DEVICE_INFLATE")
+                        try:
+                            for key, v in (("bgzf_to_gz", None), ("bgzf_to_gz_host_inflate", "0")):
+                                os.environ.pop("RD_DEVICE_INFLATE", None)
+                                if v is not None:
+                                    os.environ["RD_DEVICE_INFLATE"] = v
+                                out["e2e_cli"][key] = e2e_record(torch, synth, [torch.cat([t[0] for t in r1])] + ([torch.cat([t[0] for t in r2])] if paired else []),
+                                                                 offs_l[: ng + 1], lens.repeat(nslices), MAXLEN, args.ensure, timed_calls=2, gz=True, gz_in="bgzf")
+                                out["config"]["e2e_cli_%s_reads_per_s" % key] = out["e2e_cli"][key]["reads_per_s"]
+                        finally:
+                            os.environ.pop("RD_DEVICE_INFLATE", None)
+                            if old is not None:
+                                os.environ["RD_DEVICE_INFLATE"] = old
                 if "reads_per_s" not in out["e2e_cli"]:
                     out["e2e_cli"].update({k: e2e[k] for k in ("reads_per_s", "seconds", "records_per_file", "files", "spread", "what")})
                     out["config"]["e2e_cli_reads_per_s"] = e2e["reads_per_s"]
