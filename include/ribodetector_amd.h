@@ -235,6 +235,7 @@ typedef struct rd_gz_member {
 #define RD_GZI_SIZE 7
 #define RD_GZI_CRC 8
 #define RD_GZI_STORED 9
+#define RD_GZI_MEMBER 10   /* the descriptor itself: offsets / lengths outside comp or text */
 int rd_gz_inflate_members(const uint8_t *comp, int64_t comp_bytes, const rd_gz_member *members, int64_t n, uint8_t *text, int64_t text_bytes,
                           uint32_t *status, void *stream);
 

@@ -637,8 +637,10 @@ int rd_gz_inflate_members(const uint8_t *comp, int64_t comp_bytes, const rd_gz_m
     if (n < 0 || comp_bytes < 0 || text_bytes < 0) RD_FAIL(RD_E_INVALID, "rd_gz_inflate_members: bad size");
     if (n == 0) return RD_OK;
     if (!comp || !members || !status || (!text && text_bytes > 0)) RD_FAIL(RD_E_INVALID, "rd_gz_inflate_members: null pointer");
-    int64_t grid = n < 65536 ? n : 65536;
-    hipLaunchKernelGGL(rd_gz_inflate_kernel, dim3((unsigned)grid), dim3(64), 0, (hipStream_t)stream, comp, (const GzMemberIn *)members, n, text, status);
+    int64_t grid = (n + GZI_WAVES - 1) / GZI_WAVES;
+    if (grid > 65536) grid = 65536;
+    hipLaunchKernelGGL(rd_gz_inflate_kernel, dim3((unsigned)grid), dim3(64 * GZI_WAVES), 0, (hipStream_t)stream, comp, comp_bytes,
+                       (const GzMemberIn *)members, n, text, text_bytes, status);
     RD_HIP(hipGetLastError());
     return RD_OK;
 }

@@ -64,7 +64,7 @@ class DeviceGzip:
 
 GZI_ERRORS = {1: "invalid block type", 2: "invalid Huffman code", 3: "invalid code lengths set", 4: "more data than the member's ISIZE says",
               5: "invalid distance too far back", 6: "Compressed file ended before the end-of-stream marker was reached",
-              7: "Incorrect length of data produced", 8: "CRC check failed", 9: "invalid stored block lengths"}
+              7: "Incorrect length of data produced", 8: "CRC check failed", 9: "invalid stored block lengths", 10: "member table entry outside the buffers"}
 
 
 def is_member_indexed(path):

@@ -70,6 +70,83 @@ def test_many_blocks_per_member_and_large_members():
     assert n == 6 and got == b"".join(parts)
 
 
+def test_long_codes_far_distances_and_long_runs():
+    """what leaves the fast paths of the kernel: codewords longer than the 10-bit table (a 200-symbol alphabet with geometric
+    frequencies: zlib hands out 11 ... 15 bit codes), distances up to the full 32 KiB window, matches of 258 with distance 1 ... 7,
+    matches that straddle the 64-position rounds, a member that is one long run"""
+    rng = np.random.default_rng(42)
+    p = 0.93 ** np.arange(200)
+    skew = bytes(rng.choice(200, 60000, p=p / p.sum()).astype(np.uint8))
+    block = bytes(rng.integers(0, 256, 3000, dtype=np.uint8))
+    far = block + bytes(rng.choice(list(b"AC"), 29000).astype(np.uint8)) + block + bytes(rng.choice(list(b"GT"), 700).astype(np.uint8)) + block
+    runs = b"".join(bytes(rng.integers(65, 70, int(rng.integers(1, 8)), dtype=np.uint8)) * int(rng.integers(40, 400)) for _ in range(150))
+    mixed = b"".join(block[i:i + int(rng.integers(3, 70))] + bytes(rng.choice(list(b"ACGT"), int(rng.integers(0, 30))).astype(np.uint8))
+                     for i in rng.integers(0, 2900, 900))
+    pay = [skew, far, runs[:65000], mixed[:65000], b"Q" * 65280]
+    for level, strategy in ((6, zlib.Z_DEFAULT_STRATEGY), (9, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_HUFFMAN_ONLY), (1, zlib.Z_DEFAULT_STRATEGY)):
+        blob = b"".join(_member(x, level, strategy) for x in pay)
+        got, n = _inflate(blob)
+        assert n == len(pay) and got == b"".join(pay), (level, strategy)
+
+
+def test_random_damage_never_yields_wrong_bytes():
+    """400 members with 1 ... 4 bytes of their DEFLATE data overwritten at random: every one is either reported or (the damage hit
+    bits that do not matter) decodes to the original bytes - and the launch returns (no walk without progress, nothing out of bounds)"""
+    from ribodetector_amd import _native as N
+    from ribodetector_amd.gz import DeviceGunzip
+    rng = np.random.default_rng(5)
+    pay = _payloads(rng)
+    names = [k for k in sorted(pay) if len(pay[k]) > 2000]
+    members, plain = [], []
+    for i in range(400):
+        k = names[i % len(names)]
+        m = bytearray(_member(pay[k], (1, 6, 9)[i % 3], (zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY)[(i // 3) % 3]))
+        for _ in range(int(rng.integers(1, 5))):
+            m[int(rng.integers(18, len(m) - 8))] = int(rng.integers(0, 256))
+        members.append(bytes(m))
+        plain.append(pay[k])
+    dg = DeviceGunzip(DEV)
+    buf = np.frombuffer(b"".join(members), dtype=np.uint8).copy()
+    n, consumed, out_bytes, _ = dg.index(buf, len(buf))
+    assert n == 400 and consumed == len(buf)
+    try:
+        dg.inflate(buf, consumed, n, out_bytes)
+    except ValueError:
+        pass
+    torch.cuda.synchronize()
+    st = dg._status[:n].cpu().numpy()
+    text = dg._text_dev[:out_bytes].cpu().numpy().tobytes()
+    off, reported = 0, 0
+    for i in range(n):
+        if st[i] == 0:
+            assert text[off:off + len(plain[i])] == plain[i], i
+        else:
+            assert 1 <= st[i] <= 9
+            reported += 1
+        off += len(plain[i])
+    assert reported > 300
+
+
+def test_member_table_entries_outside_the_buffers_are_refused():
+    from ribodetector_amd import _native as N
+    lib = N.lib()
+    data = b"ACGT" * 1000
+    blob = np.frombuffer(_member(data), dtype=np.uint8).copy()
+    comp = torch.from_numpy(blob).to(DEV)
+    text = torch.zeros(len(data), dtype=torch.uint8, device=DEV)
+    rows = np.array([(18, 0, len(blob) - 26, len(data)),            # the real one
+                     (18, 0, len(blob), len(data)),                 # data + trailer past the end of comp
+                     (18, 1, len(blob) - 26, len(data)),            # output past the end of text
+                     (-4, 0, 100, 10), (18, -1, 100, 10), (18, 0, -5, 10), (18, 0, 100, -1)],
+                    dtype=np.dtype([("i", "<i8"), ("o", "<i8"), ("il", "<i4"), ("ol", "<i4")]))
+    tab = torch.from_numpy(rows.view(np.uint8)).to(DEV)
+    st = torch.full((len(rows),), 77, dtype=torch.int32, device=DEV)
+    N.check(lib.rd_gz_inflate_members(N.ptr(comp), comp.numel(), N.ptr(tab), len(rows), N.ptr(text), text.numel(), N.ptr(st),
+                                      C.c_void_p(torch.cuda.current_stream().cuda_stream)), "rd_gz_inflate_members")
+    torch.cuda.synchronize()
+    assert st.cpu().tolist() == [0, 10, 10, 10, 10, 10, 10] and text.cpu().numpy().tobytes() == data
+
+
 def test_output_of_the_device_deflate_round_trips_on_the_device():
     from ribodetector_amd import synth
     from ribodetector_amd.gz import DeviceGzip

@@ -102,6 +102,32 @@ def main():
             ims = a0.elapsed_time(a1) / 5
             ok = bool((du._status[:nm] == 0).all())
             inf = {"members": nm, "compressed_bytes": consumed, "text_bytes": ob, "ms": ims, "GB_per_s_of_text": ob / ims / 1e6, "all_members_ok": ok}
+            # how the rate depends on the members in flight (one wave each): the same members 1/4 ... 4 times in one launch
+            import numpy as np
+            mt = du._mem_dev[: nm * 24].cpu().numpy().view(np.dtype([("i", "<i8"), ("o", "<i8"), ("il", "<i4"), ("ol", "<i4")]))
+            sweep = {}
+            for k in (0.25, 0.5, 1, 2, 4):
+                reps_k = max(1, int(k))
+                take = nm if k >= 1 else int(nm * k)
+                tabs = []
+                for r in range(reps_k):
+                    t = mt[:take].copy()
+                    t["o"] += r * ob
+                    tabs.append(t)
+                tab = torch.from_numpy(np.concatenate(tabs).view(np.uint8)).to(dev)
+                txt = torch.empty(reps_k * ob + 64, dtype=torch.uint8, device=dev)
+                stt = torch.empty(take * reps_k, dtype=torch.int32, device=dev)
+                nbytes = sum(int(x) for x in np.concatenate(tabs)["ol"])
+                for it in range(4):
+                    if it == 1:
+                        a0.record()
+                    N.check(lib.rd_gz_inflate_members(N.ptr(du._comp_dev), consumed, N.ptr(tab), take * reps_k, N.ptr(txt), txt.numel(), N.ptr(stt),
+                                                      C.c_void_p(st.cuda_stream)), "rd_gz_inflate_members")
+                a1.record()
+                torch.cuda.synchronize()
+                kms = a0.elapsed_time(a1) / 3
+                sweep["%d_members" % (take * reps_k)] = {"ms": round(kms, 3), "GB_per_s_of_text": round(nbytes / kms / 1e6, 1), "ok": bool((stt == 0).all())}
+            inf["members_in_flight_sweep"] = sweep
         except Exception as e:      # noqa: BLE001
             inf = {"error": repr(e)}
         rec[name] = {"records": nr, "text_bytes": int(text.numel()), "device_gzip_bytes": comp, "ratio": int(text.numel()) / comp, "device_inflate": inf,
