@@ -10,7 +10,7 @@
 //   rd_gz_sel_* / rd_gz_pack_kernel   selected records -> one contiguous byte stream (scan of the selected lengths + coalesced copy)
 //   rd_gz_deflate_kernel              one workgroup per member of 65,280 input bytes (BGZF's block size: the file is valid BGZF -
 //                                     bgzip / htslib index it, this build's reader inflates its members in parallel):
-//        wave w owns quarter w (16,320 bytes) and its own hash table in LDS (1,024 buckets of the 8 nearest earlier positions with
+//        wave w owns part w of the member (8,160 bytes: an eighth) and its own hash table in LDS (512 buckets of the 8 nearest earlier positions with
 //        the same 8-byte hash); a STRIP of 64 consecutive positions is handled at once, one per lane: hash, the bucket's 8 candidates
 //        (positions before the strip) and distance 1 (runs) compared over the first 16 bytes; then the 64 positions are inserted; then
 //        the strip's parse is resolved from the ballot of match lanes (lazy rule: a match shorter than 16 yields to a longer one at
@@ -18,7 +18,7 @@
 //        per candidate and round; tokens go to a scratch in HBM, symbol counts to per-wave LDS histograms;
 //        ONE dynamic-Huffman block per member: lengths by two-queue merge over the rank-sorted used symbols, limited to 15 bits the
 //        way zlib's gen_bitlen does it, canonical codes; code lengths sent without the run-length symbols (+0.2 %); every wave emits
-//        its quarter's tokens with a prefix sum of bit lengths and LDS atomic-or; stored block if that is smaller; CRC-32 of the
+//        its part's tokens with a prefix sum of bit lengths and LDS atomic-or; stored block if that is smaller; CRC-32 of the
 //        member from 255 per-thread CRCs combined with x^n mod P multiplications (zlib's crc32_combine identity).
 //   rd_gz_moff_kernel / rd_gz_compact_kernel   member sizes -> offsets, members -> one contiguous stream for the D2H copy
 // Matches of 8+ bytes only (runs: 6+): on FASTQ shorter matches cost more bits than the 2-bit literals they replace; measured with
@@ -29,8 +29,11 @@
 namespace {
 
 constexpr int GZ_MEMBER = 65280;                       // input bytes per member (BGZF_BLOCK_SIZE 0xff00)
-constexpr int GZ_NQ = 4, GZ_QUARTER = GZ_MEMBER / GZ_NQ;
-constexpr int GZ_HBITS = 10, GZ_WAYS = 8;               // 1,024 buckets of the 8 nearest earlier positions per wave
+constexpr int GZ_NQ = 8, GZ_PART = GZ_MEMBER / GZ_NQ;      // waves per member; each parses its own part 
+constexpr int GZ_THREADS = 64 * GZ_NQ;
+constexpr int GZ_CRCB = 128;                                   // bytes per thread in the CRC pass (GZ_CRCB * GZ_THREADS >= GZ_MEMBER)
+static_assert(GZ_CRCB * GZ_THREADS >= GZ_MEMBER && GZ_MEMBER % (4 * GZ_NQ) == 0 && GZ_PART < (1 << 14), "deflate kernel geometry");
+constexpr int GZ_HBITS = 9, GZ_WAYS = 8;                // 512 buckets of the 8 nearest earlier positions per wave
 constexpr int GZ_MINM = 8, GZ_MINRUN = 6, GZ_MAXM = 258, GZ_CAP = 16;
 constexpr int GZ_SLOT = 65536;                         // output bytes reserved per member (BGZF: total block size <= 65536)
 constexpr int GZ_HDR = 18, GZ_TRL = 8;
@@ -175,8 +178,8 @@ __global__ __launch_bounds__(256) void rd_gz_pack_kernel(const uint8_t *__restri
 // ------------------------------------------------------------------------------------------------
 struct __attribute__((aligned(16))) GzSmem {
     uint32_t text[(GZ_MEMBER + 16) / 4];      // the member's bytes (+ zero pad); after the parse: the output (header, deflate data, trailer)
-    u32x4 tab[GZ_NQ][1 << GZ_HBITS];          // per wave: hash -> the 8 nearest earlier positions in its quarter (+ 1), 16 bits each, nearest first
-    uint32_t hist[GZ_NQ][GZ_NSYM];            // per wave: symbol counts of its quarter
+    u32x4 tab[GZ_NQ][1 << GZ_HBITS];          // per wave: hash -> the 8 nearest earlier positions in its part (+ 1), 16 bits each, nearest first
+    uint32_t hist[GZ_NQ][GZ_NSYM];            // per wave: symbol counts of its part
     uint32_t freq[GZ_NSYM];
     uint8_t lens[GZ_NSYM];
     uint16_t codes[GZ_NSYM];
@@ -190,8 +193,8 @@ struct __attribute__((aligned(16))) GzSmem {
     uint32_t crc_tab[256];
     uint8_t lsym[256];                        // match length - 3 -> length symbol - 257
     uint8_t dsym[512];                        // zlib's _dist_code
-    uint64_t litmask[GZ_NQ][(GZ_QUARTER + 63) / 64];   // per strip: which positions became literals
-    uint32_t scan[4];
+    uint64_t litmask[GZ_NQ][(GZ_PART + 63) / 64];   // per strip: which positions became literals
+    uint32_t scan[GZ_NQ];
     uint32_t qbits[GZ_NQ], qtok[GZ_NQ];
     uint32_t crc;
     int used, hlit, hdist, hclen;
@@ -259,14 +262,16 @@ __device__ __forceinline__ uint32_t gz_x8n(uint32_t nbytes) {   // x^(8 nbytes) 
     return p;
 }
 
-__device__ __forceinline__ uint32_t gz_scan256(uint32_t v, uint32_t *sh, uint32_t &total) {   // exclusive, 256 threads
+__device__ __forceinline__ uint32_t gz_scan_wg(uint32_t v, uint32_t *sh, uint32_t &total) {   // exclusive, the deflate kernel's GZ_THREADS threads
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t inc = gz_wave_scan(v);
     if (lane == 63) sh[wave] = inc;
     __syncthreads();
     uint32_t base = 0;
     for (int w = 0; w < wave; ++w) base += sh[w];
-    total = sh[0] + sh[1] + sh[2] + sh[3];
+    total = 0;
+#pragma unroll
+    for (int w = 0; w < GZ_NQ; ++w) total += sh[w];
     __syncthreads();
     return base + inc - v;
 }
@@ -284,11 +289,11 @@ __device__ __forceinline__ void gz_or_bits(uint32_t *out, uint32_t bitpos, uint6
 
 // Code lengths of an alphabet of N symbols (frequencies in LDS), at most MAXB bits: rank sort of the used symbols (all threads), then
 // one thread: two-queue merge, depths, zlib's repair of the lengths beyond MAXB, the rarest leaves get the longest codes; canonical
-// codes (bit-reversed: DEFLATE sends Huffman codes MSB first) by all threads. Called by all 256 threads.
+// codes (bit-reversed: DEFLATE sends Huffman codes MSB first) by all threads. Called by all GZ_THREADS threads.
 template <int N, int MAXB>
 __device__ void gz_huff(GzSmem &S, uint32_t *freq, uint8_t *lens, uint16_t *codes) {
     const int tid = threadIdx.x;
-    const int i0 = tid, i1 = tid + 256;
+    const int i0 = tid, i1 = tid + GZ_THREADS;
     const uint32_t f0 = i0 < N ? freq[i0] : 0, f1 = i1 < N ? freq[i1] : 0;
     int used = __syncthreads_count(f0 != 0) + __syncthreads_count(f1 != 0);
     if (used < 2) {   // at least two codes (zlib build_tree): a decoder never sees a 0-bit code
@@ -403,7 +408,7 @@ __device__ unsigned long long *g_gz_prof = nullptr;
 
 // plain: the selected records of the chunk as one stream (info[1] bytes); member m = bytes [65280 m, ...). toks: 65,280 words of
 // scratch per workgroup. slots: GZ_SLOT bytes per member; msize[m] = the member's size.
-__global__ __launch_bounds__(256) void rd_gz_deflate_kernel(const uint8_t *__restrict__ plain, const int64_t *__restrict__ info,
+__global__ __launch_bounds__(GZ_THREADS) void rd_gz_deflate_kernel(const uint8_t *__restrict__ plain, const int64_t *__restrict__ info,
                                                            uint32_t *__restrict__ toks, uint8_t *__restrict__ slots,
                                                            uint32_t *__restrict__ msize) {
     __shared__ GzSmem S;
@@ -412,13 +417,15 @@ __global__ __launch_bounds__(256) void rd_gz_deflate_kernel(const uint8_t *__res
     const int64_t total = info[1];
     const int64_t nmem = (total + GZ_MEMBER - 1) / GZ_MEMBER;
     {   // tables, once per workgroup
-        uint32_t c = (uint32_t)tid;
-        for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0xedb88320u : c >> 1;
-        S.crc_tab[tid] = c;
-        int ls = 28;
-        while (GZ_LBASE[ls] > tid + 3) --ls;
-        S.lsym[tid] = (uint8_t)(tid + 3 == 258 ? 28 : ls);
-        for (int k = tid; k < 512; k += 256) {
+        if (tid < 256) {
+            uint32_t c = (uint32_t)tid;
+            for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0xedb88320u : c >> 1;
+            S.crc_tab[tid] = c;
+            int ls = 28;
+            while (GZ_LBASE[ls] > tid + 3) --ls;
+            S.lsym[tid] = (uint8_t)(tid + 3 == 258 ? 28 : ls);
+        }
+        for (int k = tid; k < 512; k += GZ_THREADS) {
             const int d = k < 256 ? k + 1 : ((k - 256) << 7) + 1;   // a distance of the range the entry stands for
             int ds = 29;
             while (GZ_DBASE[ds] > d) --ds;
@@ -435,7 +442,7 @@ __global__ __launch_bounds__(256) void rd_gz_deflate_kernel(const uint8_t *__res
         {   // member -> LDS (dword loads: plain is 256-byte aligned and GZ_MEMBER a multiple of 4), zero pad; tables cleared
             const uint32_t *src = reinterpret_cast<const uint32_t *>(plain + m * GZ_MEMBER);
             const int nw = (len + 3) >> 2;
-            for (int k = tid; k < (GZ_MEMBER + 16) / 4; k += 256) {
+            for (int k = tid; k < (GZ_MEMBER + 16) / 4; k += GZ_THREADS) {
                 uint32_t v = 0;
                 if (k < nw) {
                     v = src[k];
@@ -443,15 +450,15 @@ __global__ __launch_bounds__(256) void rd_gz_deflate_kernel(const uint8_t *__res
                 }
                 S.text[k] = v;
             }
-            for (int k = tid; k < GZ_NQ * (1 << GZ_HBITS); k += 256) (&S.tab[0][0])[k] = u32x4{0u, 0u, 0u, 0u};
-            for (int k = tid; k < GZ_NQ * GZ_NSYM; k += 256) (&S.hist[0][0])[k] = 0;
+            for (int k = tid; k < GZ_NQ * (1 << GZ_HBITS); k += GZ_THREADS) (&S.tab[0][0])[k] = u32x4{0u, 0u, 0u, 0u};
+            for (int k = tid; k < GZ_NQ * GZ_NSYM; k += GZ_THREADS) (&S.hist[0][0])[k] = 0;
             if (tid == 0) S.crc = 0;
         }
         __syncthreads();
         GZ_STAMP(0);   // load
-        // ---- CRC-32: thread t < 255 takes bytes [256 t, 256 t + 256), the pieces are combined with x^(8 bytes after) mod P ----------------
-        if (tid < 255 && 256 * tid < len) {
-            const int b0 = 256 * tid, b1 = b0 + 256 < len ? b0 + 256 : len;
+        // ---- CRC-32: thread t takes bytes [GZ_CRCB t, GZ_CRCB (t + 1)), the pieces are combined with x^(8 bytes after) mod P ------------
+        if (GZ_CRCB * tid < len) {
+            const int b0 = GZ_CRCB * tid, b1 = b0 + GZ_CRCB < len ? b0 + GZ_CRCB : len;
             uint32_t c = 0xffffffffu;
             for (int b = b0; b < b1; b += 4) {
                 const uint32_t v = S.text[b >> 2];
@@ -463,8 +470,8 @@ __global__ __launch_bounds__(256) void rd_gz_deflate_kernel(const uint8_t *__res
             atomicXor(&S.crc, c);
         }
         GZ_STAMP(1);   // crc (thread 0's share)
-        // ---- parse: wave w, quarter w ---------------------------------------------------------------------------------------------------
-        const int q0 = wave * GZ_QUARTER, q1 = len < q0 + GZ_QUARTER ? len : q0 + GZ_QUARTER;
+        // ---- parse: wave w, part w ---------------------------------------------------------------------------------------------------
+        const int q0 = wave * GZ_PART, q1 = len < q0 + GZ_PART ? len : q0 + GZ_PART;
         uint32_t *qt = mytoks + q0;
         int ntok = 0, carry = 0;
         const uint8_t *tb = reinterpret_cast<const uint8_t *>(S.text);
@@ -474,7 +481,7 @@ __global__ __launch_bounds__(256) void rd_gz_deflate_kernel(const uint8_t *__res
             const bool in = lane < n;
             const int lim = q1 - p < GZ_MAXM ? q1 - p : GZ_MAXM;
             const bool hv = in && p + 8 <= q1;
-            const int pl = in ? p : s0;                 // (lanes past the quarter's end load somewhere harmless)
+            const int pl = in ? p : s0;                 // (lanes past the part's end load somewhere harmless)
             const uint32_t w0 = gz_ld32(S.text, pl), w1 = gz_ld32(S.text, pl + 4);
             const uint32_t hh = ((w0 * 0x9E3779B1u) ^ (w1 * 0x85EBCA77u)) * 0xC2B2AE3Du;
             const uint32_t h = hh >> (32 - GZ_HBITS);
@@ -601,13 +608,13 @@ __global__ __launch_bounds__(256) void rd_gz_deflate_kernel(const uint8_t *__res
                 }
             }
             // literal counts: not here (64 lanes adding to the same few counters - A, C, G, T ... - every strip); the strip leaves the mask
-            // of its literal positions and the quarter is counted in one pass after the loop
+            // of its literal positions and the part is counted in one pass after the loop
             const uint64_t lm = __ballot(tk && !ismatch);
             if (lane == 0) S.litmask[wave][(s0 - q0) >> 6] = lm;
             ntok += __popcll(sel);
             GZ_STAMP(10);   // strip: tokens + counts
         }
-        {   // literal counts of the quarter: lane l walks the literal positions of strips l, l + 64, ... (ds_add without return)
+        {   // literal counts of the part: lane l walks the literal positions of strips l, l + 64, ... (ds_add without return)
             const int nstrip = q1 > q0 ? (q1 - q0 + 63) >> 6 : 0;
             for (int st = lane; st < nstrip; st += 64) {
                 uint64_t lm = S.litmask[wave][st];
@@ -624,8 +631,10 @@ __global__ __launch_bounds__(256) void rd_gz_deflate_kernel(const uint8_t *__res
         __syncthreads();
         GZ_STAMP(3);   // waiting for the slowest wave
         // ---- codes --------------------------------------------------------------------------------------------------------------------
-        for (int s = tid; s < GZ_NSYM; s += 256) {
-            uint32_t f = S.hist[0][s] + S.hist[1][s] + S.hist[2][s] + S.hist[3][s];
+        for (int s = tid; s < GZ_NSYM; s += GZ_THREADS) {
+            uint32_t f = 0;
+#pragma unroll
+            for (int w = 0; w < GZ_NQ; ++w) f += S.hist[w][s];
             if (s == 256) f += 1;   // end of block
             S.freq[s] = f;
         }
@@ -645,7 +654,7 @@ __global__ __launch_bounds__(256) void rd_gz_deflate_kernel(const uint8_t *__res
         int sq[2];
 #pragma unroll
         for (int rep = 0; rep < 2; ++rep) {
-            const int i = tid + 256 * rep;
+            const int i = tid + GZ_THREADS * rep;
             sq[rep] = i < nseq ? (i < hlit ? S.lens[i] : S.lens[286 + i - hlit]) : -1;
             if (sq[rep] >= 0) atomicAdd(&S.clfreq[sq[rep]], 1u);
         }
@@ -656,7 +665,7 @@ __global__ __launch_bounds__(256) void rd_gz_deflate_kernel(const uint8_t *__res
             while (hclen > 4 && S.cllen[GZ_CLORD[hclen - 1]] == 0) --hclen;
             S.hclen = hclen;
         }
-        // bits of every quarter's tokens
+        // bits of every part's tokens
         {
             uint32_t b = 0;
             for (int s = lane; s < GZ_NSYM; s += 64) {
@@ -671,12 +680,14 @@ __global__ __launch_bounds__(256) void rd_gz_deflate_kernel(const uint8_t *__res
         const int hclen = S.hclen;
         const uint32_t c0 = sq[0] >= 0 ? S.cllen[sq[0]] : 0, c1 = sq[1] >= 0 ? S.cllen[sq[1]] : 0;
         uint32_t seqbits_lo, seqbits_total;
-        // (thread t holds entries t and t + 256: two scans, so that the entries stay in order)
-        const uint32_t ex0 = gz_scan256(c0, S.scan, seqbits_lo);
-        const uint32_t ex1 = seqbits_lo + gz_scan256(c1, S.scan, seqbits_total);
+        // (thread t holds entries t and t + GZ_THREADS: two scans, so that the entries stay in order)
+        const uint32_t ex0 = gz_scan_wg(c0, S.scan, seqbits_lo);
+        const uint32_t ex1 = seqbits_lo + gz_scan_wg(c1, S.scan, seqbits_total);
         seqbits_total += seqbits_lo;
         const uint32_t hdr_bits = 3 + 5 + 5 + 4 + 3 * (uint32_t)hclen + seqbits_total;
-        const uint32_t tok_bits = S.qbits[0] + S.qbits[1] + S.qbits[2] + S.qbits[3] + S.lens[256];
+        uint32_t tok_bits = S.lens[256];
+#pragma unroll
+        for (int w = 0; w < GZ_NQ; ++w) tok_bits += S.qbits[w];
         const uint32_t cbytes_dyn = (hdr_bits + tok_bits + 7) >> 3;
         const uint32_t cbytes_sto = 5 + (uint32_t)len;
         const uint32_t crc = S.crc;
@@ -695,11 +706,11 @@ __global__ __launch_bounds__(256) void rd_gz_deflate_kernel(const uint8_t *__res
                 for (int k = 0; k < 4; ++k) { t[k] = (uint8_t)(crc >> (8 * k)); t[4 + k] = (uint8_t)((uint32_t)len >> (8 * k)); }
                 msize[m] = tot;
             }
-            for (int k = tid; k < len; k += 256) slot[GZ_HDR + 5 + k] = tb[k];
+            for (int k = tid; k < len; k += GZ_THREADS) slot[GZ_HDR + 5 + k] = tb[k];
             continue;
         }
         // ---- output buffer = the text's LDS: header | dynamic block | trailer -----------------------------------------------------------
-        for (int k = tid; k < (GZ_MEMBER + 16) / 4; k += 256) S.text[k] = 0;
+        for (int k = tid; k < (GZ_MEMBER + 16) / 4; k += GZ_THREADS) S.text[k] = 0;
         __syncthreads();
         uint32_t *out = S.text;
         const uint32_t tot = GZ_HDR + cbytes_dyn + GZ_TRL;
@@ -713,7 +724,7 @@ __global__ __launch_bounds__(256) void rd_gz_deflate_kernel(const uint8_t *__res
         if (tid < hclen) gz_or_bits(out, B0 + 17 + 3 * tid, S.cllen[GZ_CLORD[tid]], 3);
         if (sq[0] >= 0) gz_or_bits(out, B0 + 17 + 3 * hclen + ex0, S.clcode[sq[0]], (int)c0);
         if (sq[1] >= 0) gz_or_bits(out, B0 + 17 + 3 * hclen + ex1, S.clcode[sq[1]], (int)c1);
-        {   // tokens of this wave's quarter
+        {   // tokens of this wave's part
             uint32_t bit = B0 + hdr_bits;
             for (int v = 0; v < wave; ++v) bit += S.qbits[v];
             const int nt = (int)S.qtok[wave];
@@ -754,7 +765,7 @@ __global__ __launch_bounds__(256) void rd_gz_deflate_kernel(const uint8_t *__res
         }
         __syncthreads();
         uint32_t *dst = reinterpret_cast<uint32_t *>(slot);
-        for (int k = tid; k < (int)((tot + 3) >> 2); k += 256) dst[k] = out[k];
+        for (int k = tid; k < (int)((tot + 3) >> 2); k += GZ_THREADS) dst[k] = out[k];
         GZ_STAMP(6);   // copy to the slot
     }
 }

@@ -305,7 +305,7 @@ int rd_set_prefix_table(rd_model *m, int32_t k, void *table, size_t table_bytes,
     hipStream_t st = (hipStream_t)stream;
     uint8_t *tab = (uint8_t *)table, *scr = (uint8_t *)scratch;
     // level j (the states after every j-base prefix) from level j-1, one step per launch; the levels alternate between the table
-    // and the scratch so that level k lands in the table (level k-1, a quarter of its size, is the largest one in the scratch)
+    // and the scratch so that level k lands in the table (level k-1, a part of its size, is the largest one in the scratch)
     const uint8_t *prev = m->d.zero_row;
     for (int j = 1; j <= k; ++j) {
         uint8_t *dst = ((k - j) & 1) ? scr : tab;
@@ -624,7 +624,7 @@ int rd_gz_compress_selected(const uint8_t *text, int64_t text_bytes, const int64
     hipLaunchKernelGGL(rd_gz_sel_base_kernel, dim3(1), dim3(256), 0, st, bsum, p.nb, info, text_bytes);
     hipLaunchKernelGGL(rd_gz_sel_off_kernel, dim3(p.nb), dim3(256), 0, st, rec_start, labels, n, label, bsum, out_off);
     hipLaunchKernelGGL(rd_gz_pack_kernel, dim3((unsigned)((n + GZ_PACK_RECS - 1) / GZ_PACK_RECS)), dim3(256), 0, st, text, rec_start, out_off, n, plain, info);
-    hipLaunchKernelGGL(rd_gz_deflate_kernel, dim3(p.grid), dim3(256), 0, st, plain, info, toks, slots, msize);
+    hipLaunchKernelGGL(rd_gz_deflate_kernel, dim3(p.grid), dim3(GZ_THREADS), 0, st, plain, info, toks, slots, msize);
     hipLaunchKernelGGL(rd_gz_moff_kernel, dim3(1), dim3(256), 0, st, msize, moff, info);
     hipLaunchKernelGGL(rd_gz_compact_kernel, dim3(p.grid), dim3(256), 0, st, slots, msize, moff, info, out, (int64_t)out_cap);
     RD_HIP(hipGetLastError());

@@ -6,7 +6,7 @@
 // header, BGZF framing) in a form that zlib's inflate checks on this machine. The kernel follows the same steps:
 //
 //   member  = 65,280 input bytes (BGZF's block size: the output is a valid BGZF file), one workgroup;
-//   quarter = 16,320 bytes, one wave: its own hash table of 1,024 buckets x the 8 nearest earlier positions (8-byte hashes; matches
+//   part    = 8,160 bytes (an eighth), one wave: its own hash table of 512 buckets x the 8 nearest earlier positions (8-byte hashes; matches
 //             of 8+ bytes only: on FASTQ the shorter ones cost more bits than the 2-bit literals they replace - measured here);
 //   strip   = 64 consecutive positions, one per lane: every lane hashes its position, looks its candidate up (positions before the
 //             strip), also tries distance 1 (runs), measures the match; then all 64 positions are inserted (the highest lane wins a
@@ -22,7 +22,7 @@
 #include <zlib.h>
 
 #ifndef HBITS
-#define HBITS 10
+#define HBITS 9
 #endif
 #ifndef HBYTES
 #define HBYTES 8
@@ -31,7 +31,7 @@
 #define MINM 8
 #endif
 #ifndef NQ
-#define NQ 4
+#define NQ 8
 #endif
 #ifndef NWAYS
 #define NWAYS 8
@@ -39,7 +39,7 @@
 #ifndef LAZY_MAX
 #define LAZY_MAX 16
 #endif
-enum { MEMBER = 65280, QUARTER = MEMBER / NQ, MAXM = 258 };
+enum { MEMBER = 65280, PART = MEMBER / NQ, MAXM = 258 };
 
 typedef struct { uint16_t len, dist; } Tok;   // len == 0: literal byte in dist
 
@@ -74,8 +74,8 @@ static int mlen(const uint8_t *m, int p, int c, int lim) {
 
 static int opt_dist1_min = 6, opt_lazy = 1, opt_two = 1, opt_rep = 0;
 
-// one quarter [q0, q1) of the member m; returns the number of tokens
-static int parse_quarter(const uint8_t *m, int q0, int q1, Tok *out) {
+// one part [q0, q1) of the member m; returns the number of tokens
+static int parse_part(const uint8_t *m, int q0, int q1, Tok *out) {
     static uint32_t tab[1 << HBITS][NWAYS];
     memset(tab, 0, sizeof(tab));
     int nt = 0, carry = 0, dlast = 0;
@@ -216,8 +216,8 @@ static size_t deflate_member(const uint8_t *m, int len, uint8_t *out, long *ntok
     static Tok toks[MEMBER];
     int nt = 0;
     for (int q = 0; q < NQ; ++q) {
-        const int q0 = q * QUARTER, q1 = (q + 1) * QUARTER < len ? (q + 1) * QUARTER : len;
-        if (q0 < q1) nt += parse_quarter(m, q0, q1, toks + nt);
+        const int q0 = q * PART, q1 = (q + 1) * PART < len ? (q + 1) * PART : len;
+        if (q0 < q1) nt += parse_part(m, q0, q1, toks + nt);
     }
     uint32_t fl[286] = {0}, fd[30] = {0};
     long nmatch = 0;
