@@ -334,10 +334,35 @@ def gzip_record(torch, synth, dev, arena, offsets, lens, labels):
     plain = sum(int(outs[v][1][1]) for v in (0, 1))
     sample = text[: min(int(text.numel()), 32 << 20)].cpu().numpy().tobytes()
     z5 = len(zlib.compress(sample, 5)) / len(sample)
-    return {"kernel": "rd_gz_deflate_kernel (+ select, pack, compact)", "records": n, "text_bytes": plain, "compressed_bytes": comp,
+    # the way back (csrc/rd_inflate_dev.hpp): the members of the larger of the two streams, inflated one wave per member
+    gun = None
+    try:
+        import ctypes as C
+        from ribodetector_amd import _native as NN
+        from ribodetector_amd.gz import DeviceGunzip
+        v = 0 if int(outs[0][1][0]) >= int(outs[1][1][0]) else 1
+        nb0 = int(outs[v][1][0])
+        cbuf = outs[v][0][:nb0].cpu().numpy()
+        du = DeviceGunzip(dev)
+        nm, consumed, ob, _ = du.index(cbuf, nb0)
+        du.inflate(cbuf, consumed, nm, ob)
+        st = torch.cuda.current_stream(dev)
+        a.record()
+        for _ in range(reps):
+            NN.check(NN.lib().rd_gz_inflate_members(NN.ptr(du._comp_dev), consumed, NN.ptr(du._mem_dev), nm, NN.ptr(du._text_dev), ob, NN.ptr(du._status),
+                                                    C.c_void_p(st.cuda_stream)), "rd_gz_inflate_members")
+        b.record()
+        torch.cuda.synchronize(dev)
+        ims = a.elapsed_time(b) / reps
+        gun = {"kernel": "rd_gz_inflate_kernel", "members": nm, "compressed_bytes": consumed, "text_bytes": ob, "ms": ims, "GB_per_s_of_text": ob / ims / 1e6,
+               "all_members_ok": bool((du._status[:nm] == 0).all()),
+               "bound": "latency of a wave's own chain (one wave per member; ~3,500 members = 3.4 waves per SIMD in flight)"}
+    except Exception as e:      # noqa: BLE001
+        gun = {"error": repr(e)}
+    return {"kernel": "rd_gz_deflate_kernel (+ select, pack, compact)", "records": n, "device_gunzip": gun, "text_bytes": plain, "compressed_bytes": comp,
             "ratio": plain / max(comp, 1), "size_vs_zlib_level_5": (comp / max(plain, 1)) / z5, "ms_per_chunk_both_label_files": ms,
             "GB_per_s_of_text": plain / ms / 1e6, "reads_per_s": n / ms * 1e3, "members": sum(int(outs[v][1][2]) for v in (0, 1)),
-            "bound": "VALU issue with one wave per SIMD (152 KB of LDS per workgroup); HBM: %.3f of 8 TB/s" % (plain / ms / 1e6 / HBM_PEAK_GBPS),
+            "bound": "dependent-issue latency at two waves per SIMD (155 KB of LDS: one workgroup of eight waves per CU); HBM: %.3f of 8 TB/s" % (plain / ms / 1e6 / HBM_PEAK_GBPS),
             "what": "the FASTQ text of one step's first mate (constant quality, 218 B per record) split by the step's labels into the two "
                     "gzip (BGZF) streams the CLI appends to its .gz outputs; zlib level 5 = the reference's gzip.open(..., compresslevel=5)"}
 

@@ -332,6 +332,7 @@ class _DeviceInflateFeeder:
     error of this path (the caller chose it for a file that starts as BGZF), reported through the reader like a damaged file."""
 
     BATCH = 48 << 20        # compressed bytes per launch (~200 MB of text, ~3,500 BGZF blocks)
+    FIRST = 6 << 20         # the first launch (the reader's first chunk is small too: get_seq_chunks first_chunk); doubling up to BATCH
 
     def __init__(self, path, handle):
         import threading
@@ -378,12 +379,12 @@ class _DeviceInflateFeeder:
             dg = gz.DeviceGunzip(torch.device("cuda", torch.cuda.current_device()))
             pinned = torch.empty(self.BATCH + (1 << 20), dtype=torch.uint8, pin_memory=True)
             buf = pinned.numpy()
-            have = 0
+            have, batch = 0, min(self.FIRST, self.BATCH)
             with open(self.path, "rb", buffering=0) as fh:
                 eof = False
                 while not self._stop:
-                    while have < self.BATCH and not eof:
-                        k = fh.readinto(memoryview(buf)[have:self.BATCH + (1 << 20)])
+                    while have < batch and not eof:
+                        k = fh.readinto(memoryview(buf)[have:batch + (1 << 20)])
                         if not k:
                             eof = True
                         else:
@@ -409,6 +410,7 @@ class _DeviceInflateFeeder:
                         full.put((i, out_bytes))
                     buf[: have - consumed] = buf[consumed:have].copy()
                     have -= consumed
+                    batch = min(2 * batch, self.BATCH)
                     if consumed == 0 and eof:
                         raise ValueError("Compressed file ended before the end-of-stream marker was reached")
         except BaseException as e:      # reported by rd_reader_next on the consumer's thread, after the records before the damage

@@ -47,6 +47,7 @@ def body(isa, name_re):
         line = line.split(";")[0].rstrip()
         if not line.strip() or line.lstrip().startswith((".p2align", ".section", ".type", ".size", ".globl", ".protected")):
             continue
+        line = re.sub(r"\.str(\.\d+)?@", ".str@", line)       # (the index of a string constant depends on the OTHER kernels of the translation unit)
         out.append(re.sub(r"\.LBB\d+_(\d+)", lambda m: ".L%d" % labels.setdefault(m.group(0), len(labels)), line))
     return out
 
