@@ -217,7 +217,8 @@ int rd_gz_eof_block(uint8_t *dst, size_t cap);
  * walks the member headers (no decoding needed: the size is in the 'B','C' subfield, ISIZE in the trailer) and fills one rd_gz_member
  * per member; every DEFLATE block type is handled; each member's CRC-32 and ISIZE are checked on the device.
  *   comp [dev] the compressed bytes (at least 8 readable bytes behind the last member's data: its trailer);
- *   members [dev] rd_gz_member[n]; text [dev] receives member i's out_len bytes at out_off;
+ *   members [dev] rd_gz_member[n] (in_len at most 256 MiB; an entry that points outside comp / text gets RD_GZI_MEMBER, nothing is read
+ *   or written for it); text [dev] receives member i's out_len bytes at out_off;
  *   status [dev] uint32[n]: 0 = ok, else RD_GZI_* (the member's output is then undefined). Asynchronous on `stream`. */
 typedef struct rd_gz_member {
     int64_t in_off;   /* first byte of the member's raw DEFLATE data in comp (behind the gzip header) */

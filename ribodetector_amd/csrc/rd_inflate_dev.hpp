@@ -179,7 +179,7 @@ __global__ __launch_bounds__(64 * GZI_WAVES) __attribute__((amdgpu_waves_per_eu(
     for (int64_t m = (int64_t)blockIdx.x * GZI_WAVES + wave; m < nmem; m += (int64_t)gridDim.x * GZI_WAVES) {
         const GzMemberIn me = mem[m];
         const int in_len = me.in_len, out_len = me.out_len;
-        if (me.in_off < 0 || in_len < 0 || me.in_off + in_len + 8 > comp_bytes || me.out_off < 0 || out_len < 0 || me.out_off + out_len > text_bytes) {
+        if (me.in_off < 0 || in_len < 0 || in_len > (1 << 28) || me.in_off + in_len + 8 > comp_bytes || me.out_off < 0 || out_len < 0 || me.out_off + out_len > text_bytes) {
             if (lane == 0) status[m] = GZI_MEMBER;
             continue;
         }

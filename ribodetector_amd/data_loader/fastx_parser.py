@@ -11,6 +11,7 @@ Record semantics kept from the reference:
 import ctypes as C
 import gzip
 import io
+import os
 from collections import namedtuple
 from mimetypes import guess_type
 from pathlib import Path
@@ -348,41 +349,70 @@ class _DeviceInflateFeeder:
         self.th.join()
 
     def _run(self):
-        """two stages, two threads, two pinned text buffers: this thread reads the file, walks the member headers, ships the members to
-        the GPU and fetches their text; the second one hands the text to the parser (rd_reader_feed copies it into the reader's
-        blocks: the slowest step) - so batch k + 1 is inflated while batch k is parsed"""
+        """Two threads per file. This one reads the file, walks the member headers and QUEUES the batch on the GPU (H2D of the members,
+        one wave per member, D2H of the text into a pinned buffer: gz.DeviceGunzip.submit) - without waiting for it: the recurrence
+        kernels own every CU for ~30 ms at a time, a batch runs in the gap behind the launch that was on the GPU when it was queued,
+        and the next batch is read and indexed meanwhile. The second thread waits for a batch (sleeping), checks its status words and
+        hands the text to the parser (rd_reader_feed). Two batches in flight, three pinned text buffers."""
         import queue
         import threading
+        import time
         import torch
         from .. import gz
         L = N.host_lib()
-        full, free = queue.Queue(), queue.Queue()
-        texts = [None, None]
-        for i in range(2):
+        SLOTS, TEXTS = 2, 3
+        full, free, slot_free = queue.Queue(), queue.Queue(), queue.Queue()
+        texts = [None] * TEXTS
+        for i in range(TEXTS):
             free.put(i)
+        for k in range(SLOTS):
+            slot_free.put(k)
         state = {"err": b"", "closed": False}
+        tm = self.stage_s = {"read": 0.0, "index": 0.0, "wait_slot": 0.0, "wait_buffer": 0.0, "submit": 0.0, "wait_gpu": 0.0, "feed": 0.0, "batches": 0}
+        dg = None
 
         def feed():
             while True:
                 item = full.get()
                 if item is None:
                     break
-                i, nbytes = item
+                slot, i, nbytes = item
+                t0 = time.perf_counter()
+                try:
+                    dg.finish(slot)
+                except BaseException as e:      # a damaged member: the records of the batches before it are delivered, then the error
+                    if not state["err"]:
+                        state["err"] = (str(e) or repr(e)).encode()[:400]
+                    state["closed"] = True
+                    self._stop = True
+                slot_free.put(slot)
+                t1 = time.perf_counter()
                 if not state["closed"] and L.rd_reader_feed(self.h, texts[i].data_ptr(), nbytes) != 0:
                     state["closed"] = True          # the reader was closed: drain the queue, stop the producer
                     self._stop = True
                 free.put(i)
+                tm["wait_gpu"] += t1 - t0
+                tm["feed"] += time.perf_counter() - t1
             L.rd_reader_feed_end(self.h, state["err"])
         ft = threading.Thread(target=feed, daemon=True)
-        ft.start()
         try:
-            dg = gz.DeviceGunzip(torch.device("cuda", torch.cuda.current_device()))
-            pinned = torch.empty(self.BATCH + (1 << 20), dtype=torch.uint8, pin_memory=True)
-            buf = pinned.numpy()
-            have, batch = 0, min(self.FIRST, self.BATCH)
+            dg = gz.DeviceGunzip(torch.device("cuda", torch.cuda.current_device()), slots=SLOTS)
+            ft.start()
+            pinned = [torch.empty(self.BATCH + (1 << 20), dtype=torch.uint8, pin_memory=True) for _ in range(SLOTS)]
+            bufs = [t.numpy() for t in pinned]
+            carry = None                                    # bytes of an incomplete member, to go in front of the next batch
+            batch = min(self.FIRST, self.BATCH)
             with open(self.path, "rb", buffering=0) as fh:
                 eof = False
                 while not self._stop:
+                    t0 = time.perf_counter()
+                    slot = slot_free.get()                  # (its previous batch has left the GPU: finish() returned)
+                    t1 = time.perf_counter()
+                    buf, have = bufs[slot], 0
+                    if carry is not None:
+                        have = len(carry)
+                        buf[:have] = carry
+                        carry = None
                     while have < batch and not eof:
                         k = fh.readinto(memoryview(buf)[have:batch + (1 << 20)])
                         if not k:
@@ -390,33 +420,49 @@ class _DeviceInflateFeeder:
                         else:
                             have += k
                     if have == 0:
+                        slot_free.put(slot)
                         break
-                    n, consumed, out_bytes, streaming = dg.index(buf, have)
+                    t2 = time.perf_counter()
+                    n, consumed, out_bytes, streaming = dg.index(buf, have, slot=slot)
+                    t3 = time.perf_counter()
+                    tm["wait_slot"] += t1 - t0
+                    tm["read"] += t2 - t1
+                    tm["index"] += t3 - t2
                     if streaming and n == 0:
                         raise ValueError("a gzip member without a size subfield follows the BGZF blocks of %s: set RD_DEVICE_INFLATE=0 (the host's "
                                          "decoders take mixed files)" % self.path)
-                    if n == 0 and eof:
+                    if (n == 0 or consumed == 0) and eof:
                         if consumed < have:
                             raise ValueError("Compressed file ended before the end-of-stream marker was reached")
+                        slot_free.put(slot)
                         break
+                    if consumed < have:
+                        carry = buf[consumed:have].copy()
                     if n:
-                        text = dg.inflate(buf, consumed, n, out_bytes)
                         i = free.get()
+                        t4 = time.perf_counter()
                         if texts[i] is None or texts[i].numel() < out_bytes:
+                            texts[i] = None
                             texts[i] = torch.empty(int(out_bytes * 1.25) + 4096, dtype=torch.uint8, pin_memory=True)
-                        with torch.cuda.stream(dg.stream):
-                            texts[i][:out_bytes].copy_(text, non_blocking=True)
-                        dg.stream.synchronize()
-                        full.put((i, out_bytes))
-                    buf[: have - consumed] = buf[consumed:have].copy()
-                    have -= consumed
+                        dg.submit(buf, consumed, n, out_bytes, slot=slot, host_text=texts[i])
+                        full.put((slot, i, out_bytes))
+                        tm["wait_buffer"] += t4 - t3
+                        tm["submit"] += time.perf_counter() - t4
+                        tm["batches"] += 1
+                    else:
+                        slot_free.put(slot)
                     batch = min(2 * batch, self.BATCH)
-                    if consumed == 0 and eof:
-                        raise ValueError("Compressed file ended before the end-of-stream marker was reached")
         except BaseException as e:      # reported by rd_reader_next on the consumer's thread, after the records before the damage
-            state["err"] = (str(e) or repr(e)).encode()[:400]
+            if not state["err"]:
+                state["err"] = (str(e) or repr(e)).encode()[:400]
         full.put(None)
-        ft.join()
+        if ft.ident is not None:
+            ft.join()
+        else:
+            L.rd_reader_feed_end(self.h, state["err"])
+        if os.environ.get("RD_FEED_TRACE"):
+            import sys
+            sys.stderr.write("feeder %s: %s\n" % (self.path, {k: round(v, 3) for k, v in tm.items()}))
 
 
 class NativeReader:

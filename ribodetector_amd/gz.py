@@ -89,52 +89,96 @@ def is_member_indexed(path):
     return None
 
 
-class DeviceGunzip:
-    """inflate(comp_host uint8 numpy/tensor (pinned or not) holding whole members): returns (text device tensor, nbytes) for the members
-    indexed in it. One call = H2D of the compressed bytes + one kernel launch (one wave per member); synchronises on its own stream
-    before returning so that the caller may copy the text out."""
+class _GunzipSlot:
+    """the buffers of one batch in flight: member table (pinned + device), compressed bytes, text, status"""
 
-    def __init__(self, device):
+    def __init__(self):
+        self.cap_members = 0
+        self.mem_host = self.mem_dev = self.status = self.status_host = None
+        self.comp_dev = self.text_dev = None
+        self.event = None
+        self.n = 0
+
+
+class DeviceGunzip:
+    """index(buf, nbytes) walks the member headers of a host buffer; inflate(...) ships the members to the GPU, decodes them (one wave
+    per member) and returns the text as a device tensor after synchronising. submit(...) / finish(...) are the same in two halves, for
+    a caller that keeps several batches in flight (data_loader/fastx_parser.py): everything of a batch - H2D of the compressed bytes
+    and the member table, the kernel, D2H of the text into the caller's pinned buffer and of the status words - is queued on this
+    object's stream (high priority: it runs in the gaps between the recurrence launches), and finish() sleeps until it is done."""
+
+    def __init__(self, device, slots=1):
         import numpy as np
         self.device = torch.device(device)
-        self.stream = torch.cuda.Stream(self.device)
+        with torch.cuda.device(self.device):
+            self.stream = torch.cuda.Stream(self.device, priority=-1)
         self._np = np
-        self._cap_members = 0
-        self._mem_host = self._mem_dev = self._status = None
-        self._comp_dev = self._text_dev = None
+        self._slots = [_GunzipSlot() for _ in range(max(1, slots))]
 
-    def index(self, buf, nbytes):
+    # (slot 0's buffers under their old names: tools and tests time the kernel on them)
+    _status = property(lambda self: self._slots[0].status)
+    _mem_dev = property(lambda self: self._slots[0].mem_dev)
+    _mem_host = property(lambda self: self._slots[0].mem_host)
+    _comp_dev = property(lambda self: self._slots[0].comp_dev)
+    _text_dev = property(lambda self: self._slots[0].text_dev)
+
+    def index(self, buf, nbytes, slot=0):
         """walk the members in buf[:nbytes] (host numpy uint8): (n, consumed, out_bytes, streaming_needed)"""
-        np = self._np
+        sl = self._slots[slot]
         cap = max(1024, nbytes // 64 + 16)
-        if self._mem_host is None or self._cap_members < cap:
-            self._cap_members = cap
-            self._mem_host = torch.empty(cap * 24, dtype=torch.uint8, pin_memory=True)
+        if sl.mem_host is None or sl.cap_members < cap:
+            sl.cap_members = cap
+            sl.mem_host = torch.empty(cap * 24, dtype=torch.uint8, pin_memory=True)
         n, consumed, ob = C.c_int64(0), C.c_int64(0), C.c_int64(0)
-        rc = N.host_lib().rd_host_gz_index(buf.ctypes.data, int(nbytes), 0, 0, self._mem_host.data_ptr(), cap, C.byref(n), C.byref(consumed), C.byref(ob))
+        rc = N.host_lib().rd_host_gz_index(buf.ctypes.data, int(nbytes), 0, 0, sl.mem_host.data_ptr(), cap, C.byref(n), C.byref(consumed), C.byref(ob))
         if rc < 0:
             raise ValueError(N.host_lib().rd_host_last_error().decode())
         return int(n.value), int(consumed.value), int(ob.value), rc == 1
 
+    def submit(self, buf, nbytes, n, out_bytes, slot=0, host_text=None):
+        """queue the batch indexed by the last index(..., slot) call over buf[:nbytes] (buf: pinned host memory if the copy is to be
+        asynchronous; it may be reused once finish() has returned). host_text: pinned uint8 tensor that receives the text."""
+        lib = N.lib()
+        sl = self._slots[slot]
+        with torch.cuda.device(self.device), torch.cuda.stream(self.stream):
+            if sl.comp_dev is None or sl.comp_dev.numel() < nbytes + 16:
+                sl.comp_dev = None
+                sl.comp_dev = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=self.device)
+            if sl.text_dev is None or sl.text_dev.numel() < out_bytes:
+                sl.text_dev = None
+                sl.text_dev = torch.empty(int(out_bytes * 1.25) + 4096, dtype=torch.uint8, device=self.device)
+            if sl.status is None or sl.status.numel() < n:
+                sl.status = torch.empty(max(n, 1024) * 2, dtype=torch.int32, device=self.device)
+                sl.status_host = torch.empty(max(n, 1024) * 2, dtype=torch.int32, pin_memory=True)
+            if sl.mem_dev is None or sl.mem_dev.numel() < n * 24:
+                sl.mem_dev = torch.empty(max(n, 1024) * 2 * 24, dtype=torch.uint8, device=self.device)
+            sl.comp_dev[:nbytes].copy_(torch.from_numpy(buf[:nbytes]), non_blocking=True)
+            sl.mem_dev[: n * 24].copy_(sl.mem_host[: n * 24], non_blocking=True)
+            N.check(lib.rd_gz_inflate_members(N.ptr(sl.comp_dev), int(nbytes), N.ptr(sl.mem_dev), n, N.ptr(sl.text_dev), int(out_bytes),
+                                              N.ptr(sl.status), C.c_void_p(self.stream.cuda_stream)), "rd_gz_inflate_members")
+            if host_text is not None:
+                host_text[:out_bytes].copy_(sl.text_dev[:out_bytes], non_blocking=True)
+            sl.status_host[:n].copy_(sl.status[:n], non_blocking=True)
+            sl.event = torch.cuda.Event()
+            sl.event.record(self.stream)
+        sl.n = n
+        return slot
+
+    def finish(self, slot=0):
+        """wait for the batch of `slot` (sleeping, not spinning: the host cores belong to readers and writers); ValueError names the
+        first member that did not decode"""
+        import time
+        sl = self._slots[slot]
+        while not sl.event.query():
+            time.sleep(2e-4)
+        st = sl.status_host[: sl.n].numpy()
+        bad = self._np.flatnonzero(st)
+        if bad.size:
+            i = int(bad[0])
+            raise ValueError("gzip member %d: %s" % (i, GZI_ERRORS.get(int(st[i]), "error %d" % int(st[i]))))
+
     def inflate(self, buf, nbytes, n, out_bytes):
         """the n members indexed by the last index() call over buf[:nbytes] -> device tensor of out_bytes bytes"""
-        lib = N.lib()
-        with torch.cuda.device(self.device), torch.cuda.stream(self.stream):
-            if self._comp_dev is None or self._comp_dev.numel() < nbytes + 16:
-                self._comp_dev = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=self.device)
-            if self._text_dev is None or self._text_dev.numel() < out_bytes:
-                self._text_dev = None
-                self._text_dev = torch.empty(int(out_bytes * 1.25) + 4096, dtype=torch.uint8, device=self.device)
-            if self._status is None or self._status.numel() < n:
-                self._status = torch.empty(max(n, 1024) * 2, dtype=torch.int32, device=self.device)
-                self._mem_dev = torch.empty(max(n, 1024) * 2 * 24, dtype=torch.uint8, device=self.device)
-            self._comp_dev[:nbytes].copy_(torch.from_numpy(buf[:nbytes]), non_blocking=True)
-            self._mem_dev[: n * 24].copy_(self._mem_host[: n * 24], non_blocking=True)
-            N.check(lib.rd_gz_inflate_members(N.ptr(self._comp_dev), int(nbytes), N.ptr(self._mem_dev), n, N.ptr(self._text_dev), int(out_bytes),
-                                              N.ptr(self._status), C.c_void_p(self.stream.cuda_stream)), "rd_gz_inflate_members")
-            bad = torch.nonzero(self._status[:n]).flatten()[:1]
-            self.stream.synchronize()
-            if bad.numel():
-                i = int(bad[0])
-                raise ValueError("gzip member %d: %s" % (i, GZI_ERRORS.get(int(self._status[i]), "error %d" % int(self._status[i]))))
-        return self._text_dev[:out_bytes]
+        self.submit(buf, nbytes, n, out_bytes, slot=0)
+        self.finish(0)
+        return self._slots[0].text_dev[:out_bytes]

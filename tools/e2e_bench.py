@@ -29,11 +29,11 @@ def main():
         files[mate] = p
     out = {"reads_per_file": a.reads}
 
-    def run(tag, inputs, outputs, extra=()):
-        t = time.perf_counter()
+    def run(tag, inputs, outputs, extra=(), n=None):
+        t, c = time.perf_counter(), time.process_time()
         p = detect.main(["-l", "100", "-i", *inputs, "-o", *outputs, *extra])      # default chunking: 1 Mi reads per chunk
-        dt = time.perf_counter() - t
-        out[tag] = {"reads_per_s": len(inputs) * a.reads / dt, "seconds": dt, "rrna": p.num_rrna, "non_rrna": p.num_nonrrna,
+        dt, cpu = time.perf_counter() - t, time.process_time() - c
+        out[tag] = {"reads_per_s": len(inputs) * (n or a.reads) / dt, "seconds": dt, "host_cores_busy": round(cpu / dt, 2), "rrna": p.num_rrna, "non_rrna": p.num_nonrrna,
                     "main_thread_s": {k: round(v, 3) for k, v in p._stage_s.items()}, "timing": {k: round(v, 4) for k, v in p.timing.items()}}
 
     o = lambda n: os.path.join(d, n)     # noqa: E731
@@ -57,6 +57,19 @@ def main():
     except Exception:
         pass
     run("pe_gz_to_gz_t%d" % cores, [files[1] + ".gz", files[2] + ".gz"], [o("i1.fq.gz"), o("i2.fq.gz")], ["-e", "rrna", "-t", str(cores)])
+    # BGZF inputs = the .gz files the device wrote above (non-rRNA mates of pe_gz_to_gz): members inflated on the GPU (the default for
+    # such files) or by the host's member decoder
+    with gzip.open(o("f1.fq.gz"), "rb") as fh:
+        nb = sum(chunk.count(b"\n") for chunk in iter(lambda: fh.read(1 << 24), b"")) // 4
+    out["bgzf_reads_per_file"] = nb
+    bg = [o("f1.fq.gz"), o("f2.fq.gz")]
+    run("pe_bgzf_to_gz", bg, [o("m1.fq.gz"), o("m2.fq.gz")], ["-e", "rrna"], n=nb)
+    run("pe_bgzf_to_plain", bg, [o("n1.fq"), o("n2.fq")], ["-e", "rrna"], n=nb)
+    os.environ["RD_DEVICE_INFLATE"] = "0"
+    run("pe_bgzf_to_gz_host_inflate", bg, [o("p1.fq.gz"), o("p2.fq.gz")], ["-e", "rrna"], n=nb)
+    del os.environ["RD_DEVICE_INFLATE"]
+    for f in ("m1.fq.gz", "m2.fq.gz", "n1.fq", "n2.fq", "p1.fq.gz", "p2.fq.gz"):
+        os.remove(o(f))
     os.environ["RD_DEVICE_GZIP"] = "0"
     run("se_gz_to_gz_host_deflate", [files[1] + ".gz"], [o("j.fq.gz")])
     run("pe_gz_to_gz_host_deflate", [files[1] + ".gz", files[2] + ".gz"], [o("k1.fq.gz"), o("k2.fq.gz")], ["-e", "rrna"])

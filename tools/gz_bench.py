@@ -19,6 +19,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--records", type=int, default=1 << 20)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--inflate-sweep", action="store_true", help="also time the inflate kernel with 1/4 ... 4 times the members in one launch")
     ap.add_argument("--stages", action="store_true", help="with RD_HIP_LIB=.../librd_hip_diag.so: cycles per stage of the deflate kernel")
     a = ap.parse_args()
     import numpy as np
@@ -106,7 +107,7 @@ def main():
             import numpy as np
             mt = du._mem_dev[: nm * 24].cpu().numpy().view(np.dtype([("i", "<i8"), ("o", "<i8"), ("il", "<i4"), ("ol", "<i4")]))
             sweep = {}
-            for k in (0.25, 0.5, 1, 2, 4):
+            for k in ((0.25, 0.5, 1, 2, 4) if a.inflate_sweep else ()):
                 reps_k = max(1, int(k))
                 take = nm if k >= 1 else int(nm * k)
                 tabs = []
@@ -127,7 +128,8 @@ def main():
                 torch.cuda.synchronize()
                 kms = a0.elapsed_time(a1) / 3
                 sweep["%d_members" % (take * reps_k)] = {"ms": round(kms, 3), "GB_per_s_of_text": round(nbytes / kms / 1e6, 1), "ok": bool((stt == 0).all())}
-            inf["members_in_flight_sweep"] = sweep
+            if sweep:
+                inf["members_in_flight_sweep"] = sweep
         except Exception as e:      # noqa: BLE001
             inf = {"error": repr(e)}
         rec[name] = {"records": nr, "text_bytes": int(text.numel()), "device_gzip_bytes": comp, "ratio": int(text.numel()) / comp, "device_inflate": inf,

@@ -68,6 +68,8 @@ def main():
         for k, v in traces[tr].items():
             if not k.startswith("rd_") or k not in ctrs[f] or k not in ctrs[w]:
                 continue
+            if k.startswith("rd_refine"):     # the trace run defers the float64 pass (a few small launches), the counter runs use the
+                continue                      # scan form (--inline-refine: one stream): the two do not describe the same launches
             fs = ctrs[f][k].get("FETCH_SIZE", [])
             ws = ctrs[w][k].get("WRITE_SIZE", [])
             if not fs or not ws:

@@ -36,7 +36,8 @@ pmc pmc_lds SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_WAIT_INST_LD
 stats encoders python $R/tools/encoder_bench.py
 for c in FETCH_SIZE WRITE_SIZE; do pmc enc_pmc_$c $c -- python $R/tools/encoder_bench.py; done
 # 4. device gzip (round 4): kernel table of the rd_gz_* kernels on a 2^20-record chunk, and their HBM traffic
-stats gz python $R/tools/gz_bench.py --out $O/${TAG}_gz_bench.json
+stats gz python $R/tools/gz_bench.py
+python $R/tools/gz_bench.py --inflate-sweep --out $O/${TAG}_gz_bench.json > /dev/null 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do pmc gz_pmc_$c $c -- python $R/tools/gz_bench.py; done
 pmc gz_pmc_sq SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY -- python $R/tools/gz_bench.py
 pmc gz_pmc_lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS -- python $R/tools/gz_bench.py
