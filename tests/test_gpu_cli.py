@@ -181,7 +181,22 @@ def test_cli_fasta_and_cpu_semantics(tmp_path, oracle):
         assert _read(out) == want
 
 
-@pytest.mark.parametrize("suffix,world,shared", [("", 2, "1"), (".gz", 2, "1"), ("", 3, "1"), (".gz", 3, "1"), (".gz", 2, "0")])
+def _bgzf(src, dst):
+    """src re-framed as BGZF (what bgzip writes): members of 65,280 input bytes + the empty end-of-file member"""
+    import struct
+    import zlib
+    data = open(src, "rb").read()
+    with open(dst, "wb") as fh:
+        for i in range(0, len(data), 65280):
+            piece = data[i:i + 65280]
+            co = zlib.compressobj(6, zlib.DEFLATED, -15)
+            d = co.compress(piece) + co.flush()
+            fh.write(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(d) + 25) + d
+                     + struct.pack("<II", zlib.crc32(piece) & 0xffffffff, len(piece)))
+        fh.write(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
+
+
+@pytest.mark.parametrize("suffix,world,shared", [("", 2, "1"), (".gz", 2, "1"), ("", 3, "1"), (".gz", 3, "1"), (".gz", 2, "0"), ("bgzf", 2, "1"), ("bgzf", 3, "0")])
 def test_cli_two_ranks_match_one(tmp_path, suffix, world, shared):
     """torchrun x2 (both ranks on this box's one GPU, exchange over gloo) must write the same files as one process.
     Plain input: every rank parses only its own byte range (mates cut at the same record index), writes its own parts, rank 0
@@ -197,9 +212,20 @@ def test_cli_two_ranks_match_one(tmp_path, suffix, world, shared):
     n = 5000
     a1, o1, _ = synth.reads_numpy(n, (40, 160), seed=51, rrna_frac=0.3)
     a2, o2, _ = synth.reads_numpy(n, (40, 160), seed=52, rrna_frac=0.3)
+    bgzf = suffix == "bgzf"     # BGZF inputs: the members are inflated on the GPU (by the decoding rank, or by every rank for itself)
+    if bgzf:
+        suffix = ".gz"
     i1, i2 = str(tmp_path / ("r_1.fq" + suffix)), str(tmp_path / ("r_2.fq" + suffix))
-    synth.write_fastq(i1, a1, o1, 1)
-    synth.write_fastq(i2, a2, o2, 2, prefix="the_second_mate_has_longer_headers")
+    if bgzf:
+        synth.write_fastq(str(tmp_path / "p_1.fq"), a1, o1, 1)
+        synth.write_fastq(str(tmp_path / "p_2.fq"), a2, o2, 2, prefix="the_second_mate_has_longer_headers")
+        _bgzf(str(tmp_path / "p_1.fq"), i1)
+        _bgzf(str(tmp_path / "p_2.fq"), i2)
+        from ribodetector_amd.data_loader import fastx_parser as fx
+        assert fx.device_inflate_wanted(i1)
+    else:
+        synth.write_fastq(i1, a1, o1, 1)
+        synth.write_fastq(i2, a2, o2, 2, prefix="the_second_mate_has_longer_headers")
     one = [str(tmp_path / x) for x in ("a1.fq", "a2.fq.gz", "ar1.fq", "ar2.fq")]
     p = detect.main(["-l", "120", "-i", i1, i2, "-o", *one[:2], "-r", *one[2:], "-e", "both", "--chunk_size", "1", "-m", "3"])
     two = [str(tmp_path / x) for x in ("b1.fq", "b2.fq.gz", "br1.fq", "br2.fq")]
