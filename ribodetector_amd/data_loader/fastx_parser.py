@@ -348,6 +348,29 @@ class _DeviceInflateFeeder:
     def join(self):
         self.th.join()
 
+    def _host_tail(self, fh, data, full):
+        """the rest of a file whose members stop carrying their size: zlib, member after member, text queued behind the GPU batches"""
+        import zlib
+        d, inside = zlib.decompressobj(31), False
+        while not self._stop:
+            if not data:
+                data = fh.read(4 << 20)
+                if not data:
+                    if inside:
+                        raise ValueError("Compressed file ended before the end-of-stream marker was reached")
+                    return
+            try:
+                out = d.decompress(data, 16 << 20)          # (at most 16 MB of text per call)
+            except zlib.error as e:
+                raise ValueError(str(e))
+            inside = True
+            if out:
+                full.put((None, np.frombuffer(out, dtype=np.uint8), len(out)))
+            if d.eof:
+                data, d, inside = d.unused_data, zlib.decompressobj(31), False
+            else:
+                data = d.unconsumed_tail
+
     def _run(self):
         """Two threads per file. This one reads the file, walks the member headers and QUEUES the batch on the GPU (H2D of the members,
         one wave per member, D2H of the text into a pinned buffer: gz.DeviceGunzip.submit) - without waiting for it: the recurrence
@@ -377,6 +400,11 @@ class _DeviceInflateFeeder:
                 if item is None:
                     break
                 slot, i, nbytes = item
+                if slot is None:                    # text inflated on the host (the tail of a mixed file): i is a numpy array
+                    if not state["closed"] and L.rd_reader_feed(self.h, i.ctypes.data, nbytes) != 0:
+                        state["closed"] = True
+                        self._stop = True
+                    continue
                 t0 = time.perf_counter()
                 try:
                     dg.finish(slot)
@@ -429,8 +457,11 @@ class _DeviceInflateFeeder:
                     tm["read"] += t2 - t1
                     tm["index"] += t3 - t2
                     if streaming and n == 0:
-                        raise ValueError("a gzip member without a size subfield follows the BGZF blocks of %s: set RD_DEVICE_INFLATE=0 (the host's "
-                                         "decoders take mixed files)" % self.path)
+                        # a member without a size subfield behind the BGZF blocks (`cat a.bgzf.gz b.gz` is a legal .gz): the rest of the
+                        # file is inflated here, on the host, one zlib stream after the other, and fed behind the batches in flight
+                        slot_free.put(slot)
+                        self._host_tail(fh, bytes(buf[consumed:have]), full)
+                        break
                     if (n == 0 or consumed == 0) and eof:
                         if consumed < have:
                             raise ValueError("Compressed file ended before the end-of-stream marker was reached")

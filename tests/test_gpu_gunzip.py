@@ -215,3 +215,23 @@ def test_reader_with_device_inflate_equals_the_host_reader(tmp_path, fmt, monkey
     open(path, "wb").write(bytes(raw))
     with pytest.raises(ValueError, match="gzip member"):
         read_all()
+
+
+def test_members_without_a_size_behind_bgzf_blocks_go_to_the_host(tmp_path, monkeypatch):
+    """`cat a.bgzf.gz b.gz`: the BGZF blocks are inflated on the GPU, the plain gzip members behind them by zlib on the host, in order"""
+    from ribodetector_amd.data_loader import fastx_parser as fx
+    recs = ["@r%d\n%s\n+\n%s\n" % (i, "ACGT" * 20, "F" * 80) for i in range(9000)]
+    a, b, c = "".join(recs[:5000]).encode(), "".join(recs[5000:7000]).encode(), "".join(recs[7000:]).encode()
+    path = str(tmp_path / "mixed.fastq.gz")
+    with open(path, "wb") as fh:
+        for i in range(0, len(a), 65280):
+            fh.write(_member(a[i:i + 65280]))
+        fh.write(gzip.compress(b) + gzip.compress(c))
+    monkeypatch.delenv("RD_DEVICE_INFLATE", raising=False)
+    assert fx.device_inflate_wanted(path)
+    got = b"".join(ch.buf[ch.rec_start[0]:ch.rec_start[-1]].tobytes() for ch in fx.get_seq_chunks(path, chunk_size=4000))
+    assert got == a + b + c
+    with open(path, "ab") as fh:
+        fh.write(gzip.compress(b"@x\nAC\n+\nFF\n")[:-6])               # and a truncated member at the very end is an error, not silence
+    with pytest.raises(ValueError, match="ended before the end-of-stream marker"):
+        list(fx.get_seq_chunks(path, chunk_size=4000))
