@@ -68,6 +68,19 @@ def main():
     os.environ["RD_DEVICE_INFLATE"] = "0"
     run("pe_bgzf_to_gz_host_inflate", bg, [o("p1.fq.gz"), o("p2.fq.gz")], ["-e", "rrna"], n=nb)
     del os.environ["RD_DEVICE_INFLATE"]
+    import hashlib
+
+    def sha(name):      # of the text: .gz files through Python's gzip (every member's CRC-32 and ISIZE checked on the way)
+        h = hashlib.sha1()
+        with (gzip.open(o(name), "rb") if name.endswith(".gz") else open(o(name), "rb")) as fh:
+            for chunk in iter(lambda: fh.read(1 << 24), b""):
+                h.update(chunk)
+        return h.hexdigest()
+    # the same records whatever the route: plain -> plain / gz -> gz (device deflate) of the sequencer-like inputs; BGZF -> plain (device
+    # inflate) / BGZF -> gz (device inflate + deflate) / BGZF -> gz with the host's inflate
+    out["same_text"] = {"plain_to_plain == gz_to_gz": sha("d1.fq") == sha("f1.fq.gz"),
+                        "bgzf_to_plain == bgzf_to_gz == bgzf_to_gz_host_inflate": len({sha("n1.fq"), sha("m1.fq.gz"), sha("p1.fq.gz")}) == 1,
+                        "second mates likewise": sha("d2.fq") == sha("f2.fq.gz") and len({sha("n2.fq"), sha("m2.fq.gz"), sha("p2.fq.gz")}) == 1}
     for f in ("m1.fq.gz", "m2.fq.gz", "n1.fq", "n2.fq", "p1.fq.gz", "p2.fq.gz"):
         os.remove(o(f))
     os.environ["RD_DEVICE_GZIP"] = "0"
