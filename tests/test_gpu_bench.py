@@ -70,7 +70,7 @@ def test_bench_reports_the_rate_without_the_prefix_table():
     j = _line(r.stdout)
     a = j["alt_no_prefix_table"]
     assert j["config"]["prefix_table"]["k"] >= 4 and a["timed_region"] == "ii" and a["steps"] == 4
-    assert 0.75 * j["value"] < a["value"] < 1.02 * j["value"], (a["value"], j["value"])     # (wall clock over 4 steps: noisy)
+    assert 0.70 * j["value"] < a["value"] < 1.05 * j["value"], (a["value"], j["value"])     # (wall clock over 4 steps: noisy)
     assert a["roofline"]["avg_launch_ms"] > 1.05 * j["roofline"]["avg_launch_ms"]             # (hipEvents around the launches: not noisy)
     # the strict-fp32 line: same region, same steps, its own prefix-state table, executed-work roofline
     f = j["alt_fp32_kernel"]
