@@ -29,7 +29,9 @@ extern "C" {
 typedef struct rd_reader rd_reader;
 typedef struct rd_writer rd_writer;
 
-/* format: 0 = FASTQ, 1 = FASTA, -1 = decide from the file name like get_seq_format (.fq/.fastq/.fa/.fasta/.fna/.fas [+ .gz]) */
+/* format: 0 = FASTQ, 1 = FASTA, -1 = decide from the file name like get_seq_format (.fq/.fastq/.fa/.fasta/.fna/.fas [+ .gz])
+ * A plain regular file is mapped and parsed in place (RD_READER_MMAP=0 in the environment: read through buffers instead, as pipes
+ * and gzip input always are). */
 int rd_reader_open(const char *path, int format, rd_reader **out);
 void rd_reader_close(rd_reader *r);
 

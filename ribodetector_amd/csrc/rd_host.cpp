@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <sys/uio.h>
 #include <unistd.h>
@@ -136,7 +137,10 @@ struct rd_reader {
     std::string err;
     int fasta;
     std::vector<uint8_t> in;     // raw input window
-    size_t pos, end;             // unconsumed bytes are in[pos, end)
+    const uint8_t *map = nullptr;   // plain regular file: the window IS the mapped file (no page-cache copy, no window copy, no
+    size_t map_len = 0;             // prefetch thread); pos / end are file offsets then and nothing is ever filled in
+    const uint8_t *wdata() const { return map ? map : in.data(); }
+    size_t pos, end;             // unconsumed bytes are window[pos, end)
     bool eof;
     bool flush_empty_tail = false;   // byte-range reader whose range ends before the file does: see rd_reader_open_range
     std::string pending_header;  // FASTA: header of the record being assembled ('' until the first '>' line, like the reference)
@@ -144,17 +148,17 @@ struct rd_reader {
     size_t scan_next;            // window offset just past the lines returned by scan_lines
 
     // Offsets [lb[k], le[k]) of the next `want` lines (terminators excluded) without consuming them; the offsets are
-    // relative to in.data() and stay valid until the next fill(). Returns how many lines exist (fewer only at end of file;
+    // relative to wdata() and stay valid until the next fill(). Returns how many lines exist (fewer only at end of file;
     // the last line of a file may lack its '\n').
     int scan_lines(int want, size_t *lb, size_t *le) {
         for (;;) {
             size_t p = pos;
             int k = 0;
             while (k < want) {
-                const uint8_t *nl = (const uint8_t *)memchr(in.data() + p, '\n', end - p);
+                const uint8_t *nl = (const uint8_t *)memchr(wdata() + p, '\n', end - p);
                 if (!nl) break;
                 lb[k] = p;
-                le[k] = (size_t)(nl - in.data());
+                le[k] = (size_t)(nl - wdata());
                 p = le[k] + 1;
                 ++k;
             }
@@ -369,6 +373,31 @@ extern "C" {
 
 const char *rd_host_last_error(void) { return g_err; }
 
+}  // extern "C"
+namespace {
+// A plain regular file is parsed where the page cache holds it: mapped read-only, lines scanned and records copied out of the
+// mapping - instead of fread into blocks (one copy), blocks into the window (another), and a thread for the first of the two.
+// RD_READER_MMAP=0 keeps the buffered reader (a file that is truncated while it is read ends a mapped reader with SIGBUS).
+bool map_plain_file(FILE *fp, rd_reader *r, int64_t start, int64_t end_or_neg) {
+    const char *e = getenv("RD_READER_MMAP");
+    if (e && e[0] == '0') return false;
+    struct stat st;
+    if (fstat(fileno(fp), &st) != 0 || !S_ISREG(st.st_mode) || st.st_size <= 0) return false;
+    void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fileno(fp), 0);
+    if (m == MAP_FAILED) return false;
+    madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
+    r->map = (const uint8_t *)m;
+    r->map_len = (size_t)st.st_size;
+    const int64_t b = std::min<int64_t>(std::max<int64_t>(start, 0), st.st_size);
+    const int64_t t = end_or_neg < 0 ? (int64_t)st.st_size : std::min<int64_t>(std::max<int64_t>(end_or_neg, b), st.st_size);
+    r->pos = (size_t)b;
+    r->end = (size_t)t;
+    r->eof = true;              // everything there will ever be is in the window
+    return true;
+}
+}  // namespace
+extern "C" {
+
 int rd_reader_open(const char *path, int format, rd_reader **out) {
     if (!path || !out) RDH_FAIL("rd_reader_open: null argument");
     std::string p(path), stem = p;
@@ -408,6 +437,10 @@ int rd_reader_open(const char *path, int format, rd_reader **out) {
             rdz::GzipStream *gz = r->gz = new rdz::GzipStream(fp, magic, 2);
             r->pf = new rd_prefetch([gz](uint8_t *dst, size_t cap) { return gz->read(dst, cap); }, [gz]() { return gz->err; });
         }
+    } else if (map_plain_file(fp, r, 0, -1)) {
+        r->scan_next = 0;
+        *out = r;
+        return 0;
     } else {
         memcpy(r->in.data(), magic, got);
         r->end = got;
@@ -598,6 +631,15 @@ int rd_reader_open_range(const char *path, int format, int64_t start, int64_t en
     r->fasta = format;
     r->in.resize(8 << 20);
     r->pos = r->end = 0;
+    {
+        struct stat sb;
+        r->flush_empty_tail = fstat(fileno(fp), &sb) == 0 && end < (int64_t)sb.st_size;
+    }
+    if (map_plain_file(fp, r, start, end)) {
+        r->scan_next = 0;
+        *out = r;
+        return 0;
+    }
     auto left = std::make_shared<int64_t>(end - start);
     r->pf = new rd_prefetch(
         [fp, left](uint8_t *dst, size_t cap) {
@@ -631,6 +673,7 @@ void rd_reader_close(rd_reader *r) {
     delete r->pf;   // joins the decompression thread first
     delete r->gz;
     delete r->pgz;
+    if (r->map) munmap(const_cast<uint8_t *>(r->map), r->map_len);
     if (r->fp) fclose(r->fp);
     delete r->feed;
     delete r;
@@ -749,11 +792,11 @@ int rd_reader_next(rd_reader *r, int64_t max_records, uint8_t *buf, int64_t buf_
             if (got < 4) {
                 bool blank = true;   // tolerate trailing blank lines only
                 for (int k = 0; k < got; ++k)
-                    for (size_t x = lb[k]; x < le[k]; ++x) blank = blank && is_ws(r->in[x]);
+                    for (size_t x = lb[k]; x < le[k]; ++x) blank = blank && is_ws(r->wdata()[x]);
                 if (blank) { r->pos = r->scan_next; at_eof = true; break; }
                 RDH_FAIL("truncated FASTQ record at end of file (number of lines is not a multiple of 4)");
             }
-            const uint8_t *base = r->in.data();
+            const uint8_t *base = r->wdata();
             for (int k = 0; k < 4; ++k)
                 while (le[k] > lb[k] && is_ws(base[le[k] - 1])) --le[k];
             if (le[0] == lb[0] || base[lb[0]] != '@') RDH_FAIL("FASTQ record does not start with '@'");
@@ -812,7 +855,7 @@ int rd_reader_next(rd_reader *r, int64_t max_records, uint8_t *buf, int64_t buf_
                 at_eof = true;
                 break;
             }
-            const uint8_t *base = r->in.data();
+            const uint8_t *base = r->wdata();
             while (le > lb && is_ws(base[le - 1])) --le;
             while (lb < le && is_ws(base[lb])) ++lb;
             if (lb == le) { r->pos = r->scan_next; continue; }

@@ -11,6 +11,13 @@ from ribodetector_amd import synth
 from ribodetector_amd.data_loader import fastx_parser as fx
 
 
+@pytest.fixture(autouse=True, params=["mapped", "buffered"])
+def _plain_reader_mode(request, monkeypatch):
+    """every test of this file runs twice: plain files parsed out of the mapped file (the default) and through the buffered reader
+    (RD_READER_MMAP=0: pipes, and what gzip input always uses)"""
+    monkeypatch.setenv("RD_READER_MMAP", "1" if request.param == "mapped" else "0")
+
+
 def test_seq_parser_matches_reference(golden):
     g = golden.json("parser")
     assert [list(r) for r in fx.seq_parser(io.StringIO(g["fastq_text"]), "fastq")] == g["fastq_records"]
