@@ -283,6 +283,7 @@ def e2e_record(torch, synth, arenas, offsets, lens, L, ensure, timed_calls=1, gz
             dt, cpu = time.perf_counter() - t0, time.process_time() - c0
             calls.append({"seconds": dt, "reads_per_s": len(ins) * n / dt, "main_thread_s": {k: round(v, 4) for k, v in pr._stage_s.items()},
                           "host_cores_busy": round(cpu / dt, 2),      # CPU seconds of ALL threads of the process / wall seconds
+                          "thread_cpu_s": dict(getattr(pr, "thread_cpu_s", {})),   # the pipeline's Python threads (native helpers are not in it)
                           "load_model_s": round(pr.timing["load_model_s"], 4), "detect_s": round(pr.timing["detect_s"], 4),
                           "prefix_k": pr.timing["prefix_k"], "reads_per_s_after_model_load": len(ins) * n / pr.timing["detect_s"]})
             del pr

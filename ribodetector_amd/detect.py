@@ -67,6 +67,7 @@ class Predictor:
         # under torchrun only rank 0 owns the log file (the other ranks log to the console only)
         self.logger = config.get_logger('predict', 1, self.args.log if int(os.environ.get('RANK', '0')) == 0 else None)
         self.chunk_size = self.args.chunk_size
+        self.thread_cpu_s = {}
         self.rank, self.world, self.local_rank = 0, 1, 0
         self.multi = False                       # collectives in use: several ranks (or one rank under RD_FORCE_DIST=1, dist.py)
         self._arenas = []                        # shared-memory chunk arenas of this rank (rank 0, gzip input, several ranks)
@@ -335,6 +336,8 @@ class Predictor:
                 q.put(None)
             except BaseException as e:      # surface parser errors on the main thread
                 q.put(e)
+            finally:
+                self.thread_cpu_s["reader:" + os.path.basename(str(path))] = round(time.thread_time(), 4)
         self._spawn(work)
         return q
 
@@ -462,6 +465,8 @@ class Predictor:
                 log('Writing unclassified sequences into file: {}{}{}'.format(colors.OKYELLOW, ", ".join(unclf), colors.ENDC))
         num_read = num_nonrrna = num_rrna = num_unknown = 0
         self._stage_s = {"wait_reader": 0.0, "classify": 0.0, "wait_writer": 0.0}   # main-thread seconds per pipeline stage
+        self.thread_cpu_s = {}                                                      # CPU seconds of the pipeline's Python threads, by role
+        main_cpu0 = time.thread_time()
         self._copy_stream = torch.cuda.Stream(self.device)
         self._post_stream = torch.cuda.Stream(self.device)
         # which (mate, label) files are gzip outputs deflated on the device: every rank deflates the records it classified - and writes
@@ -504,7 +509,10 @@ class Predictor:
                                         stage[0] = torch.empty(max(nb, 1 << 24) * 5 // 4, dtype=torch.uint8, pin_memory=True)
                                     with torch.cuda.stream(gz_copy):
                                         stage[0][:nb].copy_(out[:nb], non_blocking=True)
-                                    gz_copy.synchronize()
+                                        done = torch.cuda.Event()
+                                        done.record(gz_copy)
+                                    while not done.query():     # (sleeping: stream.synchronize() spins a core while the copy waits its
+                                        time.sleep(2e-4)        # turn behind the H2D of the next chunk)
                                     handles[e].write_members(stage[0].data_ptr(), nb)
                         if chunk.release is not None:   # a shared-memory slot: free for the next chunk once its text is written
                             chunk.release()
@@ -512,6 +520,8 @@ class Predictor:
                     werr.append(ex)
                     while q.get() is not None:   # keep draining so that the producer never blocks
                         pass
+                finally:
+                    self.thread_cpu_s["writer:%d" % e] = round(time.thread_time(), 4)
             for e in ends:
                 q = queue.Queue(maxsize=2)
                 wq.append(q)
@@ -552,6 +562,7 @@ class Predictor:
                 th.join()
         if werr:
             raise werr[0]
+        self.thread_cpu_s["main"] = round(time.thread_time() - main_cpu0, 4)
         self._close_arenas()
         if writer:
             self.writer_threads = sorted({fh.threads for handles in fhs.values() for fh in handles})
