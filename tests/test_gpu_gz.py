@@ -96,7 +96,7 @@ def test_sizes_around_the_member_boundary_and_empty_inputs():
     from ribodetector_amd.gz import DeviceGzip
     dg = DeviceGzip(DEV)
     rng = np.random.default_rng(3)
-    for total in (0, 1, 7, 8, 9, 63, 64, 65, 16319, 16320, 16321, 65279, 65280, 65281, 2 * 65280, 2 * 65280 + 1, 200001):
+    for total in (0, 1, 7, 8, 9, 63, 64, 65, 8159, 8160, 8161, 8223, 16319, 16320, 16321, 65279, 65280, 65281, 2 * 65280, 2 * 65280 + 1, 200001):
         body = bytes(rng.choice(list(b"ACGTN\n"), total).astype(np.uint8))
         recs = [body[i:i + 997] for i in range(0, total, 997)] or [b""]
         labels = np.ones(len(recs), dtype=np.int8)
