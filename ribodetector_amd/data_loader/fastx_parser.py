@@ -327,6 +327,23 @@ def device_inflate_wanted(path):
     return kind == "BC" or (kind == "RD" and mode == "1")
 
 
+def bgzf_all_the_way(path):
+    """does the file consist of BGZF blocks up to its last byte (the last one being BGZF's empty end-of-file block or any complete
+    block)? Checked at both ends - a plain gzip member in the middle is found by the index walk of the sharded reader, which then
+    refuses loudly"""
+    from .. import gz
+    if gz.is_member_indexed(path) != "BC":
+        return False
+    try:
+        size = os.path.getsize(path)
+        with open(path, "rb") as fh:
+            fh.seek(max(0, size - 28))
+            tail = fh.read(28)
+    except OSError:
+        return False
+    return tail == bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+
+
 class _DeviceInflateFeeder:
     """threads: compressed file -> batches of whole members -> GPU (one wave per member) -> pinned host text -> rd_reader_feed.
     Members without a size subfield (a plain gzip member concatenated behind BGZF blocks) cannot be handed to the device: that is an
@@ -335,9 +352,11 @@ class _DeviceInflateFeeder:
     BATCH = 48 << 20        # compressed bytes per launch (~200 MB of text, ~3,500 BGZF blocks)
     FIRST = 6 << 20         # the first launch (the reader's first chunk is small too: get_seq_chunks first_chunk); doubling up to BATCH
 
-    def __init__(self, path, handle):
+    def __init__(self, path, handle, span=None):
+        """span = (first file byte, one past the last, text bytes to drop in front, text bytes to deliver): a rank's share of the file
+        (BgzfView.file_span); None = the whole file"""
         import threading
-        self.path, self.h = path, handle
+        self.path, self.h, self.span = path, handle, span
         self._stop = False
         self.th = threading.Thread(target=self._run, daemon=True)
         self.th.start()
@@ -399,7 +418,8 @@ class _DeviceInflateFeeder:
                 item = full.get()
                 if item is None:
                     break
-                slot, i, nbytes = item
+                slot, i, nbytes = item[:3]
+                skip = item[3] if len(item) > 3 else 0
                 if slot is None:                    # text inflated on the host (the tail of a mixed file): i is a numpy array
                     if not state["closed"] and L.rd_reader_feed(self.h, i.ctypes.data, nbytes) != 0:
                         state["closed"] = True
@@ -415,7 +435,7 @@ class _DeviceInflateFeeder:
                     self._stop = True
                 slot_free.put(slot)
                 t1 = time.perf_counter()
-                if not state["closed"] and L.rd_reader_feed(self.h, texts[i].data_ptr(), nbytes) != 0:
+                if not state["closed"] and nbytes > 0 and L.rd_reader_feed(self.h, texts[i].data_ptr() + skip, nbytes) != 0:
                     state["closed"] = True          # the reader was closed: drain the queue, stop the producer
                     self._stop = True
                 free.put(i)
@@ -432,6 +452,11 @@ class _DeviceInflateFeeder:
             batch = min(self.FIRST, self.BATCH)
             with open(self.path, "rb", buffering=0) as fh:
                 eof = False
+                file_left = skip_text = text_left = None
+                if self.span is not None:           # a share of the file: whole members [c0, c1), text trimmed at both ends
+                    fh.seek(self.span[0])
+                    file_left, skip_text, text_left = self.span[1] - self.span[0], self.span[2], self.span[3]
+                    eof = file_left <= 0
                 while not self._stop:
                     t0 = time.perf_counter()
                     slot = slot_free.get()                  # (its previous batch has left the GPU: finish() returned)
@@ -442,11 +467,15 @@ class _DeviceInflateFeeder:
                         buf[:have] = carry
                         carry = None
                     while have < batch and not eof:
-                        k = fh.readinto(memoryview(buf)[have:batch + (1 << 20)])
+                        cap = batch + (1 << 20) if file_left is None else min(batch + (1 << 20), have + file_left)
+                        k = fh.readinto(memoryview(buf)[have:cap])
                         if not k:
                             eof = True
                         else:
                             have += k
+                            if file_left is not None:
+                                file_left -= k
+                                eof = file_left <= 0
                     if have == 0:
                         slot_free.put(slot)
                         break
@@ -476,13 +505,22 @@ class _DeviceInflateFeeder:
                             texts[i] = None
                             texts[i] = torch.empty(int(out_bytes * 1.25) + 4096, dtype=torch.uint8, pin_memory=True)
                         dg.submit(buf, consumed, n, out_bytes, slot=slot, host_text=texts[i])
-                        full.put((slot, i, out_bytes))
+                        if text_left is None:
+                            full.put((slot, i, out_bytes))
+                        else:
+                            drop = min(skip_text, out_bytes)
+                            take = min(out_bytes - drop, text_left)
+                            skip_text -= drop
+                            text_left -= take
+                            full.put((slot, i, take, drop))
                         tm["wait_buffer"] += t4 - t3
                         tm["submit"] += time.perf_counter() - t4
                         tm["batches"] += 1
                     else:
                         slot_free.put(slot)
                     batch = min(2 * batch, self.BATCH)
+                    if text_left is not None and text_left <= 0:
+                        break
         except BaseException as e:      # reported by rd_reader_next on the consumer's thread, after the records before the damage
             if not state["err"]:
                 state["err"] = (str(e) or repr(e)).encode()[:400]
@@ -510,7 +548,14 @@ class NativeReader:
         self.h = C.c_void_p()
         self._feeder = None
         f = 1 if fmt.startswith("fa") else 0
-        if byte_range is None and fmt.endswith("gz") and device_inflate_wanted(path):
+        if isinstance(byte_range, BgzfRange):
+            # a rank's share of a BGZF file (plan_ranges with BgzfView): its members are inflated on this rank's GPU, the text before
+            # the first and behind the last record of the share is dropped
+            a, b = byte_range
+            c0, c1, drop = byte_range.view.file_span(a, b)
+            N.host_check(N.host_lib().rd_reader_open_feed(f, C.byref(self.h)), "rd_reader_open_feed")
+            self._feeder = _DeviceInflateFeeder(path, self.h, span=(c0, c1, drop, b - a))
+        elif byte_range is None and fmt.endswith("gz") and device_inflate_wanted(path):
             # a .gz whose members say how long they are (BGZF; this build's own outputs): the members are inflated on the GPU and the
             # text is FED to the parser (ribodetector_amd/gz.py:DeviceGunzip, csrc/rd_inflate_dev.hpp) - no host inflate thread at all
             N.host_check(N.host_lib().rd_reader_open_feed(f, C.byref(self.h)), "rd_reader_open_feed")
@@ -622,8 +667,203 @@ def skip_records(path, start, k):
     return int(out.value)
 
 
-def plan_ranges(paths, rank, world, all_gather=None):
-    """Byte ranges [(start, end)] - one per input file - that rank `rank` of `world` parses, for plain (not gzip) inputs.
+class _PlainView:
+    """what plan_ranges needs of an input: its size and the three record-boundary helpers (librd_host.so, on the file's own bytes)"""
+
+    def __init__(self, path):
+        self.path = path
+        self.size = file_info(path)[0]
+
+    def find_record_start(self, pos):
+        return find_record_start(self.path, pos)
+
+    def count_records(self, start, end):
+        return count_records(self.path, start, end)
+
+    def skip_records(self, start, k):
+        return skip_records(self.path, start, k)
+
+    def make_range(self, start, end):
+        return (start, end)
+
+
+class BgzfRange(tuple):
+    """(start, end) in the DECOMPRESSED stream of a BGZF file, with the member index that maps them to file bytes (`.view`)"""
+    view = None
+
+
+class BgzfView:
+    """The same four answers for the decompressed stream of a BGZF FASTQ file (members that say how long they are: rd_host_gz_index
+    walks the headers, nothing is decoded for the index). Positions are offsets into the text. find_record_start and skip_records
+    look at small windows of text (a few members, inflated by zlib here); count_records covers a rank's whole share: on the GPU when
+    there is one (gz.DeviceGunzip: the members are inflated in batches and the newlines counted where they land), by zlib otherwise.
+    The rules are those of csrc/rd_host.cpp's rd_host_find_record_start / rd_host_count_records / rd_host_skip_records for FASTQ."""
+
+    WINDOW = 1 << 18
+
+    def __init__(self, path, index=None):
+        self.path = str(path)
+        if index is None:
+            index = self.build_index(self.path)
+        self.comp_off, self.comp_len, self.out_off = index      # per non-empty member: file offset / size; text offsets (n + 1 entries)
+        self.size = int(self.out_off[-1])
+
+    @staticmethod
+    def build_index(path):
+        """(comp_off int64[n], comp_len int64[n], out_off int64[n + 1]) of the non-empty members; ValueError if a member without a
+        size subfield is met (the file is not BGZF all the way: not for the sharded reader)"""
+        L = N.host_lib()
+        size = os.path.getsize(path)
+        mm = np.memmap(path, dtype=np.uint8, mode="r") if size else np.zeros(0, dtype=np.uint8)
+        offs, lens, outs = [], [], []
+        pos, PIECE = 0, 64 << 20
+        ent = np.zeros(((PIECE // 28) + 16, 3), dtype=np.int64)       # 24-byte entries: in_off, out_off, (in_len, out_len)
+        while pos < size:
+            piece = mm[pos:min(size, pos + PIECE + (1 << 17))]
+            n, consumed, ob = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+            rc = L.rd_host_gz_index(piece.ctypes.data, len(piece), 0, 0, ent.ctypes.data, len(ent), C.byref(n), C.byref(consumed), C.byref(ob))
+            if rc < 0:
+                raise ValueError(L.rd_host_last_error().decode())
+            if rc == 1 and n.value == 0 or consumed.value == 0:
+                raise ValueError("%s: a gzip member without a size subfield at byte %d" % (path, pos + consumed.value) if rc == 1 else
+                                 "Compressed file ended before the end-of-stream marker was reached")
+            e = ent[: n.value]
+            il = (e[:, 2] & 0xffffffff).astype(np.int64)
+            ol = (e[:, 2] >> 32).astype(np.int64)
+            # a member's bytes in the file: header (in_off is behind it) .. trailer; its start = the previous member's end
+            offs.append(pos + e[:, 0])            # (start of the DEFLATE data; the gzip header lies before it)
+            lens.append(il)
+            outs.append(ol)
+            pos += consumed.value
+        if not offs:
+            return np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros(1, np.int64)
+        data_off, il, ol = np.concatenate(offs), np.concatenate(lens), np.concatenate(outs)
+        return data_off, il, np.concatenate([[0], np.cumsum(ol)]).astype(np.int64)
+
+    # ---- text of a range, by zlib (small windows) ---------------------------------------------------------------------------
+    def _member_of(self, u):
+        return int(np.searchsorted(self.out_off, u, side="right") - 1)
+
+    def text(self, a, b):
+        import zlib
+        a, b = max(0, int(a)), min(self.size, int(b))
+        if b <= a:
+            return b""
+        m0, m1 = self._member_of(a), self._member_of(b - 1)
+        out = []
+        with open(self.path, "rb") as fh:
+            for m in range(m0, m1 + 1):
+                fh.seek(int(self.comp_off[m]))
+                out.append(zlib.decompress(fh.read(int(self.comp_len[m])), -15))
+        t = b"".join(out)
+        base = int(self.out_off[m0])
+        return t[a - base:b - base]
+
+    def _next_line(self, u):
+        """position behind the next newline at or after u (the size if there is none)"""
+        while u < self.size:
+            w = self.text(u, u + self.WINDOW)
+            k = w.find(b"\n")
+            if k >= 0:
+                return u + k + 1
+            u += len(w)
+        return self.size
+
+    def find_record_start(self, pos):
+        pos = int(pos)
+        if pos <= 0:
+            return 0
+        if pos >= self.size:
+            return self.size
+        line = pos if self.text(pos - 1, pos) == b"\n" else self._next_line(pos)
+        while line < self.size:
+            if self.text(line, line + 1) == b"@":
+                l2 = self._next_line(self._next_line(line))
+                if l2 < self.size and self.text(l2, l2 + 1) == b"+":
+                    return line
+            line = self._next_line(line)
+        return self.size
+
+    def skip_records(self, start, k):
+        at, left = int(start), 4 * int(k)
+        while left > 0 and at < self.size:
+            w = np.frombuffer(self.text(at, at + (4 << 20)), dtype=np.uint8)
+            nl = np.flatnonzero(w == 10)
+            if len(nl) >= left:
+                return at + int(nl[left - 1]) + 1
+            left -= len(nl)
+            at += len(w)
+        return min(at, self.size)
+
+    def count_records(self, start, end):
+        start, end = max(0, int(start)), min(self.size, int(end))
+        if end <= start:
+            return 0
+        lines = self._count_newlines(start, end)
+        if self.text(end - 1, end) != b"\n":
+            lines += 1                      # last line without terminator
+        return lines // 4
+
+    def _count_newlines(self, a, b):
+        m0, m1 = self._member_of(a), self._member_of(b - 1)
+        import torch
+        if not torch.cuda.is_available():
+            total = 0
+            for m in range(m0, m1 + 1, 64):
+                lo, hi = int(self.out_off[m]), int(self.out_off[min(m + 64, m1 + 1)])
+                total += self.text(max(a, lo), min(b, hi)).count(b"\n")
+            return total
+        from .. import gz
+        dg = gz.DeviceGunzip(torch.device("cuda", torch.cuda.current_device()))
+        total, m = 0, m0
+        hdr = 64                                               # bytes read in front of a member's DEFLATE data: its gzip header
+        with open(self.path, "rb") as fh:
+            while m <= m1:
+                e = m
+                nbytes = 0
+                while e <= m1 and nbytes < (32 << 20):
+                    nbytes += int(self.comp_len[e]) + 64
+                    e += 1
+                c0 = max(0, int(self.comp_off[m]) - hdr)
+                c1 = int(self.comp_off[e - 1]) + int(self.comp_len[e - 1]) + 8
+                fh.seek(c0)
+                buf = np.frombuffer(fh.read(c1 - c0), dtype=np.uint8).copy()
+                # the member table of this batch, built from the index (no second walk over the headers)
+                sl = dg._slots[0]
+                need = (e - m) * 24
+                if sl.mem_host is None or sl.mem_host.numel() < need:
+                    sl.mem_host = torch.empty(max(need, 1 << 16), dtype=torch.uint8, pin_memory=True)
+                    sl.cap_members = sl.mem_host.numel() // 24
+                tab = np.zeros((e - m, 3), dtype=np.int64)
+                tab[:, 0] = self.comp_off[m:e] - c0
+                tab[:, 1] = self.out_off[m:e] - self.out_off[m]
+                tab[:, 2] = self.comp_len[m:e] | ((self.out_off[m + 1:e + 1] - self.out_off[m:e]) << 32)
+                sl.mem_host[:need].copy_(torch.from_numpy(tab.view(np.uint8).reshape(-1)))
+                ob = int(self.out_off[e] - self.out_off[m])
+                text = dg.inflate(buf, len(buf), e - m, ob)
+                lo = max(a, int(self.out_off[m])) - int(self.out_off[m])
+                hi = min(b, int(self.out_off[e])) - int(self.out_off[m])
+                total += int((text[lo:hi] == 10).sum())
+                m = e
+        return total
+
+    def make_range(self, start, end):
+        r = BgzfRange((int(start), int(end)))
+        r.view = self
+        return r
+
+    def file_span(self, a, b):
+        """(first file byte, one past the last, text bytes to drop in front) of the members that hold the text [a, b)"""
+        if b <= a:
+            return 0, 0, 0
+        m0, m1 = self._member_of(a), self._member_of(b - 1)
+        prev_end = int(self.comp_off[m0 - 1] + self.comp_len[m0 - 1] + 8) if m0 > 0 else 0
+        return prev_end, int(self.comp_off[m1] + self.comp_len[m1] + 8), int(a - self.out_off[m0])
+
+
+def plan_ranges(paths, rank, world, all_gather=None, views=None):
+    """Ranges [(start, end)] - one per input file - that rank `rank` of `world` parses: bytes of a plain file, or (views = BgzfView
+    objects) positions in the decompressed stream of a BGZF file.
 
     One file: the file is cut at the record boundaries next to size*r/world. Two mate files: record i of R1 and record i of R2 must
     land on the same rank although their byte positions differ. Every rank counts the records of its own first-cut range of both
@@ -632,24 +872,25 @@ def plan_ranges(paths, rank, world, all_gather=None):
     only forward scans, each rank touches only its own bytes plus a few records past its end. The ranges concatenate to the
     whole file and hold the same record indices in every file, so the ranks' outputs concatenate to the single-rank output."""
     paths = list(paths)
-    sizes = [file_info(p)[0] for p in paths]
-    cuts = [[0] + [find_record_start(p, (sz * r) // world) for r in range(1, world)] + [sz] for p, sz in zip(paths, sizes)]
+    views = list(views) if views is not None else [_PlainView(p) for p in paths]
+    sizes = [v.size for v in views]
+    cuts = [[0] + [v.find_record_start((sz * r) // world) for r in range(1, world)] + [sz] for v, sz in zip(views, sizes)]
     for c in cuts:
         for r in range(1, world + 1):
             c[r] = max(c[r], c[r - 1])
     if len(paths) == 1 or world == 1:
-        return [(c[rank], c[rank + 1]) for c in cuts]
+        return [v.make_range(c[rank], c[rank + 1]) for v, c in zip(views, cuts)]
     if all_gather is None:
         raise ValueError("plan_ranges: several files need an all_gather callable")
-    mine = [count_records(p, c[rank], c[rank + 1]) for p, c in zip(paths, cuts)]
+    mine = [v.count_records(c[rank], c[rank + 1]) for v, c in zip(views, cuts)]
     counts = all_gather(mine)                                   # [world][files]
     before = [[sum(counts[q][f] for q in range(r)) for f in range(len(paths))] for r in range(world + 1)]
     if len(set(before[world])) != 1:
         raise ValueError("paired-end files have different numbers of records")
     K = [max(before[r]) for r in range(world)]
-    start = [skip_records(p, c[rank], K[rank] - before[rank][f]) for f, (p, c) in enumerate(zip(paths, cuts))]
+    start = [v.skip_records(c[rank], K[rank] - before[rank][f]) for f, (v, c) in enumerate(zip(views, cuts))]
     starts = all_gather(start)                                  # [world][files]
-    return [(starts[rank][f], starts[rank + 1][f] if rank + 1 < world else sizes[f]) for f in range(len(paths))]
+    return [views[f].make_range(starts[rank][f], starts[rank + 1][f] if rank + 1 < world else sizes[f]) for f in range(len(paths))]
 
 
 def chunk_schedule(seq_file, chunk_size, byte_range=None, first_chunk=1 << 17):

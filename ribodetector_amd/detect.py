@@ -423,7 +423,28 @@ class Predictor:
             chunk_reads = self.batch_size * self.chunk_size
         self._chunk_reads, self._shared = chunk_reads, None
         # plain inputs under several ranks: every rank parses, classifies and writes its own byte range (no label exchange)
-        self.sharded_parse = self.multi and not any(fx.file_info(p)[1] for p in self.input)
+        plain = not any(fx.file_info(p)[1] for p in self.input)
+        # ... and BGZF FASTQ inputs likewise: their members are independent, so every rank inflates (on its own GPU), parses, classifies
+        # and writes the members of its share (positions in the decompressed stream, fx.BgzfView). RD_BGZF_SHARD=0: one decoding rank
+        bgzf = (self.multi and not plain and os.environ.get("RD_BGZF_SHARD", "1") != "0"
+                and all(fx.get_seq_format(p) == "fqgz" and fx.bgzf_all_the_way(p) and fx.device_inflate_wanted(p) for p in self.input))
+        views = None
+        if bgzf:                    # the member index: rank 0 walks the headers, the others receive the three arrays per file
+            import torch.distributed as dist
+            idx = [None]
+            if self.rank == 0:
+                try:
+                    idx = [[fx.BgzfView.build_index(p) for p in self.input]]
+                except ValueError as e:     # not BGZF all the way (a plain member in the middle): the one-decoder path reads such files
+                    idx = [str(e)]
+            dist.broadcast_object_list(idx, src=0)
+            if isinstance(idx[0], str):
+                if self.rank == 0:
+                    self.logger.info('{}: one rank decodes'.format(idx[0]))
+                bgzf = False
+            else:
+                views = [fx.BgzfView(p, index=i) for p, i in zip(self.input, idx[0])]
+        self.sharded_parse = self.multi and (plain or bgzf)
         self.bytes_parsed = None
         if self.sharded_parse:
             import torch.distributed as dist
@@ -432,12 +453,13 @@ class Predictor:
                 out = [None] * self.world
                 dist.all_gather_object(out, obj)
                 return out
-            self._ranges = fx.plan_ranges(self.input, self.rank, self.world, all_gather)
+            self._ranges = fx.plan_ranges(self.input, self.rank, self.world, all_gather, views=views)
             self.bytes_parsed = [e - b for b, e in self._ranges]
+            totals = [v.size for v in views] if views else [fx.file_info(p)[0] for p in self.input]
             for r, bp in enumerate(all_gather(self.bytes_parsed)):
                 if self.rank == 0:
-                    self.logger.info('Rank {} parses {} bytes of {}'.format(
-                        r, ", ".join(str(b) for b in bp), ", ".join(str(fx.file_info(p)[0]) for p in self.input)))
+                    self.logger.info('Rank {} parses {} bytes of {}{}'.format(
+                        r, ", ".join(str(b) for b in bp), ", ".join(str(t) for t in totals), " (decompressed; BGZF members)" if bgzf else ""))
         def part(path):
             if not self.sharded_parse:
                 return path

@@ -575,3 +575,80 @@ def test_chunk_schedule_pairs_up_mate_files(tmp_path):
     short = [len(c.seq_len) for c in fx.get_seq_chunks(r1, 4096, schedule=[1000, 500])]        # ends early: chunks of its last entry
     assert short[:2] == [1000, 500] and set(short[2:-1]) == {500} and sum(short) == n
     assert fx.chunk_schedule(str(tmp_path / "s_1.fq"), 4096, byte_range=(0, 0)) == []
+
+
+def _bgzf_file(src, dst, blk):
+    """src re-framed as BGZF with members of `blk` input bytes, empty members sprinkled in, BGZF's end-of-file block last"""
+    import struct
+    import zlib
+    eof = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+    data = open(src, "rb").read()
+    with open(dst, "wb") as fh:
+        for i in range(0, len(data), blk):
+            piece = data[i:i + blk]
+            co = zlib.compressobj(6, zlib.DEFLATED, -15)
+            d = co.compress(piece) + co.flush()
+            fh.write(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(d) + 25) + d
+                     + struct.pack("<II", zlib.crc32(piece) & 0xffffffff, len(piece)))
+            if i % (3 * blk) == 0:
+                fh.write(eof)
+        fh.write(eof)
+
+
+def test_bgzf_view_gives_the_plain_files_answers(tmp_path):
+    """fx.BgzfView (positions in the decompressed stream of a BGZF file; the member index comes from the headers alone): size, text,
+    find_record_start, count_records, skip_records equal the librd_host.so helpers on the plain file - and so do the ranges plan_ranges
+    makes of them for mate files, for 1 ... 5 ranks"""
+    import threading
+    a1, o1, _ = synth.reads_numpy(6000, (40, 160), seed=51)
+    a2, o2, _ = synth.reads_numpy(6000, (40, 160), seed=52)
+    p1, p2 = str(tmp_path / "p_1.fq"), str(tmp_path / "p_2.fq")
+    synth.write_fastq(p1, a1, o1, 1)
+    synth.write_fastq(p2, a2, o2, 2, prefix="the_second_mate_has_longer_headers")
+    g1, g2 = str(tmp_path / "r_1.fq.gz"), str(tmp_path / "r_2.fq.gz")
+    _bgzf_file(p1, g1, 5000)
+    _bgzf_file(p2, g2, 65280)
+    assert fx.bgzf_all_the_way(g1) and not fx.bgzf_all_the_way(p1)
+    rng = np.random.default_rng(3)
+    for plain, gzp in ((p1, g1), (p2, g2)):
+        v = fx.BgzfView(gzp)
+        raw = open(plain, "rb").read()
+        assert v.size == len(raw) and v.text(0, v.size) == raw and v.text(777, 70001) == raw[777:70001]
+        for pos in list(rng.integers(0, v.size, 40)) + [0, 1, v.size - 1, v.size, v.size + 5]:
+            assert v.find_record_start(pos) == fx.find_record_start(plain, pos), pos
+        for _ in range(12):
+            a = fx.find_record_start(plain, int(rng.integers(0, v.size)))
+            b = fx.find_record_start(plain, int(rng.integers(a, v.size + 1)))
+            assert v.count_records(a, b) == fx.count_records(plain, a, b)
+            k = int(rng.integers(0, 2000))
+            assert v.skip_records(a, k) == fx.skip_records(plain, a, k)
+        c0, c1, drop = v.file_span(12345, v.size - 999)
+        assert 0 <= c0 < c1 <= os.path.getsize(gzp) and 0 <= drop < 65280
+
+    def plan(paths, views_of, world):
+        res, store, bar = [None] * world, {}, threading.Barrier(world)
+
+        def work(r):
+            calls = [0]
+
+            def ag(obj):
+                k = calls[0]
+                calls[0] += 1
+                store.setdefault(k, [None] * world)[r] = obj
+                bar.wait()
+                out = list(store[k])
+                bar.wait()
+                return out
+            res[r] = fx.plan_ranges(paths, r, world, ag, views=views_of() if views_of else None)
+        th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        return [[tuple(x) for x in r] for r in res]
+    for world in (1, 2, 3, 5):
+        assert plan([p1, p2], None, world) == plan([g1, g2], lambda: [fx.BgzfView(g1), fx.BgzfView(g2)], world)
+    # a plain gzip member behind the blocks: the index walk refuses (such a file goes to the one-decoder path)
+    import gzip
+    with open(g1, "ab") as fh:
+        fh.write(gzip.compress(b"@x\nAC\n+\nFF\n"))
+    with pytest.raises(ValueError, match="without a size subfield"):
+        fx.BgzfView(g1)

@@ -196,7 +196,7 @@ def _bgzf(src, dst):
         fh.write(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
 
 
-@pytest.mark.parametrize("suffix,world,shared", [("", 2, "1"), (".gz", 2, "1"), ("", 3, "1"), (".gz", 3, "1"), (".gz", 2, "0"), ("bgzf", 2, "1"), ("bgzf", 3, "0")])
+@pytest.mark.parametrize("suffix,world,shared", [("", 2, "1"), (".gz", 2, "1"), ("", 3, "1"), (".gz", 3, "1"), (".gz", 2, "0"), ("bgzf", 2, "1"), ("bgzf", 3, "1"), ("bgzf-gather", 2, "1"), ("bgzf-gather", 3, "0"), ("bgzf-mixed", 2, "1")])
 def test_cli_two_ranks_match_one(tmp_path, suffix, world, shared):
     """torchrun x2 (both ranks on this box's one GPU, exchange over gloo) must write the same files as one process.
     Plain input: every rank parses only its own byte range (mates cut at the same record index), writes its own parts, rank 0
@@ -212,7 +212,10 @@ def test_cli_two_ranks_match_one(tmp_path, suffix, world, shared):
     n = 5000
     a1, o1, _ = synth.reads_numpy(n, (40, 160), seed=51, rrna_frac=0.3)
     a2, o2, _ = synth.reads_numpy(n, (40, 160), seed=52, rrna_frac=0.3)
-    bgzf = suffix == "bgzf"     # BGZF inputs: the members are inflated on the GPU (by the decoding rank, or by every rank for itself)
+    # BGZF inputs: every rank inflates, parses and writes the members of its own share on its GPU ("bgzf"), or - RD_BGZF_SHARD=0,
+    # "bgzf-gather" - one decoding rank (or every rank for itself) inflates them all and the labels are gathered
+    suffix_in = suffix
+    bgzf, bgzf_shard = suffix.startswith("bgzf"), suffix == "bgzf"
     if bgzf:
         suffix = ".gz"
     i1, i2 = str(tmp_path / ("r_1.fq" + suffix)), str(tmp_path / ("r_2.fq" + suffix))
@@ -221,6 +224,18 @@ def test_cli_two_ranks_match_one(tmp_path, suffix, world, shared):
         synth.write_fastq(str(tmp_path / "p_2.fq"), a2, o2, 2, prefix="the_second_mate_has_longer_headers")
         _bgzf(str(tmp_path / "p_1.fq"), i1)
         _bgzf(str(tmp_path / "p_2.fq"), i2)
+        if suffix_in == "bgzf-mixed":      # a plain gzip member between the blocks of the first file: BGZF at both ends, but the index
+            import gzip                    # walk of the sharded reader meets the member and the run falls back to one decoding rank
+            raw = open(str(tmp_path / "p_1.fq"), "rb").read()
+            cut = [raw.rfind(b"\n@syn.", 0, len(raw) * k // 10) + 1 for k in (4, 6)]
+            for k, piece in enumerate((raw[:cut[0]], raw[cut[0]:cut[1]], raw[cut[1]:])):
+                open(str(tmp_path / ("piece%d.fq" % k)), "wb").write(piece)
+            _bgzf(str(tmp_path / "piece0.fq"), str(tmp_path / "piece0.gz"))
+            _bgzf(str(tmp_path / "piece2.fq"), str(tmp_path / "piece2.gz"))
+            with open(i1, "wb") as fh:
+                fh.write(open(str(tmp_path / "piece0.gz"), "rb").read()[:-28] + gzip.compress(open(str(tmp_path / "piece1.fq"), "rb").read())
+                         + open(str(tmp_path / "piece2.gz"), "rb").read())
+            bgzf_shard = True              # (asked for; the run itself must decide against it)
         from ribodetector_amd.data_loader import fastx_parser as fx
         assert fx.device_inflate_wanted(i1)
     else:
@@ -233,7 +248,8 @@ def test_cli_two_ranks_match_one(tmp_path, suffix, world, shared):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    env = dict(os.environ, RD_DIST_BACKEND="gloo", RD_LOCAL_DEVICE="0", PYTHONPATH=root, RD_SHARED_DECODE=shared)
+    env = dict(os.environ, RD_DIST_BACKEND="gloo", RD_LOCAL_DEVICE="0", PYTHONPATH=root, RD_SHARED_DECODE=shared,
+               RD_BGZF_SHARD="1" if bgzf_shard else "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(port), "-m", "ribodetector_amd.detect", "-l", "120", "-i", i1, i2, "-o", *two[:2], "-r", *two[2:],
            "-e", "both", "--chunk_size", "1", "-m", "3"]
@@ -247,12 +263,15 @@ def test_cli_two_ranks_match_one(tmp_path, suffix, world, shared):
     assert not [f for f in os.listdir(tmp_path) if ".part" in f]                      # the parts were joined and removed
     text = r.stdout + r.stderr                                                         # the logger writes to the console
     assert "Processed" in text and str(n) in text
-    if not suffix:
+    if suffix_in == "bgzf-mixed":
+        assert "one rank decodes" in text and "parses" not in text
+    elif not suffix or bgzf_shard:
         rows = re.findall(r"Rank (\d) parses (\d+), (\d+) bytes of (\d+), (\d+)", text)
         assert len(rows) == world
         for rk, b1, b2, t1, t2 in rows:
             assert 0.8 / world < int(b1) / int(t1) < 1.2 / world and 0.8 / world < int(b2) / int(t2) < 1.2 / world   # 1/W of each file per rank
-        assert sum(int(x[1]) for x in rows) == os.path.getsize(i1) and sum(int(x[2]) for x in rows) == os.path.getsize(i2)
+        plain1, plain2 = (str(tmp_path / "p_1.fq"), str(tmp_path / "p_2.fq")) if bgzf else (i1, i2)     # (BGZF: positions in the text)
+        assert sum(int(x[1]) for x in rows) == os.path.getsize(plain1) and sum(int(x[2]) for x in rows) == os.path.getsize(plain2)
     else:
         assert "parses" not in text
 

@@ -93,9 +93,27 @@ def main():
             with open(p, "rb") as fi, gzip.open(p + ".gz", "wb", compresslevel=4) as fo:
                 shutil.copyfileobj(fi, fo, 1 << 24)
             files.append(p)
+        # the same files as BGZF (framed by the device writer): under several ranks every rank inflates the members of its own share
+        import numpy as np
+        import torch
+        from ribodetector_amd.gz import DeviceGzip, eof_block
+        dgz = DeviceGzip("cuda:0")
+        for p in files:
+            t = torch.from_numpy(np.fromfile(p, dtype=np.uint8)).cuda()
+            nl = torch.nonzero(t == 10).flatten()
+            rs = torch.cat([torch.zeros(1, dtype=torch.int64, device="cuda"), nl[3::4] + 1])
+            o, info = dgz.compress_selected(t, rs, torch.zeros(rs.numel() - 1, dtype=torch.int8, device="cuda"), 0)
+            torch.cuda.synchronize()
+            os.makedirs(os.path.join(d, "bgzf"), exist_ok=True)
+            with open(os.path.join(d, "bgzf", os.path.basename(p) + ".gz"), "wb") as fh:
+                fh.write(o[: int(info[0])].cpu().numpy().tobytes())
+                fh.write(eof_block())
+            del t, nl, rs, o
+        del dgz
+        torch.cuda.empty_cache()
         out["cli_reads_per_file"] = a.reads
         out["cli"] = {}
-        for tag, ins in (("pe_plain", files), ("pe_gz", [f + ".gz" for f in files])):
+        for tag, ins in (("pe_plain", files), ("pe_gz", [f + ".gz" for f in files]), ("pe_bgzf", [os.path.join(d, "bgzf", os.path.basename(f) + ".gz") for f in files])):
             rows = []
             for w in (1, 8):
                 rows.append(run_cli(w, ins, d, tag, threads=10 if w == 1 else 2))
