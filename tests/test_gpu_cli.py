@@ -334,6 +334,38 @@ def test_cli_damaged_gz_under_two_ranks_ends_the_job(tmp_path):
     assert not [f for f in os.listdir("/dev/shm") if f.startswith("rd_%d_" % port)]
 
 
+def test_cli_damaged_bgzf_member_in_one_ranks_share_ends_the_job(tmp_path):
+    """BGZF input sharded over two ranks, one byte flipped in a member of rank 1's share: rank 1's GPU reports the member (CRC-32 /
+    code check), rank 1 leaves with the error, the job ends - no rank waits forever, no part file stays behind"""
+    import socket
+    import subprocess
+    import sys
+    import time
+    from ribodetector_amd import synth
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    arena, off, _ = synth.reads_numpy(30000, 100, seed=61)
+    plain = str(tmp_path / "p.fq")
+    synth.write_fastq(plain, arena, off, 1)
+    bad = str(tmp_path / "bad.fq.gz")
+    _bgzf(plain, bad)
+    blob = bytearray(open(bad, "rb").read())
+    blob[len(blob) * 3 // 4] ^= 0x5a
+    open(bad, "wb").write(bytes(blob))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, RD_DIST_BACKEND="gloo", RD_LOCAL_DEVICE="0", PYTHONPATH=root)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "-m", "ribodetector_amd.detect", "-l", "100", "-i", bad, "-o", str(tmp_path / "o.fq"),
+           "--chunk_size", "1", "-m", "3"]
+    t0 = time.time()
+    r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and time.time() - t0 < 200
+    assert "gzip member" in r.stderr + r.stdout or "size too small" in r.stderr + r.stdout or "not a gzip member" in r.stderr + r.stdout
+    assert not os.path.exists(str(tmp_path / "o.fq"))
+
+
 def test_cli_damaged_input_is_an_error(tmp_path):
     """a truncated .gz (or a FASTQ cut inside a record) stops the run with an error instead of writing a short output"""
     from ribodetector_amd import detect, synth
