@@ -114,8 +114,8 @@ struct rd_prefetch {
 };
 
 // a reader whose bytes are FED by the caller (rd_reader_open_feed): the decompressed text of gzip members inflated elsewhere - on the
-// GPU, librd_hip.so rd_gz_inflate_members. rd_reader_feed hands a span over and returns when the reader's prefetch thread has copied
-// all of it (a synchronous hand-over: the caller may reuse the buffer at once, no second copy, no queue of buffers to own).
+// GPU, librd_hip.so rd_gz_inflate_members. rd_reader_feed hands a span over and returns when the reader (the thread in rd_reader_next)
+// has copied all of it into its window (a synchronous hand-over: the caller may reuse the buffer at once, no queue of buffers to own).
 struct rd_feed {
     std::mutex m;
     std::condition_variable cv;
@@ -181,7 +181,27 @@ struct rd_reader {
         }
         if (end == in.size()) in.resize(in.size() * 2);
         long got;
-        if (pf) {
+        if (feed && !pf) {
+            // fed text goes straight from the feeder's buffer into the window (one copy, no thread in between); rd_reader_feed
+            // returns when its span has been taken. The stream's end - and a feeder's error - come after everything that was fed.
+            rd_feed *f = feed;
+            std::unique_lock<std::mutex> lk(f->m);
+            f->cv.wait(lk, [f]() { return f->left > 0 || f->eof; });
+            if (f->left == 0) {
+                if (!f->err.empty()) {
+                    failed = true;
+                    err = f->err;
+                }
+                got = 0;
+            } else {
+                const size_t k = std::min(in.size() - end, f->left);
+                memcpy(in.data() + end, f->p, k);
+                f->p += k;
+                f->left -= k;
+                if (f->left == 0) f->cv.notify_all();
+                got = (long)k;
+            }
+        } else if (pf) {
             if (blk_off == blk.size()) {
                 blk = pf->next(std::move(blk));
                 blk_off = 0;
@@ -685,20 +705,7 @@ int rd_reader_open_feed(int format, rd_reader **out) {
     r->fasta = format;
     r->in.resize(8 << 20);
     r->pos = r->end = 0;
-    rd_feed *f = r->feed = new rd_feed();
-    r->pf = new rd_prefetch(
-        [f](uint8_t *dst, size_t cap) -> long {
-            std::unique_lock<std::mutex> lk(f->m);
-            f->cv.wait(lk, [f]() { return f->left > 0 || f->eof; });
-            if (f->left == 0) return f->err.empty() ? 0L : -1L;   // (what was fed before the end is delivered first)
-            const size_t k = std::min(cap, f->left);
-            memcpy(dst, f->p, k);
-            f->p += k;
-            f->left -= k;
-            if (f->left == 0) f->cv.notify_all();
-            return (long)k;
-        },
-        [f]() { return f->err; });
+    r->feed = new rd_feed();
     r->eof = false;
     r->scan_next = 0;
     *out = r;
@@ -787,7 +794,10 @@ int rd_reader_next(rd_reader *r, int64_t max_records, uint8_t *buf, int64_t buf_
         while (n < max_records) {
             size_t lb[4], le[4];
             const int got = r->scan_lines(4, lb, le);
-            if (r->failed) RDH_FAIL("%s", r->err.c_str());
+            if (r->failed) {                 // a damaged stream: what was parsed before the damage is delivered, the next call fails
+                if (n > 0) break;
+                RDH_FAIL("%s", r->err.c_str());
+            }
             if (got == 0) { at_eof = true; break; }   // clean end of file
             if (got < 4) {
                 bool blank = true;   // tolerate trailing blank lines only
@@ -843,7 +853,10 @@ int rd_reader_next(rd_reader *r, int64_t max_records, uint8_t *buf, int64_t buf_
         while (n < max_records) {
             size_t lb, le;
             const int got = r->scan_lines(1, &lb, &le);
-            if (r->failed) RDH_FAIL("%s", r->err.c_str());
+            if (r->failed) {                 // a damaged stream: what was parsed before the damage is delivered, the next call fails
+                if (n > 0) break;
+                RDH_FAIL("%s", r->err.c_str());
+            }
             if (got == 0) {   // end of input
                 if (!r->pending_seq.empty() || (r->flush_empty_tail && !r->pending_header.empty())) {
                     int rc = emit();

@@ -652,3 +652,59 @@ def test_bgzf_view_gives_the_plain_files_answers(tmp_path):
         fh.write(gzip.compress(b"@x\nAC\n+\nFF\n"))
     with pytest.raises(ValueError, match="without a size subfield"):
         fx.BgzfView(g1)
+
+
+def test_feed_reader_equals_the_file_reader(tmp_path):
+    """rd_reader_open_feed: the text arrives in pieces of any size from another thread (what the device inflate does with a BGZF
+    file's text); the chunks equal the file reader's; an error given to rd_reader_feed_end surfaces after the records fed before it"""
+    import ctypes as C
+    import threading
+    from ribodetector_amd import _native as N
+    L = N.host_lib()
+    arena, off, _ = synth.reads_numpy(5000, (30, 150), seed=9)
+    p = str(tmp_path / "r.fq")
+    synth.write_fastq(p, arena, off, 1)
+    raw = open(p, "rb").read()
+    want = [(c.buf[c.rec_start[0]:c.rec_start[-1]].tobytes(), c.seq_len.copy()) for c in fx.get_seq_chunks(p, chunk_size=700)]
+
+    def run(pieces, error=b""):
+        h = C.c_void_p()
+        N.host_check(L.rd_reader_open_feed(0, C.byref(h)), "rd_reader_open_feed")
+
+        def feeder():
+            at = 0
+            for k in pieces:
+                piece = np.frombuffer(raw[at:at + k], dtype=np.uint8).copy()
+                if len(piece) and L.rd_reader_feed(h, piece.ctypes.data, len(piece)) != 0:
+                    return
+                at += k
+            L.rd_reader_feed_end(h, error)
+        th = threading.Thread(target=feeder)
+        th.start()
+        got, err = [], None
+        buf = np.zeros(1 << 20, dtype=np.uint8)
+        rs, so, sl = np.zeros(701, np.int64), np.zeros(700, np.int64), np.zeros(700, np.int32)
+        n, nb = C.c_int64(0), C.c_int64(0)
+        try:
+            while True:
+                rc = L.rd_reader_next(h, 700, buf.ctypes.data, buf.size, rs.ctypes.data, so.ctypes.data, sl.ctypes.data, C.byref(n), C.byref(nb))
+                if rc < 0:
+                    err = L.rd_host_last_error().decode()
+                    break
+                if n.value:
+                    got.append((buf[: nb.value].tobytes(), sl[: n.value].copy()))
+                if rc == 1:
+                    break
+        finally:
+            L.rd_reader_close(h)
+            th.join()
+        return got, err
+    rng = np.random.default_rng(1)
+    for pieces in ([len(raw)], [1] * 300 + [len(raw)], list(rng.integers(1, 70000, 4000)), [9 << 20]):
+        got, err = run(pieces)
+        # (chunks are "up to 700 records": compare the concatenation and the record lengths)
+        assert err is None and b"".join(g[0] for g in got) == b"".join(w[0] for w in want)
+        assert np.array_equal(np.concatenate([g[1] for g in got]), np.concatenate([w[1] for w in want]))
+    cut = raw.index(b"\n@", len(raw) // 2) + 1
+    got, err = run([cut], error=b"gzip member 7: CRC check failed")
+    assert err == "gzip member 7: CRC check failed" and b"".join(g[0] for g in got) == raw[:cut]
