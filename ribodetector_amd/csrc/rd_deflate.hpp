@@ -10,7 +10,8 @@
 //   rd_gz_sel_* / rd_gz_pack_kernel   selected records -> one contiguous byte stream (scan of the selected lengths + coalesced copy)
 //   rd_gz_deflate_kernel              one workgroup per member of 65,280 input bytes (BGZF's block size: the file is valid BGZF -
 //                                     bgzip / htslib index it, this build's reader inflates its members in parallel):
-//        wave w owns part w of the member (8,160 bytes: an eighth) and its own hash table in LDS (512 buckets of the 8 nearest earlier positions with
+//        wave w owns part w of the member (8,160 bytes: an eighth) and its own hash table in LDS (seeded with the last 512 bytes of the part
+//        before; 512 buckets of the 8 nearest earlier positions with
 //        the same 8-byte hash); a STRIP of 64 consecutive positions is handled at once, one per lane: hash, the bucket's 8 candidates
 //        (positions before the strip) and distance 1 (runs) compared over the first 16 bytes; then the 64 positions are inserted; then
 //        the strip's parse is resolved from the ballot of match lanes (lazy rule: a match shorter than 16 yields to a longer one at
@@ -31,8 +32,9 @@ namespace {
 constexpr int GZ_MEMBER = 65280;                       // input bytes per member (BGZF_BLOCK_SIZE 0xff00)
 constexpr int GZ_NQ = 8, GZ_PART = GZ_MEMBER / GZ_NQ;      // waves per member; each parses its own part 
 constexpr int GZ_THREADS = 64 * GZ_NQ;
+constexpr int GZ_SEED = 512;                                   // bytes of the part before that a wave's table starts with
 constexpr int GZ_CRCB = 128;                                   // bytes per thread in the CRC pass (GZ_CRCB * GZ_THREADS >= GZ_MEMBER)
-static_assert(GZ_CRCB * GZ_THREADS >= GZ_MEMBER && GZ_MEMBER % (4 * GZ_NQ) == 0 && GZ_PART < (1 << 14), "deflate kernel geometry");
+static_assert(GZ_CRCB * GZ_THREADS >= GZ_MEMBER && GZ_MEMBER % (4 * GZ_NQ) == 0 && GZ_PART + GZ_SEED < (1 << 14) && GZ_SEED % 64 == 0, "deflate kernel geometry");
 constexpr int GZ_HBITS = 9, GZ_WAYS = 8;                // 512 buckets of the 8 nearest earlier positions per wave
 constexpr int GZ_MINM = 8, GZ_MINRUN = 6, GZ_MAXM = 258, GZ_CAP = 16;
 constexpr int GZ_SLOT = 65536;                         // output bytes reserved per member (BGZF: total block size <= 65536)
@@ -475,6 +477,23 @@ __global__ __launch_bounds__(GZ_THREADS) void rd_gz_deflate_kernel(const uint8_t
         uint32_t *qt = mytoks + q0;
         int ntok = 0, carry = 0;
         const uint8_t *tb = reinterpret_cast<const uint8_t *>(S.text);
+        // the last GZ_SEED bytes of the part before are INSERTED into this wave's table first (hashed, not parsed): the first records of a
+        // part find their header and quality matches in the record before them like any other record (-3 % of size on sequencer-like
+        // FASTQ for 8 more strips of hashing per part; positions in the table count from qb)
+        const int qb = q0 >= GZ_SEED ? q0 - GZ_SEED : 0;
+        if (q0 < len)
+            for (int s0 = qb; s0 < q0; s0 += 64) {
+                const int p = s0 + lane;
+                if (p < q0) {
+                    const uint32_t w0 = gz_ld32(S.text, p), w1 = gz_ld32(S.text, p + 4);
+                    const uint32_t hh = ((w0 * 0x9E3779B1u) ^ (w1 * 0x85EBCA77u)) * 0xC2B2AE3Du;
+                    const uint32_t h = hh >> (32 - GZ_HBITS);
+                    const uint32_t tag = ((hh >> (30 - GZ_HBITS)) & 3u) << 14;
+                    const u32x4 ent = S.tab[wave][h];
+                    S.tab[wave][h] = u32x4{(ent.x << 16) | tag | (uint32_t)(p - qb + 1), (ent.y << 16) | (ent.x >> 16), (ent.z << 16) | (ent.y >> 16),
+                                           (ent.w << 16) | (ent.z >> 16)};
+                }
+            }
         for (int s0 = q0; s0 < q1; s0 += 64) {
             const int n = q1 - s0 < 64 ? q1 - s0 : 64;
             const int p = s0 + lane;
@@ -504,7 +523,7 @@ __global__ __launch_bounds__(GZ_THREADS) void rd_gz_deflate_kernel(const uint8_t
                     const uint32_t e16 = (ent[wy >> 1] >> (16 * (wy & 1))) & 0xffffu;
                     const uint32_t c16 = e16 & 0x3fffu;
                     const bool ok = c16 != 0 && (e16 & 0xc000u) == tag;
-                    const int c = ok ? q0 + (int)c16 - 1 : pl;
+                    const int c = ok ? qb + (int)c16 - 1 : pl;
                     const uint32_t *cq = S.text + (c >> 2);
                     const uint32_t sh = (uint32_t)(c & 3);
                     const uint32_t d0 = cq[0], d1 = cq[1], d2 = cq[2], d3 = cq[3], d4 = cq[4];
@@ -527,7 +546,7 @@ __global__ __launch_bounds__(GZ_THREADS) void rd_gz_deflate_kernel(const uint8_t
             }
             // insert: the occupants from before this strip move one way down (lanes of this strip with the same hash differ only in the
             // low half of .x: whichever of them wins the store leaves a valid bucket)
-            if (hv) S.tab[wave][h] = u32x4{(ent.x << 16) | tag | (uint32_t)(p - q0 + 1), (ent.y << 16) | (ent.x >> 16), (ent.z << 16) | (ent.y >> 16),
+            if (hv) S.tab[wave][h] = u32x4{(ent.x << 16) | tag | (uint32_t)(p - qb + 1), (ent.y << 16) | (ent.x >> 16), (ent.z << 16) | (ent.y >> 16),
                                            (ent.w << 16) | (ent.z >> 16)};
             GZ_STAMP(8);    // strip: per-lane candidates + insert
             if (carry >= n) {
@@ -561,7 +580,7 @@ __global__ __launch_bounds__(GZ_THREADS) void rd_gz_deflate_kernel(const uint8_t
                         const int way = lane >> 3, sub = lane & 7;
                         const uint32_t ew = way < 2 ? e0 : way < 4 ? e1 : way < 6 ? e2 : e3;
                         const bool act = (fullf >> way) & 1u;
-                        const int c = act ? q0 + (int)((ew >> (16 * (way & 1))) & 0x3fffu) - 1 : pf;
+                        const int c = act ? qb + (int)((ew >> (16 * (way & 1))) & 0x3fffu) - 1 : pf;
                         int glen = act ? limf : 0;
                         bool open = act;
                         for (int base = GZ_CAP; base < limf; base += 32) {
@@ -576,7 +595,7 @@ __global__ __launch_bounds__(GZ_THREADS) void rd_gz_deflate_kernel(const uint8_t
                         const int bw = 7 - (key & 7);
                         const uint32_t eb = bw < 2 ? e0 : bw < 4 ? e1 : bw < 6 ? e2 : e3;
                         bestL = key >> 3;
-                        bestD = pf - (q0 + (int)((eb >> (16 * (bw & 1))) & 0x3fffu) - 1);
+                        bestD = pf - (qb + (int)((eb >> (16 * (bw & 1))) & 0x3fffu) - 1);
                     }
                     if (fullf >> 8) {   // the run: the first byte from pf + 16 on that differs from the byte before pf
                         const uint32_t sp = (uint32_t)tb[pf - 1] * 0x01010101u;

@@ -6,7 +6,7 @@
 // header, BGZF framing) in a form that zlib's inflate checks on this machine. The kernel follows the same steps:
 //
 //   member  = 65,280 input bytes (BGZF's block size: the output is a valid BGZF file), one workgroup;
-//   part    = 8,160 bytes (an eighth), one wave: its own hash table of 512 buckets x the 8 nearest earlier positions (8-byte hashes; matches
+//   part    = 8,160 bytes (an eighth), one wave: its own hash table (seeded with the last 512 bytes of the part before) of 512 buckets x the 8 nearest earlier positions (8-byte hashes; matches
 //             of 8+ bytes only: on FASTQ the shorter ones cost more bits than the 2-bit literals they replace - measured here);
 //   strip   = 64 consecutive positions, one per lane: every lane hashes its position, looks its candidate up (positions before the
 //             strip), also tries distance 1 (runs), measures the match; then all 64 positions are inserted (the highest lane wins a
@@ -35,6 +35,9 @@
 #endif
 #ifndef NWAYS
 #define NWAYS 8
+#endif
+#ifndef SEED
+#define SEED 512   /* bytes of the part before that a part's table starts with */
 #endif
 #ifndef LAZY_MAX
 #define LAZY_MAX 16
@@ -79,6 +82,15 @@ static int parse_part(const uint8_t *m, int q0, int q1, Tok *out) {
     static uint32_t tab[1 << HBITS][NWAYS];
     memset(tab, 0, sizeof(tab));
     int nt = 0, carry = 0, dlast = 0;
+    for (int s0 = q0 - SEED < 0 ? 0 : q0 - SEED; s0 < q0; s0 += 64) {     // the end of the part before: inserted, not parsed
+        const int n = q0 - s0 < 64 ? q0 - s0 : 64;
+        for (int l = 0; l < n; ++l) {
+            const int h = hashn(m + s0 + l);
+            if (tab[h][0] && (int)tab[h][0] - 1 < s0)
+                for (int wy = NWAYS - 1; wy > 0; --wy) tab[h][wy] = tab[h][wy - 1];
+            tab[h][0] = (uint32_t)(s0 + l + 1);
+        }
+    }
     for (int s0 = q0; s0 < q1; s0 += 64) {
         const int n = q1 - s0 < 64 ? q1 - s0 : 64;
         int L[64], D[64], H[64];
