@@ -363,7 +363,7 @@ def gzip_record(torch, synth, dev, arena, offsets, lens, labels):
     return {"kernel": "rd_gz_deflate_kernel (+ select, pack, compact)", "records": n, "device_gunzip": gun, "text_bytes": plain, "compressed_bytes": comp,
             "ratio": plain / max(comp, 1), "size_vs_zlib_level_5": (comp / max(plain, 1)) / z5, "ms_per_chunk_both_label_files": ms,
             "GB_per_s_of_text": plain / ms / 1e6, "reads_per_s": n / ms * 1e3, "members": sum(int(outs[v][1][2]) for v in (0, 1)),
-            "bound": "dependent-issue latency at two waves per SIMD (155 KB of LDS: one workgroup of eight waves per CU); HBM: %.3f of 8 TB/s" % (plain / ms / 1e6 / HBM_PEAK_GBPS),
+            "bound": "dependent-issue latency at four waves per SIMD (155 KB of LDS: one workgroup of sixteen waves per CU); HBM: %.3f of 8 TB/s" % (plain / ms / 1e6 / HBM_PEAK_GBPS),
             "what": "the FASTQ text of one step's first mate (constant quality, 218 B per record) split by the step's labels into the two "
                     "gzip (BGZF) streams the CLI appends to its .gz outputs; zlib level 5 = the reference's gzip.open(..., compresslevel=5)"}
 

@@ -10,8 +10,8 @@
 //   rd_gz_sel_* / rd_gz_pack_kernel   selected records -> one contiguous byte stream (scan of the selected lengths + coalesced copy)
 //   rd_gz_deflate_kernel              one workgroup per member of 65,280 input bytes (BGZF's block size: the file is valid BGZF -
 //                                     bgzip / htslib index it, this build's reader inflates its members in parallel):
-//        wave w owns part w of the member (8,160 bytes: an eighth) and its own hash table in LDS (seeded with the last 512 bytes of the part
-//        before; 512 buckets of the 8 nearest earlier positions with
+//        wave w owns part w of the member (4,080 bytes: a sixteenth) and its own hash table in LDS (seeded with the last 512 bytes of the
+//        part before; 256 buckets of the 8 nearest earlier positions with
 //        the same 8-byte hash); a STRIP of 64 consecutive positions is handled at once, one per lane: hash, the bucket's 8 candidates
 //        (positions before the strip) and distance 1 (runs) compared over the first 16 bytes; then the 64 positions are inserted; then
 //        the strip's parse is resolved from the ballot of match lanes (lazy rule: a match shorter than 16 yields to a longer one at
@@ -30,12 +30,12 @@
 namespace {
 
 constexpr int GZ_MEMBER = 65280;                       // input bytes per member (BGZF_BLOCK_SIZE 0xff00)
-constexpr int GZ_NQ = 8, GZ_PART = GZ_MEMBER / GZ_NQ;      // waves per member; each parses its own part 
+constexpr int GZ_NQ = 16, GZ_PART = GZ_MEMBER / GZ_NQ;      // waves per member; each parses its own part 
 constexpr int GZ_THREADS = 64 * GZ_NQ;
 constexpr int GZ_SEED = 512;                                   // bytes of the part before that a wave's table starts with
-constexpr int GZ_CRCB = 128;                                   // bytes per thread in the CRC pass (GZ_CRCB * GZ_THREADS >= GZ_MEMBER)
+constexpr int GZ_CRCB = 64;                                    // bytes per thread in the CRC pass (GZ_CRCB * GZ_THREADS >= GZ_MEMBER)
 static_assert(GZ_CRCB * GZ_THREADS >= GZ_MEMBER && GZ_MEMBER % (4 * GZ_NQ) == 0 && GZ_PART + GZ_SEED < (1 << 14) && GZ_SEED % 64 == 0, "deflate kernel geometry");
-constexpr int GZ_HBITS = 9, GZ_WAYS = 8;                // 512 buckets of the 8 nearest earlier positions per wave
+constexpr int GZ_HBITS = 8, GZ_WAYS = 8;                // 256 buckets of the 8 nearest earlier positions per wave
 constexpr int GZ_MINM = 8, GZ_MINRUN = 6, GZ_MAXM = 258, GZ_CAP = 16;
 constexpr int GZ_SLOT = 65536;                         // output bytes reserved per member (BGZF: total block size <= 65536)
 constexpr int GZ_HDR = 18, GZ_TRL = 8;
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void rd_gz_pack_kernel(const uint8_t *__restri
 struct __attribute__((aligned(16))) GzSmem {
     uint32_t text[(GZ_MEMBER + 16) / 4];      // the member's bytes (+ zero pad); after the parse: the output (header, deflate data, trailer)
     u32x4 tab[GZ_NQ][1 << GZ_HBITS];          // per wave: hash -> the 8 nearest earlier positions in its part (+ 1), 16 bits each, nearest first
-    uint32_t hist[GZ_NQ][GZ_NSYM];            // per wave: symbol counts of its part
+    uint32_t hist[GZ_NQ][GZ_NSYM / 2];        // per wave: symbol counts of its part, two 16-bit counters per word (a part has < 2^16 tokens)
     uint32_t freq[GZ_NSYM];
     uint8_t lens[GZ_NSYM];
     uint16_t codes[GZ_NSYM];
@@ -263,6 +263,10 @@ __device__ __forceinline__ uint32_t gz_x8n(uint32_t nbytes) {   // x^(8 nbytes) 
         if (nbytes & 1) p = gz_multmodp(GZ_X2N[k & 31], p);
     return p;
 }
+
+// per-wave symbol counters: two 16-bit counters in a 32-bit word (LDS atomics are 32 bits wide; a part holds < 2^16 tokens)
+__device__ __forceinline__ void gz_count(uint32_t *hist, int sym) { atomicAdd(&hist[sym >> 1], 1u << (16 * (sym & 1))); }
+__device__ __forceinline__ uint32_t gz_counted(const uint32_t *hist, int sym) { return (hist[sym >> 1] >> (16 * (sym & 1))) & 0xffffu; }
 
 __device__ __forceinline__ uint32_t gz_scan_wg(uint32_t v, uint32_t *sh, uint32_t &total) {   // exclusive, the deflate kernel's GZ_THREADS threads
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -453,7 +457,7 @@ __global__ __launch_bounds__(GZ_THREADS) void rd_gz_deflate_kernel(const uint8_t
                 S.text[k] = v;
             }
             for (int k = tid; k < GZ_NQ * (1 << GZ_HBITS); k += GZ_THREADS) (&S.tab[0][0])[k] = u32x4{0u, 0u, 0u, 0u};
-            for (int k = tid; k < GZ_NQ * GZ_NSYM; k += GZ_THREADS) (&S.hist[0][0])[k] = 0;
+            for (int k = tid; k < GZ_NQ * (GZ_NSYM / 2); k += GZ_THREADS) (&S.hist[0][0])[k] = 0;
             if (tid == 0) S.crc = 0;
         }
         __syncthreads();
@@ -479,7 +483,7 @@ __global__ __launch_bounds__(GZ_THREADS) void rd_gz_deflate_kernel(const uint8_t
         const uint8_t *tb = reinterpret_cast<const uint8_t *>(S.text);
         // the last GZ_SEED bytes of the part before are INSERTED into this wave's table first (hashed, not parsed): the first records of a
         // part find their header and quality matches in the record before them like any other record (-3 % of size on sequencer-like
-        // FASTQ for 8 more strips of hashing per part; positions in the table count from qb)
+        // FASTQ for 8 more strips of hashing per part of 64; positions in the table count from qb)
         const int qb = q0 >= GZ_SEED ? q0 - GZ_SEED : 0;
         if (q0 < len)
             for (int s0 = qb; s0 < q0; s0 += 64) {
@@ -622,8 +626,8 @@ __global__ __launch_bounds__(GZ_THREADS) void rd_gz_deflate_kernel(const uint8_t
                 const int idx = __popcll(sel & ((1ull << lane) - 1));
                 qt[ntok + idx] = ismatch ? ((uint32_t)L << 16) | (uint32_t)D : byte;
                 if (ismatch) {
-                    atomicAdd(&S.hist[wave][257 + S.lsym[L - 3]], 1u);
-                    atomicAdd(&S.hist[wave][286 + S.dsym[D <= 256 ? D - 1 : 256 + ((D - 1) >> 7)]], 1u);
+                    gz_count(S.hist[wave], 257 + S.lsym[L - 3]);
+                    gz_count(S.hist[wave], 286 + S.dsym[D <= 256 ? D - 1 : 256 + ((D - 1) >> 7)]);
                 }
             }
             // literal counts: not here (64 lanes adding to the same few counters - A, C, G, T ... - every strip); the strip leaves the mask
@@ -641,7 +645,7 @@ __global__ __launch_bounds__(GZ_THREADS) void rd_gz_deflate_kernel(const uint8_t
                 while (lm) {
                     const int b = __builtin_ctzll(lm);
                     lm &= lm - 1;
-                    atomicAdd(&S.hist[wave][sb[b]], 1u);
+                    gz_count(S.hist[wave], sb[b]);
                 }
             }
         }
@@ -653,7 +657,7 @@ __global__ __launch_bounds__(GZ_THREADS) void rd_gz_deflate_kernel(const uint8_t
         for (int s = tid; s < GZ_NSYM; s += GZ_THREADS) {
             uint32_t f = 0;
 #pragma unroll
-            for (int w = 0; w < GZ_NQ; ++w) f += S.hist[w][s];
+            for (int w = 0; w < GZ_NQ; ++w) f += gz_counted(S.hist[w], s);
             if (s == 256) f += 1;   // end of block
             S.freq[s] = f;
         }
@@ -689,7 +693,7 @@ __global__ __launch_bounds__(GZ_THREADS) void rd_gz_deflate_kernel(const uint8_t
             uint32_t b = 0;
             for (int s = lane; s < GZ_NSYM; s += 64) {
                 const uint32_t extra = s >= 286 ? GZ_DEXTRA[s - 286 < 30 ? s - 286 : 0] : s >= 257 ? GZ_LEXTRA[s - 257] : 0;
-                if (s < 316) b += S.hist[wave][s] * (S.lens[s] + extra);
+                if (s < 316) b += gz_counted(S.hist[wave], s) * (S.lens[s] + extra);
             }
             b = gz_wave_scan(b);
             if (lane == 63) S.qbits[wave] = b;
