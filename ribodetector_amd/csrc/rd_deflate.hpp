@@ -197,6 +197,7 @@ struct __attribute__((aligned(16))) GzSmem {
     uint8_t dsym[512];                        // zlib's _dist_code
     uint64_t litmask[GZ_NQ][(GZ_PART + 63) / 64];   // per strip: which positions became literals
     uint32_t scan[GZ_NQ];
+    uint32_t blc[16];                         // leaves per code length (tree scratch)
     uint32_t qbits[GZ_NQ], qtok[GZ_NQ];
     uint32_t crc;
     int used, hlit, hdist, hclen;
@@ -338,19 +339,29 @@ __device__ void gz_huff(GzSmem &S, uint32_t *freq, uint8_t *lens, uint16_t *code
             S.parent[pick1] = (uint16_t)nn;
             ++nn;
         }
+        // depths of the INTERNAL nodes only (each hangs below a node made later): the leaves - most of the nodes - take theirs from
+        // their parents in parallel below, and are counted and given their lengths in parallel too
         S.depth[nn - 1] = 0;
-        for (int i = nn - 2; i >= 0; --i) S.depth[i] = (uint8_t)(S.depth[S.parent[i]] + 1);   // (<= 287: fits)
+        for (int i = nn - 2; i >= ns; --i) S.depth[i] = (uint8_t)(S.depth[S.parent[i]] + 1);   // (<= 287: fits)
+    }
+    if (tid <= MAXB) S.blc[tid] = 0;
+    __syncthreads();
+    const int ns = used;
+    if (tid < ns) {
+        int d = S.depth[S.parent[tid]] + 1;
+        if (d > MAXB) d = MAXB;
+        atomicAdd(&S.blc[d], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
         int bl[MAXB + 1];
-#pragma unroll
-        for (int k = 0; k <= MAXB; ++k) bl[k] = 0;
         long K = 0;
-        for (int i = 0; i < ns; ++i) {
-            int d = S.depth[i];
-            if (d > MAXB) d = MAXB;
 #pragma unroll
-            for (int k = 1; k <= MAXB; ++k) bl[k] += (k == d) ? 1 : 0;
-            K += 1L << (MAXB - d);
+        for (int k = 0; k <= MAXB; ++k) {
+            bl[k] = k ? (int)S.blc[k] : 0;
+            if (k) K += (long)bl[k] << (MAXB - k);
         }
+        bool moved = false;
         while (K > (1L << MAXB)) {   // zlib gen_bitlen: a leaf moves one level down and takes an overflowed leaf as its brother
             int bits = MAXB - 1;
             for (;;) {
@@ -367,11 +378,22 @@ __device__ void gz_huff(GzSmem &S, uint32_t *freq, uint8_t *lens, uint16_t *code
             }
             bl[MAXB] -= 1;
             K -= 1;
+            moved = true;
         }
-        int i = 0;
+        if (moved) {
 #pragma unroll
-        for (int k = MAXB; k >= 1; --k)
-            for (int c = 0; c < bl[k]; ++c) lens[S.order[i++]] = (uint8_t)k;
+            for (int k = 1; k <= MAXB; ++k) S.blc[k] = (uint32_t)bl[k];
+        }
+    }
+    __syncthreads();
+    if (tid < ns) {   // leaf tid of the (frequency, symbol) order: the rarest leaves get the longest codes
+        int len = 0, cum = 0;
+        for (int k = MAXB; k >= 1; --k) {
+            const int c = (int)S.blc[k];
+            if (len == 0 && tid < cum + c) len = k;
+            cum += c;
+        }
+        lens[S.order[tid]] = (uint8_t)len;
     }
     __syncthreads();
     // canonical codes
