@@ -819,26 +819,17 @@ class BgzfView:
         hdr = 64                                               # bytes read in front of a member's DEFLATE data: its gzip header
         with open(self.path, "rb") as fh:
             while m <= m1:
-                e = m
-                nbytes = 0
-                while e <= m1 and nbytes < (32 << 20):
-                    nbytes += int(self.comp_len[e]) + 64
-                    e += 1
+                e = min(m1 + 1, max(m + 1, int(np.searchsorted(self.comp_off, self.comp_off[m] + (32 << 20)))))   # ~32 MB of members
                 c0 = max(0, int(self.comp_off[m]) - hdr)
                 c1 = int(self.comp_off[e - 1]) + int(self.comp_len[e - 1]) + 8
                 fh.seek(c0)
                 buf = np.frombuffer(fh.read(c1 - c0), dtype=np.uint8).copy()
                 # the member table of this batch, built from the index (no second walk over the headers)
-                sl = dg._slots[0]
-                need = (e - m) * 24
-                if sl.mem_host is None or sl.mem_host.numel() < need:
-                    sl.mem_host = torch.empty(max(need, 1 << 16), dtype=torch.uint8, pin_memory=True)
-                    sl.cap_members = sl.mem_host.numel() // 24
                 tab = np.zeros((e - m, 3), dtype=np.int64)
                 tab[:, 0] = self.comp_off[m:e] - c0
                 tab[:, 1] = self.out_off[m:e] - self.out_off[m]
                 tab[:, 2] = self.comp_len[m:e] | ((self.out_off[m + 1:e + 1] - self.out_off[m:e]) << 32)
-                sl.mem_host[:need].copy_(torch.from_numpy(tab.view(np.uint8).reshape(-1)))
+                dg.set_members(tab)
                 ob = int(self.out_off[e] - self.out_off[m])
                 text = dg.inflate(buf, len(buf), e - m, ob)
                 lo = max(a, int(self.out_off[m])) - int(self.out_off[m])

@@ -135,6 +135,18 @@ class DeviceGunzip:
             raise ValueError(N.host_lib().rd_host_last_error().decode())
         return int(n.value), int(consumed.value), int(ob.value), rc == 1
 
+    def set_members(self, table, slot=0):
+        """a member table made by the caller instead of index(): int64[n, 3] rows of (offset of the DEFLATE data in the buffer, offset of
+        the text, in_len | out_len << 32) - the 24-byte layout of rd_gz_member. Returns n."""
+        sl = self._slots[slot]
+        rows = self._np.ascontiguousarray(table, dtype=self._np.int64).reshape(-1, 3)
+        need = rows.shape[0] * 24
+        if sl.mem_host is None or sl.mem_host.numel() < need:
+            sl.mem_host = torch.empty(max(need, 1 << 16), dtype=torch.uint8, pin_memory=True)
+            sl.cap_members = sl.mem_host.numel() // 24
+        sl.mem_host[:need].copy_(torch.from_numpy(rows.view(self._np.uint8).reshape(-1)))
+        return rows.shape[0]
+
     def submit(self, buf, nbytes, n, out_bytes, slot=0, host_text=None):
         """queue the batch indexed by the last index(..., slot) call over buf[:nbytes] (buf: pinned host memory if the copy is to be
         asynchronous; it may be reused once finish() has returned). host_text: pinned uint8 tensor that receives the text."""
