@@ -37,25 +37,14 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+sys.path.insert(1, os.path.join(ROOT, "tools"))
+from e2e_bench import E2E, encoder_record, gzip_record, shm_free, thread_cpu, usable_cores      # noqa: E402  (tools/e2e_bench.py)
 
 READ_LEN = 100
 PEAKS = {"mfma_f32": 157.3, "simple": 157.3, "mfma_f16x3_t32": 2500.0}   # dense TFLOP/s, MI355X_MICROARCH.md
 MFMA_FLOPS_PER_ALGO_FLOP = {"mfma_f32": 1, "simple": 1, "mfma_f16x3_t32": 3}   # f16x3 issues three f16 products per fp32 product
 HBM_PEAK_GBPS = 8000.0
 WORKLOADS = {"pe100": (True, 100, 100), "se100": (False, 100, 100), "pe150": (True, 150, 150), "var300": (False, 300, 300)}
-
-
-def usable_cores():
-    """host cores this process may actually use: min(affinity, cgroup cpu quota). The GPU boxes expose 256 logical CPUs
-    but cap the container at 16 CPUs' worth of time (cpu.max = 1600000 100000)."""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
-        if quota != "max":
-            n = min(n, max(1, int(int(quota) / int(period))))
-    except Exception:
-        pass
-    return n
 
 
 def cpu_baseline(arena_np, n_reads, target_s=12.0):
@@ -86,6 +75,7 @@ def cpu_baseline(arena_np, n_reads, target_s=12.0):
     enc_model = 1.0 / (1.0 / (n / dt) + t_enc_per_read)
     return {"logits": cpu_logits, "n": n, "value": n / dt, "unit": "reads/s", "cores": cores, "kind": "port",
             "encode_plus_model_reads_per_s": enc_model, "os_cpu_count": os.cpu_count() or 0,
+            "sample_short": "first %d reads of rank 0's R1 stream; C port (AVX + OpenMP) of the padded 100-step BiLSTM, batch 1024/thread, %d threads, %.1f s" % (n, cores, dt),
             "sample": "first %d reads of the rank-0 R1 stream (100 bp); oracle rdo_forward_padded_batched = the ribodetector_cpu "
                       "algorithm (padded BiLSTM over all 100 steps x 2 directions, batch 1024, one batch per thread) as a hand-vectorised "
                       "AVX-512/AVX2 + OpenMP C port, %d threads = usable cores of this container (os.cpu_count() = %d), %.1f s. "
@@ -93,21 +83,6 @@ def cpu_baseline(arena_np, n_reads, target_s=12.0):
                       "[1024,100,4] fp32 one-hot input in C (the reference's Python encoder is ~100x slower than that and would "
                       "dominate). onnxruntime is not installed, so this port stands in for ribodetector_cpu"
                       % (n, cores, os.cpu_count() or 0, dt)}
-
-
-def thread_cpu():
-    """CPU seconds (user + system) of every thread of this process, by thread id: {tid: (name, seconds)}"""
-    out = {}
-    tick = os.sysconf("SC_CLK_TCK")
-    for tid in os.listdir("/proc/self/task"):
-        try:
-            st = open("/proc/self/task/%s/stat" % tid).read()
-            name = st[st.index("(") + 1:st.rindex(")")]
-            f = st[st.rindex(")") + 2:].split()
-            out[tid] = (name, (int(f[11]) + int(f[12])) / tick)
-        except Exception:
-            pass
-    return out
 
 
 def free_port():
@@ -176,235 +151,112 @@ def pmc_traffic(args, kernel_substr, timeout_s=240):
     return out, None
 
 
-def shutil_free(path):
-    import shutil
-    try:
-        return shutil.disk_usage(path).free
-    except OSError:
-        return 0
-
-
-def gzip_file(src, dst, level=4):
-    """src -> dst as ONE gzip member (what a sequencer's .fastq.gz is: one DEFLATE stream). libdeflate when the box has it
-    (outside every timed region: the input of the gz -> gz measurement), zlib otherwise."""
-    import ctypes as C
-    import zlib
-    data = open(src, "rb").read()
-    try:
-        ld = C.CDLL("libdeflate.so.0")
-        ld.libdeflate_alloc_compressor.restype = C.c_void_p
-        ld.libdeflate_alloc_compressor.argtypes = [C.c_int]
-        ld.libdeflate_gzip_compress_bound.restype = C.c_size_t
-        ld.libdeflate_gzip_compress_bound.argtypes = [C.c_void_p, C.c_size_t]
-        ld.libdeflate_gzip_compress.restype = C.c_size_t
-        ld.libdeflate_gzip_compress.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t]
-        ld.libdeflate_free_compressor.argtypes = [C.c_void_p]
-        c = ld.libdeflate_alloc_compressor(level)
-        cap = ld.libdeflate_gzip_compress_bound(c, len(data))
-        buf = C.create_string_buffer(cap)
-        n = ld.libdeflate_gzip_compress(c, data, len(data), buf, cap)
-        ld.libdeflate_free_compressor(c)
-        if n == 0:
-            raise OSError("libdeflate_gzip_compress failed")
-        with open(dst, "wb") as fh:
-            fh.write(memoryview(buf)[:n])
-        return "libdeflate level %d" % level
-    except OSError:
-        co = zlib.compressobj(1, zlib.DEFLATED, 31)
-        with open(dst, "wb") as fh:
-            for i in range(0, len(data), 1 << 24):
-                fh.write(co.compress(data[i:i + (1 << 24)]))
-            fh.write(co.flush())
-        return "zlib level 1"
-
-
-def e2e_record(torch, synth, arenas, offsets, lens, L, ensure, timed_calls=1, gz=False, threads=None, gz_in=None):
-    """Timed region (iii) of SURVEY §8d: the whole `ribodetector` CLI - detect.main(): model load (incl. building the prefix-state
-    table), native FASTQ parse, H2D, kernels, label D2H, output write - on a FASTQ file (pair) built from the rank-0 stream of this
-    run in tmpfs (the reference flow: detect.py:464-499). One warm call (it pays one-off costs of the process: first pinned
-    allocations, page cache), then `timed_calls` calls; the MEDIAN is reported. gz: the inputs are single-member .gz files and the
-    outputs are written as .gz (the reference compresses by extension at level 5, detect.py:729-741) - the form sequencer data
-    arrives in, bound by the host's inflate / deflate threads."""
-    import shutil
-    import tempfile
-    import threading
-    from ribodetector_amd import detect
-    d = tempfile.mkdtemp(prefix="rd_e2e_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
-    try:
-        n = int(lens.numel())
-        ins, how = [], None
-        for m, a in enumerate(arenas):
-            p = os.path.join(d, "r_%d.fq" % (m + 1))
-            synth.fastq_image_torch(a, offsets, lens, mate=m + 1).cpu().numpy().tofile(p)
-            ins.append(p)
-        plain_bytes = sum(os.path.getsize(p) for p in ins)
-        if gz and gz_in == "bgzf":
-            # BGZF inputs (what bgzip and this build's own writer produce): framed by the device writer, outside every timed region
-            from ribodetector_amd.gz import DeviceGzip, eof_block
-            dg = DeviceGzip(arenas[0].device)
-            for p in ins:
-                import numpy as np
-                t = torch.from_numpy(np.fromfile(p, dtype=np.uint8)).to(arenas[0].device)
-                rs = torch.zeros(n + 1, dtype=torch.int64, device=t.device)
-                torch.cumsum(18 + 2 * lens.to(torch.int64), 0, out=rs[1:])
-                o, info = dg.compress_selected(t, rs, torch.zeros(n, dtype=torch.int8, device=t.device), 0)
-                torch.cuda.synchronize(t.device)
-                with open(p + ".gz", "wb") as fh:
-                    fh.write(o[: int(info[0])].cpu().numpy().tobytes())
-                    fh.write(eof_block())
-                os.remove(p)
-                del t, o
-            del dg
-            ins, how = [p + ".gz" for p in ins], "BGZF members of 65,280 bytes (device writer)"
-        elif gz and gz_in is not False:
-            res = [None] * len(ins)
-
-            def comp(i):
-                res[i] = gzip_file(ins[i], ins[i] + ".gz")
-            ths = [threading.Thread(target=comp, args=(i,)) for i in range(len(ins))]
-            for t in ths:
-                t.start()
-            for t in ths:
-                t.join()
-            for p in ins:
-                os.remove(p)
-            ins, how = [p + ".gz" for p in ins], res[0]
-        ext = ".fq.gz" if gz else ".fq"
-        outs = [os.path.join(d, "non_%d%s" % (m + 1, ext)) for m in range(len(ins))]
-        rrs = [os.path.join(d, "rrna_%d%s" % (m + 1, ext)) for m in range(len(ins))]
-        argv = ["-l", str(L), "-i", *ins, "-o", *outs, "-r", *rrs] + (["-e", ensure] if len(ins) == 2 else []) + (["-t", str(threads)] if threads else [])
-        calls = []
-        for call in range(1 + timed_calls):
-            for q in outs + rrs:                      # every call writes NEW files (truncating GBs of tmpfs pages is not the CLI's work)
-                if os.path.exists(q):
-                    os.remove(q)
-            t0, c0 = time.perf_counter(), time.process_time()
-            pr = detect.main(argv)
-            dt, cpu = time.perf_counter() - t0, time.process_time() - c0
-            calls.append({"seconds": dt, "reads_per_s": len(ins) * n / dt, "main_thread_s": {k: round(v, 4) for k, v in pr._stage_s.items()},
-                          "host_cores_busy": round(cpu / dt, 2),      # CPU seconds of ALL threads of the process / wall seconds
-                          "thread_cpu_s": dict(getattr(pr, "thread_cpu_s", {})),   # the pipeline's Python threads (native helpers are not in it)
-                          "load_model_s": round(pr.timing["load_model_s"], 4), "detect_s": round(pr.timing["detect_s"], 4),
-                          "prefix_k": pr.timing["prefix_k"], "reads_per_s_after_model_load": len(ins) * n / pr.timing["detect_s"]})
-            del pr
-        timed = sorted(calls[1:], key=lambda c: c["seconds"])
-        med = timed[len(timed) // 2]
-        out_bytes = sum(os.path.getsize(p) for p in outs + rrs)
-        return {"reads_per_s": med["reads_per_s"], "seconds": med["seconds"], "files": len(ins),
-                "reads_per_s_after_model_load": med["reads_per_s_after_model_load"], "timed_calls": timed_calls,
-                "host_cores_busy": med["host_cores_busy"],
-                "spread": (timed[-1]["seconds"] - timed[0]["seconds"]) / med["seconds"],
-                "records_per_file": n, "input_bytes": sum(os.path.getsize(p) for p in ins), "plain_input_bytes": plain_bytes,
-                "output_bytes": out_bytes, "input_compressor": how,
-                "threads_flag": threads or 10,
-                "what": "whole detect.main() call on FASTQ in tmpfs, %s, -t %d%s: model load + prefix table build + parse + H2D + "
-                        "kernels + D2H + write; median of %d call(s) after one warm call"
-                        % (("BGZF -> gz (RD_DEVICE_INFLATE=%s)" % os.environ.get("RD_DEVICE_INFLATE", "auto") if gz_in == "bgzf" else
-                            "gz -> gz" if gz_in is not False else "plain -> gz") if gz else "plain -> plain", threads or 10,
-                           "" if threads else " (the CLI's default)", timed_calls),
-                "warm_call": calls[0], "calls": calls[1:]}
-    finally:
-        shutil.rmtree(d, ignore_errors=True)
-
-
-def gzip_record(torch, synth, dev, arena, offsets, lens, labels):
-    """device gzip (csrc/rd_deflate.hpp) on the FASTQ text of one step's first mate, partitioned by the step's own labels into the two
-    files a CLI run writes: compressed size against zlib level 5 (the reference's writer, on a 32 MB sample), time per chunk by events"""
-    import zlib
-    from ribodetector_amd.gz import DeviceGzip
-    text = synth.fastq_image_torch(arena, offsets, lens, mate=1)
-    n = int(lens.numel())
-    rs = torch.zeros(n + 1, dtype=torch.int64, device=dev)
-    torch.cumsum(18 + 2 * lens.to(torch.int64), 0, out=rs[1:])
-    lab = labels.view(torch.int8).contiguous()
-    dg = DeviceGzip(dev)
-    outs = {}
-    for v in (0, 1):
-        outs[v] = dg.compress_selected(text, rs, lab, v, slot=v)
-    torch.cuda.synchronize(dev)
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = 5
-    a.record()
-    for _ in range(reps):
-        for v in (0, 1):
-            outs[v] = dg.compress_selected(text, rs, lab, v, slot=v)
-    b.record()
-    torch.cuda.synchronize(dev)
-    ms = a.elapsed_time(b) / reps
-    comp = sum(int(outs[v][1][0]) for v in (0, 1))
-    plain = sum(int(outs[v][1][1]) for v in (0, 1))
-    sample = text[: min(int(text.numel()), 32 << 20)].cpu().numpy().tobytes()
-    z5 = len(zlib.compress(sample, 5)) / len(sample)
-    # the way back (csrc/rd_inflate_dev.hpp): the members of the larger of the two streams, inflated one wave per member
-    gun = None
-    try:
-        import ctypes as C
-        from ribodetector_amd import _native as NN
-        from ribodetector_amd.gz import DeviceGunzip
-        v = 0 if int(outs[0][1][0]) >= int(outs[1][1][0]) else 1
-        nb0 = int(outs[v][1][0])
-        cbuf = outs[v][0][:nb0].cpu().numpy()
-        du = DeviceGunzip(dev)
-        nm, consumed, ob, _ = du.index(cbuf, nb0)
-        du.inflate(cbuf, consumed, nm, ob)
-        st = torch.cuda.current_stream(dev)
-        a.record()
-        for _ in range(reps):
-            NN.check(NN.lib().rd_gz_inflate_members(NN.ptr(du._comp_dev), consumed, NN.ptr(du._mem_dev), nm, NN.ptr(du._text_dev), ob, NN.ptr(du._status),
-                                                    C.c_void_p(st.cuda_stream)), "rd_gz_inflate_members")
-        b.record()
-        torch.cuda.synchronize(dev)
-        ims = a.elapsed_time(b) / reps
-        gun = {"kernel": "rd_gz_inflate_kernel", "members": nm, "compressed_bytes": consumed, "text_bytes": ob, "ms": ims, "GB_per_s_of_text": ob / ims / 1e6,
-               "all_members_ok": bool((du._status[:nm] == 0).all()),
-               "bound": "latency of a wave's own chain (one wave per member; ~3,500 members = 3.4 waves per SIMD in flight)"}
-    except Exception as e:      # noqa: BLE001
-        gun = {"error": repr(e)}
-    return {"kernel": "rd_gz_deflate_kernel (+ select, pack, compact)", "records": n, "device_gunzip": gun, "text_bytes": plain, "compressed_bytes": comp,
-            "ratio": plain / max(comp, 1), "size_vs_zlib_level_5": (comp / max(plain, 1)) / z5, "ms_per_chunk_both_label_files": ms,
-            "GB_per_s_of_text": plain / ms / 1e6, "reads_per_s": n / ms * 1e3, "members": sum(int(outs[v][1][2]) for v in (0, 1)),
-            "bound": "dependent-issue latency at four waves per SIMD (155 KB of LDS: one workgroup of sixteen waves per CU); HBM: %.3f of 8 TB/s" % (plain / ms / 1e6 / HBM_PEAK_GBPS),
-            "what": "the FASTQ text of one step's first mate (constant quality, 218 B per record) split by the step's labels into the two "
-                    "gzip (BGZF) streams the CLI appends to its .gz outputs; zlib level 5 = the reference's gzip.open(..., compresslevel=5)"}
-
-
-def encoder_record(torch, N, dev, arena, offs, lens, n, L):
-    """standalone encoder kernels on the first n reads: algorithmic bytes / kernel time (events on the launch stream)"""
-    lib, st = N.lib(), N.stream_ptr(dev)
-
-    def timed(fn, reps=10):
-        for _ in range(2):
-            fn()
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        for _ in range(reps):
-            fn()
-        b.record()
-        torch.cuda.synchronize(dev)
-        return a.elapsed_time(b) / reps * 1e-3
-
-    rec = {"reads": n, "read_len": L, "bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s", "kernels": {}}
-
-    def put(name, t, nbytes, what):
-        rec["kernels"][name] = {"ms": t * 1e3, "achieved": nbytes / t / 1e9, "frac": nbytes / t / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes": what}
-    codes = torch.empty((n, L), dtype=torch.uint8, device=dev)
-    t = timed(lambda: N.check(lib.rd_encode_codes(N.ptr(arena), N.ptr(offs), N.ptr(lens), n, L, L, N.ptr(codes), st), "rd_encode_codes"))
-    put("rd_encode_codes_kernel", t, n * (2 * L + 12), "L in + L out + 12 index per read")
-    del codes
-    oh = torch.empty((n, L, 4), dtype=torch.float32, device=dev)
-    t = timed(lambda: N.check(lib.rd_encode_onehot_padded(N.ptr(arena), N.ptr(offs), N.ptr(lens), n, L, N.ptr(oh), st), "rd_encode_onehot_padded"))
-    put("rd_encode_onehot_padded_kernel", t, n * (17 * L + 12), "L in + 16 L out + 12 index per read")
-    del oh
-    ws = torch.empty(int(lib.rd_classify_workspace_bytes(n, L)), dtype=torch.uint8, device=dev)
-    si = torch.empty(n, dtype=torch.int64, device=dev)
-    ui = torch.empty(n, dtype=torch.int64, device=dev)
-    bs = torch.empty(L, dtype=torch.int64, device=dev)
-    tot = torch.empty(1, dtype=torch.int64, device=dev)
-    N.check(lib.rd_pack_plan(N.ptr(lens), n, L, N.ptr(si), N.ptr(ui), N.ptr(bs), N.ptr(tot), N.ptr(ws), ws.numel(), st), "rd_pack_plan")
-    data = torch.empty((int(tot.item()), 4), dtype=torch.float32, device=dev)
-    t = timed(lambda: N.check(lib.rd_pack_onehot(N.ptr(arena), N.ptr(offs), N.ptr(lens), n, L, N.ptr(si), N.ptr(bs), N.ptr(data), st), "rd_pack_onehot"))
-    put("rd_pack_onehot_kernel", t, n * (17 * L + 16), "L in + 16 L out + 16 index per read")
+def e2e_legs(torch, synth, args, r1, r2, lens, P, RL, MAXLEN, paired, nslices, dev):
+    """timed region (iii): the whole CLI (tools/e2e_bench.py:E2E) on FASTQ files built from the rank-0 stream of this run.
+    one_step_batch: the batch of one step (the pipeline-fill-bound point: a 2 M-read input is 0.15 s of CLI), one call after a warm one.
+    Then every flow on files of --e2e-records records (default 16 Mi: >= 1 s of CLI per call), median of three calls after a warm one:
+    plain -> plain, plain -> gz, BGZF -> gz (device inflate; and with the host's), gz -> gz (one member per file; -t 10 and -t = cores)."""
+    ne = min(P, 1 << 20)
+    rec = {}
+    cat = lambda ts, rep=1: torch.cat([t[0] for t in ts] * rep)      # noqa: E731
+    with E2E(torch, synth, [r1[0][0][: ne * RL]] + ([r2[0][0][: ne * RL]] if paired else []), r1[0][1][: ne + 1], lens[:ne].contiguous(),
+             MAXLEN, args.ensure) as e:
+        rec["one_step_batch"] = e.leg("plain", False, timed_calls=1)
+    if not (nslices > 1 and ne == P and args.e2e_records > 0):
+        rec["plain_to_plain"] = rec["one_step_batch"]
+        return rec
+    nm = 2 if paired else 1
+    rec_bytes = nm * (2 * RL + 20)
+    rep = max(1, args.e2e_records // (nslices * P))
+    while rep > 1 and shm_free() < 3.2 * rep * nslices * P * rec_bytes:     # plain + gz + BGZF inputs, plain outputs of one call, margin
+        rep //= 2
+    if shm_free() < 3.2 * rep * nslices * P * rec_bytes:
+        rec["plain_to_plain"] = rec["one_step_batch"]
+        rec["skipped"] = "not enough free /dev/shm for %d records per file" % (rep * nslices * P)
+        return rec
+    nbig = rep * nslices * P
+    offs_l = torch.arange(nbig + 1, dtype=torch.int64, device=dev) * RL
+    arenas = [cat(r1, rep)] + ([cat(r2, rep)] if paired else [])
+    with E2E(torch, synth, arenas, offs_l, lens.repeat(rep * nslices), MAXLEN, args.ensure) as e:
+        del arenas
+        rec["plain_to_plain"] = e.leg("plain", False)
+        rec["plain_to_gz"] = e.leg("plain", True)
+        rec["bgzf_to_gz"] = e.leg("bgzf", True)
+        rec["bgzf_to_plain"] = e.leg("bgzf", False)
+        rec["bgzf_to_gz_host_parse"] = e.leg("bgzf", True, env={"RD_DEVICE_PARSE": "0"})
+        rec["plain_to_plain_host_parse"] = e.leg("plain", False, env={"RD_DEVICE_PARSE": "0"})
+        rec["gz_to_gz"] = e.leg("gz", True)
+        rec["gz_to_gz_all_cores"] = e.leg("gz", True, threads=usable_cores())
     return rec
+
+
+def compact(full):
+    """the ONE stdout line: the driver keeps an 8,000-byte tail of stdout, so the line stays under 4,000 bytes (asserted in
+    tests/test_gpu_bench.py): contract keys, a dozen config scalars, the roofline's numbers, cpu_baseline, parity_sample and one
+    scalar per alt / e2e leg. Everything else is in bench_full.json (--full-out)."""
+    r3 = lambda x: (float("%.5g" % x) if isinstance(x, float) else x)      # noqa: E731
+    c, rf = full["config"], full["roofline"]
+    out = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                    "vs_baseline", "dtype", "data")}
+    out["config"] = {k: r3(c[k]) for k in ("workload", "timed_region", "per_step_per_gpu", "read_len", "ensure", "kernel_variant", "parallelism",
+                                           "kernel_only_reads_per_s", "host_cores_busy", "host_cores_usable", "dist_backend", "rccl_ranks",
+                                           "gather_self_check", "gpu_over_cpu", "host_labels_nonzero_last_step") if k in c}
+    out["config"]["prefix_k"] = c["prefix_table"]["k"]
+    out["config"]["refine_band"] = c["refine"]["band"]
+    out["config"]["label_counts"] = [c["label_counts"][k] for k in ("non_rrna", "rrna", "unclassified")]
+    out["roofline"] = {k: r3(rf[k]) for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "launches", "avg_launch_ms", "traffic",
+                                              "traffic_over_algorithmic", "steps_executed_over_steps", "frac_counting_table_steps",
+                                              "mfma_pipe_frac", "algorithmic_flops_per_launch", "algorithmic_bytes_per_launch")}
+    if isinstance(rf.get("traffic_source"), str):
+        out["roofline"]["traffic_source"] = rf["traffic_source"][:120]
+    for name, key in (("alt_fp32", "alt_fp32_kernel"), ("alt_no_prefix_table", "alt_no_prefix_table")):
+        if key in full:
+            out[name + "_reads_per_s"] = r3(full[key]["value"])
+            out[name + "_frac"] = r3(full[key]["roofline"]["frac"])
+    e = full.get("e2e_cli") or {}
+    if "error" in e:
+        out["e2e_error"] = e["error"][:200]
+    for k, v in e.items():
+        if isinstance(v, dict) and "reads_per_s" in v and k != "one_step_batch":
+            out["e2e_" + k] = {"rps": r3(v["reads_per_s"]), "steady_rps": r3(v.get("reads_per_s_after_first_chunk")),
+                               "host_cores_busy": v["host_cores_busy"], "spread": r3(v["spread"])}
+    if "plain_to_plain" in e:
+        out["e2e_what"] = "whole CLI call, median of %d; steady = after first chunk; %s records/file" % (
+            e["plain_to_plain"].get("timed_calls", 0), e["plain_to_plain"].get("records_per_file"))
+    if "encoder" in full and "kernels" in full["encoder"]:
+        out["encoder_GBps"] = {k.replace("rd_", "").replace("_kernel", ""): r3(v["achieved"]) for k, v in full["encoder"]["kernels"].items()}
+    g = full.get("device_gzip") or {}
+    if "GB_per_s_of_text" in g:
+        out["device_gzip"] = {"deflate_ms_per_chunk": r3(g["ms_per_chunk_both_label_files"]), "deflate_GBps_text": r3(g["GB_per_s_of_text"]),
+                              "size_vs_zlib5": r3(g["size_vs_zlib_level_5"]),
+                              "inflate_GBps_text": r3((g.get("device_gunzip") or {}).get("GB_per_s_of_text"))}
+    cb = full.get("cpu_baseline")
+    if cb:
+        out["cpu_baseline"] = ({k: r3(cb[k]) for k in ("value", "unit", "cores", "kind", "encode_plus_model_reads_per_s") if k in cb}
+                               if "error" not in cb else {"error": cb["error"][:200]})
+        if "sample" in cb:
+            out["cpu_baseline"]["sample"] = cb["sample_short"]
+    if "parity_sample" in full:
+        out["parity_sample"] = {k: r3(v) for k, v in full["parity_sample"].items() if k != "vs"}
+    out["full_record"] = os.path.basename(full.get("_full_out", "bench_full.json"))
+    return out
+
+
+def emit(full, args):
+    """bench_full.json (everything) + the compact line as the LAST line of stdout"""
+    path = args.full_out or os.path.join(ROOT, "bench_full.json")
+    full["_full_out"] = path
+    try:
+        with open(path, "w") as fh:
+            json.dump(full, fh, indent=1)
+    except OSError as e:
+        sys.stderr.write("bench.py: cannot write %s: %s\n" % (path, e))
+    line = json.dumps(compact(full), separators=(",", ":"))
+    if args.verbose:
+        sys.stderr.write(json.dumps(full) + "\n")
+    sys.stderr.flush()
+    sys.stdout.write(line + "\n")
+    sys.stdout.flush()
 
 
 def main():
@@ -434,6 +286,8 @@ def main():
     ap.add_argument("--traffic", default="live", choices=["live", "off"],
                     help="live: collect FETCH_SIZE/WRITE_SIZE with rocprofv3 --pmc over a child run of this command (adds ~40 s)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--full-out", default=None, help="where the full record goes (default: bench_full.json next to this script)")
+    ap.add_argument("--verbose", action="store_true", help="also print the full record on stderr")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -730,7 +584,7 @@ def main():
                    "pe150": "BASELINE configs[3] per-GPU shard: paired-end 150 bp, -l 150, --ensure %s" % args.ensure,
                    "var300": "BASELINE configs[4] per-GPU shard: single-end 40-300 bp, -l 300, length-bucketed"}[args.workload]
         region = ("read bytes resident in HBM (region i)" if args.resident_only else
-                  "read bytes start in pinned host memory, H2D double-buffered on a copy stream, labels D2H to pinned memory (SURVEY 8d region ii)")
+                  "pinned host bytes -> H2D -> kernels -> labels D2H (SURVEY 8d region ii)")
         out = {
             "metric": "reads/sec classified, 100 bp paired-end" if args.workload == "pe100" else "reads/sec classified, " + args.workload,
             "value": mult * total_pairs / dt,
@@ -858,61 +712,10 @@ def main():
                 out["device_gzip"] = {"error": repr(e)}
         if world == 1 and not args.no_e2e and not multi:
             try:
-                # the batch of one step: the pipeline-fill-bound point (a 2 M-read input is 0.15 s of CLI)
-                ne = min(P, 1 << 20)
-                e2e = e2e_record(torch, synth, [r1[0][0][: ne * RL]] + ([r2[0][0][: ne * RL]] if paired else []),
-                                 r1[0][1][: ne + 1], lens[:ne].contiguous(), MAXLEN, args.ensure)
-                out["e2e_cli"] = {"one_step_batch": e2e}
-                # long enough to be a number: every slice of the stream, repeated up to 16 Mi records per file (>= 1.5 s of CLI);
-                # median of three calls after a warm one. Then the same flow gz -> gz on the un-repeated slices.
-                if nslices > 1 and ne == P and args.e2e_records > 0:
-                    free_shm = shutil_free("/dev/shm")
-                    rec_bytes = nm * (2 * RL + 20)
-                    rep = max(1, args.e2e_records // (nslices * P))
-                    while rep > 1 and free_shm < 2.6 * rep * nslices * P * rec_bytes:
-                        rep //= 2
-                    if free_shm > 2.6 * rep * nslices * P * rec_bytes:
-                        nbig = rep * nslices * P
-                        offs_l = torch.arange(nbig + 1, dtype=torch.int64, device=dev) * RL
-                        big = e2e_record(torch, synth, [torch.cat([t[0] for t in r1] * rep)] + ([torch.cat([t[0] for t in r2] * rep)] if paired else []),
-                                         offs_l, lens.repeat(rep * nslices), MAXLEN, args.ensure, timed_calls=3)
-                        out["e2e_cli"]["large"] = big
-                        out["e2e_cli"].update({k: big[k] for k in ("reads_per_s", "seconds", "records_per_file", "files", "spread", "what")})
-                        out["config"]["e2e_cli_reads_per_s"] = big["reads_per_s"]
-                        ng = nslices * P
-                        gzr = e2e_record(torch, synth, [torch.cat([t[0] for t in r1])] + ([torch.cat([t[0] for t in r2])] if paired else []),
-                                         offs_l[: ng + 1], lens.repeat(nslices), MAXLEN, args.ensure, timed_calls=2, gz=True)
-                        out["e2e_cli"]["gz_to_gz"] = gzr
-                        out["e2e_cli"]["gz_to_gz_reads_per_s"] = gzr["reads_per_s"]
-                        out["config"]["e2e_cli_gz_to_gz_reads_per_s"] = gzr["reads_per_s"]
-                        # the same with -t = the usable host cores: with the deflate on the GPU every core can inflate the inputs
-                        gza = e2e_record(torch, synth, [torch.cat([t[0] for t in r1])] + ([torch.cat([t[0] for t in r2])] if paired else []),
-                                         offs_l[: ng + 1], lens.repeat(nslices), MAXLEN, args.ensure, timed_calls=2, gz=True, threads=usable_cores())
-                        out["e2e_cli"]["gz_to_gz_all_cores"] = gza
-                        out["config"]["e2e_cli_gz_to_gz_all_cores_reads_per_s"] = gza["reads_per_s"]
-                        # plain -> gz: no inflate, so the GPU is the bound - recurrences plus the deflate of every chunk
-                        p2g = e2e_record(torch, synth, [torch.cat([t[0] for t in r1])] + ([torch.cat([t[0] for t in r2])] if paired else []),
-                                         offs_l[: ng + 1], lens.repeat(nslices), MAXLEN, args.ensure, timed_calls=2, gz=True, gz_in=False)
-                        out["e2e_cli"]["plain_to_gz"] = p2g
-                        out["config"]["e2e_cli_plain_to_gz_reads_per_s"] = p2g["reads_per_s"]
-                        # BGZF -> gz: the members of the inputs inflated on the GPU (the default for such files), then by the host's
-                        # member decoder on the same files
-                        old = os.environ.get("RD_DEVICE_INFLATE")
-                        try:
-                            for key, v in (("bgzf_to_gz", None), ("bgzf_to_gz_host_inflate", "0")):
-                                os.environ.pop("RD_DEVICE_INFLATE", None)
-                                if v is not None:
-                                    os.environ["RD_DEVICE_INFLATE"] = v
-                                out["e2e_cli"][key] = e2e_record(torch, synth, [torch.cat([t[0] for t in r1])] + ([torch.cat([t[0] for t in r2])] if paired else []),
-                                                                 offs_l[: ng + 1], lens.repeat(nslices), MAXLEN, args.ensure, timed_calls=2, gz=True, gz_in="bgzf")
-                                out["config"]["e2e_cli_%s_reads_per_s" % key] = out["e2e_cli"][key]["reads_per_s"]
-                        finally:
-                            os.environ.pop("RD_DEVICE_INFLATE", None)
-                            if old is not None:
-                                os.environ["RD_DEVICE_INFLATE"] = old
-                if "reads_per_s" not in out["e2e_cli"]:
-                    out["e2e_cli"].update({k: e2e[k] for k in ("reads_per_s", "seconds", "records_per_file", "files", "spread", "what")})
-                    out["config"]["e2e_cli_reads_per_s"] = e2e["reads_per_s"]
+                out["e2e_cli"] = e2e_legs(torch, synth, args, r1, r2, lens, P, RL, MAXLEN, paired, nslices, dev)
+                for k, v in out["e2e_cli"].items():
+                    if isinstance(v, dict) and "reads_per_s" in v:
+                        out["config"]["e2e_cli_%s_reads_per_s" % k] = v["reads_per_s"]
             except Exception as e:
                 out["e2e_cli"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1 and args.workload in ("pe100", "se100"):
@@ -939,8 +742,7 @@ def main():
                                         "largest_margin_among_mismatches": float(margin[diff].max()) if len(diff) else None}
             except Exception as e:  # the checker is not the product: report, don't hide
                 out["cpu_baseline"] = {"error": repr(e)}
-        print(json.dumps(out))
-        sys.stdout.flush()
+        emit(out, args)
     if multi:
         dist.barrier()
         dist.destroy_process_group()

@@ -23,6 +23,11 @@
 #include <stddef.h>
 #include <stdint.h>
 
+/* every entry point is exported explicitly: the libraries are built with -fvisibility=hidden, so `nm -D` lists exactly these */
+#ifndef RD_API
+#define RD_API __attribute__((visibility("default")))
+#endif
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -72,17 +77,17 @@ typedef struct rd_weights {
  * (reference detect.py:93,115-119, model/model.py:10-29). Uploads the weights to `device` and pre-packs them
  * (per-lane MFMA operand order for W_hh, fused input table  W_ih[:,base]+b_ih+b_hh, reverse-direction table).
  * Synchronous. */
-int rd_model_create(const rd_weights *w, int device, rd_model **out);
-void rd_model_destroy(rd_model *m);
+RD_API int rd_model_create(const rd_weights *w, int device, rd_model **out);
+RD_API void rd_model_destroy(rd_model *m);
 
 /* Select the recurrence kernel (RD_VARIANT_*); default AUTO = MFMA_F16X3_T32. Ids this build does not contain are
  * refused with RD_E_UNSUPPORTED (the model keeps its current kernel). rd_variant_available: 1 if `variant` can be selected. */
-int rd_set_variant(rd_model *m, int variant);
-int rd_variant_available(int variant);
+RD_API int rd_set_variant(rd_model *m, int variant);
+RD_API int rd_variant_available(int variant);
 
 /* Select which of the reference's two products rd_classify reproduces (RD_SEM_*); default RD_SEM_PACKED. The two differ
  * only for reads shorter than max_len or ending in non-ACGT bases. */
-int rd_set_semantics(rd_model *m, int semantics);
+RD_API int rd_set_semantics(rd_model *m, int semantics);
 
 /* Label stability. The label is argmax(logits) (reference detect.py:288,481); every fp32 evaluation of the recurrence - the
  * reference's own included - carries up to ~1e-4 of rounding noise on the logits, so for the few reads per million whose margin
@@ -116,10 +121,10 @@ int rd_set_semantics(rd_model *m, int semantics);
  * Candidates beyond the queue's 8,192 entries are evaluated inside rd_classify. rd_model_destroy / changing K require
  * rd_sync_results first (candidates still waiting at destroy keep their fp32 results). */
 #define RD_REFINE_DEFAULT 2.5e-4f
-int rd_set_refine(rd_model *m, float thresh);
-int rd_set_refine_async(rd_model *m, int calls_per_group);
-int rd_sync_results(rd_model *m, void *stream);
-int rd_refine(const rd_model *m, const uint8_t *arena, const int64_t *seq_off, const int32_t *seq_len, int64_t n,
+RD_API int rd_set_refine(rd_model *m, float thresh);
+RD_API int rd_set_refine_async(rd_model *m, int calls_per_group);
+RD_API int rd_sync_results(rd_model *m, void *stream);
+RD_API int rd_refine(const rd_model *m, const uint8_t *arena, const int64_t *seq_off, const int32_t *seq_len, int64_t n,
               int32_t max_len, float *logits, uint8_t *labels, const float *mate_logits, float thresh, void *stream);
 
 /* Prefix-state table (an extension; nothing in the reference to replace - its cuDNN call steps over every
@@ -141,42 +146,42 @@ int rd_refine(const rd_model *m, const uint8_t *arena, const int64_t *seq_off, c
  *   rd_prefix_k: k of the attached table, 0 if none. */
 #define RD_PREFIX_K_MIN 4
 #define RD_PREFIX_K_MAX 13
-size_t rd_prefix_table_bytes(int32_t k);
-size_t rd_prefix_scratch_bytes(int32_t k);
-int rd_set_prefix_table(rd_model *m, int32_t k, void *table, size_t table_bytes, void *scratch, size_t scratch_bytes, void *stream);
-int rd_prefix_k(const rd_model *m);
+RD_API size_t rd_prefix_table_bytes(int32_t k);
+RD_API size_t rd_prefix_scratch_bytes(int32_t k);
+RD_API int rd_set_prefix_table(rd_model *m, int32_t k, void *table, size_t table_bytes, void *scratch, size_t scratch_bytes, void *stream);
+RD_API int rd_prefix_k(const rd_model *m);
 
 /* Bytes of [dev] scratch rd_classify needs for n reads with truncation length max_len. */
-size_t rd_classify_workspace_bytes(int64_t n, int32_t max_len);
+RD_API size_t rd_classify_workspace_bytes(int64_t n, int32_t max_len);
 
 /* Replaces: collate (one-hot + pack_sequence, reference detect.py:666-689) + model(x) (model/model.py:32-37
  * forward1: BiLSTM over min(len,max_len) steps, last-timestep gather, Linear) + torch.argmax (detect.py:288,481).
  *   arena   [dev] ASCII bytes;  seq_off [dev] int64[n] start of read i in arena;  seq_len [dev] int32[n]
  *   logits  [dev] float[n*2], row i <-> read i (input order);  labels [dev] uint8[n] or NULL (1 = rRNA)
  *   workspace [dev] >= rd_classify_workspace_bytes(n, max_len), 256-byte aligned */
-int rd_classify(const rd_model *m, const uint8_t *arena, const int64_t *seq_off, const int32_t *seq_len, int64_t n,
+RD_API int rd_classify(const rd_model *m, const uint8_t *arena, const int64_t *seq_off, const int32_t *seq_len, int64_t n,
                 int32_t max_len, float *logits, uint8_t *labels, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Replaces: Predictor.separate_paired_reads label logic (reference detect.py:616-663).
  *   logits1/logits2 [dev] float[n*2];  pair_labels [dev] int8[n] in {0,1,-1}
  *   counts [dev] uint64[3] or NULL: (non-rRNA, rRNA, unclassified) ADDED to the existing values
  *   (the running counters of detect.py:331-333,388-389,400). */
-int rd_pair_fuse(const float *logits1, const float *logits2, int64_t n, int32_t ensure_mode, int8_t *pair_labels,
+RD_API int rd_pair_fuse(const float *logits1, const float *logits2, int64_t n, int32_t ensure_mode, int8_t *pair_labels,
                  uint64_t *counts, void *stream);
 
 /* Replaces: Predictor.separate_reads counters for single-end (reference detect.py:600-614,485-486).
  *   labels [dev] uint8[n]; counts [dev] uint64[3], ADDED to. */
-int rd_count_labels(const uint8_t *labels, int64_t n, uint64_t *counts, void *stream);
+RD_API int rd_count_labels(const uint8_t *labels, int64_t n, uint64_t *counts, void *stream);
 
 /* Replaces: SeqEncoder.encode_read / BASE_DICT (reference data_loader/seq_encoder.py:11-18,126-127) for a batch.
  * codes [dev] uint8[n*stride]: 0 A, 1 C, 2 G, 3 T/U, 4 anything else; positions >= min(len,max_len) hold 4.
  * stride >= max_len. */
-int rd_encode_codes(const uint8_t *arena, const int64_t *seq_off, const int32_t *seq_len, int64_t n, int32_t max_len,
+RD_API int rd_encode_codes(const uint8_t *arena, const int64_t *seq_off, const int32_t *seq_len, int64_t n, int32_t max_len,
                     int32_t stride, uint8_t *codes, void *stream);
 
 /* Replaces: encode_variable_len_read + np.array(..., float32) (reference seq_encoder.py:130-145,
  * detect_cpu.py:699-700): onehot [dev] float[n*max_len*4], zero rows after the read. */
-int rd_encode_onehot_padded(const uint8_t *arena, const int64_t *seq_off, const int32_t *seq_len, int64_t n,
+RD_API int rd_encode_onehot_padded(const uint8_t *arena, const int64_t *seq_off, const int32_t *seq_len, int64_t n,
                             int32_t max_len, float *onehot, void *stream);
 
 /* Replaces: torch.FloatTensor(encode_read(...)) + pack_sequence(enforce_sorted=False) (reference
@@ -186,9 +191,9 @@ int rd_encode_onehot_padded(const uint8_t *arena, const int64_t *seq_off, const 
  *     int64[1] = sum_i min(len_i,max_len).  workspace as for rd_classify. API parity only: rd_classify does NOT call it (it
  *     buckets by step count with atomics, order inside a bucket free).
  *   rd_pack_onehot: writes data [dev] float[total_steps*4], time-major over the sorted reads. */
-int rd_pack_plan(const int32_t *seq_len, int64_t n, int32_t max_len, int64_t *sorted_idx, int64_t *unsorted_idx,
+RD_API int rd_pack_plan(const int32_t *seq_len, int64_t n, int32_t max_len, int64_t *sorted_idx, int64_t *unsorted_idx,
                  int64_t *batch_sizes, int64_t *total_steps, void *workspace, size_t workspace_bytes, void *stream);
-int rd_pack_onehot(const uint8_t *arena, const int64_t *seq_off, const int32_t *seq_len, int64_t n, int32_t max_len,
+RD_API int rd_pack_onehot(const uint8_t *arena, const int64_t *seq_off, const int32_t *seq_len, int64_t n, int32_t max_len,
                    const int64_t *sorted_idx, const int64_t *batch_sizes, float *data, void *stream);
 
 /* Device-side gzip of the output files (round 4). Replaces, for the GPU path: gzip.open(out, 'wt', compresslevel=5) fed with the
@@ -204,12 +209,12 @@ int rd_pack_onehot(const uint8_t *arena, const int64_t *seq_off, const int32_t *
  *     info[2] = members, info[3] != 0: rec_start does not describe `text` (the selected records hold more bytes than the text:
  *     nothing was compressed). Asynchronous on `stream`; the caller copies info and out[0, info[0]) to the host afterwards.
  *   rd_gz_eof_block: [host] BGZF's 28-byte end-of-file marker (an empty member), to be appended once when the file is closed. */
-size_t rd_gz_workspace_bytes(int64_t n, int64_t text_bytes);
-size_t rd_gz_out_bound(int64_t text_bytes);
-int rd_gz_compress_selected(const uint8_t *text, int64_t text_bytes, const int64_t *rec_start, const int8_t *labels, int64_t n,
+RD_API size_t rd_gz_workspace_bytes(int64_t n, int64_t text_bytes);
+RD_API size_t rd_gz_out_bound(int64_t text_bytes);
+RD_API int rd_gz_compress_selected(const uint8_t *text, int64_t text_bytes, const int64_t *rec_start, const int8_t *labels, int64_t n,
                             int32_t label, uint8_t *out, size_t out_cap, int64_t *info, void *workspace, size_t workspace_bytes,
                             void *stream);
-int rd_gz_eof_block(uint8_t *dst, size_t cap);
+RD_API int rd_gz_eof_block(uint8_t *dst, size_t cap);
 
 /* The input side of the same idea (round 4): a .gz whose members say how long they are - BGZF (bgzip / htslib, and every .gz this
  * build's CLI writes) - is a list of independent DEFLATE streams, and they are inflated on the device, one wave per member
@@ -237,17 +242,68 @@ typedef struct rd_gz_member {
 #define RD_GZI_CRC 8
 #define RD_GZI_STORED 9
 #define RD_GZI_MEMBER 10   /* the descriptor itself: offsets / lengths outside comp or text */
-int rd_gz_inflate_members(const uint8_t *comp, int64_t comp_bytes, const rd_gz_member *members, int64_t n, uint8_t *text, int64_t text_bytes,
+RD_API int rd_gz_inflate_members(const uint8_t *comp, int64_t comp_bytes, const rd_gz_member *members, int64_t n, uint8_t *text, int64_t text_bytes,
                           uint32_t *status, void *stream);
+
+/* The FASTQ record index, on the device (round 5). Replaces, for text that already lies in HBM - BGZF members inflated there by
+ * rd_gz_inflate_members, or a plain file's bytes copied there - the parser's FASTQ state machine (reference
+ * data_loader/fastx_parser.py:15-37: four lines per record, each rstrip()-ed, header / '+' / quality verbatim, bases not upper-cased),
+ * so that inflate -> index -> classify -> select -> deflate never returns text to the host. The stream arrives in batches; a batch
+ * buffer `text` [dev] has `pad` spare bytes in front of its new bytes [pad, end) and >= 65 readable / writable bytes behind `end`:
+ *   rd_fastq_index: the bytes behind the last complete record of the batch before (prev_text / prev: that batch's buffer and its
+ *     summary, both [dev], read on the device - or both NULL for the first batch) are copied in front of `pad`; the window [begin,
+ *     end) is framed: line_end [dev] int32[cap_lines] receives the offset in `text` of the '\n' ending line j (cap_lines >= end - pad
+ *     + carry + 1 is always enough); record r = lines 4r .. 4r + 3, its text = [start of line 4r, line_end[4r + 3] + 1), its bases =
+ *     line 4r + 1. final != 0: the stream ends with this batch - a last line without '\n' gets one, and fewer than four trailing lines
+ *     are tolerated when blank. summary [dev] rd_fq_summary: status RD_FQ_* (HEADER: record `bad_record` does not start with '@';
+ *     TRUNCATED: the stream ends inside a record; CARRY: a record longer than `pad`; CHAIN: the batch before had failed);
+ *     dirty != 0: some line has trailing whitespace (CR LF files) - the records are NOT verbatim ranges then: the caller strips the
+ *     window (rd_fastq_strip_mark + a compaction of the marked bytes) and indexes the result with final = 1; `consumed` / `end`
+ *     of the ORIGINAL summary stay the carry of the next batch. Asynchronous on `stream`; no host round trip between batches.
+ *   rd_fastq_gather: records [rec_lo, rec_hi) of an indexed batch appended to a chunk: their text is copied to out_text [dev,
+ *     16-byte aligned] at *cursor_in [dev] and *cursor_out [dev, another address] = the position behind it (-1 if it did not fit
+ *     out_cap, or the batch / the cursor was bad: every later piece then fails too); rec_start [dev] int64[rec_hi - rec_lo + 1],
+ *     seq_off int64[..], seq_len int32[..] = the chunk's entries for these records (offsets into out_text) - the arrays rd_classify and
+ *     rd_gz_compress_selected take. max_bytes: an upper bound of the bytes (sizes the launch), e.g. the batch's window size.
+ *   rd_fastq_strip_mark: del [dev, zeroed by the caller] gets 1 at every byte rstrip() removes from lines [0, n_lines) of the batch. */
+typedef struct rd_fq_summary {
+    int64_t begin, end;       /* the window framed: [begin, end) in the batch buffer (begin = pad - carry; end includes an added '\n') */
+    int64_t n_lines, n_records;
+    int64_t consumed;         /* offset behind the last complete record (final: = end): the next batch's carry is [consumed, end) */
+    uint64_t bad_record;      /* ~0, or the first record whose header line does not start with '@' */
+    int32_t status, dirty;
+    int64_t reserved;
+} rd_fq_summary;
+#define RD_FQ_OK 0
+#define RD_FQ_HEADER 1
+#define RD_FQ_TRUNCATED 2
+#define RD_FQ_CARRY 3
+#define RD_FQ_CHAIN 4
+#define RD_FQ_LINES 5      /* more lines than cap_lines */
+RD_API size_t rd_fastq_index_workspace_bytes(int64_t text_end);
+RD_API int rd_fastq_index(uint8_t *text, int64_t pad, int64_t end, const uint8_t *prev_text, const rd_fq_summary *prev, int32_t final, int32_t *line_end,
+                   int64_t cap_lines, rd_fq_summary *summary, void *workspace, size_t workspace_bytes, void *stream);
+RD_API int rd_fastq_gather(const uint8_t *text, const int32_t *line_end, const rd_fq_summary *summary, int64_t rec_lo, int64_t rec_hi, int64_t max_bytes,
+                    uint8_t *out_text, int64_t out_cap, const int64_t *cursor_in, int64_t *cursor_out, int64_t *rec_start, int64_t *seq_off,
+                    int32_t *seq_len, void *stream);
+RD_API int rd_fastq_strip_mark(const uint8_t *text, const int32_t *line_end, const rd_fq_summary *summary, int64_t max_lines, uint8_t *del, void *stream);
+
+/* The records of a chunk that carry one label as ONE contiguous text in `out` [dev, 16-byte aligned], in input order - what the
+ * reference's writer joins on the host (detect.py:485-492: fh.write('\n'.join(selected) + '\n')) - for plain (uncompressed) outputs of
+ * chunks whose text lives on the device; arguments as rd_gz_compress_selected. info [dev] int64[4]: info[1] = bytes written,
+ * info[3] != 0: the selection holds more bytes than the text or than out_cap (nothing written). */
+RD_API size_t rd_select_workspace_bytes(int64_t n);
+RD_API int rd_select_pack(const uint8_t *text, int64_t text_bytes, const int64_t *rec_start, const int8_t *labels, int64_t n, int32_t label, uint8_t *out,
+                   size_t out_cap, int64_t *info, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Timing of the dominant kernel, for bench.py's roofline: rd_classify records hipEvents around the recurrence
  * kernel on the launch stream when enabled. rd_profile_read synchronises those events and returns the number of
  * recorded launches and their total duration. */
-int rd_profile_enable(rd_model *m, int enable);
-int rd_profile_read(rd_model *m, int64_t *launches, double *total_ms);
+RD_API int rd_profile_enable(rd_model *m, int enable);
+RD_API int rd_profile_read(rd_model *m, int64_t *launches, double *total_ms);
 
-const char *rd_last_error(void);
-const char *rd_version(void);
+RD_API const char *rd_last_error(void);
+RD_API const char *rd_version(void);
 
 #ifdef __cplusplus
 }

@@ -22,6 +22,11 @@
 #include <stddef.h>
 #include <stdint.h>
 
+/* every entry point is exported explicitly: the libraries are built with -fvisibility=hidden, so `nm -D` lists exactly these */
+#ifndef RD_API
+#define RD_API __attribute__((visibility("default")))
+#endif
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -32,8 +37,8 @@ typedef struct rd_writer rd_writer;
 /* format: 0 = FASTQ, 1 = FASTA, -1 = decide from the file name like get_seq_format (.fq/.fastq/.fa/.fasta/.fna/.fas [+ .gz])
  * A plain regular file is mapped and parsed in place (RD_READER_MMAP=0 in the environment: read through buffers instead, as pipes
  * and gzip input always are). */
-int rd_reader_open(const char *path, int format, rd_reader **out);
-void rd_reader_close(rd_reader *r);
+RD_API int rd_reader_open(const char *path, int format, rd_reader **out);
+RD_API void rd_reader_close(rd_reader *r);
 
 /* Byte-range ingest for the multi-rank CLI (one process per GPU): every rank parses only its own part of a PLAIN input file.
  *   rd_host_file_info          size in bytes; is_gzip = 1 if the file starts with the gzip magic (no byte ranges then)
@@ -43,11 +48,11 @@ void rd_reader_close(rd_reader *r);
  *   rd_host_skip_records       the boundary k records after the boundary `start`
  *   rd_reader_open_range       a reader over [start, end) (both boundaries): parses exactly like a file holding those bytes
  * Record semantics stay those of the reference parser (fastx_parser.py:15-55). */
-int rd_host_file_info(const char *path, int64_t *size, int32_t *is_gzip);
-int rd_host_find_record_start(const char *path, int format, int64_t pos, int64_t *out);
-int rd_host_count_records(const char *path, int format, int64_t start, int64_t end, int64_t *n);
-int rd_host_skip_records(const char *path, int format, int64_t start, int64_t k, int64_t *out);
-int rd_reader_open_range(const char *path, int format, int64_t start, int64_t end, rd_reader **out);
+RD_API int rd_host_file_info(const char *path, int64_t *size, int32_t *is_gzip);
+RD_API int rd_host_find_record_start(const char *path, int format, int64_t pos, int64_t *out);
+RD_API int rd_host_count_records(const char *path, int format, int64_t start, int64_t end, int64_t *n);
+RD_API int rd_host_skip_records(const char *path, int format, int64_t start, int64_t k, int64_t *out);
+RD_API int rd_reader_open_range(const char *path, int format, int64_t start, int64_t end, rd_reader **out);
 
 /* Parse up to max_records records into caller buffers.
  *   buf[0 .. *nbytes)      normalised record text: for record i, buf[rec_start[i] .. rec_start[i+1]) is exactly
@@ -59,38 +64,42 @@ int rd_reader_open_range(const char *path, int format, int64_t start, int64_t en
  * *nbytes then holds the bytes that record needs, so that the caller can grow the buffer (the reference parser has no
  * record-size limit, fastx_parser.py:15-55). EVERY caller must handle that case - grow and call again, or stop: calling again
  * with the same buffer returns the same answer forever (examples/classify_fastq.cpp stops, fastx_parser.py grows). */
-int rd_reader_next(rd_reader *r, int64_t max_records, uint8_t *buf, int64_t buf_cap, int64_t *rec_start, int64_t *seq_off,
+RD_API int rd_reader_next(rd_reader *r, int64_t max_records, uint8_t *buf, int64_t buf_cap, int64_t *rec_start, int64_t *seq_off,
                    int32_t *seq_len, int64_t *n, int64_t *nbytes);
 
 /* Decompress a whole gzip file (all members) into out[0..cap) with the reader's own DEFLATE decoder (csrc/rd_inflate.h);
  * *n = bytes produced. Errors follow Python's gzip module, which the reference reads .gz input with: truncated stream,
  * CRC / length mismatch, bad magic -> -1 + message. Used by the tests and for small side files. */
-int rd_host_gunzip(const char *path, uint8_t *out, int64_t cap, int64_t *n);
+RD_API int rd_host_gunzip(const char *path, uint8_t *out, int64_t cap, int64_t *n);
 
 /* The same through the parallel decoder (csrc/rd_pgzip.h: sections of `section_bytes` compressed bytes decoded by `threads`
  * threads with an unknown window, markers resolved in order; 0 = defaults). The reader uses it for large .gz inputs; anything it
  * cannot handle (binary payload, damaged data, further members) is finished by the sequential decoder, so results and error
  * messages are those of rd_host_gunzip. stats[0..3] (may be null) = sections used, sections dropped (a block start that was not
  * one), batches, 1 if the sequential decoder took over inside the first member. */
-int rd_host_gunzip_parallel(const char *path, uint8_t *out, int64_t cap, int64_t *n, int threads, int64_t section_bytes, int64_t *stats);
+RD_API int rd_host_gunzip_parallel(const char *path, uint8_t *out, int64_t cap, int64_t *n, int threads, int64_t section_bytes, int64_t *stats);
 
 /* Worker threads for gzip output (independent level-5 members compressed in parallel, by libdeflate.so.0 when the system
  * has it - bound at run time - else zlib; RD_HOST_ZLIB=1 forces zlib); 0 = auto (usable cores, <= 32).
  * Mirrors the reference's -t/--threads flag (detect.py:787). */
-int rd_host_set_threads(int threads);
+RD_API int rd_host_set_threads(int threads);
 
 /* Decoder threads per .gz input opened from now on (csrc/rd_pgzip.h; files >= 16 MB): 0 = the sequential decoder, < 0 = auto.
  * The CLI divides its -t value among its input files. */
-int rd_host_set_gz_threads(int threads);
+RD_API int rd_host_set_gz_threads(int threads);
 
 /* A reader whose bytes are fed by the caller instead of read from a file: the decompressed text of gzip members inflated elsewhere
  * (on the GPU: librd_hip.so rd_gz_inflate_members). Records come out of rd_reader_next exactly as from a file of those bytes.
  *   rd_reader_open_feed(format: 0 FASTQ / 1 FASTA); rd_reader_feed: hands `len` bytes over and returns when the reader has copied
  *   them (call it from a thread other than the one in rd_reader_next); rd_reader_feed_end: end of the stream (error non-empty: the
  *   stream is damaged - rd_reader_next fails with that text after the records before it). */
-int rd_reader_open_feed(int format, rd_reader **out);
-int rd_reader_feed(rd_reader *r, const uint8_t *bytes, int64_t len);
-int rd_reader_feed_end(rd_reader *r, const char *error);
+RD_API int rd_reader_open_feed(int format, rd_reader **out);
+RD_API int rd_reader_feed(rd_reader *r, const uint8_t *bytes, int64_t len);
+RD_API int rd_reader_feed_end(rd_reader *r, const char *error);
+/* Closing a feed reader before its stream ended (an error elsewhere, the consumer stopped): rd_reader_feed_abort wakes a feeder that
+ * waits inside rd_reader_feed (which then returns -1) and fails every later feed call; nothing is freed. The owner then JOINS its
+ * feeder threads and only then calls rd_reader_close (which frees the reader: no thread may still be inside a feed call). */
+RD_API int rd_reader_feed_abort(rd_reader *r);
 
 /* Walk gzip members that carry their own size - BGZF ('B','C') and this library's writer ('R','D') - without decoding them: one
  * entry per non-empty member (layout = rd_gz_member of include/ribodetector_amd.h), offsets relative to in_base / out_base.
@@ -100,22 +109,28 @@ typedef struct rd_host_gz_member {
     int64_t in_off, out_off;
     int32_t in_len, out_len;
 } rd_host_gz_member;
-int rd_host_gz_index(const uint8_t *buf, int64_t len, int64_t in_base, int64_t out_base, rd_host_gz_member *out, int64_t cap, int64_t *n,
+RD_API int rd_host_gz_index(const uint8_t *buf, int64_t len, int64_t in_base, int64_t out_base, rd_host_gz_member *out, int64_t cap, int64_t *n,
                      int64_t *consumed, int64_t *out_bytes);
 
-int rd_writer_open(const char *path, rd_writer **out);
+RD_API int rd_writer_open(const char *path, rd_writer **out);
 /* compressor threads this writer was opened with (= the rd_host_set_threads value in force at rd_writer_open) */
-int rd_writer_threads(const rd_writer *w);
+RD_API int rd_writer_threads(const rd_writer *w);
 /* append, in input order, every record i of the chunk with labels[i] == want */
-int rd_writer_write_selected(rd_writer *w, const uint8_t *buf, const int64_t *rec_start, int64_t n, const int8_t *labels,
+RD_API int rd_writer_write_selected(rd_writer *w, const uint8_t *buf, const int64_t *rec_start, int64_t n, const int8_t *labels,
                              int32_t want);
 /* append complete gzip members made elsewhere (the GPU: librd_hip.so rd_gz_compress_selected) to a gzip output, as they are; data
  * the host path has buffered for the file is compressed and written first (input order). A file that received such members is
  * closed with BGZF's end-of-file marker. */
-int rd_writer_write_members(rd_writer *w, const uint8_t *members, int64_t len);
-int rd_writer_close(rd_writer *w);
+RD_API int rd_writer_write_members(rd_writer *w, const uint8_t *members, int64_t len);
+/* append text that already is the selected records in input order (packed on the GPU: librd_hip.so rd_select_pack) - the same bytes
+ * rd_writer_write_selected would have gathered (reference detect.py:485-492: fh.write('\n'.join(selected) + '\n')) */
+RD_API int rd_writer_write_text(rd_writer *w, const uint8_t *text, int64_t len);
+/* on (default): a file that received device-made members is closed with BGZF's end-of-file marker. off: for '<out>.partN.gz' files
+ * of a multi-rank run, which are joined afterwards - the joined file gets ONE marker at its end */
+RD_API int rd_writer_set_eof_marker(rd_writer *w, int on);
+RD_API int rd_writer_close(rd_writer *w);
 
-const char *rd_host_last_error(void);
+RD_API const char *rd_host_last_error(void);
 
 #ifdef __cplusplus
 }

@@ -25,6 +25,7 @@ SYMBOLS = [
     "rd_pair_fuse", "rd_count_labels", "rd_encode_codes", "rd_encode_onehot_padded", "rd_pack_plan",
     "rd_pack_onehot", "rd_profile_enable", "rd_profile_read", "rd_last_error", "rd_version",
     "rd_gz_workspace_bytes", "rd_gz_out_bound", "rd_gz_compress_selected", "rd_gz_eof_block", "rd_gz_inflate_members",
+    "rd_fastq_index_workspace_bytes", "rd_fastq_index", "rd_fastq_gather", "rd_fastq_strip_mark", "rd_select_workspace_bytes", "rd_select_pack",
 ]
 
 
@@ -84,6 +85,14 @@ def lib():
     L.rd_gz_compress_selected.argtypes = [vp, i64, vp, vp, i64, i32, vp, sz, vp, vp, sz, vp]
     L.rd_gz_eof_block.argtypes = [vp, sz]
     L.rd_gz_inflate_members.argtypes = [vp, i64, vp, i64, vp, i64, vp, vp]
+    L.rd_fastq_index_workspace_bytes.argtypes = [i64]
+    L.rd_fastq_index_workspace_bytes.restype = sz
+    L.rd_fastq_index.argtypes = [vp, i64, i64, vp, vp, i32, vp, i64, vp, vp, sz, vp]
+    L.rd_fastq_gather.argtypes = [vp, vp, vp, i64, i64, i64, vp, i64, vp, vp, vp, vp, vp, vp]
+    L.rd_fastq_strip_mark.argtypes = [vp, vp, vp, i64, vp, vp]
+    L.rd_select_workspace_bytes.argtypes = [i64]
+    L.rd_select_workspace_bytes.restype = sz
+    L.rd_select_pack.argtypes = [vp, i64, vp, vp, i64, i32, vp, sz, vp, vp, sz, vp]
     L.rd_profile_enable.argtypes = [vp, C.c_int]
     L.rd_profile_read.argtypes = [vp, C.POINTER(i64), C.POINTER(C.c_double)]
     L.rd_last_error.restype = C.c_char_p
@@ -113,7 +122,7 @@ def ptr(t):
 HOST_LIB_PATH = os.path.join(_HERE, "csrc", "librd_host.so")
 HOST_SYMBOLS = ["rd_reader_open", "rd_reader_close", "rd_reader_next", "rd_host_file_info", "rd_host_find_record_start",
                 "rd_host_count_records", "rd_host_skip_records", "rd_reader_open_range", "rd_writer_open", "rd_writer_write_selected",
-                "rd_writer_write_members", "rd_writer_close", "rd_reader_open_feed", "rd_reader_feed", "rd_reader_feed_end", "rd_host_gz_index", "rd_writer_threads", "rd_host_last_error", "rd_host_set_threads", "rd_host_set_gz_threads", "rd_host_gunzip", "rd_host_gunzip_parallel"]
+                "rd_writer_write_members", "rd_writer_close", "rd_reader_open_feed", "rd_reader_feed", "rd_reader_feed_end", "rd_reader_feed_abort", "rd_writer_write_text", "rd_writer_set_eof_marker", "rd_host_gz_index", "rd_writer_threads", "rd_host_last_error", "rd_host_set_threads", "rd_host_set_gz_threads", "rd_host_gunzip", "rd_host_gunzip_parallel"]
 _host = None
 
 
@@ -138,6 +147,9 @@ def host_lib():
     L.rd_reader_open_feed.argtypes = [C.c_int, C.POINTER(vp)]
     L.rd_reader_feed.argtypes = [vp, vp, i64]
     L.rd_reader_feed_end.argtypes = [vp, C.c_char_p]
+    L.rd_reader_feed_abort.argtypes = [vp]
+    L.rd_writer_write_text.argtypes = [vp, vp, i64]
+    L.rd_writer_set_eof_marker.argtypes = [vp, C.c_int]
     L.rd_host_gz_index.argtypes = [vp, i64, i64, i64, vp, i64, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
     L.rd_writer_open.argtypes = [C.c_char_p, C.POINTER(vp)]
     L.rd_writer_write_selected.argtypes = [vp, vp, vp, i64, vp, C.c_int32]

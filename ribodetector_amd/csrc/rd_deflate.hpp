@@ -738,7 +738,9 @@ __global__ __launch_bounds__(GZ_THREADS) void rd_gz_deflate_kernel(const uint8_t
         const uint32_t crc = S.crc;
         uint8_t *slot = slots + (size_t)m * GZ_SLOT;
         __syncthreads();
-        if (cbytes_dyn >= cbytes_sto) {
+        // (the dynamic block is assembled in S.text - GZ_MEMBER + 16 bytes: header + block + trailer, and the 8 bytes gz_or_bits may touch
+        // past its last bit, must fit there; a member that compresses by less than that margin is stored too)
+        if (cbytes_dyn >= cbytes_sto || GZ_HDR + cbytes_dyn + GZ_TRL + 8 > (uint32_t)sizeof(S.text)) {
             // ---- stored block (text that does not compress): header, LEN, NLEN, the bytes as they are -----------------------------------
             const uint32_t tot = GZ_HDR + cbytes_sto + GZ_TRL;
             if (tid == 0) {

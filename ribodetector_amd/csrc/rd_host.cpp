@@ -236,6 +236,7 @@ struct rd_writer {
     std::vector<uint8_t> pending;   // gz only: selected record bytes not yet compressed
     std::vector<void *> comp;       // gz only: one libdeflate compressor per worker slot (empty: zlib)
     bool bgzf = false;              // members written by rd_writer_write_members (BGZF blocks made on the GPU)
+    bool eof_marker = true;         // ... then the file ends with BGZF's empty block (rd_writer_set_eof_marker)
 };
 
 // libdeflate (a system library of this image, libdeflate0 1.10) compresses level 5 ~2.5x faster than zlib at the same
@@ -726,6 +727,18 @@ int rd_reader_feed(rd_reader *r, const uint8_t *bytes, int64_t len) {
     return 0;
 }
 
+// the reader is about to be closed before its stream ended: wake a feeder that waits in rd_reader_feed (it returns -1) and make every
+// later feed call fail, WITHOUT freeing anything - the caller joins its feeder threads, then calls rd_reader_close
+int rd_reader_feed_abort(rd_reader *r) {
+    if (!r || !r->feed) RDH_FAIL("rd_reader_feed_abort: not a feed reader");
+    rd_feed *f = r->feed;
+    std::lock_guard<std::mutex> lk(f->m);
+    f->aborted = true;
+    f->eof = true;
+    f->cv.notify_all();
+    return 0;
+}
+
 int rd_reader_feed_end(rd_reader *r, const char *error) {
     if (!r || !r->feed) RDH_FAIL("rd_reader_feed_end: not a feed reader");
     rd_feed *f = r->feed;
@@ -767,7 +780,9 @@ int rd_host_gz_index(const uint8_t *buf, int64_t len, int64_t in_base, int64_t o
         if (msize > len - p) break;                                        // incomplete: more bytes needed
         const uint8_t *t = h + msize - 8;
         const uint32_t isize = t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
-        if (isize > 0x7fffffffu) { rc = 1; break; }
+        // a member of more than 64 MiB (either side) is not for the member-per-wave decoder: the caller's batch buffers are sized for
+        // BGZF blocks / this writer's 4 MiB members, and a crafted size field must not drive its allocations - streaming decoder
+        if (isize > (64u << 20) || msize - 12 - (int64_t)xlen - 8 > (64 << 20)) { rc = 1; break; }
         if (isize) {
             out[n].in_off = in_base + p + 12 + (int64_t)xlen;
             out[n].out_off = out_base + ob;
@@ -1055,12 +1070,36 @@ int rd_writer_write_members(rd_writer *w, const uint8_t *members, int64_t len) {
     return 0;
 }
 
+// Text that already IS the selected records in input order (packed on the GPU: librd_hip.so rd_select_pack), appended as it is to a
+// plain output; for a gzip output it joins the bytes waiting for the host's compressor.
+int rd_writer_write_text(rd_writer *w, const uint8_t *text, int64_t len) {
+    if (!w || len < 0 || (!text && len)) RDH_FAIL("rd_writer_write_text: bad argument");
+    if (w->gz) {
+        w->pending.insert(w->pending.end(), text, text + len);
+        const size_t full = (w->pending.size() / GZ_BLOCK) * GZ_BLOCK;
+        if (full >= GZ_BLOCK * (size_t)w->threads && gz_flush(w, full) != 0) RDH_FAIL("gzip compression/write failed");
+        return 0;
+    }
+    if (len && !pwrite_all(w->fd, text, (size_t)len, w->off)) RDH_FAIL("write failed");
+    w->off += len;
+    return 0;
+}
+
+// BGZF's end-of-file marker at close (default on): off for a PART of a file that is joined with others afterwards - the joined file
+// gets one marker at its end (an empty block in the middle would end the file for readers that stop at the first one)
+int rd_writer_set_eof_marker(rd_writer *w, int on) {
+    if (!w) RDH_FAIL("rd_writer_set_eof_marker: null writer");
+    w->eof_marker = on != 0;
+    return 0;
+}
+
 int rd_writer_close(rd_writer *w) {
     if (!w) return 0;
     int rc = 0;
     if (w->gz) {
         if (!w->pending.empty()) rc = gz_flush(w, w->pending.size());
-        if (w->bgzf) {            // device-written members are BGZF blocks: the file ends with BGZF's end-of-file marker (an empty member)
+        if (w->bgzf && !w->eof_marker) {
+        } else if (w->bgzf) {            // device-written members are BGZF blocks: the file ends with BGZF's end-of-file marker (an empty member)
             static const uint8_t eof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
             if (rc == 0 && pwrite_all(w->fd, eof, sizeof(eof), w->off)) w->off += (int64_t)sizeof(eof);
             else rc = -1;

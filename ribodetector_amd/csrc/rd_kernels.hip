@@ -36,6 +36,7 @@
 #include "rd_encode.hpp"
 #include "rd_deflate.hpp"
 #include "rd_inflate_dev.hpp"
+#include "rd_fastq_index.hpp"
 
 // ================================================================================================
 // C ABI
@@ -641,6 +642,93 @@ int rd_gz_inflate_members(const uint8_t *comp, int64_t comp_bytes, const rd_gz_m
     if (grid > 65536) grid = 65536;
     hipLaunchKernelGGL(rd_gz_inflate_kernel, dim3((unsigned)grid), dim3(64 * GZI_WAVES), 0, (hipStream_t)stream, comp, comp_bytes,
                        (const GzMemberIn *)members, n, text, text_bytes, status);
+    RD_HIP(hipGetLastError());
+    return RD_OK;
+}
+
+// ---- FASTQ record index on the device (rd_fastq_index.hpp) ----------------------------------------------------------------------------------
+size_t rd_fastq_index_workspace_bytes(int64_t text_end) {
+    if (text_end < 0 || text_end >= 0x7fffffffLL) return 0;
+    return fq_plan(text_end).total;
+}
+
+int rd_fastq_index(uint8_t *text, int64_t pad, int64_t end, const uint8_t *prev_text, const rd_fq_summary *prev, int32_t final, int32_t *line_end,
+                   int64_t cap_lines, rd_fq_summary *summary, void *workspace, size_t workspace_bytes, void *stream) {
+    if (!text || !line_end || !summary || !workspace) RD_FAIL(RD_E_INVALID, "rd_fastq_index: null pointer");
+    if (pad < 0 || end < pad || end >= 0x7fffffffLL - 64 || cap_lines < 0) RD_FAIL(RD_E_INVALID, "rd_fastq_index: bad pad / end / cap_lines (a batch buffer is < 2 GiB)");
+    if ((prev == nullptr) != (prev_text == nullptr)) RD_FAIL(RD_E_INVALID, "rd_fastq_index: prev and prev_text go together");
+    if (((uintptr_t)text & 63) || ((uintptr_t)workspace & 255)) RD_FAIL(RD_E_INVALID, "rd_fastq_index: text must be 64-byte aligned, workspace 256-byte aligned");
+    const FqPlan p = fq_plan(end);
+    if (workspace_bytes < p.total) RD_FAIL(RD_E_WORKSPACE, "rd_fastq_index: workspace too small: %zu < %zu", workspace_bytes, p.total);
+    hipStream_t st = (hipStream_t)stream;
+    uint32_t *tiles = (uint32_t *)workspace;
+    FqSummary *sum = (FqSummary *)summary;
+    hipLaunchKernelGGL(rd_fq_begin_kernel, dim3(1), dim3(FQ_THREADS), 0, st, text, pad, end, prev_text, (const FqSummary *)prev, (int)final, sum);
+    hipLaunchKernelGGL(rd_fq_count_kernel, dim3(p.ntiles), dim3(FQ_THREADS), 0, st, text, sum, tiles);
+    hipLaunchKernelGGL(rd_fq_scan_kernel, dim3(1), dim3(FQ_THREADS), 0, st, tiles, p.ntiles, sum, cap_lines);
+    hipLaunchKernelGGL(rd_fq_fill_kernel, dim3(p.ntiles), dim3(FQ_THREADS), 0, st, text, sum, tiles, line_end);
+    int grid = (int)((end - pad) / (64 * FQ_THREADS)) + 1;      // one thread per ~64 bytes of new text is more than one per record
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(rd_fq_check_kernel, dim3(grid), dim3(FQ_THREADS), 0, st, text, line_end, sum, (int)final);
+    hipLaunchKernelGGL(rd_fq_verdict_kernel, dim3(1), dim3(1), 0, st, sum);
+    RD_HIP(hipGetLastError());
+    return RD_OK;
+}
+
+int rd_fastq_gather(const uint8_t *text, const int32_t *line_end, const rd_fq_summary *summary, int64_t rec_lo, int64_t rec_hi, int64_t max_bytes,
+                    uint8_t *out_text, int64_t out_cap, const int64_t *cursor_in, int64_t *cursor_out, int64_t *rec_start, int64_t *seq_off,
+                    int32_t *seq_len, void *stream) {
+    if (!text || !line_end || !summary || !out_text || !cursor_in || !cursor_out || !rec_start || !seq_off || !seq_len)
+        RD_FAIL(RD_E_INVALID, "rd_fastq_gather: null pointer");
+    if (rec_lo < 0 || rec_hi < rec_lo || max_bytes < 0 || out_cap < 0 || cursor_in == cursor_out) RD_FAIL(RD_E_INVALID, "rd_fastq_gather: bad range");
+    if ((uintptr_t)out_text & 15) RD_FAIL(RD_E_INVALID, "rd_fastq_gather: out_text must be 16-byte aligned");
+    int64_t grid = max_bytes / (16 * FQ_THREADS * 4) + 1;       // four 16-byte pieces per thread
+    const int64_t grid_r = (rec_hi - rec_lo) / FQ_THREADS + 1;
+    if (grid < grid_r) grid = grid_r;
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(rd_fq_gather_kernel, dim3((unsigned)grid), dim3(FQ_THREADS), 0, (hipStream_t)stream, text, line_end, (const FqSummary *)summary, rec_lo,
+                       rec_hi, out_text, out_cap, cursor_in, cursor_out, rec_start, seq_off, seq_len);
+    RD_HIP(hipGetLastError());
+    return RD_OK;
+}
+
+int rd_fastq_strip_mark(const uint8_t *text, const int32_t *line_end, const rd_fq_summary *summary, int64_t max_lines, uint8_t *del, void *stream) {
+    if (!text || !line_end || !summary || !del || max_lines < 0) RD_FAIL(RD_E_INVALID, "rd_fastq_strip_mark: bad argument");
+    int64_t grid = max_lines / FQ_THREADS + 1;
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(rd_fq_strip_mark_kernel, dim3((unsigned)grid), dim3(FQ_THREADS), 0, (hipStream_t)stream, text, line_end, (const FqSummary *)summary, del);
+    RD_HIP(hipGetLastError());
+    return RD_OK;
+}
+
+// the selected records of a chunk as one contiguous text (the selection scan and the pack kernel of the device gzip, without the deflate)
+size_t rd_select_workspace_bytes(int64_t n) {
+    if (n < 0) return 0;
+    const GzPlan p = gz_plan(n, 0);
+    return p.off_bytes + p.bsum_bytes;
+}
+
+int rd_select_pack(const uint8_t *text, int64_t text_bytes, const int64_t *rec_start, const int8_t *labels, int64_t n, int32_t label, uint8_t *out,
+                   size_t out_cap, int64_t *info, void *workspace, size_t workspace_bytes, void *stream) {
+    if (n < 0 || n > 0x7fffffffLL || text_bytes < 0) RD_FAIL(RD_E_INVALID, "rd_select_pack: bad n or text_bytes");
+    if (!info) RD_FAIL(RD_E_INVALID, "rd_select_pack: null info");
+    if (label < -128 || label > 127) RD_FAIL(RD_E_INVALID, "rd_select_pack: label %d is not an int8 value", label);
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 0) {
+        RD_HIP(hipMemsetAsync(info, 0, 4 * sizeof(int64_t), st));
+        return RD_OK;
+    }
+    if ((!text && text_bytes > 0) || !rec_start || !labels || !out || !workspace) RD_FAIL(RD_E_INVALID, "rd_select_pack: null pointer");
+    if (((uintptr_t)workspace & 255) || ((uintptr_t)out & 15)) RD_FAIL(RD_E_INVALID, "rd_select_pack: workspace must be 256-byte aligned, out 16-byte aligned");
+    const GzPlan p = gz_plan(n, 0);
+    if (workspace_bytes < p.off_bytes + p.bsum_bytes) RD_FAIL(RD_E_WORKSPACE, "rd_select_pack: workspace too small: %zu < %zu", workspace_bytes, p.off_bytes + p.bsum_bytes);
+    int64_t *out_off = (int64_t *)workspace;
+    int64_t *bsum = (int64_t *)((char *)workspace + p.off_bytes);
+    const int64_t limit = text_bytes < (int64_t)out_cap ? text_bytes : (int64_t)out_cap;   // more selected bytes than text, or than `out` holds: info[3] = 1, nothing packed
+    hipLaunchKernelGGL(rd_gz_sel_sum_kernel, dim3(p.nb), dim3(256), 0, st, rec_start, labels, n, label, bsum);
+    hipLaunchKernelGGL(rd_gz_sel_base_kernel, dim3(1), dim3(256), 0, st, bsum, p.nb, info, limit);
+    hipLaunchKernelGGL(rd_gz_sel_off_kernel, dim3(p.nb), dim3(256), 0, st, rec_start, labels, n, label, bsum, out_off);
+    hipLaunchKernelGGL(rd_gz_pack_kernel, dim3((unsigned)((n + GZ_PACK_RECS - 1) / GZ_PACK_RECS)), dim3(256), 0, st, text, rec_start, out_off, n, out, info);
     RD_HIP(hipGetLastError());
     return RD_OK;
 }

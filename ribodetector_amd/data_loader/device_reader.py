@@ -1,0 +1,511 @@
+"""Device-resident FASTQ ingest: the text of the input never comes back to the host.
+
+The reference parses its input on the host - `gzip.open(path, 'rt')` / `open(path)` (data_loader/seq_encoder.py:21-39) feeding the
+four-line state machine of data_loader/fastx_parser.py:15-37 - and so did this build up to round 4, even for BGZF inputs whose
+members it inflated on the GPU (the text went HBM -> pinned host -> parser -> chunk buffer -> HBM again). Here
+
+    BGZF file   : compressed bytes -> pinned -> H2D -> rd_gz_inflate_members (one wave per member) ┐
+    plain file  : file bytes       -> pinned -> H2D ─────────────────────────────────────────────────┴-> batch text in HBM
+    batch text  -> rd_fastq_index (newline scan, record framing, carry of the partial record chained ON THE DEVICE)
+    batches     -> rd_fastq_gather -> chunks of exactly N records: text + rec_start / seq_off / seq_len, all in HBM
+    chunk       -> rd_classify -> labels -> rd_gz_compress_selected (.gz outputs) | rd_select_pack (plain outputs) -> D2H -> file
+
+so the host moves compressed bytes (or the file's bytes once, in and out) and a 64-byte summary per batch. Record semantics are
+those of csrc/rd_host.cpp's reader (tests/test_gpu_device_reader.py holds the two to each other and to the reference's parser):
+every line rstrip()-ed (a batch with trailing whitespace - CR LF files - is stripped on the device and indexed again), header must
+start with '@', last line may lack its newline, fewer than four blank trailing lines tolerated.
+RD_DEVICE_PARSE=0 keeps the host parser; FASTA always uses it.
+"""
+import ctypes as C
+import os
+import queue
+import threading
+import time
+from collections import deque
+
+import numpy as np
+import torch
+
+from .. import _native as N
+from .. import gz
+
+PAD = 16 << 20                 # bytes in front of a batch's new text: room for the carry (= the longest record the device path frames)
+FQ_ERRORS = {1: "FASTQ record does not start with '@'",
+             2: "truncated FASTQ record at end of file (number of lines is not a multiple of 4)",
+             3: "a FASTQ record longer than %d bytes: set RD_DEVICE_PARSE=0 (the host parser has no record-size limit)" % PAD,
+             4: "the batch before this one could not be framed", 5: "more lines than the line table holds"}
+
+
+def device_parse_wanted(path, fmt=None):
+    """FASTQ input, a GPU, and RD_DEVICE_PARSE != 0: plain files and .gz files made of size-carrying members (BGZF)"""
+    if os.environ.get("RD_DEVICE_PARSE", "1") == "0" or not torch.cuda.is_available():
+        return False
+    from . import fastx_parser as fx
+    fmt = fmt or fx.get_seq_format(path)
+    if not fmt.startswith("fq"):
+        return False
+    if fmt.endswith("gz"):
+        return fx.device_inflate_wanted(path)
+    return not fx.file_info(path)[1]          # (a gzip file under a plain name goes to the host reader, which sniffs the magic)
+
+
+class DeviceChunk:
+    """A chunk of n records whose text and index live in HBM. The attribute names follow fastx_parser.Chunk where the meaning is the
+    same: seq_len (len() = n), verbatim, release; `dev` = (text, seq_off, seq_len, rec_start) device tensors, `ready` = the event
+    behind the kernels that wrote them, `total` = pinned int64[1]: the chunk's text bytes (-1: assembly failed), valid after `ready`."""
+    tensors = None
+    records = None
+    release = None
+    shm = None
+    verbatim = True
+
+    def __init__(self, n, text, rec_start, seq_off, seq_len, ready, total):
+        self.n, self.dev, self.ready, self.total = n, (text, seq_off, seq_len, rec_start), ready, total
+        self.seq_len = seq_len
+        self.buf = self.rec_start = self.seq_off = None
+
+    def to_host(self):
+        """(text bytes, rec_start, seq_off, seq_len) as numpy arrays - tests and small tools only (this is the copy the path avoids)"""
+        self.ready.synchronize()
+        nb = int(self.total[0])
+        if nb < 0:
+            raise RuntimeError("device chunk assembly failed")
+        text, so, sl, rs = self.dev
+        return text[:nb].cpu().numpy(), rs.cpu().numpy(), so.cpu().numpy(), sl.cpu().numpy()
+
+
+class _Batch:
+    __slots__ = ("text", "line_end", "summary", "host", "event", "slot", "gz_slot", "n", "begin", "end", "consumed", "status", "dirty",
+                 "bad_record", "n_lines", "final", "orig")
+
+
+class FastqIndexer:
+    """rd_fastq_index / rd_fastq_gather on one stream: index() queues the framing of a batch behind whatever produced its text (and
+    behind the batch before: the carry is read on the device), finish() sleeps until its 64-byte summary has arrived, gather() makes
+    a chunk of records of finished batches."""
+
+    def __init__(self, device, stream):
+        self.device, self.stream = torch.device(device), stream
+        self.lib = N.lib()
+        self.prev = None
+        self.stats = {"batches": 0, "stripped": 0, "index_wait_s": 0.0}
+
+    def _sp(self):
+        return C.c_void_p(self.stream.cuda_stream)
+
+    def alloc_text(self, new_bytes):
+        """a batch buffer: PAD + new_bytes + slack (the framing reads whole 64-byte pieces and may append one '\\n')"""
+        with torch.cuda.stream(self.stream):
+            return torch.empty(((PAD + int(new_bytes) + 64 + 127) // 64) * 64, dtype=torch.uint8, device=self.device)
+
+    def index(self, text, start, end, final=False, chain=True):
+        """frame text[start:end] (offsets in the batch buffer; start >= PAD unless the batch stands alone) behind the carry of the
+        batch indexed before (chain). Asynchronous: returns the batch, to be finish()-ed later."""
+        b = _Batch()
+        prev = self.prev if chain else None      # (text, summary) as they were queued: a strip replaces the batch's own fields, not these
+        with torch.cuda.device(self.device), torch.cuda.stream(self.stream):
+            window = (end - start) + (PAD if prev is not None else 0)
+            b.text = text
+            b.line_end = torch.empty(window + 2, dtype=torch.int32, device=self.device)
+            b.summary = torch.empty(8, dtype=torch.int64, device=self.device)
+            b.host = torch.empty(8, dtype=torch.int64, pin_memory=True)
+            ws = torch.empty(max(int(self.lib.rd_fastq_index_workspace_bytes(end)), 256), dtype=torch.uint8, device=self.device)
+            N.check(self.lib.rd_fastq_index(N.ptr(text), int(start), int(end), N.ptr(prev[0]) if prev is not None else None,
+                                            N.ptr(prev[1]) if prev is not None else None, 1 if final else 0, N.ptr(b.line_end),
+                                            b.line_end.numel(), N.ptr(b.summary), N.ptr(ws), ws.numel(), self._sp()), "rd_fastq_index")
+            b.host.copy_(b.summary, non_blocking=True)
+            b.event = torch.cuda.Event()
+            b.event.record(self.stream)
+        b.final, b.orig, b.slot, b.gz_slot, b.n = final, None, None, None, None
+        if chain:
+            self.prev = (text, b.summary)
+        self.stats["batches"] += 1
+        return b
+
+    def wait(self, b):
+        t0 = time.perf_counter()
+        while not b.event.query():
+            time.sleep(2e-4)
+        self.stats["index_wait_s"] += time.perf_counter() - t0
+
+    def finish(self, b):
+        """wait (sleeping) for the batch's summary; strips a dirty batch. Returns the batch with n / status filled in - a status != 0 is
+        left to the caller (the records before the damage are delivered first)."""
+        self.wait(b)
+        h = b.host.numpy()
+        b.begin, b.end, b.n_lines, b.n, b.consumed, b.bad_record, sd = (int(x) for x in h[:7])
+        b.status, b.dirty = sd & 0xffffffff, (sd >> 32) & 0xffffffff
+        if b.dirty and b.status == 0:
+            self._strip(b)
+        if b.status == 0 and b.bad_record != -1 and b.bad_record < b.n:
+            b.status = 1
+        return b
+
+    def _strip(self, b):
+        """a batch with trailing whitespace on some line: the bytes rstrip() removes are marked, the window is compacted and indexed
+        again as a stream of its own (the complete records of the window: [begin, consumed); everything when the batch is final).
+        The ORIGINAL buffer and summary stay what the next batch's carry is read from."""
+        self.stats["stripped"] += 1
+        with torch.cuda.device(self.device), torch.cuda.stream(self.stream):
+            stop = b.end if b.final else b.consumed
+            dele = torch.zeros(b.text.numel(), dtype=torch.uint8, device=self.device)
+            N.check(self.lib.rd_fastq_strip_mark(N.ptr(b.text), N.ptr(b.line_end), N.ptr(b.summary), b.n_lines, N.ptr(dele), self._sp()),
+                    "rd_fastq_strip_mark")
+            kept = b.text[b.begin:stop][dele[b.begin:stop] == 0]
+            text = torch.empty(((kept.numel() + 64 + 127) // 64) * 64, dtype=torch.uint8, device=self.device)
+            text[:kept.numel()] = kept
+            nb = self.index(text, 0, int(kept.numel()), final=True, chain=False)
+        self.stats["batches"] -= 1
+        nb = self.finish(nb)
+        b.orig = (b.text, b.summary)          # (alive until the next batch's carry copy has been queued behind it)
+        for k in ("text", "line_end", "summary", "begin", "end", "consumed", "n", "n_lines", "status", "bad_record"):
+            setattr(b, k, getattr(nb, k))
+        b.dirty = 0
+
+    def gather(self, pieces):
+        """pieces: [(batch, lo, hi)] -> DeviceChunk of sum(hi - lo) records, in that order"""
+        n = sum(hi - lo for _, lo, hi in pieces)
+        cap = sum(b.consumed - b.begin for b, _, _ in pieces)
+        with torch.cuda.device(self.device), torch.cuda.stream(self.stream):
+            text = torch.empty(((cap + 255) // 256) * 256 + 256, dtype=torch.uint8, device=self.device)
+            rs = torch.empty(n + 1, dtype=torch.int64, device=self.device)
+            so = torch.empty(n, dtype=torch.int64, device=self.device)
+            sl = torch.empty(n, dtype=torch.int32, device=self.device)
+            cursor = torch.zeros(len(pieces) + 1, dtype=torch.int64, device=self.device)
+            at = 0
+            for i, (b, lo, hi) in enumerate(pieces):
+                N.check(self.lib.rd_fastq_gather(N.ptr(b.text), N.ptr(b.line_end), N.ptr(b.summary), lo, hi, b.consumed - b.begin, N.ptr(text),
+                                                 text.numel(), C.c_void_p(cursor.data_ptr() + 8 * i), C.c_void_p(cursor.data_ptr() + 8 * (i + 1)),
+                                                 C.c_void_p(rs.data_ptr() + 8 * at), C.c_void_p(so.data_ptr() + 8 * at),
+                                                 C.c_void_p(sl.data_ptr() + 4 * at), self._sp()), "rd_fastq_gather")
+                at += hi - lo
+            total = torch.empty(1, dtype=torch.int64, pin_memory=True)
+            total.copy_(cursor[len(pieces):], non_blocking=True)
+            ready = torch.cuda.Event()
+            ready.record(self.stream)
+        return DeviceChunk(n, text, rs, so, sl, ready, total)
+
+
+class DeviceFeeder:
+    """The producer thread of one input file: file bytes -> batches on the GPU (H2D, members inflated where the file is BGZF, records
+    framed), two batches in flight; next_batch() hands them over in order, finished."""
+
+    BATCH = 48 << 20          # compressed bytes per BGZF batch (~200 MB of text)
+    FIRST = 6 << 20           # the first batch (the first chunk is small too); doubling up to BATCH
+    MAX_MEMBERS = 4096        # members per batch: at most 256 MiB of text whatever the members claim
+    PLAIN_BATCH = 96 << 20    # bytes of a plain file per batch
+    PLAIN_FIRST = 12 << 20
+    SLOTS = 2
+
+    def __init__(self, path, device, compressed, span=None, byte_range=None):
+        """compressed: the file is BGZF (span = (first file byte, one past the last, text bytes to drop in front, text bytes to
+        deliver) for a rank's share, fastx_parser.BgzfView.file_span); else plain text (byte_range = (start, end), record-aligned)"""
+        self.path, self.device, self.compressed, self.span, self.byte_range = str(path), torch.device(device), compressed, span, byte_range
+        self._stop = False
+        self.out = queue.Queue(maxsize=self.SLOTS)
+        self.slot_free = queue.Queue()
+        for k in range(self.SLOTS):
+            self.slot_free.put(k)
+        self.dg = self.ix = None
+        self.stage_s = {"read": 0.0, "index": 0.0, "wait_slot": 0.0, "submit": 0.0, "batches": 0, "bytes": 0}
+        self._ready = threading.Event()
+        self._init_err = None
+        self.th = threading.Thread(target=self._run, name="rd-feed", daemon=True)
+        self.th.start()
+        self._ready.wait()
+        if self._init_err is not None:
+            raise self._init_err
+
+    def stop(self):
+        self._stop = True
+        while True:                      # unblock a producer waiting for a slot or for room in the queue
+            try:
+                self.out.get_nowait()
+            except queue.Empty:
+                break
+        self.slot_free.put(0)
+
+    def join(self):
+        self.th.join()
+
+    # ---- consumer side --------------------------------------------------------------------------------
+    def next_batch(self):
+        """the next batch, finished (its record count is known) - None at the end of the stream; raises what the producer raised"""
+        item = self.out.get()
+        if item is None:
+            return None
+        if isinstance(item, BaseException):
+            raise item
+        b = item
+        self.ix.wait(b)
+        try:
+            if b.gz_slot is not None:
+                self.dg.finish(b.gz_slot)              # (over already: the summary came later on the same stream) - the members' status words
+        finally:
+            if b.slot is not None:
+                self.slot_free.put(b.slot)
+        return self.ix.finish(b)
+
+    # ---- producer thread ---------------------------------------------------------------------------------
+    def _put(self, item):
+        while not self._stop:
+            try:
+                self.out.put(item, timeout=0.05)
+                return True
+            except queue.Full:
+                pass
+        return False
+
+    def _run(self):
+        try:
+            torch.cuda.set_device(self.device)          # the current device is per thread (and defaults to 0)
+            self.dg = gz.DeviceGunzip(self.device, slots=self.SLOTS)
+            self.ix = FastqIndexer(self.device, self.dg.stream)
+        except BaseException as e:      # noqa: BLE001
+            self._init_err = e
+            self._ready.set()
+            return
+        self._ready.set()
+        try:
+            if self.compressed:
+                self._run_bgzf()
+            else:
+                self._run_plain()
+            if not self._stop:           # the end of the stream: an empty final batch judges what the last batch left over
+                text = self.ix.alloc_text(0)
+                self._put(self.ix.index(text, PAD, PAD, final=True))
+            self._put(None)
+        except BaseException as e:      # noqa: BLE001 - raised by next_batch() on the consumer's thread, behind the batches before it
+            self._put(e)
+        if os.environ.get("RD_FEED_TRACE"):
+            import sys
+            sys.stderr.write("device feeder %s: %s %s\n" % (self.path, {k: (round(v, 3) if isinstance(v, float) else v) for k, v in self.stage_s.items()},
+                                                            self.ix.stats))
+
+    def _submit_text(self, src, nbytes, slot, start_skip=0, limit=None):
+        """pinned host bytes -> a batch buffer -> index"""
+        text = self.ix.alloc_text(nbytes)
+        with torch.cuda.device(self.device), torch.cuda.stream(self.dg.stream):
+            text[PAD:PAD + nbytes].copy_(src[:nbytes], non_blocking=True)
+        end = PAD + nbytes if limit is None else PAD + min(nbytes, start_skip + limit)
+        b = self.ix.index(text, PAD + start_skip, end)
+        b.slot = slot
+        return b
+
+    def _run_plain(self):
+        tm = self.stage_s
+        pinned = [torch.empty(self.PLAIN_BATCH, dtype=torch.uint8, pin_memory=True) for _ in range(self.SLOTS)]
+        views = [t.numpy() for t in pinned]
+        batch = min(self.PLAIN_FIRST, self.PLAIN_BATCH)
+        with open(self.path, "rb", buffering=0) as fh:
+            left = None
+            if self.byte_range is not None:
+                fh.seek(int(self.byte_range[0]))
+                left = int(self.byte_range[1]) - int(self.byte_range[0])
+            while not self._stop and (left is None or left > 0):
+                t0 = time.perf_counter()
+                slot = self.slot_free.get()
+                if self._stop:
+                    break
+                t1 = time.perf_counter()
+                want, have = (batch if left is None else min(batch, left)), 0
+                while have < want:
+                    k = fh.readinto(memoryview(views[slot])[have:want])
+                    if not k:
+                        break
+                    have += k
+                t2 = time.perf_counter()
+                if have == 0:
+                    self.slot_free.put(slot)
+                    break
+                if left is not None:
+                    left -= have
+                b = self._submit_text(pinned[slot], have, slot)
+                tm["wait_slot"] += t1 - t0
+                tm["read"] += t2 - t1
+                tm["submit"] += time.perf_counter() - t2
+                tm["batches"] += 1
+                tm["bytes"] += have
+                if not self._put(b):
+                    break
+                if have < want:
+                    break
+                batch = min(2 * batch, self.PLAIN_BATCH)
+
+    def _host_tail(self, fh, data):
+        """the rest of a file whose members stop carrying their size (`cat a.bgzf.gz b.gz` is a legal .gz): zlib, member after member,
+        the text shipped to the device in pieces and framed behind the batches in flight"""
+        import zlib
+        d, inside = zlib.decompressobj(31), False
+        while not self._stop:
+            if not data:
+                data = fh.read(4 << 20)
+                if not data:
+                    if inside:
+                        raise ValueError("Compressed file ended before the end-of-stream marker was reached")
+                    return
+            try:
+                out = d.decompress(data, 16 << 20)          # (at most 16 MB of text per call)
+            except zlib.error as e:
+                raise ValueError(str(e))
+            inside = True
+            if out:
+                src = torch.from_numpy(np.frombuffer(out, dtype=np.uint8).copy()).pin_memory()
+                b = self._submit_text(src, len(out), None)
+                b.orig = src                                  # (keeps the pinned bytes alive until the batch is consumed)
+                if not self._put(b):
+                    return
+            if d.eof:
+                data, d, inside = d.unused_data, zlib.decompressobj(31), False
+            else:
+                data = d.unconsumed_tail
+
+    def _run_bgzf(self):
+        tm = self.stage_s
+        dg = self.dg
+        pinned = [torch.empty(self.BATCH + (1 << 20), dtype=torch.uint8, pin_memory=True) for _ in range(self.SLOTS)]
+        bufs = [t.numpy() for t in pinned]
+        carry = None                                    # bytes of an incomplete member, to go in front of the next batch
+        batch = min(self.FIRST, self.BATCH)
+        with open(self.path, "rb", buffering=0) as fh:
+            eof = False
+            file_left = text_left = None
+            skip_text = 0
+            if self.span is not None:           # a share of the file: whole members [c0, c1), text trimmed at both ends
+                fh.seek(self.span[0])
+                file_left, skip_text, text_left = self.span[1] - self.span[0], self.span[2], self.span[3]
+                eof = file_left <= 0
+            while not self._stop:
+                t0 = time.perf_counter()
+                slot = self.slot_free.get()                  # (its previous batch has left the GPU: next_batch() finished it)
+                if self._stop:
+                    break
+                t1 = time.perf_counter()
+                buf, have = bufs[slot], 0
+                if carry is not None:
+                    have = len(carry)
+                    buf[:have] = carry
+                    carry = None
+                while have < batch and not eof:
+                    cap = batch + (1 << 20) if file_left is None else min(batch + (1 << 20), have + file_left)
+                    k = fh.readinto(memoryview(buf)[have:cap])
+                    if not k:
+                        eof = True
+                    else:
+                        have += k
+                        if file_left is not None:
+                            file_left -= k
+                            eof = file_left <= 0
+                if have == 0:
+                    self.slot_free.put(slot)
+                    break
+                t2 = time.perf_counter()
+                n, consumed, out_bytes, streaming = dg.index(buf, have, slot=slot, max_members=self.MAX_MEMBERS)
+                t3 = time.perf_counter()
+                tm["wait_slot"] += t1 - t0
+                tm["read"] += t2 - t1
+                tm["index"] += t3 - t2
+                if streaming and n == 0:
+                    self.slot_free.put(slot)
+                    self._host_tail(fh, bytes(buf[consumed:have]))
+                    break
+                if n == 0 or consumed == 0:
+                    if eof:
+                        if consumed < have:
+                            raise ValueError("Compressed file ended before the end-of-stream marker was reached")
+                        self.slot_free.put(slot)
+                        break
+                    if consumed == 0 and have >= self.BATCH:       # a member that claims to be larger than the batch buffer: no progress possible
+                        raise ValueError("gzip member larger than %d bytes: not a BGZF file (RD_DEVICE_INFLATE=0 reads it with the host's "
+                                         "decoders)" % self.BATCH)
+                if consumed < have:
+                    carry = buf[consumed:have].copy()
+                if n:
+                    text = self.ix.alloc_text(out_bytes)
+                    dg.submit(buf, consumed, n, out_bytes, slot=slot, text_out=text[PAD:PAD + out_bytes])
+                    drop = min(skip_text, out_bytes)
+                    skip_text -= drop
+                    end = PAD + out_bytes
+                    if text_left is not None:
+                        take = min(out_bytes - drop, text_left)
+                        text_left -= take
+                        end = PAD + drop + take
+                    b = self.ix.index(text, PAD + drop, end)
+                    b.slot, b.gz_slot = slot, slot
+                    tm["submit"] += time.perf_counter() - t3
+                    tm["batches"] += 1
+                    tm["bytes"] += out_bytes
+                    if not self._put(b):
+                        break
+                else:
+                    self.slot_free.put(slot)
+                batch = min(2 * batch, self.BATCH)
+                if text_left is not None and text_left <= 0:
+                    break
+
+
+def get_seq_chunks_device(seq_file, chunk_size=1048576, byte_range=None, first_chunk=None, schedule=None, device=None, stats=None):
+    """fastx_parser.get_seq_chunks for FASTQ whose text stays on the device: DeviceChunk objects of exactly the scheduled number of
+    records (fewer only at the end of the stream). byte_range: (start, end) of a plain file or a fastx_parser.BgzfRange. A damaged
+    stream delivers the chunks before the damage, then raises ValueError like the host reader."""
+    from . import fastx_parser as fx
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    torch.cuda.set_device(device)
+    fmt = fx.get_seq_format(seq_file)
+    compressed = fmt.endswith("gz")
+    span = None
+    if isinstance(byte_range, fx.BgzfRange):
+        a, b = byte_range
+        c0, c1, drop = byte_range.view.file_span(a, b)
+        span, byte_range = (c0, c1, drop, b - a), None
+    feeder = DeviceFeeder(seq_file, device, compressed, span=span, byte_range=byte_range)
+    want = chunk_size if not first_chunk else max(1, min(int(first_chunk), chunk_size))
+    sched = list(schedule) if schedule else None
+    pend = deque()                   # [batch, next record]
+    avail, eof, err, framing = 0, False, None, False
+    try:
+        while True:
+            if sched is not None:
+                want = sched.pop(0) if len(sched) > 1 else sched[0]
+            while avail < want and not eof:
+                try:
+                    b = feeder.next_batch()
+                except ValueError as e:
+                    err, eof = e, True
+                    break
+                if b is None:
+                    eof = True
+                    break
+                good = b.n
+                if b.status:             # a malformed record: the chunks in front of it are delivered, then the error
+                    err, eof, framing = ValueError(FQ_ERRORS.get(b.status, "FASTQ framing error %d" % b.status)), True, True
+                    good = min(b.n, b.bad_record) if b.status == 1 and b.bad_record >= 0 else (b.n if b.status == 2 else 0)
+                if good > 0:
+                    pend.append([b, 0, good])
+                    avail += good
+            if avail == 0 or (framing and avail < want):
+                # (the host reader meets a malformed record while it fills a chunk and fails that call: the records it had gathered for
+                # THAT chunk are not delivered, csrc/rd_host.cpp rd_reader_next - the same chunks come out of both readers)
+                break
+            take, pieces = min(want, avail), []
+            left = take
+            while left > 0:
+                b, lo, hi = pend[0]
+                k = min(left, hi - lo)
+                pieces.append((b, lo, lo + k))
+                left -= k
+                if lo + k == hi:
+                    pend.popleft()
+                else:
+                    pend[0][1] = lo + k
+            avail -= take
+            yield feeder.ix.gather(pieces)
+            if sched is None:
+                want = min(chunk_size, want * 2)
+        if err is not None:
+            raise err
+    finally:
+        feeder.stop()
+        feeder.join()
+        if stats is not None:
+            stats.update({"feeder": dict(feeder.stage_s), "indexer": dict(feeder.ix.stats) if feeder.ix else None})

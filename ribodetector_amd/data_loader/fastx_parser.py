@@ -352,11 +352,14 @@ class _DeviceInflateFeeder:
     BATCH = 48 << 20        # compressed bytes per launch (~200 MB of text, ~3,500 BGZF blocks)
     FIRST = 6 << 20         # the first launch (the reader's first chunk is small too: get_seq_chunks first_chunk); doubling up to BATCH
 
-    def __init__(self, path, handle, span=None):
+    def __init__(self, path, handle, span=None, device=None):
         """span = (first file byte, one past the last, text bytes to drop in front, text bytes to deliver): a rank's share of the file
-        (BgzfView.file_span); None = the whole file"""
+        (BgzfView.file_span); None = the whole file. device: where the members are inflated - captured HERE, on the caller's thread (the
+        current device is per thread and defaults to 0 in a new one: under torchrun every rank would inflate on GPU 0)"""
         import threading
+        import torch
         self.path, self.h, self.span = path, handle, span
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self._stop = False
         self.th = threading.Thread(target=self._run, daemon=True)
         self.th.start()
@@ -414,6 +417,7 @@ class _DeviceInflateFeeder:
         dg = None
 
         def feed():
+            torch.cuda.set_device(self.device)
             while True:
                 item = full.get()
                 if item is None:
@@ -444,7 +448,8 @@ class _DeviceInflateFeeder:
             L.rd_reader_feed_end(self.h, state["err"])
         ft = threading.Thread(target=feed, daemon=True)
         try:
-            dg = gz.DeviceGunzip(torch.device("cuda", torch.cuda.current_device()), slots=SLOTS)
+            torch.cuda.set_device(self.device)
+            dg = gz.DeviceGunzip(self.device, slots=SLOTS)
             ft.start()
             pinned = [torch.empty(self.BATCH + (1 << 20), dtype=torch.uint8, pin_memory=True) for _ in range(SLOTS)]
             bufs = [t.numpy() for t in pinned]
@@ -496,6 +501,9 @@ class _DeviceInflateFeeder:
                             raise ValueError("Compressed file ended before the end-of-stream marker was reached")
                         slot_free.put(slot)
                         break
+                    if consumed == 0 and have >= self.BATCH:      # (nothing more can be read into the buffer: the loop would spin)
+                        raise ValueError("gzip member larger than %d bytes: not a BGZF file (RD_DEVICE_INFLATE=0 reads it with the host's "
+                                         "decoders)" % self.BATCH)
                     if consumed < have:
                         carry = buf[consumed:have].copy()
                     if n:
@@ -539,8 +547,9 @@ class NativeReader:
 
     h = None
 
-    def __init__(self, path, est_record_bytes=320, byte_range=None, arena=None):
-        """byte_range = (start, end): parse only those bytes of a plain file; both must be record boundaries (plan_ranges)."""
+    def __init__(self, path, est_record_bytes=320, byte_range=None, arena=None, device=None):
+        """byte_range = (start, end): parse only those bytes of a plain file; both must be record boundaries (plan_ranges).
+        device: the GPU that inflates the members of a BGZF input (the caller's rank's device; default: the calling thread's current one)"""
         import torch
         self._torch = torch
         self._pin = torch.cuda.is_available()
@@ -554,12 +563,12 @@ class NativeReader:
             a, b = byte_range
             c0, c1, drop = byte_range.view.file_span(a, b)
             N.host_check(N.host_lib().rd_reader_open_feed(f, C.byref(self.h)), "rd_reader_open_feed")
-            self._feeder = _DeviceInflateFeeder(path, self.h, span=(c0, c1, drop, b - a))
+            self._feeder = _DeviceInflateFeeder(path, self.h, span=(c0, c1, drop, b - a), device=device)
         elif byte_range is None and fmt.endswith("gz") and device_inflate_wanted(path):
             # a .gz whose members say how long they are (BGZF; this build's own outputs): the members are inflated on the GPU and the
             # text is FED to the parser (ribodetector_amd/gz.py:DeviceGunzip, csrc/rd_inflate_dev.hpp) - no host inflate thread at all
             N.host_check(N.host_lib().rd_reader_open_feed(f, C.byref(self.h)), "rd_reader_open_feed")
-            self._feeder = _DeviceInflateFeeder(path, self.h)
+            self._feeder = _DeviceInflateFeeder(path, self.h, device=device)
         elif byte_range is None:
             N.host_check(N.host_lib().rd_reader_open(str(path).encode(), f, C.byref(self.h)), "rd_reader_open")
         else:
@@ -571,12 +580,12 @@ class NativeReader:
 
     def close(self):
         if self.h:
-            if self._feeder is not None:
-                self._feeder.stop()
-            N.host_lib().rd_reader_close(self.h)
-            if self._feeder is not None:
+            if self._feeder is not None:         # abort (wakes a feeder inside rd_reader_feed) -> join -> free: no thread is inside a
+                self._feeder.stop()              # feed call when the reader goes away
+                N.host_lib().rd_reader_feed_abort(self.h)
                 self._feeder.join()
                 self._feeder = None
+            N.host_lib().rd_reader_close(self.h)
             self.h = None
 
     def __del__(self):
@@ -919,12 +928,12 @@ def chunk_schedule(seq_file, chunk_size, byte_range=None, first_chunk=1 << 17):
     return up + [top] * (body // top) + ([rest] if rest >= first else []) + down
 
 
-def get_seq_chunks(seq_file, chunk_size=1048576, byte_range=None, first_chunk=None, arena=None, schedule=None):
+def get_seq_chunks(seq_file, chunk_size=1048576, byte_range=None, first_chunk=None, arena=None, schedule=None, device=None):
     """Chunks of at most `chunk_size` records (reference seq_encoder.py:75-87), as `Chunk` arrays, parsed by librd_host.so.
     byte_range: parse only that part of a plain file (multi-rank CLI, plan_ranges). first_chunk: the first chunk holds that many
     records, the following ones twice as many each up to chunk_size (the kernels start earlier; mate files given the same
     schedule still pair up chunk by chunk)."""
-    r = NativeReader(seq_file, byte_range=byte_range, arena=arena)
+    r = NativeReader(seq_file, byte_range=byte_range, arena=arena, device=device)
     want = chunk_size if not first_chunk else max(1, min(int(first_chunk), chunk_size))
     sched = list(schedule) if schedule else None    # explicit record counts (chunk_schedule); afterwards: chunks of its last entry
     try:
@@ -1083,6 +1092,14 @@ class NativeWriter:
         rs = np.ascontiguousarray(chunk.rec_start, dtype=np.int64)
         N.host_check(N.host_lib().rd_writer_write_selected(self.h, buf.ctypes.data, rs.ctypes.data, len(labels), labels.ctypes.data,
                                                            int(want)), "rd_writer_write_selected")
+
+    def write_text(self, ptr, nbytes):
+        """append text that already is the selected records in input order (packed on the GPU: gz.DeviceSelect); ptr: host address"""
+        N.host_check(N.host_lib().rd_writer_write_text(self.h, ptr, int(nbytes)), "rd_writer_write_text")
+
+    def set_eof_marker(self, on):
+        """off: a part of a file that is joined with others afterwards gets no BGZF end-of-file block of its own"""
+        N.host_check(N.host_lib().rd_writer_set_eof_marker(self.h, 1 if on else 0), "rd_writer_set_eof_marker")
 
     def write_members(self, ptr, nbytes):
         """append complete gzip members made on the GPU (ribodetector_amd/gz.py); ptr: host address of the bytes"""

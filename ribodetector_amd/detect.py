@@ -28,6 +28,7 @@ import torch
 
 from . import __version__
 from . import dist as rdist
+from .data_loader import device_reader as dr
 from .data_loader import fastx_parser as fx
 from .model import model as module_arch
 from .parse_config import ConfigParser
@@ -61,11 +62,14 @@ class Predictor:
 
     GZ_RING = 6          # device gzip: sets of output buffers in flight (submitted x2, queued x2, being written, + 1)
 
-    def __init__(self, config, args):
+    def __init__(self, config, args, log_level=None):
         self.config = config
         self.args = args
         # under torchrun only rank 0 owns the log file (the other ranks log to the console only)
         self.logger = config.get_logger('predict', 1, self.args.log if int(os.environ.get('RANK', '0')) == 0 else None)
+        log_level = log_level or os.environ.get('RD_LOG_LEVEL')     # (benchmarks call main() with "WARNING": no per-chunk lines)
+        import logging
+        self.logger.setLevel(getattr(logging, str(log_level).upper()) if log_level else logging.NOTSET)
         self.chunk_size = self.args.chunk_size
         self.thread_cpu_s = {}
         self.rank, self.world, self.local_rank = 0, 1, 0
@@ -227,9 +231,15 @@ class Predictor:
             bounds = rdist.shard_bounds(n, self.world, work)
         lo, hi = (0, n) if bounds is None else (bounds[self.rank], bounds[self.rank + 1])
         cs = self._copy_stream
-        dev_in = [self._to_device(c, lo, hi, cs) for c in chunks]
         cur = torch.cuda.current_stream(self.device)
-        cur.wait_stream(cs)
+        on_dev = isinstance(chunks[0], dr.DeviceChunk)      # text and index already in HBM (data_loader/device_reader.py): nothing to copy
+        if on_dev:
+            dev_in = [c.dev[:3] for c in chunks]
+            for c in chunks:
+                cur.wait_event(c.ready)
+        else:
+            dev_in = [self._to_device(c, lo, hi, cs) for c in chunks]
+            cur.wait_stream(cs)
         # (dev_in stays referenced by the ticket: its tensors were allocated on the copy stream and must not return to that
         # stream's pool while other streams read them - and the deferred float64 pass reads the bases until the post-pass has run)
         outs = [self.model.classify_bytes(a, o, l, self.len, want_labels=not self.is_paired) for a, o, l in dev_in]
@@ -255,11 +265,26 @@ class Predictor:
             if not self.multi or self.sharded_parse:
                 host = torch.empty(labels.shape, dtype=torch.int8, pin_memory=True)
                 host.copy_(labels, non_blocking=True)
+            if on_dev:
+                # a chunk whose text lives on the device: every output file's records are selected there - deflated (.gz outputs, as
+                # below) or packed into one contiguous text (plain outputs, rd_select_pack) - and only those bytes travel to the host
+                ring = self._gz_seq % self.GZ_RING
+                self._gz_seq += 1
+                lab8 = labels.view(torch.int8)
+                for e, lab in self._out_files:
+                    text, rs = chunks[e].dev[0], chunks[e].dev[3]
+                    if (e, lab) in self._gz_files:
+                        out, info = self._gz.compress_selected(text, rs, lab8, lab, slot=(e, lab, ring))
+                    else:
+                        out, info = self._sel.pack_selected(text, rs, lab8, lab, slot=(e, lab, ring))
+                    ih = torch.empty(4, dtype=torch.int64, pin_memory=True)
+                    ih.copy_(info, non_blocking=True)
+                    gzparts[(e, lab)] = [(out, ih)]
             # .gz outputs: the records of every label file of this chunk - under the label gather: of this rank's shard of it - are
             # deflated here, where the text already is (BGZF members, csrc/rd_deflate.hpp), beside the next chunk's recurrences; the
             # writer threads fetch the compressed bytes and append them (reference: gzip.open(..., compresslevel=5) on the host,
             # detect.py:729-741). Every rank takes the same decision (the chunks of a shared decode are the same chunks).
-            if self._gz_files and all(c.tensors is not None and len(c.tensors) > 3 and c.verbatim for c in chunks):
+            if not on_dev and self._gz_files and all(c.tensors is not None and len(c.tensors) > 3 and c.verbatim for c in chunks):
                 ring = self._gz_seq % self.GZ_RING
                 self._gz_seq += 1
                 for e, lab in self._gz_files:
@@ -278,7 +303,7 @@ class Predictor:
             done = torch.cuda.Event()
             done.record(post)
         return {"n": n, "bounds": bounds, "labels": labels, "host": host, "finish": finish, "done": done, "keep": (dev_in, outs),
-                "gz": gzparts}
+                "gz": gzparts, "totals": [c.total for c in chunks] if on_dev else ()}
 
     def collect_chunk(self, tk):
         """Labels of a submitted chunk: int8 numpy on rank 0 (whole chunk, input order), None elsewhere."""
@@ -303,6 +328,9 @@ class Predictor:
             return None if self.rank != 0 else labels.cpu().numpy()
         while not tk["done"].query():              # sleep-poll instead of hipEventSynchronize: that one spins a host core for the
             time.sleep(2e-4)                       # whole run, and the ranks of a node share their cores with readers and writers
+        for t in tk.get("totals", ()):
+            if int(t[0]) < 0:
+                raise RuntimeError("device chunk assembly failed (rd_fastq_gather)")
         return tk["host"].numpy()
 
     def classify_chunk(self, chunks):
@@ -324,13 +352,19 @@ class Predictor:
 
         def work():
             try:
+                # FASTQ whose text can stay on the device (plain files, BGZF): H2D of the file's bytes, members inflated and records
+                # framed there - no parser thread at all (data_loader/device_reader.py; RD_DEVICE_PARSE=0 keeps the host parser)
+                if arena is None and self._device_parse(path):
+                    st = self.ingest.setdefault(os.path.basename(str(path)), {"path": "device"})
+                    stream = dr.get_seq_chunks_device(path, chunk_size=chunk_reads, byte_range=byte_range, first_chunk=1 << 17, schedule=schedule,
+                                                      device=self.device, stats=st)
                 # one plain input file: its parser thread was the slowest stage of the pipeline - two readers over byte segments,
                 # small first chunks (mate files keep one reader each and exact chunk sizes: their chunks must pair up)
-                if arena is None and len(self.input) == 1 and not fx.file_info(path)[1] and int(self.args.threads) >= 4:
+                elif arena is None and len(self.input) == 1 and not fx.file_info(path)[1] and int(self.args.threads) >= 4:
                     stream = fx.get_seq_chunks_parallel(path, chunk_size=chunk_reads, byte_range=byte_range, workers=2)
                 else:
                     stream = fx.get_seq_chunks(path, chunk_size=chunk_reads, byte_range=byte_range, first_chunk=1 << 17, arena=arena,
-                                               schedule=schedule)
+                                               schedule=schedule, device=self.device)
                 for c in stream:
                     q.put(c)
                 q.put(None)
@@ -340,6 +374,11 @@ class Predictor:
                 self.thread_cpu_s["reader:" + os.path.basename(str(path))] = round(time.thread_time(), 4)
         self._spawn(work)
         return q
+
+    def _device_parse(self, path):
+        """does this input's text stay on the device? FASTQ, plain or BGZF, when every record a rank reads is a record it classifies
+        (one rank, or the sharded parse) - under the label gather the chunk's lengths are needed on the host for the shard bounds"""
+        return (not self.multi or self.sharded_parse) and dr.device_parse_wanted(path)
 
     def _shared_decode(self):
         """several ranks of ONE node on gzip input: rank 0 inflates and parses the stream once into shared memory (fx.ShmArena)
@@ -485,10 +524,16 @@ class Predictor:
                 fhs[-1] = [fx.open_for_write(part(u)) for u in unclf]
                 finals += unclf
                 log('Writing unclassified sequences into file: {}{}{}'.format(colors.OKYELLOW, ", ".join(unclf), colors.ENDC))
+        if writer and self.sharded_parse:          # parts are joined below: the joined file gets ONE BGZF end-of-file block, at its end
+            for handles in fhs.values():
+                for fh in handles:
+                    fh.set_eof_marker(False)
         num_read = num_nonrrna = num_rrna = num_unknown = 0
         self._stage_s = {"wait_reader": 0.0, "classify": 0.0, "wait_writer": 0.0}   # main-thread seconds per pipeline stage
         self.thread_cpu_s = {}                                                      # CPU seconds of the pipeline's Python threads, by role
         main_cpu0 = time.thread_time()
+        self._first_chunk = None
+        self.ingest = {}                           # per input file: which reader took it, and the device feeder's stage times
         self._copy_stream = torch.cuda.Stream(self.device)
         self._post_stream = torch.cuda.Stream(self.device)
         # which (mate, label) files are gzip outputs deflated on the device: every rank deflates the records it classified - and writes
@@ -499,13 +544,19 @@ class Predictor:
             self._gz_files = self.gz_output_files(self.output, self.rrna, self.is_paired, self.args.ensure)
             if self._gz_files:
                 self._gz = DeviceGzip(self.device)
+        # every (mate, label) file this run writes; for chunks on the device the plain ones are packed there (rd_select_pack)
+        self._out_files = [(e, lab) for lab in fhs for e in ends]
+        if any(self._device_parse(p) for p in self.input):
+            from .gz import DeviceSelect
+            self._sel = DeviceSelect(self.device)
 
         # writer threads (rank 0): one per mate, records of every label file in input order
         wq, werr, wth = [], [], []
         if writer:
             def write_end(e, q):
                 stage = [None]                          # pinned staging buffer of this thread
-                gz_copy = torch.cuda.Stream(self.device) if self._gz_files else None
+                torch.cuda.set_device(self.device)          # (the current device is per thread)
+                gz_copy = torch.cuda.Stream(self.device)
                 try:
                     while True:
                         item = q.get()
@@ -517,15 +568,17 @@ class Predictor:
                             if part is None:
                                 handles[e].write_selected(chunk, labels, lab)
                                 continue
-                            for out, info in part:      # members made on the GPU (one piece per rank under the label gather): fetch, append
-                                nb = int(info[0]) if info is not None else int(out.numel())
+                            as_text = (e, lab) not in self._gz_files      # packed records (rd_select_pack) instead of gzip members
+                            put = handles[e].write_text if as_text else handles[e].write_members
+                            for out, info in part:      # made on the GPU (one piece per rank under the label gather): fetch, append
+                                nb = int(info[1 if as_text else 0]) if info is not None else int(out.numel())
                                 if info is not None and int(info[3]):
-                                    raise RuntimeError("device gzip: the chunk's record table does not describe its text")
+                                    raise RuntimeError("device %s: the chunk's record table does not describe its text" % ("select" if as_text else "gzip"))
                                 if nb > out.numel():        # text that does not compress into the reserved half: the host deflates this piece
                                     handles[e].write_selected(chunk, labels, lab)
                                     continue
                                 if nb and not out.is_cuda:
-                                    handles[e].write_members(out.data_ptr(), nb)
+                                    put(out.data_ptr(), nb)
                                 elif nb:
                                     if stage[0] is None or stage[0].numel() < nb:
                                         stage[0] = torch.empty(max(nb, 1 << 24) * 5 // 4, dtype=torch.uint8, pin_memory=True)
@@ -535,7 +588,7 @@ class Predictor:
                                         done.record(gz_copy)
                                     while not done.query():     # (sleeping: stream.synchronize() spins a core while the copy waits its
                                         time.sleep(2e-4)        # turn behind the H2D of the next chunk)
-                                    handles[e].write_members(stage[0].data_ptr(), nb)
+                                    put(stage[0].data_ptr(), nb)
                         if chunk.release is not None:   # a shared-memory slot: free for the next chunk once its text is written
                             chunk.release()
                 except BaseException as ex:
@@ -566,6 +619,8 @@ class Predictor:
                 labels = self.collect_chunk(tk)
                 self._stage_s["classify"] += time.perf_counter() - t0
                 num_read += len(chunks[0].seq_len)
+                if self._first_chunk is None:
+                    self._first_chunk = (time.perf_counter(), num_read)
                 if writer:
                     if werr:
                         raise werr[0]
@@ -606,10 +661,17 @@ class Predictor:
             # being placed never leaves a full-size, partly zero-filled file under the final name
             tmps = [path + '.joining' for path in finals]
             self._part_files += tmps if self.rank == 0 else []
+            # .gz files whose members were made on the device are BGZF: one end-of-file block (an empty member) behind the last part
+            from .gz import eof_block
+            tails = [eof_block() if (self.gzip_on_device and path.endswith('gz')) else b'' for path in finals]
             if self.rank == 0:
                 for f, tmp in enumerate(tmps):
                     with open(tmp, 'wb') as fh:
-                        fh.truncate(sum(sz[f] for sz in sizes))
+                        body = sum(sz[f] for sz in sizes)
+                        fh.truncate(body + len(tails[f]))
+                        if tails[f]:
+                            fh.seek(body)
+                            fh.write(tails[f])
             dist.barrier()
             for f, path in enumerate(finals):
                 fx.place_part(tmps[f], part_path(path, self.rank), sum(sizes[r][f] for r in range(self.rank)))
@@ -725,17 +787,23 @@ none: give label based on the mean probability of read pair.
     return args
 
 
-def main(argv=None):
+def main(argv=None, log_level=None):
     args = build_parser().parse_args(argv)
     config_file = os.path.join(cd, 'config.json') if args.config is None else args.config
     config = ConfigParser.from_json(config_file)
-    seq_pred = Predictor(config, args)
+    seq_pred = Predictor(config, args, log_level=log_level)
     try:
         t0 = time.perf_counter()
         seq_pred.load_model()
         t1 = time.perf_counter()
         seq_pred.detect()
-        seq_pred.timing = {"load_model_s": t1 - t0, "detect_s": time.perf_counter() - t1, "prefix_k": seq_pred.model.prefix_k}
+        t2 = time.perf_counter()
+        fc = getattr(seq_pred, "_first_chunk", None)      # (time its labels arrived, its records): the rate after the pipeline filled
+        steady = None
+        if fc is not None and seq_pred.num_read > fc[1] and t2 > fc[0]:
+            steady = len(seq_pred.input) * (seq_pred.num_read - fc[1]) / (t2 - fc[0])
+        seq_pred.timing = {"load_model_s": t1 - t0, "detect_s": t2 - t1, "prefix_k": seq_pred.model.prefix_k,
+                           "reads_per_s_after_first_chunk": steady, "ingest": getattr(seq_pred, "ingest", None)}
     except BaseException:
         seq_pred.cleanup()                       # a failed run leaves no slot, '<out>.partN' or '<out>.joining' files behind
         if seq_pred.multi:

@@ -60,6 +60,38 @@ class DeviceGzip:
         return out, info
 
 
+class DeviceSelect:
+    """pack_selected(text, rec_start, labels, label): the records with labels[i] == label as ONE contiguous text on the device, in input
+    order (C ABI rd_select_pack) - the plain-output counterpart of DeviceGzip for chunks whose text lives in HBM
+    (data_loader/device_reader.py). Returns (out, info): info int64[4] on the device, info[1] = bytes, info[3] != 0 = bad record table."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self._ws = None
+        self._out = {}
+
+    def pack_selected(self, text, rec_start, labels, label, slot=0):
+        lib = N.lib()
+        n, tb = int(labels.numel()), int(text.numel())
+        if rec_start.dtype != torch.int64 or rec_start.numel() < n + 1 or not rec_start.is_contiguous():
+            raise TypeError("pack_selected: rec_start must be a contiguous int64 tensor of n + 1 entries")
+        if labels.dtype not in (torch.int8, torch.uint8) or text.dtype != torch.uint8:
+            raise TypeError("pack_selected: labels must be int8 / uint8 and text uint8")
+        need = int(lib.rd_select_workspace_bytes(n))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(max(need, 1 << 16), dtype=torch.uint8, device=self.device)
+        out = self._out.get(slot)
+        if out is None or out.numel() < tb + 16:
+            self._out[slot] = None
+            out = self._out[slot] = torch.empty(tb + 256, dtype=torch.uint8, device=self.device)
+        info = torch.empty(4, dtype=torch.int64, device=self.device)
+        with torch.cuda.device(self.device):
+            N.check(lib.rd_select_pack(N.ptr(text), tb, N.ptr(rec_start), N.ptr(labels), n, int(label), N.ptr(out), out.numel(), N.ptr(info),
+                                       N.ptr(self._ws), self._ws.numel(), N.stream_ptr(self.device)), "rd_select_pack")
+        return out, info
+
+
 # ---- the input side: gzip members inflated on the device (csrc/rd_inflate_dev.hpp) ---------------------------------------------------------
 
 GZI_ERRORS = {1: "invalid block type", 2: "invalid Huffman code", 3: "invalid code lengths set", 4: "more data than the member's ISIZE says",
@@ -122,13 +154,16 @@ class DeviceGunzip:
     _comp_dev = property(lambda self: self._slots[0].comp_dev)
     _text_dev = property(lambda self: self._slots[0].text_dev)
 
-    def index(self, buf, nbytes, slot=0):
-        """walk the members in buf[:nbytes] (host numpy uint8): (n, consumed, out_bytes, streaming_needed)"""
+    def index(self, buf, nbytes, slot=0, max_members=None):
+        """walk the members in buf[:nbytes] (host numpy uint8): (n, consumed, out_bytes, streaming_needed). max_members bounds the walk
+        (the rest of the bytes stays unconsumed): a batch of m BGZF blocks inflates to at most m * 65,536 bytes, whatever it claims"""
         sl = self._slots[slot]
         cap = max(1024, nbytes // 64 + 16)
         if sl.mem_host is None or sl.cap_members < cap:
             sl.cap_members = cap
             sl.mem_host = torch.empty(cap * 24, dtype=torch.uint8, pin_memory=True)
+        if max_members is not None:
+            cap = max(1, min(cap, int(max_members)))
         n, consumed, ob = C.c_int64(0), C.c_int64(0), C.c_int64(0)
         rc = N.host_lib().rd_host_gz_index(buf.ctypes.data, int(nbytes), 0, 0, sl.mem_host.data_ptr(), cap, C.byref(n), C.byref(consumed), C.byref(ob))
         if rc < 0:
@@ -147,18 +182,26 @@ class DeviceGunzip:
         sl.mem_host[:need].copy_(torch.from_numpy(rows.view(self._np.uint8).reshape(-1)))
         return rows.shape[0]
 
-    def submit(self, buf, nbytes, n, out_bytes, slot=0, host_text=None):
+    def submit(self, buf, nbytes, n, out_bytes, slot=0, host_text=None, text_out=None):
         """queue the batch indexed by the last index(..., slot) call over buf[:nbytes] (buf: pinned host memory if the copy is to be
-        asynchronous; it may be reused once finish() has returned). host_text: pinned uint8 tensor that receives the text."""
+        asynchronous; it may be reused once finish() has returned). host_text: pinned uint8 tensor that receives the text.
+        text_out: device uint8 tensor of >= out_bytes bytes that receives the text instead of this object's own buffer (the caller's
+        batch buffer: data_loader/device_reader.py indexes the records where the members land)."""
         lib = N.lib()
         sl = self._slots[slot]
         with torch.cuda.device(self.device), torch.cuda.stream(self.stream):
             if sl.comp_dev is None or sl.comp_dev.numel() < nbytes + 16:
                 sl.comp_dev = None
                 sl.comp_dev = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=self.device)
-            if sl.text_dev is None or sl.text_dev.numel() < out_bytes:
+            if text_out is not None:
+                if text_out.numel() < out_bytes or text_out.dtype != torch.uint8 or not text_out.is_cuda:
+                    raise ValueError("DeviceGunzip.submit: text_out must be a device uint8 tensor of at least out_bytes bytes")
+                text_dev = text_out
+            elif sl.text_dev is None or sl.text_dev.numel() < out_bytes:
                 sl.text_dev = None
                 sl.text_dev = torch.empty(int(out_bytes * 1.25) + 4096, dtype=torch.uint8, device=self.device)
+            if text_out is None:
+                text_dev = sl.text_dev
             if sl.status is None or sl.status.numel() < n:
                 sl.status = torch.empty(max(n, 1024) * 2, dtype=torch.int32, device=self.device)
                 sl.status_host = torch.empty(max(n, 1024) * 2, dtype=torch.int32, pin_memory=True)
@@ -166,10 +209,10 @@ class DeviceGunzip:
                 sl.mem_dev = torch.empty(max(n, 1024) * 2 * 24, dtype=torch.uint8, device=self.device)
             sl.comp_dev[:nbytes].copy_(torch.from_numpy(buf[:nbytes]), non_blocking=True)
             sl.mem_dev[: n * 24].copy_(sl.mem_host[: n * 24], non_blocking=True)
-            N.check(lib.rd_gz_inflate_members(N.ptr(sl.comp_dev), int(nbytes), N.ptr(sl.mem_dev), n, N.ptr(sl.text_dev), int(out_bytes),
+            N.check(lib.rd_gz_inflate_members(N.ptr(sl.comp_dev), int(nbytes), N.ptr(sl.mem_dev), n, N.ptr(text_dev), int(out_bytes),
                                               N.ptr(sl.status), C.c_void_p(self.stream.cuda_stream)), "rd_gz_inflate_members")
             if host_text is not None:
-                host_text[:out_bytes].copy_(sl.text_dev[:out_bytes], non_blocking=True)
+                host_text[:out_bytes].copy_(text_dev[:out_bytes], non_blocking=True)
             sl.status_host[:n].copy_(sl.status[:n], non_blocking=True)
             sl.event = torch.cuda.Event()
             sl.event.record(self.stream)

@@ -15,19 +15,33 @@ KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "
         "dtype", "data", "config", "roofline")         # cpu_baseline is skipped here (--no-cpu-baseline): it takes ~20 s
 
 
-def _line(out):
-    lines = [l for l in out.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out[-2000:]
-    return json.loads(lines[0])
+def _line(out, full_path=None):
+    """the compact line: the ONLY JSON line, the LAST line of stdout, under 4,000 bytes (the driver keeps an 8,000-byte tail of
+    stdout: round 4's 22 KB line was cut and the round went unmeasured). With full_path: (line, the full record written there)."""
+    all_lines = out.splitlines()
+    lines = [l for l in all_lines if l.startswith("{")]
+    assert len(lines) == 1 and all_lines[-1] == lines[0], out[-2000:]
+    assert len(lines[0]) < 4000, len(lines[0])
+    j = json.loads(lines[0])
+    if full_path is None:
+        return j
+    return j, json.load(open(full_path))
 
 
-def test_bench_single_gpu_contract():
+def test_bench_single_gpu_contract(tmp_path):
+    fp = str(tmp_path / "full.json")
     r = subprocess.run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--pairs-per-step", "65536", "--no-alt",
-                        "--no-cpu-baseline", "--traffic", "off", "--e2e-records", "0"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+                        "--no-cpu-baseline", "--traffic", "off", "--e2e-records", "0", "--full-out", fp], cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
-    j = _line(r.stdout)
+    assert len(r.stderr) < 6000, r.stderr[-3000:]                     # the e2e legs log at WARNING: no per-chunk lines
+    line, j = _line(r.stdout, fp)
     for k in KEYS:
-        assert k in j, k
+        assert k in j and k in line, k
+    # the compact line carries the same numbers as the full record
+    assert line["value"] == j["value"] and line["ms_per_step"] == j["ms_per_step"] and line["config"]["timed_region"] == "ii"
+    assert abs(line["roofline"]["frac"] - j["roofline"]["frac"]) < 1e-4 and line["roofline"]["kernel"] == j["roofline"]["kernel"]
+    assert set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "launches", "avg_launch_ms", "steps_executed_over_steps"}
+    assert line["e2e_plain_to_plain"]["rps"] > 1e5 and "workload" in line["config"] and "model" not in line["config"]
     assert j["n_gpus"] == 1 and j["steps"] == 3 and j["warmup"] == 1 and j["unit"] == "reads/s" and j["scaling"] == "weak"
     assert j["metric"] == "reads/sec classified, 100 bp paired-end" and j["higher_is_better"] is True
     assert j["value"] > 1e6 and abs(j["value"] - 2 * 65536 * 3 / (j["ms_per_step"] * 3e-3)) < 1e-6 * j["value"]
@@ -51,7 +65,7 @@ def test_bench_single_gpu_contract():
     assert (pt["k"] == 0) == (rf["table_bytes_per_launch"] == 0) and rf["table_bytes_per_launch"] <= 65536 * 1024
     assert j["config"]["refine"]["placement"].startswith("deferred")
     e = j["e2e_cli"]["one_step_batch"]
-    assert j["config"]["e2e_cli_reads_per_s"] > 1e5 and e["records_per_file"] == 65536 and e["files"] == 2 and e["timed_calls"] == 1
+    assert j["config"]["e2e_cli_plain_to_plain_reads_per_s"] > 1e5 and e["records_per_file"] == 65536 and e["files"] == 2 and e["timed_calls"] == 1
     assert e["calls"][0]["prefix_k"] == 8                                    # the CLI sizes its table by its input
     assert 0 < j["config"]["host_cores_busy"] < 4
     enc = j["encoder"]["kernels"]
@@ -62,12 +76,15 @@ def test_bench_single_gpu_contract():
     assert gz["size_vs_zlib_level_5"] < 1.10 and gz["ratio"] > 4 and gz["GB_per_s_of_text"] > 1
 
 
-def test_bench_reports_the_rate_without_the_prefix_table():
+def test_bench_reports_the_rate_without_the_prefix_table(tmp_path):
     """alt_no_prefix_table: same timed region, same steps, k = 0 - lower rate, same roofline definition; alt_fp32_kernel rides along"""
+    fp = str(tmp_path / "full.json")
     r = subprocess.run([sys.executable, "bench.py", "--steps", "4", "--warmup", "2", "--pairs-per-step", "524288", "--no-cpu-baseline",
-                        "--no-encoder", "--no-e2e", "--traffic", "off"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+                        "--no-encoder", "--no-e2e", "--traffic", "off", "--full-out", fp], cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
-    j = _line(r.stdout)
+    line, j = _line(r.stdout, fp)
+    assert abs(line["alt_no_prefix_table_reads_per_s"] - j["alt_no_prefix_table"]["value"]) < 1e-4 * line["alt_no_prefix_table_reads_per_s"]
+    assert abs(line["alt_fp32_frac"] - j["alt_fp32_kernel"]["roofline"]["frac"]) < 1e-4
     a = j["alt_no_prefix_table"]
     assert j["config"]["prefix_table"]["k"] >= 4 and a["timed_region"] == "ii" and a["steps"] == 4
     assert 0.70 * j["value"] < a["value"] < 1.05 * j["value"], (a["value"], j["value"])     # (wall clock over 4 steps: noisy)
@@ -80,31 +97,35 @@ def test_bench_reports_the_rate_without_the_prefix_table():
     assert abs(f["value"] - 2 * 524288 * 4 / (f["ms_per_step"] * 4e-3)) < 1e-6 * f["value"]
 
 
-def test_bench_self_launches_two_ranks_one_gpu():
+def test_bench_self_launches_two_ranks_one_gpu(tmp_path):
     """`python bench.py --gpus 2` with no WORLD_SIZE: bench.py starts its own two ranks (torch.distributed.run). Here they
     share the one GPU and exchange labels over gloo; on an N-GPU node the same path runs one rank per GPU over RCCL."""
     env = dict(os.environ, RD_DIST_BACKEND="gloo", RD_LOCAL_DEVICE="0")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
+    fp = str(tmp_path / "full.json")
     cmd = [sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--pairs-per-step", "65536", "--no-alt",
-           "--no-cpu-baseline"]
+           "--no-cpu-baseline", "--full-out", fp]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    j = _line(r.stdout)
+    line, j = _line(r.stdout, fp)
+    assert line["n_gpus"] == 2 and line["value"] == j["value"] and line["config"]["gather_self_check"] == "passed" and len(j["config"]["ranks"]) == 2
     assert j["n_gpus"] == 2 and j["value"] > 1e6 and j["config"]["rccl_ranks"] == 2 and j["config"]["dist_backend"] == "gloo"
     assert abs(j["value"] - 2 * 2 * 65536 * 3 / (j["ms_per_step"] * 3e-3)) < 1e-6 * j["value"]     # whole-job aggregate
 
 
-def test_bench_self_launches_eight_ranks_one_gpu():
+def test_bench_self_launches_eight_ranks_one_gpu(tmp_path):
     """the driver's largest point (--gpus 8) as far as a 1-GPU box can take it: eight ranks share the GPU, labels over gloo"""
     env = dict(os.environ, RD_DIST_BACKEND="gloo", RD_LOCAL_DEVICE="0")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
+    fp = str(tmp_path / "full.json")
     cmd = [sys.executable, "bench.py", "--gpus", "8", "--steps", "2", "--warmup", "1", "--pairs-per-step", "16384", "--no-alt",
-           "--no-cpu-baseline"]
+           "--no-cpu-baseline", "--full-out", fp]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    j = _line(r.stdout)
+    line, j = _line(r.stdout, fp)             # (the N = 8 line is under 4,000 bytes too: the per-rank table is in the full record)
+    assert line["n_gpus"] == 8 and len(j["config"]["ranks"]) == 8 and line["config"]["label_counts"] == [j["config"]["label_counts"][k] for k in ("non_rrna", "rrna", "unclassified")]
     assert j["n_gpus"] == 8 and j["config"]["rccl_ranks"] == 8
     assert abs(j["value"] - 2 * 8 * 16384 * 2 / (j["ms_per_step"] * 2e-3)) < 1e-6 * j["value"]
     c = j["config"]["label_counts"]
@@ -176,10 +197,12 @@ def test_two_gpu_rccl_when_available():
     if torch.cuda.device_count() < 2:
         pytest.skip("needs 2 GPUs")
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "RD_LOCAL_DEVICE", "RD_DIST_BACKEND")}
-    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-alt", "--no-cpu-baseline"],
+    import tempfile
+    fp = os.path.join(tempfile.mkdtemp(), "full.json")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-alt", "--no-cpu-baseline", "--full-out", fp],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    j = _line(r.stdout)
+    _, j = _line(r.stdout, fp)
     assert j["n_gpus"] == 2 and j["config"]["dist_backend"] == "nccl" and j["config"]["gather_self_check"] == "passed"
     assert len({rk["device_uuid"] for rk in j["config"]["ranks"]}) == 2
     # the CLI across the two devices: gz input (one decode per node through shared memory, label gather over RCCL) and plain input

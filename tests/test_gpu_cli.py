@@ -457,3 +457,50 @@ def test_cli_mismatched_pairs_and_fasta_gz(tmp_path, oracle):
     synth.write_fastq(f2, arena[: off[-2]], off[:-1], 2)
     with pytest.raises(ValueError, match="different numbers of records"):
         detect.main(["-l", "100", "-i", f1, f2, "-o", str(tmp_path / "x1.fq"), str(tmp_path / "x2.fq")])
+
+
+@pytest.mark.parametrize("paired,ensure", [(False, "none"), (True, "rrna"), (True, "both")])
+def test_cli_device_resident_ingest_writes_the_same_files(tmp_path, paired, ensure, monkeypatch):
+    """round 5: FASTQ text stays on the device (plain files copied there, BGZF members inflated there; records framed by
+    rd_fastq_index, selected by rd_select_pack / deflated by rd_gz_compress_selected). Every flow - plain / BGZF in, plain / gz out,
+    CR LF input - writes the bytes RD_DEVICE_PARSE=0 (the host parser, the round-4 route) writes, with the same counts, and the run's
+    record says which reader took each input."""
+    from ribodetector_amd import detect, synth
+    n = 150000
+    ins = []
+    for m in range(2 if paired else 1):
+        a, o, _ = synth.reads_numpy(n, (40, 140), seed=70 + m, rrna_frac=0.3)
+        p = str(tmp_path / ("r_%d.fq" % (m + 1)))
+        synth.write_fastq(p, a, o, m + 1)
+        ins.append(p)
+    crlf = [p[:-3] + ".crlf.fq" for p in ins]
+    for p, q in zip(ins, crlf):
+        open(q, "wb").write(open(p, "rb").read().replace(b"\n", b"\r\n"))
+    bg = [p + ".gz" for p in ins]
+    for p, q in zip(ins, bg):
+        _bgzf(p, q)
+    ends = range(len(ins))
+
+    def run(inputs, gz_out, tag):
+        ext = ".fq.gz" if gz_out else ".fq"
+        outs = [str(tmp_path / ("%s.non%d%s" % (tag, e, ext))) for e in ends]
+        rrs = [str(tmp_path / ("%s.rr%d%s" % (tag, e, ext))) for e in ends]
+        pr = detect.main(["-l", "100", "-i", *inputs, "-o", *outs, "-r", *rrs, "--chunk_size", "8", "-m", "3"] + (["-e", ensure] if paired else []))
+        files = outs + rrs + ([o + ".unclassified.gz" for o in outs] if ensure == "both" else [])
+        return pr, [_read(f) for f in files]
+    monkeypatch.setenv("RD_DEVICE_PARSE", "0")
+    want = {}
+    for kind, inputs in (("plain", ins), ("bgzf", bg)):
+        pr, want[kind] = run(inputs, False, "host_" + kind)
+        assert not getattr(pr, "ingest", None)
+    counts = (pr.num_read, pr.num_rrna, pr.num_nonrrna, pr.num_unknown)
+    assert want["plain"] == want["bgzf"] and pr.num_read == n and pr.num_rrna > 0 and (ensure != "both" or pr.num_unknown > 0)
+    monkeypatch.delenv("RD_DEVICE_PARSE")
+    for kind, inputs in (("plain", ins), ("bgzf", bg), ("crlf", crlf)):
+        for gz_out in (False, True):
+            pr, got = run(inputs, gz_out, "dev_%s_%d" % (kind, gz_out))
+            assert got == want["plain"], (kind, gz_out)
+            assert (pr.num_read, pr.num_rrna, pr.num_nonrrna, pr.num_unknown) == counts
+            assert len(pr.ingest) == len(inputs) and all(v["path"] == "device" and v["feeder"]["batches"] >= 1 for v in pr.ingest.values())
+            if kind == "crlf":
+                assert all(v["indexer"]["stripped"] >= 1 for v in pr.ingest.values())

@@ -1,0 +1,271 @@
+"""The FASTQ record index on the device (C ABI rd_fastq_index / rd_fastq_gather / rd_fastq_strip_mark, csrc/rd_fastq_index.hpp) and
+the reader built on it (data_loader/device_reader.py): text that is inflated / copied onto the GPU is framed there.
+
+What it replaces: the parser's FASTQ state machine (reference data_loader/fastx_parser.py:15-37). The property: the device's chunks -
+record text, rec_start, seq_off, seq_len - equal the host reader's (csrc/rd_host.cpp, itself pinned to the reference's parser by
+tests/test_fastx.py) bit for bit, on the reference-made parser.json text and on fuzzed files (CR LF, '@' / '+' inside quality lines,
+'+name' lines, no final newline, empty sequences, blank tails, lower case) with batch boundaries falling on every byte; malformed
+streams are reported like the host reader reports them, after the records before the damage."""
+import io
+import os
+import struct
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+EOF = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+
+
+def _member(data, level=6):
+    co = zlib.compressobj(level, zlib.DEFLATED, -15, 9)
+    d = co.compress(data) + co.flush()
+    n = 18 + len(d) + 8
+    assert n <= 65536
+    return b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", n - 1) + d + struct.pack("<II", zlib.crc32(data) & 0xffffffff, len(data))
+
+
+def _bgzf(text, block=65280, rng=None):
+    out, i = [], 0
+    while i < len(text):
+        k = block if rng is None else int(rng.integers(1, block + 1))
+        out.append(_member(text[i:i + k]))
+        i += k
+    return b"".join(out) + EOF
+
+
+def _host_chunks(path, chunk, first=None, errors=None):
+    """errors: a list that receives the reader's error message instead of the exception (the chunks before it are returned)"""
+    from ribodetector_amd.data_loader import fastx_parser as fx
+    old = os.environ.get("RD_DEVICE_INFLATE")
+    os.environ["RD_DEVICE_INFLATE"] = "0"
+    out = []
+    try:
+        for c in fx.get_seq_chunks(path, chunk_size=chunk, first_chunk=first):
+            out.append((c.buf[c.rec_start[0]:c.rec_start[-1]].tobytes(), np.asarray(c.rec_start) - c.rec_start[0], np.asarray(c.seq_off) - c.rec_start[0],
+                        np.asarray(c.seq_len)))
+        return out
+    except ValueError as e:
+        if errors is None:
+            raise
+        errors.append(str(e).split(": ", 1)[-1])
+        return out
+    finally:
+        os.environ.pop("RD_DEVICE_INFLATE")
+        if old is not None:
+            os.environ["RD_DEVICE_INFLATE"] = old
+
+
+def _dev_chunks(path, chunk, first=None, byte_range=None, stats=None, errors=None):
+    from ribodetector_amd.data_loader import device_reader as dr
+    out = []
+    try:
+        for c in dr.get_seq_chunks_device(path, chunk_size=chunk, first_chunk=first, byte_range=byte_range, device=DEV, stats=stats):
+            text, rs, so, sl = c.to_host()
+            assert len(rs) == c.n + 1 and len(so) == len(sl) == c.n == len(c.seq_len) and rs[0] == 0 and rs[-1] == len(text)
+            out.append((text.tobytes(), rs, so, sl))
+    except ValueError as e:
+        if errors is None:
+            raise
+        errors.append(str(e))
+    return out
+
+
+def _same(host, dev, records_only=False):
+    if records_only:         # a stream that ends in an error: the same records in front of it (the chunking of the tail may differ)
+        def cat(cs):
+            return (b"".join(c[0] for c in cs), np.concatenate([c[3] for c in cs]) if cs else np.zeros(0, np.int32),
+                    np.concatenate([c[2][: len(c[3])] - c[1][: len(c[3])] for c in cs]) if cs else np.zeros(0, np.int64))
+        h, d = cat(host), cat(dev)
+        assert h[0] == d[0] and np.array_equal(h[1], d[1]) and np.array_equal(h[2], d[2])
+        return
+    assert len(host) == len(dev), (len(host), len(dev))
+    for k, (h, d) in enumerate(zip(host, dev)):
+        assert h[0] == d[0], "chunk %d: record text differs" % k
+        for a, b, what in ((h[1], d[1], "rec_start"), (h[2], d[2], "seq_off"), (h[3], d[3], "seq_len")):
+            assert np.array_equal(a, b), "chunk %d: %s differs" % (k, what)
+
+
+@pytest.fixture
+def small_batches(monkeypatch):
+    """batch sizes of a few hundred bytes: record, line and carry boundaries fall on every byte position of a small file"""
+    from ribodetector_amd.data_loader import device_reader as dr
+
+    def set_sizes(first, full, members=None):
+        monkeypatch.setattr(dr.DeviceFeeder, "PLAIN_FIRST", first)
+        monkeypatch.setattr(dr.DeviceFeeder, "PLAIN_BATCH", full)
+        monkeypatch.setattr(dr.DeviceFeeder, "FIRST", first)
+        if members:
+            monkeypatch.setattr(dr.DeviceFeeder, "MAX_MEMBERS", members)
+    return set_sizes
+
+
+def test_reference_parser_text(golden, tmp_path, small_batches):
+    """tests/golden/parser.json: the text the reference's own seq_parser was run on - the device's records are the reference's records"""
+    g = golden.json("parser")
+    text = g["fastq_text"].encode()
+    want = ["\n".join(r) + "\n" for r in g["fastq_records"]]
+    p = str(tmp_path / "ref.fastq")
+    open(p, "wb").write(text)
+    for first, full in ((1 << 20, 1 << 20), (64, 64), (7, 13), (1, 1)):
+        small_batches(first, full)
+        dev = _dev_chunks(p, 1000)
+        assert b"".join(d[0] for d in dev).decode() == "".join(want)
+        rs, so, sl = dev[0][1], dev[0][2], dev[0][3]
+        for i, r in enumerate(g["fastq_records"]):
+            assert dev[0][0][rs[i]:rs[i + 1]].decode() == "\n".join(r) + "\n" and dev[0][0][so[i]:so[i] + sl[i]].decode() == r[1]
+        _same(_host_chunks(p, 1000), dev)
+
+
+def _fuzz_text(rng, nrec):
+    qual = b"!\"#$%&'()*+,-./0123456789:;<=>?@ABCDEFGHIJ"
+    crlf = rng.random() < 0.25
+    nl = b"\r\n" if crlf else b"\n"
+    recs = []
+    for i in range(nrec):
+        L = int(rng.choice([0, 1, 2, 30, 100, 151, 300]))
+        seq = bytes(rng.choice(list(b"ACGTNacgtn"), L).astype(np.uint8))
+        q = bytes(rng.choice(list(qual), L).astype(np.uint8))
+        if L and rng.random() < 0.2:
+            q = (b"@" if rng.random() < 0.5 else b"+") + q[1:]                 # quality lines that start like a header / a '+' line
+        plus = b"+" if rng.random() < 0.7 else b"+name %d" % i
+        hdr = b"@r%d" % i + (b" 1:N:0:ACGT" if rng.random() < 0.5 else b"")
+        trail = [b"", b"", b"", b""]
+        if not crlf and rng.random() < 0.03:
+            trail[int(rng.integers(0, 4))] = bytes(rng.choice(list(b" \t\r"), int(rng.integers(1, 4))).astype(np.uint8))   # stray trailing blanks
+        recs.append(hdr + trail[0] + nl + seq + trail[1] + nl + plus + trail[2] + nl + q + trail[3] + nl)
+    text = b"".join(recs)
+    tail = rng.random()
+    if tail < 0.2 and text:
+        text = text[:-len(nl)]                                # no final newline
+    elif tail < 0.35:
+        text += nl * int(rng.integers(1, 4))                  # up to three blank lines behind the last record
+    elif tail < 0.4:
+        text += b" \t" + nl                                   # a line of blanks
+    return text
+
+
+def test_fuzz_plain_and_bgzf_against_the_host_reader(tmp_path, small_batches):
+    """500 files: the chunks of the device reader == the chunks of the host reader, plain and BGZF, with small random batch sizes and
+    chunk sizes (the records of a chunk come from up to dozens of batches; the carry is exercised at every offset)"""
+    rng = np.random.default_rng(11)
+    n_files = n_err = 0
+    for it in range(250):
+        nrec = int(rng.choice([0, 1, 2, 3, 5, 17, 100, 400, 1500]))
+        text = _fuzz_text(rng, nrec)
+        first = int(rng.choice([1, 3, 50, 700, 5000, 1 << 20]))
+        small_batches(first, max(first, int(rng.choice([1, 9, 333, 4096, 1 << 20]))), members=int(rng.choice([1, 2, 7, 4096])))
+        chunk, fc = int(rng.choice([1, 2, 7, 64, 1000, 100000])), (None if rng.random() < 0.5 else int(rng.choice([1, 5, 100])))
+        p = str(tmp_path / "f.fastq")
+        open(p, "wb").write(text)
+        he = []
+        host = _host_chunks(p, chunk, fc, errors=he)        # (a file whose last record lost its empty quality line with the final newline
+        n_err += len(he)                                    # is truncated for both readers: same records before, same message)
+        pz = str(tmp_path / "f.fastq.gz")
+        open(pz, "wb").write(_bgzf(text, block=int(rng.choice([40, 700, 65280])), rng=rng if rng.random() < 0.5 else None))
+        for q in (p, pz):
+            de = []
+            dev = _dev_chunks(q, chunk, fc, errors=de)
+            assert de == he, (q, de, he)
+            _same(host, dev)
+            n_files += 1
+    assert n_files == 500 and n_err < 25
+
+
+def test_large_file_many_batches(tmp_path):
+    """a file of several default-sized batches (12 MB first, doubling): chunks of exactly the scheduled sizes, text == the file"""
+    from ribodetector_amd import synth
+    arena, off, lens = synth.reads_numpy(700000, (40, 150), seed=3)
+    p = str(tmp_path / "big.fastq")
+    synth.write_fastq(p, arena, off, 1)
+    st = {}
+    dev = _dev_chunks(p, 200000, first=1 << 17, stats=st)
+    assert [len(d[3]) for d in dev] == [131072, 200000, 200000, 168928] and st["feeder"]["batches"] >= 3 and st["indexer"]["stripped"] == 0
+    assert b"".join(d[0] for d in dev) == open(p, "rb").read()
+    _same(_host_chunks(p, 200000, 1 << 17), dev)
+    # a byte range (the multi-rank CLI's share of a plain file): both ends on record boundaries
+    from ribodetector_amd.data_loader import fastx_parser as fx
+    a, b = fx.find_record_start(p, 30_000_000), fx.find_record_start(p, 90_000_000)
+    part = _dev_chunks(p, 1 << 20, byte_range=(a, b))
+    assert b"".join(d[0] for d in part) == open(p, "rb").read()[a:b]
+
+
+def test_malformed_streams_are_reported_like_the_host_reader_reports_them(tmp_path, small_batches):
+    from ribodetector_amd.data_loader import device_reader as dr
+    good = b"".join(b"@r%d\nACGT\n+\nFFFF\n" % i for i in range(50))
+    cases = {"header": (good + b"r50\nAC\n+\nFF\n" + good, "does not start with '@'", 50),
+             "truncated": (good + b"@x\nAC\n+\n", "truncated FASTQ record", 50),
+             "truncated_one_line": (good + b"@x", "truncated FASTQ record", 50),
+             "four_blank_lines": (good + b"\n\n\n\n", "does not start with '@'", 50),
+             "blank_header_crlf": (b"\r\n" + good, "does not start with '@'", 0)}
+    for name, (text, msg, n_before) in cases.items():
+        for first in (1 << 20, 37):
+            for chunk in (1000, 16, 10, 1):
+                small_batches(first, first)
+                p = str(tmp_path / (name + ".fastq"))
+                open(p, "wb").write(text)
+                he, de = [], []
+                host = _host_chunks(p, chunk, errors=he)                     # the host reader's verdict and the chunks in front of it ...
+                dev = _dev_chunks(p, chunk, errors=de)                       # ... are the device reader's
+                assert len(he) == 1 and msg in he[0] and de == he, (name, first, chunk, he, de)
+                _same(host, dev)
+                assert sum(len(c[3]) for c in dev) == (n_before // chunk) * chunk
+    # a damaged BGZF member: named, never bytes
+    raw = bytearray(_bgzf(good * 40, block=700))
+    at, k = 0, 0
+    while k < 20:                                             # the 21st member: one bit of its CRC-32
+        at += struct.unpack_from("<H", raw, at + 16)[0] + 1
+        k += 1
+    raw[at + struct.unpack_from("<H", raw, at + 16)[0] + 1 - 8] ^= 0x01
+    p = str(tmp_path / "dmg.fastq.gz")
+    open(p, "wb").write(bytes(raw))
+    with pytest.raises(ValueError, match="gzip member|not a gzip member|member size"):
+        _dev_chunks(p, 1000)
+    # a record longer than the carry pad is refused with the way out named
+    small_batches(1 << 20, 1 << 20)
+    monkey_pad = dr.PAD
+    try:
+        dr.PAD = 4096
+        big = b"@long\n" + b"A" * 9000 + b"\n+\n" + b"F" * 9000 + b"\n"
+        p = str(tmp_path / "long.fastq")
+        open(p, "wb").write(good + big + good)
+        small_batches(1000, 1000)
+        with pytest.raises(ValueError, match="RD_DEVICE_PARSE=0"):
+            _dev_chunks(p, 1000)
+    finally:
+        dr.PAD = monkey_pad
+
+
+def test_c_abi_argument_errors():
+    from ribodetector_amd import _native as N
+    L = N.lib()
+    t = torch.zeros(4096, dtype=torch.uint8, device=DEV)
+    assert L.rd_fastq_index(None, 0, 0, None, None, 0, None, 0, None, None, 0, None) != 0 and b"null" in L.rd_last_error()
+    s = torch.zeros(8, dtype=torch.int64, device=DEV)
+    le = torch.zeros(64, dtype=torch.int32, device=DEV)
+    ws = torch.zeros(4096, dtype=torch.uint8, device=DEV)
+    assert L.rd_fastq_index(N.ptr(t), 10, 5, None, None, 0, N.ptr(le), 64, N.ptr(s), N.ptr(ws), 4096, None) != 0      # end < pad
+    assert L.rd_fastq_index(N.ptr(t), 0, 100, N.ptr(t), None, 0, N.ptr(le), 64, N.ptr(s), N.ptr(ws), 4096, None) != 0  # prev_text without prev
+    assert L.rd_fastq_index_workspace_bytes(-1) == 0 and L.rd_fastq_index_workspace_bytes(1 << 20) >= 4 * 65
+    assert L.rd_select_pack(None, 10, None, None, 5, 300, None, 0, N.ptr(s), None, 0, None) != 0 and b"int8" in L.rd_last_error()
+
+
+def test_select_pack_equals_a_host_gather():
+    """rd_select_pack: the records of one label as one text == b''.join of those records, for random labels and ragged records"""
+    from ribodetector_amd.gz import DeviceSelect
+    rng = np.random.default_rng(2)
+    for n in (1, 2, 255, 256, 257, 5000, 70000):
+        lens = rng.integers(0, 400, n)
+        rs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        text = rng.integers(32, 127, int(rs[-1]) + 1, dtype=np.uint8)
+        labels = rng.choice(np.array([0, 1, -1], dtype=np.int8), n, p=[0.6, 0.3, 0.1])
+        ds = DeviceSelect(DEV)
+        T, R, Lb = torch.from_numpy(text).to(DEV), torch.from_numpy(rs).to(DEV), torch.from_numpy(labels).to(DEV)
+        for lab in (0, 1, -1):
+            out, info = ds.pack_selected(T, R, Lb, lab)
+            info = info.cpu().numpy()
+            want = b"".join(text[rs[i]:rs[i + 1]].tobytes() for i in range(n) if labels[i] == lab)
+            assert info[3] == 0 and info[1] == len(want) and out[: len(want)].cpu().numpy().tobytes() == want

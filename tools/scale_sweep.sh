@@ -17,12 +17,16 @@ cd "$R"
 # a throw-away run first: the first process on a box pays cold caches and clocks, and the plain line is compared with the N = 1 group
 env -u RD_FORCE_DIST -u WORLD_SIZE -u RANK -u LOCAL_RANK python bench.py --gpus 1 $FLAGS --steps 2 > /dev/null 2>&1
 # the plain line (no process group at all)
-env -u RD_FORCE_DIST -u WORLD_SIZE -u RANK -u LOCAL_RANK python bench.py --gpus 1 $FLAGS 2> $TMP/plain.err | grep '^{' > $TMP/plain.json
+# (the full record of every run - per-rank table included - goes to --full-out; stdout carries the compact line only)
+env -u RD_FORCE_DIST -u WORLD_SIZE -u RANK -u LOCAL_RANK python bench.py --gpus 1 $FLAGS --full-out $TMP/plain.json > /dev/null 2> $TMP/plain.err
 for N in $NS; do
   if [ "$N" = 1 ]; then   # one rank THROUGH the collectives (a one-rank group): what the N > 1 runs add to a rank, at N = 1
-    RD_FORCE_DIST=1 python bench.py --gpus 1 $FLAGS 2> $TMP/n1.err | grep '^{' > $TMP/n1.json; echo "N=1 rc=${PIPESTATUS[0]}" >> $TMP/rc
+    RD_FORCE_DIST=1 python bench.py --gpus 1 $FLAGS --full-out $TMP/n1.json > /dev/null 2> $TMP/n1.err; echo "N=1 rc=$?" >> $TMP/rc
+    # ... and the plain line once more, BEHIND the group run: the box keeps warming up over the first runs of a fresh lease, so the
+    # N = 1 group is compared with the mean of the plain runs on either side of it (same flags, same pairs per step)
+    env -u RD_FORCE_DIST -u WORLD_SIZE -u RANK -u LOCAL_RANK python bench.py --gpus 1 $FLAGS --full-out $TMP/plain2.json > /dev/null 2>> $TMP/plain.err
   else
-    env -u RD_FORCE_DIST python bench.py --gpus $N $FLAGS 2> $TMP/n$N.err | grep '^{' > $TMP/n$N.json; echo "N=$N rc=${PIPESTATUS[0]}" >> $TMP/rc
+    env -u RD_FORCE_DIST python bench.py --gpus $N $FLAGS --full-out $TMP/n$N.json > /dev/null 2> $TMP/n$N.err; echo "N=$N rc=$?" >> $TMP/rc
   fi
 done
 python - "$TMP" "$OUT" $NS <<'PY'
@@ -30,11 +34,14 @@ import json, os, sys
 tmp, out, ns = sys.argv[1], sys.argv[2], [int(x) for x in sys.argv[3:]]
 def load(name):
     try:
-        return json.loads(open(os.path.join(tmp, name)).read().strip().splitlines()[0])
+        return json.load(open(os.path.join(tmp, name)))
     except Exception:
         return None
-plain = load("plain.json")
-rec = {"plain_line_reads_per_s": plain and plain["value"], "points": [], "rc": open(os.path.join(tmp, "rc")).read().split("\n")[:-1]}
+plain, plain2 = load("plain.json"), load("plain2.json")
+if plain and plain2:
+    plain = dict(plain, value=0.5 * (plain["value"] + plain2["value"]), values=[plain["value"], plain2["value"]])
+rec = {"plain_line_reads_per_s": plain and plain["value"], "plain_runs": plain and plain.get("values"), "points": [],
+       "rc": open(os.path.join(tmp, "rc")).read().split("\n")[:-1]}
 base = None
 for n in ns:
     j = load("n%d.json" % n)
