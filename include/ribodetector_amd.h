@@ -265,7 +265,10 @@ RD_API int rd_gz_inflate_members(const uint8_t *comp, int64_t comp_bytes, const 
  *     out_cap, or the batch / the cursor was bad: every later piece then fails too); rec_start [dev] int64[rec_hi - rec_lo + 1],
  *     seq_off int64[..], seq_len int32[..] = the chunk's entries for these records (offsets into out_text) - the arrays rd_classify and
  *     rd_gz_compress_selected take. max_bytes: an upper bound of the bytes (sizes the launch), e.g. the batch's window size.
- *   rd_fastq_strip_mark: del [dev, zeroed by the caller] gets 1 at every byte rstrip() removes from lines [0, n_lines) of the batch. */
+ *   rd_fastq_strip_mark: del [dev, zeroed by the caller] gets 1 at every byte rstrip() removes from lines [0, n_lines) of the batch.
+ *   rd_fastq_sample: samples [dev] int32[cap]: samples[k] = offset in `text` where record k * every starts (-1 beyond the batch's
+ *     records; entry n / every ... the summary's `consumed` closes the last interval): copied to the host with the summary, they bound
+ *     the bytes of any record range, so that a caller sizes a chunk's buffer without a round trip per range. */
 typedef struct rd_fq_summary {
     int64_t begin, end;       /* the window framed: [begin, end) in the batch buffer (begin = pad - carry; end includes an added '\n') */
     int64_t n_lines, n_records;
@@ -286,6 +289,7 @@ RD_API int rd_fastq_index(uint8_t *text, int64_t pad, int64_t end, const uint8_t
 RD_API int rd_fastq_gather(const uint8_t *text, const int32_t *line_end, const rd_fq_summary *summary, int64_t rec_lo, int64_t rec_hi, int64_t max_bytes,
                     uint8_t *out_text, int64_t out_cap, const int64_t *cursor_in, int64_t *cursor_out, int64_t *rec_start, int64_t *seq_off,
                     int32_t *seq_len, void *stream);
+RD_API int rd_fastq_sample(const int32_t *line_end, const rd_fq_summary *summary, int64_t every, int32_t *samples, int64_t cap, void *stream);
 RD_API int rd_fastq_strip_mark(const uint8_t *text, const int32_t *line_end, const rd_fq_summary *summary, int64_t max_lines, uint8_t *del, void *stream);
 
 /* The records of a chunk that carry one label as ONE contiguous text in `out` [dev, 16-byte aligned], in input order - what the

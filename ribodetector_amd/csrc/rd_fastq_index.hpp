@@ -276,6 +276,17 @@ __global__ __launch_bounds__(FQ_THREADS) void rd_fq_strip_mark_kernel(const uint
     }
 }
 
+// samples[k] = offset where record k * every starts (k * every <= n_records): with the summary's `consumed` they bound the bytes of
+// any record range from the host without a round trip per range
+__global__ __launch_bounds__(FQ_THREADS) void rd_fq_sample_kernel(const int32_t *__restrict__ line_end, const FqSummary *__restrict__ sum, int64_t every,
+                                                                 int32_t *__restrict__ samples, int64_t cap) {
+    const bool framed = sum->status == RD_FQ_OK || sum->status == RD_FQ_HEADER || sum->status == RD_FQ_TRUNCATED;
+    const int64_t n = framed ? sum->n_records : -1, begin = sum->begin;
+    const int64_t stride = (int64_t)gridDim.x * FQ_THREADS;
+    for (int64_t k = (int64_t)blockIdx.x * FQ_THREADS + threadIdx.x; k < cap; k += stride)
+        samples[k] = k * every <= n ? (int32_t)fq_line_start(line_end, 4 * k * every, begin) : -1;
+}
+
 struct FqPlan {
     int ntiles;
     size_t count_bytes, total;

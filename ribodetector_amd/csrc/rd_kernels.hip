@@ -692,6 +692,16 @@ int rd_fastq_gather(const uint8_t *text, const int32_t *line_end, const rd_fq_su
     return RD_OK;
 }
 
+int rd_fastq_sample(const int32_t *line_end, const rd_fq_summary *summary, int64_t every, int32_t *samples, int64_t cap, void *stream) {
+    if (!line_end || !summary || !samples || every < 1 || cap < 0) RD_FAIL(RD_E_INVALID, "rd_fastq_sample: bad argument");
+    if (cap == 0) return RD_OK;
+    int64_t grid = cap / FQ_THREADS + 1;
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(rd_fq_sample_kernel, dim3((unsigned)grid), dim3(FQ_THREADS), 0, (hipStream_t)stream, line_end, (const FqSummary *)summary, every, samples, cap);
+    RD_HIP(hipGetLastError());
+    return RD_OK;
+}
+
 int rd_fastq_strip_mark(const uint8_t *text, const int32_t *line_end, const rd_fq_summary *summary, int64_t max_lines, uint8_t *del, void *stream) {
     if (!text || !line_end || !summary || !del || max_lines < 0) RD_FAIL(RD_E_INVALID, "rd_fastq_strip_mark: bad argument");
     int64_t grid = max_lines / FQ_THREADS + 1;

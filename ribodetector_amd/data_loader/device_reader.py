@@ -30,6 +30,9 @@ from .. import _native as N
 from .. import gz
 
 PAD = 16 << 20                 # bytes in front of a batch's new text: room for the carry (= the longest record the device path frames)
+LINE_DIV = 4                   # the line table of a batch holds window / LINE_DIV lines (a FASTQ line of reads is >= 4 bytes; a batch of
+                               # shorter lines overflows it, is framed again with a full-size table, and so are the batches chained to it)
+EVERY = 4096                   # one record-offset sample per EVERY records travels to the host with the summary: bounds a chunk's bytes
 FQ_ERRORS = {1: "FASTQ record does not start with '@'",
              2: "truncated FASTQ record at end of file (number of lines is not a multiple of 4)",
              3: "a FASTQ record longer than %d bytes: set RD_DEVICE_PARSE=0 (the host parser has no record-size limit)" % PAD,
@@ -76,7 +79,14 @@ class DeviceChunk:
 
 class _Batch:
     __slots__ = ("text", "line_end", "summary", "host", "event", "slot", "gz_slot", "n", "begin", "end", "consumed", "status", "dirty",
-                 "bad_record", "n_lines", "final", "orig")
+                 "bad_record", "n_lines", "final", "orig", "samples", "samples_host", "args", "chain")
+
+    def bytes_bound(self, lo, hi):
+        """an upper bound (tight within 2 * EVERY records) of the text bytes of records [lo, hi)"""
+        s = self.samples_host
+        k1 = -(-hi // EVERY)
+        top = int(s[k1]) if k1 * EVERY <= self.n and k1 < len(s) else self.consumed
+        return top - int(s[lo // EVERY])
 
 
 class FastqIndexer:
@@ -87,8 +97,9 @@ class FastqIndexer:
     def __init__(self, device, stream):
         self.device, self.stream = torch.device(device), stream
         self.lib = N.lib()
-        self.prev = None
-        self.stats = {"batches": 0, "stripped": 0, "index_wait_s": 0.0}
+        self.prev = None               # producer side: (text, summary) of the batch queued last - what the next one chains to
+        self.last_good = None          # consumer side: the same of the batch FINISHED last (differs after a repair)
+        self.stats = {"batches": 0, "stripped": 0, "reframed": 0, "index_wait_s": 0.0}
 
     def _sp(self):
         return C.c_void_p(self.stream.cuda_stream)
@@ -98,25 +109,32 @@ class FastqIndexer:
         with torch.cuda.stream(self.stream):
             return torch.empty(((PAD + int(new_bytes) + 64 + 127) // 64) * 64, dtype=torch.uint8, device=self.device)
 
-    def index(self, text, start, end, final=False, chain=True):
+    def index(self, text, start, end, final=False, chain=True, prev=None, full_table=False):
         """frame text[start:end] (offsets in the batch buffer; start >= PAD unless the batch stands alone) behind the carry of the
-        batch indexed before (chain). Asynchronous: returns the batch, to be finish()-ed later."""
+        batch indexed before (chain) or of an explicit `prev` = (text, summary). Asynchronous: returns the batch, to be finish()-ed."""
         b = _Batch()
-        prev = self.prev if chain else None      # (text, summary) as they were queued: a strip replaces the batch's own fields, not these
+        if prev is None and chain:
+            prev = self.prev      # (text, summary) as they were queued: a strip replaces the batch's own fields, not these
         with torch.cuda.device(self.device), torch.cuda.stream(self.stream):
             window = (end - start) + (PAD if prev is not None else 0)
             b.text = text
-            b.line_end = torch.empty(window + 2, dtype=torch.int32, device=self.device)
+            b.line_end = torch.empty((window + 2) if full_table else (window // LINE_DIV + 4096), dtype=torch.int32, device=self.device)
             b.summary = torch.empty(8, dtype=torch.int64, device=self.device)
+            ns = window // (4 * EVERY) + 3
+            b.samples = torch.empty(ns, dtype=torch.int32, device=self.device)
+            b.samples_host = torch.empty(ns, dtype=torch.int32, pin_memory=True)
             b.host = torch.empty(8, dtype=torch.int64, pin_memory=True)
             ws = torch.empty(max(int(self.lib.rd_fastq_index_workspace_bytes(end)), 256), dtype=torch.uint8, device=self.device)
             N.check(self.lib.rd_fastq_index(N.ptr(text), int(start), int(end), N.ptr(prev[0]) if prev is not None else None,
                                             N.ptr(prev[1]) if prev is not None else None, 1 if final else 0, N.ptr(b.line_end),
                                             b.line_end.numel(), N.ptr(b.summary), N.ptr(ws), ws.numel(), self._sp()), "rd_fastq_index")
+            N.check(self.lib.rd_fastq_sample(N.ptr(b.line_end), N.ptr(b.summary), EVERY, N.ptr(b.samples), ns, self._sp()), "rd_fastq_sample")
             b.host.copy_(b.summary, non_blocking=True)
+            b.samples_host.copy_(b.samples, non_blocking=True)
             b.event = torch.cuda.Event()
             b.event.record(self.stream)
         b.final, b.orig, b.slot, b.gz_slot, b.n = final, None, None, None, None
+        b.args, b.chain = (start, end, final), (text, b.summary)
         if chain:
             self.prev = (text, b.summary)
         self.stats["batches"] += 1
@@ -128,13 +146,33 @@ class FastqIndexer:
             time.sleep(2e-4)
         self.stats["index_wait_s"] += time.perf_counter() - t0
 
+    @staticmethod
+    def _read(b):
+        h = b.host.numpy()
+        b.begin, b.end, b.n_lines, b.n, b.consumed, b.bad_record, sd = (int(x) for x in h[:7])
+        b.status, b.dirty = sd & 0xffffffff, (sd >> 32) & 0xffffffff
+        b.samples_host = b.samples_host.numpy() if torch.is_tensor(b.samples_host) else b.samples_host
+
     def finish(self, b):
         """wait (sleeping) for the batch's summary; strips a dirty batch. Returns the batch with n / status filled in - a status != 0 is
         left to the caller (the records before the damage are delivered first)."""
         self.wait(b)
-        h = b.host.numpy()
-        b.begin, b.end, b.n_lines, b.n, b.consumed, b.bad_record, sd = (int(x) for x in h[:7])
-        b.status, b.dirty = sd & 0xffffffff, (sd >> 32) & 0xffffffff
+        self._read(b)
+        if b.status in (4, 5) and b.chain is not None:
+            # more lines than the table holds (lines of < LINE_DIV bytes on average), or chained to such a batch: framed again, with a
+            # full-size table, behind the batch finished last - the producer keeps chaining new batches to the stale summaries, and
+            # every one of them comes through here (rare: no FASTQ of reads has such lines)
+            self.stats["reframed"] += 1
+            start, end, final = b.args
+            nb = self.index(b.text, start, end, final=final, chain=False, prev=self.last_good, full_table=True)
+            self.stats["batches"] -= 1
+            self.wait(nb)
+            self._read(nb)
+            for k in ("line_end", "summary", "host", "samples", "samples_host", "begin", "end", "consumed", "n", "n_lines", "status", "dirty",
+                      "bad_record", "chain"):
+                setattr(b, k, getattr(nb, k))
+        if b.chain is not None:
+            self.last_good = b.chain
         if b.dirty and b.status == 0:
             self._strip(b)
         if b.status == 0 and b.bad_record != -1 and b.bad_record < b.n:
@@ -154,18 +192,19 @@ class FastqIndexer:
             kept = b.text[b.begin:stop][dele[b.begin:stop] == 0]
             text = torch.empty(((kept.numel() + 64 + 127) // 64) * 64, dtype=torch.uint8, device=self.device)
             text[:kept.numel()] = kept
-            nb = self.index(text, 0, int(kept.numel()), final=True, chain=False)
+            nb = self.index(text, 0, int(kept.numel()), final=True, chain=False, full_table=True)
         self.stats["batches"] -= 1
+        nb.chain = None                       # (a stream of its own: nothing chains to it)
         nb = self.finish(nb)
         b.orig = (b.text, b.summary)          # (alive until the next batch's carry copy has been queued behind it)
-        for k in ("text", "line_end", "summary", "begin", "end", "consumed", "n", "n_lines", "status", "bad_record"):
+        for k in ("text", "line_end", "summary", "samples", "samples_host", "begin", "end", "consumed", "n", "n_lines", "status", "bad_record"):
             setattr(b, k, getattr(nb, k))
         b.dirty = 0
 
     def gather(self, pieces):
         """pieces: [(batch, lo, hi)] -> DeviceChunk of sum(hi - lo) records, in that order"""
         n = sum(hi - lo for _, lo, hi in pieces)
-        cap = sum(b.consumed - b.begin for b, _, _ in pieces)
+        cap = sum(b.bytes_bound(lo, hi) for b, lo, hi in pieces)
         with torch.cuda.device(self.device), torch.cuda.stream(self.stream):
             text = torch.empty(((cap + 255) // 256) * 256 + 256, dtype=torch.uint8, device=self.device)
             rs = torch.empty(n + 1, dtype=torch.int64, device=self.device)
@@ -174,7 +213,7 @@ class FastqIndexer:
             cursor = torch.zeros(len(pieces) + 1, dtype=torch.int64, device=self.device)
             at = 0
             for i, (b, lo, hi) in enumerate(pieces):
-                N.check(self.lib.rd_fastq_gather(N.ptr(b.text), N.ptr(b.line_end), N.ptr(b.summary), lo, hi, b.consumed - b.begin, N.ptr(text),
+                N.check(self.lib.rd_fastq_gather(N.ptr(b.text), N.ptr(b.line_end), N.ptr(b.summary), lo, hi, b.bytes_bound(lo, hi), N.ptr(text),
                                                  text.numel(), C.c_void_p(cursor.data_ptr() + 8 * i), C.c_void_p(cursor.data_ptr() + 8 * (i + 1)),
                                                  C.c_void_p(rs.data_ptr() + 8 * at), C.c_void_p(so.data_ptr() + 8 * at),
                                                  C.c_void_p(sl.data_ptr() + 4 * at), self._sp()), "rd_fastq_gather")
@@ -228,6 +267,15 @@ class DeviceFeeder:
     def join(self):
         self.th.join()
 
+    def close(self):
+        """stop, join, and give the stream back once it has drained"""
+        self.stop()
+        self.join()
+        st, self.stream = getattr(self, "stream", None), None
+        if st is not None:
+            st.synchronize()
+            gz.release_stream(st, priority=-1)
+
     # ---- consumer side --------------------------------------------------------------------------------
     def next_batch(self):
         """the next batch, finished (its record count is known) - None at the end of the stream; raises what the producer raised"""
@@ -259,8 +307,9 @@ class DeviceFeeder:
     def _run(self):
         try:
             torch.cuda.set_device(self.device)          # the current device is per thread (and defaults to 0)
-            self.dg = gz.DeviceGunzip(self.device, slots=self.SLOTS)
-            self.ix = FastqIndexer(self.device, self.dg.stream)
+            self.stream = gz.acquire_stream(self.device, priority=-1)
+            self.dg = gz.DeviceGunzip(self.device, slots=self.SLOTS, stream=self.stream)
+            self.ix = FastqIndexer(self.device, self.stream)
         except BaseException as e:      # noqa: BLE001
             self._init_err = e
             self._ready.set()
@@ -505,7 +554,6 @@ def get_seq_chunks_device(seq_file, chunk_size=1048576, byte_range=None, first_c
         if err is not None:
             raise err
     finally:
-        feeder.stop()
-        feeder.join()
+        feeder.close()
         if stats is not None:
             stats.update({"feeder": dict(feeder.stage_s), "indexer": dict(feeder.ix.stats) if feeder.ix else None})

@@ -534,8 +534,10 @@ class Predictor:
         main_cpu0 = time.thread_time()
         self._first_chunk = None
         self.ingest = {}                           # per input file: which reader took it, and the device feeder's stage times
-        self._copy_stream = torch.cuda.Stream(self.device)
-        self._post_stream = torch.cuda.Stream(self.device)
+        from . import gz as _gzmod
+        self._copy_stream = _gzmod.acquire_stream(self.device)      # (pooled: the allocator's cache is per stream, gz.acquire_stream)
+        self._post_stream = _gzmod.acquire_stream(self.device)
+        wr_streams = []
         # which (mate, label) files are gzip outputs deflated on the device: every rank deflates the records it classified - and writes
         # them itself (one rank, or the sharded parse of plain inputs) or, under the label gather, sends the members to rank 0
         self._gz_files, self._gz_seq = [], 0
@@ -556,7 +558,8 @@ class Predictor:
             def write_end(e, q):
                 stage = [None]                          # pinned staging buffer of this thread
                 torch.cuda.set_device(self.device)          # (the current device is per thread)
-                gz_copy = torch.cuda.Stream(self.device)
+                gz_copy = _gzmod.acquire_stream(self.device)
+                wr_streams.append(gz_copy)
                 try:
                     while True:
                         item = q.get()
@@ -637,6 +640,12 @@ class Predictor:
                 q.put(None)
             for th in wth:
                 th.join()
+            for st in [self._copy_stream, self._post_stream] + wr_streams:
+                try:
+                    st.synchronize()
+                except Exception:      # noqa: BLE001 - (a failed run: the stream is given back all the same)
+                    pass
+                _gzmod.release_stream(st)
         if werr:
             raise werr[0]
         self.thread_cpu_s["main"] = round(time.thread_time() - main_cpu0, 4)

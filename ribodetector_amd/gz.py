@@ -12,6 +12,31 @@ from . import _native as N
 
 MEMBER = 65280      # input bytes per gzip member (BGZF's block size)
 
+# Side streams are taken from a process-wide pool and given back: torch's caching allocator keeps freed blocks PER STREAM, so a run
+# that creates its own streams leaves its gigabytes of batch / chunk buffers cached under streams nobody will use again - a process
+# that calls detect.main() repeatedly (a service, the benchmarks) grew by ~20 GB per call until the runtime itself ran out of memory.
+_stream_pool = {}
+_stream_lock = __import__("threading").Lock()
+
+
+def acquire_stream(device, priority=0):
+    device = torch.device(device)
+    key = (device.index if device.index is not None else torch.cuda.current_device(), priority)
+    with _stream_lock:
+        free = _stream_pool.setdefault(key, [])
+        if free:
+            return free.pop()
+    with torch.cuda.device(device):
+        return torch.cuda.Stream(device, priority=priority)
+
+
+def release_stream(stream, priority=0):
+    """give a stream back - once everything queued on it has finished"""
+    if stream is None:
+        return
+    with _stream_lock:
+        _stream_pool.setdefault((stream.device.index, priority), []).append(stream)
+
 
 def eof_block():
     """BGZF's 28-byte end-of-file marker (an empty gzip member); appended once when a device-written file is closed"""
@@ -139,11 +164,14 @@ class DeviceGunzip:
     and the member table, the kernel, D2H of the text into the caller's pinned buffer and of the status words - is queued on this
     object's stream (high priority: it runs in the gaps between the recurrence launches), and finish() sleeps until it is done."""
 
-    def __init__(self, device, slots=1):
+    def __init__(self, device, slots=1, stream=None):
         import numpy as np
         self.device = torch.device(device)
-        with torch.cuda.device(self.device):
-            self.stream = torch.cuda.Stream(self.device, priority=-1)
+        if stream is not None:
+            self.stream = stream
+        else:
+            with torch.cuda.device(self.device):
+                self.stream = torch.cuda.Stream(self.device, priority=-1)
         self._np = np
         self._slots = [_GunzipSlot() for _ in range(max(1, slots))]
 

@@ -127,8 +127,10 @@ def test_cli_gz_outputs_are_deflated_on_the_device(tmp_path, paired, chunk, monk
 
 
 def test_cli_gz_output_of_text_that_does_not_compress(tmp_path, monkeypatch):
-    """the device path reserves half of the worst-case output size per chunk and file; records that do not shrink into it (IUPAC
-    letters, full-range qualities: ~0.6 of their size) are deflated by the host for that chunk - same file contents, valid gzip"""
+    """records that barely shrink (IUPAC letters, full-range qualities: ~0.6 of their size). A chunk parsed on the host reserves half
+    of the worst-case output size per file on the device: what does not fit is deflated by the host for that chunk. A chunk whose
+    text lives on the device (the default for plain FASTQ since round 5) has no host copy to fall back to and reserves the full
+    bound. Same file contents either way, valid gzip."""
     from ribodetector_amd import detect
     rng = np.random.default_rng(5)
     n = 30000
@@ -139,17 +141,19 @@ def test_cli_gz_output_of_text_that_does_not_compress(tmp_path, monkeypatch):
             L = int(rng.integers(80, 151))
             fh.write(b"@r%d\n%s\n+\n%s\n" % (i, iupac[rng.integers(0, 16, L)].tobytes(), quals[rng.integers(0, 94, L)].tobytes()))
     res = {}
-    for tag, env in (("device", None), ("host", "0")):
-        if env is None:
-            monkeypatch.delenv("RD_DEVICE_GZIP", raising=False)
-        else:
-            monkeypatch.setenv("RD_DEVICE_GZIP", env)
+    for tag, gzip_env, parse_env in (("device", None, None), ("hostparse", None, "0"), ("host", "0", None)):
+        for k, v in (("RD_DEVICE_GZIP", gzip_env), ("RD_DEVICE_PARSE", parse_env)):
+            if v is None:
+                monkeypatch.delenv(k, raising=False)
+            else:
+                monkeypatch.setenv(k, v)
         out = str(tmp_path / (tag + ".fq.gz"))
         p = detect.main(["-l", "100", "-i", inp, "-o", out, "--chunk_size", "64", "-m", "3"])
         res[tag] = (_read(out), p.num_read)
-    assert res["device"] == res["host"] and res["device"][1] == n and len(res["device"][0]) > 0
-    raw = open(str(tmp_path / "device.fq.gz"), "rb").read()
+    assert res["device"] == res["host"] == res["hostparse"] and res["device"][1] == n and len(res["device"][0]) > 0
+    raw = open(str(tmp_path / "hostparse.fq.gz"), "rb").read()
     assert b"RD\x04\x00" in raw[:64]                                    # the first member is the host writer's ('R','D' subfield), not a BGZF block
+    assert b"BC\x02\x00" in open(str(tmp_path / "device.fq.gz"), "rb").read()[:64]      # device chunk: BGZF blocks (stored ones where nothing is gained)
 
 
 def test_cli_argument_errors(tmp_path):

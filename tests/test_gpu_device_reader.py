@@ -269,3 +269,18 @@ def test_select_pack_equals_a_host_gather():
             info = info.cpu().numpy()
             want = b"".join(text[rs[i]:rs[i + 1]].tobytes() for i in range(n) if labels[i] == lab)
             assert info[3] == 0 and info[1] == len(want) and out[: len(want)].cpu().numpy().tobytes() == want
+
+
+def test_short_lines_overflow_the_line_table_and_are_framed_again(tmp_path, small_batches):
+    """the line table of a batch holds window / 4 lines; records like '@\\n\\n+\\n\\n' (1.5 bytes per line) overflow it: the batch - and
+    every batch the producer had chained to it meanwhile - is framed again with a full-size table, behind the batch finished last"""
+    text = b"".join((b"@\n\n+\n\n" if i % 3 else b"@r%d\nA\n+\nF\n" % i) for i in range(60000))
+    p = str(tmp_path / "tiny.fastq")
+    open(p, "wb").write(text)
+    for first, full in ((1 << 20, 1 << 20), (30000, 50000)):
+        small_batches(first, full)
+        st = {}
+        dev = _dev_chunks(p, 7000, stats=st)
+        assert st["indexer"]["reframed"] >= (1 if first > 100000 else 3), st
+        assert b"".join(d[0] for d in dev) == text
+        _same(_host_chunks(p, 7000), dev)
