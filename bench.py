@@ -37,6 +37,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+import ribodetector_amd      # noqa: E402,F401  (sets ROC_SIGNAL_POOL_SIZE before the HIP runtime starts: ribodetector_amd/__init__.py)
 sys.path.insert(1, os.path.join(ROOT, "tools"))
 from e2e_bench import E2E, encoder_record, gzip_record, shm_free, thread_cpu, usable_cores      # noqa: E402  (tools/e2e_bench.py)
 

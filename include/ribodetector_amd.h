@@ -300,6 +300,19 @@ RD_API size_t rd_select_workspace_bytes(int64_t n);
 RD_API int rd_select_pack(const uint8_t *text, int64_t text_bytes, const int64_t *rec_start, const int8_t *labels, int64_t n, int32_t label, uint8_t *out,
                    size_t out_cap, int64_t *info, void *workspace, size_t workspace_bytes, void *stream);
 
+/* n bytes moved by a kernel on `stream` instead of a DMA engine: dst / src [dev, or pinned host memory mapped into the device]. The
+ * feeder's H2D of file bytes and the writers' D2H of output bytes use it: an SDMA queue is shared in order with other streams' copies,
+ * and a copy that waits for kernels (a label D2H behind two recurrence launches) held a 96 MB H2D back for 60-100 ms. workgroups: 0 = 32. */
+RD_API int rd_copy_bytes(void *dst, const void *src, int64_t n, int32_t workgroups, void *stream);
+
+/* A HIP stream whose kernels run on a subset of the compute units (hipExtStreamCreateWithCUMask): cu_mask [host] uint32[words], bit i =
+ * CU i may be used (MI355X: 256 CUs = 8 words; the driver spreads consecutive bits over the XCDs). words == 0: an ordinary stream,
+ * priority < 0 = the device's highest. Why: the latency-bound side kernels (inflate, FASTQ index, deflate) otherwise queue behind a
+ * recurrence launch that holds every register file for ~30 ms; on CUs of their own they run beside it. The caller
+ * wraps the handle (torch.cuda.ExternalStream) and destroys it when done. */
+RD_API int rd_stream_create(int device, const uint32_t *cu_mask, int words, int priority, void **stream);
+RD_API int rd_stream_destroy(void *stream);
+
 /* Timing of the dominant kernel, for bench.py's roofline: rd_classify records hipEvents around the recurrence
  * kernel on the launch stream when enabled. rd_profile_read synchronises those events and returns the number of
  * recorded launches and their total duration. */

@@ -25,7 +25,7 @@ SYMBOLS = [
     "rd_pair_fuse", "rd_count_labels", "rd_encode_codes", "rd_encode_onehot_padded", "rd_pack_plan",
     "rd_pack_onehot", "rd_profile_enable", "rd_profile_read", "rd_last_error", "rd_version",
     "rd_gz_workspace_bytes", "rd_gz_out_bound", "rd_gz_compress_selected", "rd_gz_eof_block", "rd_gz_inflate_members",
-    "rd_fastq_index_workspace_bytes", "rd_fastq_index", "rd_fastq_gather", "rd_fastq_sample", "rd_fastq_strip_mark", "rd_select_workspace_bytes", "rd_select_pack",
+    "rd_fastq_index_workspace_bytes", "rd_fastq_index", "rd_fastq_gather", "rd_fastq_sample", "rd_fastq_strip_mark", "rd_select_workspace_bytes", "rd_select_pack", "rd_stream_create", "rd_stream_destroy", "rd_copy_bytes",
 ]
 
 
@@ -94,6 +94,9 @@ def lib():
     L.rd_select_workspace_bytes.argtypes = [i64]
     L.rd_select_workspace_bytes.restype = sz
     L.rd_select_pack.argtypes = [vp, i64, vp, vp, i64, i32, vp, sz, vp, vp, sz, vp]
+    L.rd_stream_create.argtypes = [C.c_int, vp, C.c_int, C.c_int, C.POINTER(vp)]
+    L.rd_stream_destroy.argtypes = [vp]
+    L.rd_copy_bytes.argtypes = [vp, vp, i64, i32, vp]
     L.rd_profile_enable.argtypes = [vp, C.c_int]
     L.rd_profile_read.argtypes = [vp, C.POINTER(i64), C.POINTER(C.c_double)]
     L.rd_last_error.restype = C.c_char_p
@@ -112,6 +115,37 @@ def check(rc, what):
 def stream_ptr(device=None):
     import torch
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def new_event():
+    import torch
+    return torch.cuda.Event(blocking=True)
+
+
+def wait_event(ev):
+    """sleep until `ev` has happened: the event is queried every 0.5 ms. hipEventSynchronize SPINS a host core on this stack even for
+    an event created with the blocking-sync flag (measured: the waiting thread's CPU time = its wall time), and the ranks of a node
+    share 16 cores with their readers and writers. RD_EVENT_WAIT=sync uses it all the same."""
+    if os.environ.get("RD_EVENT_WAIT") == "sync":
+        ev.synchronize()
+        return
+    import time
+    while not ev.query():
+        time.sleep(5e-4)
+
+
+def copy_bytes(dst, src, nbytes, stream, workgroups=0):
+    """dst[:nbytes] = src[:nbytes] (uint8 tensors: device memory or pinned host memory) by a kernel on `stream` (C ABI rd_copy_bytes);
+    RD_COPY_ENGINE=1 keeps hipMemcpyAsync (the DMA engines)"""
+    import torch
+    if os.environ.get("RD_COPY_ENGINE") == "1":
+        with torch.cuda.stream(stream):
+            dst[:nbytes].copy_(src[:nbytes], non_blocking=True)
+        return
+    dev = dst.device if dst.is_cuda else src.device
+    with torch.cuda.device(dev):
+        check(lib().rd_copy_bytes(C.c_void_p(dst.data_ptr()), C.c_void_p(src.data_ptr()), int(nbytes), int(workgroups), C.c_void_p(stream.cuda_stream)),
+              "rd_copy_bytes")
 
 
 def ptr(t):

@@ -287,6 +287,35 @@ __global__ __launch_bounds__(FQ_THREADS) void rd_fq_sample_kernel(const int32_t 
         samples[k] = k * every <= n ? (int32_t)fq_line_start(line_end, 4 * k * every, begin) : -1;
 }
 
+// bytes moved by a kernel instead of a DMA engine: dst / src are device memory or pinned host memory (mapped into the device's address
+// space). hipMemcpyAsync between pinned memory and HBM goes to an SDMA queue that other streams' copies share IN ORDER - a 96 MB H2D of
+// the feeder was seen waiting 60-100 ms behind a label D2H that itself waited for two recurrence launches; a kernel on the feeder's own
+// stream waits for nothing but a free workgroup slot (~1 ms). 64 bytes per thread and trip keep ~50 GB/s of PCIe busy from 32 workgroups.
+__global__ __launch_bounds__(FQ_THREADS) void rd_copy_kernel(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src, int64_t n) {
+    const int64_t gtid = (int64_t)blockIdx.x * FQ_THREADS + threadIdx.x, stride = (int64_t)gridDim.x * FQ_THREADS;
+    const int64_t head = (16 - ((uintptr_t)dst & 15)) & 15;                 // bytes before dst's first 16-byte boundary
+    if (gtid < head && gtid < n) dst[gtid] = src[gtid];
+    const int64_t body = n > head ? (n - head) / 16 : 0;                    // 16-byte pieces, aligned at dst
+    u32x4 *d = reinterpret_cast<u32x4 *>(dst + head);
+    const uint8_t *s0 = src + head;
+    int64_t i = gtid;
+    for (; i + 3 * stride < body; i += 4 * stride) {
+        u32x4 v0, v1, v2, v3;
+        __builtin_memcpy(&v0, s0 + 16 * i, 16);
+        __builtin_memcpy(&v1, s0 + 16 * (i + stride), 16);
+        __builtin_memcpy(&v2, s0 + 16 * (i + 2 * stride), 16);
+        __builtin_memcpy(&v3, s0 + 16 * (i + 3 * stride), 16);
+        d[i] = v0; d[i + stride] = v1; d[i + 2 * stride] = v2; d[i + 3 * stride] = v3;
+    }
+    for (; i < body; i += stride) {
+        u32x4 v;
+        __builtin_memcpy(&v, s0 + 16 * i, 16);
+        d[i] = v;
+    }
+    const int64_t tail0 = head + 16 * body;
+    if (tail0 + gtid < n && gtid < 16) dst[tail0 + gtid] = src[tail0 + gtid];
+}
+
 struct FqPlan {
     int ntiles;
     size_t count_bytes, total;

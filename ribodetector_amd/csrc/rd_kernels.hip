@@ -646,6 +646,38 @@ int rd_gz_inflate_members(const uint8_t *comp, int64_t comp_bytes, const rd_gz_m
     return RD_OK;
 }
 
+// ---- streams restricted to a set of compute units --------------------------------------------------------------------------------------------
+int rd_stream_create(int device, const uint32_t *cu_mask, int words, int priority, void **stream) {
+    if (!stream || words < 0 || (words > 0 && !cu_mask)) RD_FAIL(RD_E_INVALID, "rd_stream_create: bad argument");
+    RD_HIP(hipSetDevice(device));
+    hipStream_t st = nullptr;
+    if (words > 0) {
+        RD_HIP(hipExtStreamCreateWithCUMask(&st, (uint32_t)words, cu_mask));      // (no priority argument in this entry point: default priority)
+    } else {
+        int lo = 0, hi = 0;
+        RD_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        RD_HIP(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, priority < 0 ? hi : lo));
+    }
+    *stream = (void *)st;
+    return RD_OK;
+}
+
+int rd_stream_destroy(void *stream) {
+    if (stream) RD_HIP(hipStreamDestroy((hipStream_t)stream));
+    return RD_OK;
+}
+
+int rd_copy_bytes(void *dst, const void *src, int64_t n, int32_t workgroups, void *stream) {
+    if (n < 0 || (n > 0 && (!dst || !src))) RD_FAIL(RD_E_INVALID, "rd_copy_bytes: bad argument");
+    if (n == 0) return RD_OK;
+    int64_t grid = workgroups > 0 ? workgroups : 32;
+    const int64_t need = n / (16 * FQ_THREADS) + 1;
+    if (grid > need) grid = need;
+    hipLaunchKernelGGL(rd_copy_kernel, dim3((unsigned)grid), dim3(FQ_THREADS), 0, (hipStream_t)stream, (uint8_t *)dst, (const uint8_t *)src, n);
+    RD_HIP(hipGetLastError());
+    return RD_OK;
+}
+
 // ---- FASTQ record index on the device (rd_fastq_index.hpp) ----------------------------------------------------------------------------------
 size_t rd_fastq_index_workspace_bytes(int64_t text_end) {
     if (text_end < 0 || text_end >= 0x7fffffffLL) return 0;

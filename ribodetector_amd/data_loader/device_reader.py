@@ -119,19 +119,20 @@ class FastqIndexer:
             window = (end - start) + (PAD if prev is not None else 0)
             b.text = text
             b.line_end = torch.empty((window + 2) if full_table else (window // LINE_DIV + 4096), dtype=torch.int32, device=self.device)
-            b.summary = torch.empty(8, dtype=torch.int64, device=self.device)
+            # what travels to the host: the 64-byte summary and the record-offset samples, in ONE buffer, fetched by a kernel
+            # (rd_copy_bytes: an SDMA queue is shared in order with copies that wait for kernels)
             ns = window // (4 * EVERY) + 3
-            b.samples = torch.empty(ns, dtype=torch.int32, device=self.device)
-            b.samples_host = torch.empty(ns, dtype=torch.int32, pin_memory=True)
-            b.host = torch.empty(8, dtype=torch.int64, pin_memory=True)
+            meta = torch.empty(64 + 4 * ns, dtype=torch.uint8, device=self.device)
+            meta_host = torch.empty(64 + 4 * ns, dtype=torch.uint8, pin_memory=True)
+            b.summary, b.samples = meta[:64].view(torch.int64), meta[64:].view(torch.int32)
+            b.host, b.samples_host = meta_host[:64].view(torch.int64), meta_host[64:].view(torch.int32)
             ws = torch.empty(max(int(self.lib.rd_fastq_index_workspace_bytes(end)), 256), dtype=torch.uint8, device=self.device)
             N.check(self.lib.rd_fastq_index(N.ptr(text), int(start), int(end), N.ptr(prev[0]) if prev is not None else None,
                                             N.ptr(prev[1]) if prev is not None else None, 1 if final else 0, N.ptr(b.line_end),
                                             b.line_end.numel(), N.ptr(b.summary), N.ptr(ws), ws.numel(), self._sp()), "rd_fastq_index")
             N.check(self.lib.rd_fastq_sample(N.ptr(b.line_end), N.ptr(b.summary), EVERY, N.ptr(b.samples), ns, self._sp()), "rd_fastq_sample")
-            b.host.copy_(b.summary, non_blocking=True)
-            b.samples_host.copy_(b.samples, non_blocking=True)
-            b.event = torch.cuda.Event()
+            N.copy_bytes(meta_host, meta, meta.numel(), self.stream, workgroups=4)
+            b.event = N.new_event()
             b.event.record(self.stream)
         b.final, b.orig, b.slot, b.gz_slot, b.n = final, None, None, None, None
         b.args, b.chain = (start, end, final), (text, b.summary)
@@ -142,8 +143,7 @@ class FastqIndexer:
 
     def wait(self, b):
         t0 = time.perf_counter()
-        while not b.event.query():
-            time.sleep(2e-4)
+        N.wait_event(b.event)
         self.stats["index_wait_s"] += time.perf_counter() - t0
 
     @staticmethod
@@ -219,7 +219,7 @@ class FastqIndexer:
                                                  C.c_void_p(sl.data_ptr() + 4 * at), self._sp()), "rd_fastq_gather")
                 at += hi - lo
             total = torch.empty(1, dtype=torch.int64, pin_memory=True)
-            total.copy_(cursor[len(pieces):], non_blocking=True)
+            N.copy_bytes(total.view(torch.uint8), cursor[len(pieces):].view(torch.uint8), 8, self.stream, workgroups=1)
             ready = torch.cuda.Event()
             ready.record(self.stream)
         return DeviceChunk(n, text, rs, so, sl, ready, total)
@@ -247,6 +247,7 @@ class DeviceFeeder:
             self.slot_free.put(k)
         self.dg = self.ix = None
         self.stage_s = {"read": 0.0, "index": 0.0, "wait_slot": 0.0, "submit": 0.0, "batches": 0, "bytes": 0}
+        self._trace = [] if os.environ.get("RD_FEED_TRACE") else None
         self._ready = threading.Event()
         self._init_err = None
         self.th = threading.Thread(target=self._run, name="rd-feed", daemon=True)
@@ -326,6 +327,11 @@ class DeviceFeeder:
             self._put(None)
         except BaseException as e:      # noqa: BLE001 - raised by next_batch() on the consumer's thread, behind the batches before it
             self._put(e)
+        if self._trace:
+            self.stream.synchronize()
+            t00 = self._trace[0][0]
+            self.stage_s["gpu_trace"] = [(round(1e3 * (t - t00), 1), nb >> 20, round(e0.elapsed_time(e1), 2), round(e1.elapsed_time(e2), 2))
+                                         for t, nb, e0, e1, e2 in self._trace][:60]      # (submit time ms, MB, H2D ms, index ms)
         if os.environ.get("RD_FEED_TRACE"):
             import sys
             sys.stderr.write("device feeder %s: %s %s\n" % (self.path, {k: (round(v, 3) if isinstance(v, float) else v) for k, v in self.stage_s.items()},
@@ -334,10 +340,20 @@ class DeviceFeeder:
     def _submit_text(self, src, nbytes, slot, start_skip=0, limit=None):
         """pinned host bytes -> a batch buffer -> index"""
         text = self.ix.alloc_text(nbytes)
+        trace = self._trace
         with torch.cuda.device(self.device), torch.cuda.stream(self.dg.stream):
-            text[PAD:PAD + nbytes].copy_(src[:nbytes], non_blocking=True)
+            if trace is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(self.dg.stream)
+            N.copy_bytes(text[PAD:PAD + nbytes], src, nbytes, self.dg.stream)      # (a kernel: an SDMA queue is shared with copies that wait)
+            if trace is not None:
+                e1.record(self.dg.stream)
         end = PAD + nbytes if limit is None else PAD + min(nbytes, start_skip + limit)
         b = self.ix.index(text, PAD + start_skip, end)
+        if trace is not None:
+            e2 = torch.cuda.Event(enable_timing=True)
+            e2.record(self.dg.stream)
+            trace.append((time.perf_counter(), nbytes, e0, e1, e2))
         b.slot = slot
         return b
 

@@ -27,6 +27,7 @@ import numpy as np
 import torch
 
 from . import __version__
+from . import _native as _native_mod
 from . import dist as rdist
 from .data_loader import device_reader as dr
 from .data_loader import fastx_parser as fx
@@ -300,7 +301,7 @@ class Predictor:
                     gzparts[(e, lab)] = [(out, ih)]
             if self.multi and not self.sharded_parse:   # label gather (1 B per read) queued behind the kernels, collected later
                 _, finish = rdist.gather_labels(labels, n, dst=0, bounds=bounds, async_op=True)
-            done = torch.cuda.Event()
+            done = _native_mod.new_event()
             done.record(post)
         return {"n": n, "bounds": bounds, "labels": labels, "host": host, "finish": finish, "done": done, "keep": (dev_in, outs),
                 "gz": gzparts, "totals": [c.total for c in chunks] if on_dev else ()}
@@ -312,8 +313,7 @@ class Predictor:
             if tk.get("gz"):
                 # the members every rank made of its shard travel to rank 0, which appends them in rank order = input order (sizes
                 # first: one small all-gather per chunk; then one padded gather per output file)
-                while not tk["done"].query():
-                    time.sleep(2e-4)
+                _native_mod.wait_event(tk["done"])
                 mine = [int(tk["gz"][key][0][1][0]) for key in self._gz_files]
                 sizes = rdist.all_gather_sizes(mine)
                 gathered = {}
@@ -326,8 +326,7 @@ class Predictor:
                         gathered[key] = [(t, None) for t in parts]
                 tk["gz"] = gathered
             return None if self.rank != 0 else labels.cpu().numpy()
-        while not tk["done"].query():              # sleep-poll instead of hipEventSynchronize: that one spins a host core for the
-            time.sleep(2e-4)                       # whole run, and the ranks of a node share their cores with readers and writers
+        _native_mod.wait_event(tk["done"])         # (a blocking event: the thread sleeps in the driver, it does not spin a host core)
         for t in tk.get("totals", ()):
             if int(t[0]) < 0:
                 raise RuntimeError("device chunk assembly failed (rd_fastq_gather)")
@@ -556,44 +555,77 @@ class Predictor:
         wq, werr, wth = [], [], []
         if writer:
             def write_end(e, q):
-                stage = [None]                          # pinned staging buffer of this thread
+                # Two sets of pinned staging buffers: the bytes an item's files get from the GPU (gzip members / packed records) are
+                # fetched for item k+1 while item k is being written. The fetch is a kernel on this thread's stream (C ABI
+                # rd_copy_bytes), not a DMA copy - an SDMA queue is shared in order with copies that wait for kernels.
+                from . import _native
+                stages = [[], []]
                 torch.cuda.set_device(self.device)          # (the current device is per thread)
                 gz_copy = _gzmod.acquire_stream(self.device)
                 wr_streams.append(gz_copy)
+
+                def issue(item, k):
+                    """queue the D2H of everything the item's files take from the GPU; returns the jobs to complete() in file order"""
+                    chunk, labels, gzparts = item
+                    jobs, slot = [], 0
+                    for lab, handles in fhs.items():
+                        part = gzparts.get((e, lab)) if gzparts else None
+                        if part is None:
+                            jobs.append(("selected", handles[e], lab, None, None))
+                            continue
+                        as_text = (e, lab) not in self._gz_files      # packed records (rd_select_pack) instead of gzip members
+                        put = handles[e].write_text if as_text else handles[e].write_members
+                        for out, info in part:      # made on the GPU (one piece per rank under the label gather): fetch, append
+                            nb = int(info[1 if as_text else 0]) if info is not None else int(out.numel())
+                            if info is not None and int(info[3]):
+                                raise RuntimeError("device %s: the chunk's record table does not describe its text" % ("select" if as_text else "gzip"))
+                            if nb > out.numel():        # text that does not compress into the reserved half: the host deflates this piece
+                                jobs.append(("selected", handles[e], lab, None, None))
+                            elif nb and not out.is_cuda:
+                                jobs.append(("host", put, out, nb, None))
+                            elif nb:
+                                st = stages[k]
+                                if slot == len(st):
+                                    st.append(None)
+                                if st[slot] is None or st[slot].numel() < nb:
+                                    st[slot] = None
+                                    st[slot] = torch.empty(max(nb, 1 << 22) * 5 // 4, dtype=torch.uint8, pin_memory=True)
+                                _native.copy_bytes(st[slot], out, nb, gz_copy)
+                                done = _native.new_event()
+                                done.record(gz_copy)
+                                jobs.append(("dev", put, st[slot], nb, done))
+                                slot += 1
+                    return item, jobs
+
+                def complete(pending):
+                    (chunk, labels, _), jobs = pending
+                    for kind, put, src, nb, done in jobs:
+                        if kind == "selected":
+                            put.write_selected(chunk, labels, src)
+                            continue
+                        if done is not None:
+                            _native.wait_event(done)    # (sleeping in the driver: stream.synchronize() would spin a core)
+                        put(src.data_ptr(), nb)
+                    if chunk.release is not None:   # a shared-memory slot: free for the next chunk once its text is written
+                        chunk.release()
                 try:
+                    pending, k = None, 0
                     while True:
-                        item = q.get()
+                        try:
+                            item = q.get() if pending is None else q.get_nowait()
+                        except queue.Empty:         # nothing to prefetch: write what is in hand, then wait
+                            complete(pending)
+                            pending = None
+                            continue
                         if item is None:
+                            if pending is not None:
+                                complete(pending)
                             return
-                        chunk, labels, gzparts = item
-                        for lab, handles in fhs.items():
-                            part = gzparts.get((e, lab)) if gzparts else None
-                            if part is None:
-                                handles[e].write_selected(chunk, labels, lab)
-                                continue
-                            as_text = (e, lab) not in self._gz_files      # packed records (rd_select_pack) instead of gzip members
-                            put = handles[e].write_text if as_text else handles[e].write_members
-                            for out, info in part:      # made on the GPU (one piece per rank under the label gather): fetch, append
-                                nb = int(info[1 if as_text else 0]) if info is not None else int(out.numel())
-                                if info is not None and int(info[3]):
-                                    raise RuntimeError("device %s: the chunk's record table does not describe its text" % ("select" if as_text else "gzip"))
-                                if nb > out.numel():        # text that does not compress into the reserved half: the host deflates this piece
-                                    handles[e].write_selected(chunk, labels, lab)
-                                    continue
-                                if nb and not out.is_cuda:
-                                    put(out.data_ptr(), nb)
-                                elif nb:
-                                    if stage[0] is None or stage[0].numel() < nb:
-                                        stage[0] = torch.empty(max(nb, 1 << 24) * 5 // 4, dtype=torch.uint8, pin_memory=True)
-                                    with torch.cuda.stream(gz_copy):
-                                        stage[0][:nb].copy_(out[:nb], non_blocking=True)
-                                        done = torch.cuda.Event()
-                                        done.record(gz_copy)
-                                    while not done.query():     # (sleeping: stream.synchronize() spins a core while the copy waits its
-                                        time.sleep(2e-4)        # turn behind the H2D of the next chunk)
-                                    put(stage[0].data_ptr(), nb)
-                        if chunk.release is not None:   # a shared-memory slot: free for the next chunk once its text is written
-                            chunk.release()
+                        nxt = issue(item, k)
+                        k ^= 1
+                        if pending is not None:
+                            complete(pending)
+                        pending = nxt
                 except BaseException as ex:
                     werr.append(ex)
                     while q.get() is not None:   # keep draining so that the producer never blocks

@@ -235,14 +235,18 @@ class DeviceGunzip:
                 sl.status_host = torch.empty(max(n, 1024) * 2, dtype=torch.int32, pin_memory=True)
             if sl.mem_dev is None or sl.mem_dev.numel() < n * 24:
                 sl.mem_dev = torch.empty(max(n, 1024) * 2 * 24, dtype=torch.uint8, device=self.device)
-            sl.comp_dev[:nbytes].copy_(torch.from_numpy(buf[:nbytes]), non_blocking=True)
-            sl.mem_dev[: n * 24].copy_(sl.mem_host[: n * 24], non_blocking=True)
+            src = torch.from_numpy(buf[:nbytes])
+            if src.is_pinned():
+                N.copy_bytes(sl.comp_dev, src, nbytes, self.stream)                # (a kernel: see rd_copy_bytes)
+            else:
+                sl.comp_dev[:nbytes].copy_(src, non_blocking=True)
+            N.copy_bytes(sl.mem_dev, sl.mem_host, n * 24, self.stream, workgroups=4)
             N.check(lib.rd_gz_inflate_members(N.ptr(sl.comp_dev), int(nbytes), N.ptr(sl.mem_dev), n, N.ptr(text_dev), int(out_bytes),
                                               N.ptr(sl.status), C.c_void_p(self.stream.cuda_stream)), "rd_gz_inflate_members")
             if host_text is not None:
                 host_text[:out_bytes].copy_(text_dev[:out_bytes], non_blocking=True)
-            sl.status_host[:n].copy_(sl.status[:n], non_blocking=True)
-            sl.event = torch.cuda.Event()
+            N.copy_bytes(sl.status_host.view(torch.uint8), sl.status.view(torch.uint8), n * 4, self.stream, workgroups=4)
+            sl.event = N.new_event()
             sl.event.record(self.stream)
         sl.n = n
         return slot
@@ -252,8 +256,7 @@ class DeviceGunzip:
         first member that did not decode"""
         import time
         sl = self._slots[slot]
-        while not sl.event.query():
-            time.sleep(2e-4)
+        N.wait_event(sl.event)
         st = sl.status_host[: sl.n].numpy()
         bad = self._np.flatnonzero(st)
         if bad.size:

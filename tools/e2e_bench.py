@@ -174,14 +174,18 @@ class E2E:
                 for q in outs + rrs:                      # every call writes NEW files (truncating GBs of tmpfs pages is not the CLI's work)
                     if os.path.exists(q):
                         os.remove(q)
+                th0 = thread_cpu()
                 t0, c0 = time.perf_counter(), time.process_time()
                 pr = detect.main(argv, log_level="WARNING")
                 dt, cpu = time.perf_counter() - t0, time.process_time() - c0
+                th1 = thread_cpu()
+                top = sorted(((th1[t][1] - th0.get(t, (None, 0.0))[1], th1[t][0]) for t in th1), reverse=True)
                 tm = pr.timing
                 calls.append({"seconds": round(dt, 4), "reads_per_s": len(ins) * self.n / dt,
                               "host_cores_busy": round(cpu / dt, 2),      # CPU seconds of ALL threads of the process / wall seconds
                               "main_thread_s": {k: round(v, 4) for k, v in pr._stage_s.items()},
                               "thread_cpu_s": dict(getattr(pr, "thread_cpu_s", {})),
+                              "os_threads_cpu_s": [[nm, round(c, 3)] for c, nm in top if c >= 0.02][:8],     # (threads alive at the end of the call)
                               "load_model_s": round(tm["load_model_s"], 4), "detect_s": round(tm["detect_s"], 4), "prefix_k": tm["prefix_k"],
                               "ingest": tm.get("ingest"),
                               "reads_per_s_after_model_load": len(ins) * self.n / tm["detect_s"],
