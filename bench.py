@@ -201,7 +201,7 @@ def compact(full):
                                     "vs_baseline", "dtype", "data")}
     out["config"] = {k: r3(c[k]) for k in ("workload", "timed_region", "per_step_per_gpu", "read_len", "ensure", "kernel_variant", "parallelism",
                                            "kernel_only_reads_per_s", "host_cores_busy", "host_cores_usable", "dist_backend", "rccl_ranks",
-                                           "gather_self_check", "gpu_over_cpu", "host_labels_nonzero_last_step") if k in c}
+                                           "gather_self_check", "forced_dist", "gpu_over_cpu", "host_labels_nonzero_last_step") if k in c}
     out["config"]["prefix_k"] = c["prefix_table"]["k"]
     out["config"]["refine_band"] = c["refine"]["band"]
     out["config"]["label_counts"] = [c["label_counts"][k] for k in ("non_rrna", "rrna", "unclassified")]

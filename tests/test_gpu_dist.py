@@ -59,7 +59,7 @@ def test_one_rank_rccl_gather_and_allreduce():
 def test_bench_forced_dist_one_rank_rccl(report):
     """`RD_FORCE_DIST=1 python bench.py --gpus 1`: the label gather over a one-rank RCCL communicator inside the timed region;
     the rate must be the normal line's (the exchange hides behind the next step's recurrences)."""
-    common = ["--steps", "6", "--warmup", "2", "--no-alt", "--no-cpu-baseline", "--no-encoder", "--traffic", "off"]
+    common = ["--steps", "6", "--warmup", "2", "--no-alt", "--no-cpu-baseline", "--no-encoder", "--no-e2e", "--traffic", "off"]
     lines = {}
     for name, env in (("forced", _env()), ("plain", {k: v for k, v in _env().items() if k != "RD_FORCE_DIST"})):
         r = subprocess.run([sys.executable, "bench.py", "--gpus", "1"] + common, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
