@@ -39,7 +39,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import ribodetector_amd      # noqa: E402,F401  (sets ROC_SIGNAL_POOL_SIZE before the HIP runtime starts: ribodetector_amd/__init__.py)
 sys.path.insert(1, os.path.join(ROOT, "tools"))
-from e2e_bench import E2E, encoder_record, gzip_record, shm_free, thread_cpu, usable_cores      # noqa: E402  (tools/e2e_bench.py)
+from e2e_bench import encoder_record, gzip_record, thread_cpu, usable_cores      # noqa: E402  (tools/e2e_bench.py)
 
 READ_LEN = 100
 PEAKS = {"mfma_f32": 157.3, "simple": 157.3, "mfma_f16x3_t32": 2500.0}   # dense TFLOP/s, MI355X_MICROARCH.md
@@ -152,43 +152,23 @@ def pmc_traffic(args, kernel_substr, timeout_s=240):
     return out, None
 
 
-def e2e_legs(torch, synth, args, r1, r2, lens, P, RL, MAXLEN, paired, nslices, dev):
-    """timed region (iii): the whole CLI (tools/e2e_bench.py:E2E) on FASTQ files built from the rank-0 stream of this run.
-    one_step_batch: the batch of one step (the pipeline-fill-bound point: a 2 M-read input is 0.15 s of CLI), one call after a warm one.
-    Then every flow on files of --e2e-records records (default 16 Mi: >= 1 s of CLI per call), median of three calls after a warm one:
-    plain -> plain, plain -> gz, BGZF -> gz (device inflate; and with the host's), gz -> gz (one member per file; -t 10 and -t = cores)."""
-    ne = min(P, 1 << 20)
-    rec = {}
-    cat = lambda ts, rep=1: torch.cat([t[0] for t in ts] * rep)      # noqa: E731
-    with E2E(torch, synth, [r1[0][0][: ne * RL]] + ([r2[0][0][: ne * RL]] if paired else []), r1[0][1][: ne + 1], lens[:ne].contiguous(),
-             MAXLEN, args.ensure) as e:
-        rec["one_step_batch"] = e.leg("plain", False, timed_calls=1)
-    if not (nslices > 1 and ne == P and args.e2e_records > 0):
-        rec["plain_to_plain"] = rec["one_step_batch"]
-        return rec
-    nm = 2 if paired else 1
-    rec_bytes = nm * (2 * RL + 20)
-    rep = max(1, args.e2e_records // (nslices * P))
-    while rep > 1 and shm_free() < 3.2 * rep * nslices * P * rec_bytes:     # plain + gz + BGZF inputs, plain outputs of one call, margin
-        rep //= 2
-    if shm_free() < 3.2 * rep * nslices * P * rec_bytes:
-        rec["plain_to_plain"] = rec["one_step_batch"]
-        rec["skipped"] = "not enough free /dev/shm for %d records per file" % (rep * nslices * P)
-        return rec
-    nbig = rep * nslices * P
-    offs_l = torch.arange(nbig + 1, dtype=torch.int64, device=dev) * RL
-    arenas = [cat(r1, rep)] + ([cat(r2, rep)] if paired else [])
-    with E2E(torch, synth, arenas, offs_l, lens.repeat(rep * nslices), MAXLEN, args.ensure) as e:
-        del arenas
-        rec["plain_to_plain"] = e.leg("plain", False)
-        rec["plain_to_gz"] = e.leg("plain", True)
-        rec["bgzf_to_gz"] = e.leg("bgzf", True)
-        rec["bgzf_to_plain"] = e.leg("bgzf", False)
-        rec["bgzf_to_gz_host_parse"] = e.leg("bgzf", True, env={"RD_DEVICE_PARSE": "0"})
-        rec["plain_to_plain_host_parse"] = e.leg("plain", False, env={"RD_DEVICE_PARSE": "0"})
-        rec["gz_to_gz"] = e.leg("gz", True)
-        rec["gz_to_gz_all_cores"] = e.leg("gz", True, threads=usable_cores())
-    return rec
+def e2e_legs(args, P, RL, MAXLEN, paired):
+    """timed region (iii): the whole CLI on FASTQ files built from the rank-0 stream of this run (same seeds, same slices), in a CHILD
+    process (tools/e2e_bench.py --bench-legs): a CLI invocation is a process of its own, and inside this one the runtime's helper
+    thread - after the timed region, the alt kernels and the probes have run - spins a full core through every call (BGZF -> gz read
+    1.3 host cores here, 0.6 in a process of its own).
+    one_step_batch: the batch of one step (the pipeline-fill-bound point), one call after a warm one. Then every flow on files of
+    --e2e-records records (default 16 Mi: >= 1 s of CLI per call), median of three calls after a warm one: plain -> plain, plain -> gz,
+    BGZF -> gz / plain (text stays on the device), the same two through the host parser, gz -> gz (one member per file; -t 10, -t = cores)."""
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "e2e_bench.py"), "--bench-legs", "--pairs-per-step", str(P), "--records", str(args.e2e_records),
+           "--read-len", str(RL), "--max-len", str(MAXLEN), "--ensure", args.ensure] + ([] if paired else ["--single-end"]) + (
+               ["--var-len"] if args.workload == "var300" else [])
+    env = {k: v for k, v in os.environ.items() if k not in ("RD_FORCE_DIST", "WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    lines = [l for l in r.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
+    if r.returncode != 0 or not lines:
+        raise RuntimeError("tools/e2e_bench.py --bench-legs failed (rc %d): %s" % (r.returncode, r.stderr.decode(errors="replace")[-400:]))
+    return json.loads(lines[-1])
 
 
 def compact(full):
@@ -713,7 +693,8 @@ def main():
                 out["device_gzip"] = {"error": repr(e)}
         if world == 1 and not args.no_e2e and not multi:
             try:
-                out["e2e_cli"] = e2e_legs(torch, synth, args, r1, r2, lens, P, RL, MAXLEN, paired, nslices, dev)
+                torch.cuda.empty_cache()
+                out["e2e_cli"] = e2e_legs(args, P, RL, MAXLEN, paired)
                 for k, v in out["e2e_cli"].items():
                     if isinstance(v, dict) and "reads_per_s" in v:
                         out["config"]["e2e_cli_%s_reads_per_s" % k] = v["reads_per_s"]

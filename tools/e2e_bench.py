@@ -312,11 +312,75 @@ def encoder_record(torch, N, dev, arena, offs, lens, n, L):
     return rec
 
 
+def bench_legs(a):
+    """the legs bench.py reports (timed region iii), in a process of their own - what a CLI invocation is: the rank-0 stream of bench.py
+    (same seeds, same slices) as FASTQ files in tmpfs; one JSON on the last stdout line"""
+    import ribodetector_amd      # noqa: F401  (before torch: the runtime knobs of ribodetector_amd/__init__.py)
+    import torch
+    from ribodetector_amd import synth
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    P, RL, paired = a.pairs_per_step, a.read_len, a.paired
+    nslices = 4
+    r1 = [synth.reads_torch(P, RL, seed=2000 + i, device=dev) for i in range(nslices)]
+    r2 = [synth.reads_torch(P, RL, seed=7000 + i, device=dev) for i in range(nslices)] if paired else None
+    lens = r1[0][2]
+    if a.var_len:                                           # bench.py's var300 workload: lengths ~ U{40..300}
+        g = torch.Generator(device=dev)
+        g.manual_seed(4)
+        lens = torch.randint(40, 301, (P,), generator=g, device=dev, dtype=torch.int32)
+    rec = {}
+    cat = lambda ts, rep=1: torch.cat([t[0] for t in ts] * rep)      # noqa: E731
+    ne = min(P, 1 << 20)
+    with E2E(torch, synth, [r1[0][0][: ne * RL]] + ([r2[0][0][: ne * RL]] if paired else []), r1[0][1][: ne + 1], lens[:ne].contiguous(),
+             a.max_len, a.ensure) as e:
+        rec["one_step_batch"] = e.leg("plain", False, timed_calls=1)
+    if a.records <= 0 or ne != P:
+        rec["plain_to_plain"] = rec["one_step_batch"]
+        print(json.dumps(rec))
+        return
+    nm = 2 if paired else 1
+    rec_bytes = nm * (2 * RL + 20)
+    rep = max(1, a.records // (nslices * P))
+    while rep > 1 and shm_free() < 3.2 * rep * nslices * P * rec_bytes:     # plain + gz + BGZF inputs, plain outputs of one call, margin
+        rep //= 2
+    if shm_free() < 3.2 * rep * nslices * P * rec_bytes:
+        rec["plain_to_plain"] = rec["one_step_batch"]
+        rec["skipped"] = "not enough free /dev/shm for %d records per file" % (rep * nslices * P)
+        print(json.dumps(rec))
+        return
+    nbig = rep * nslices * P
+    offs_l = torch.arange(nbig + 1, dtype=torch.int64, device=dev) * RL
+    arenas = [cat(r1, rep)] + ([cat(r2, rep)] if paired else [])
+    with E2E(torch, synth, arenas, offs_l, lens.repeat(rep * nslices), a.max_len, a.ensure) as e:
+        del arenas, r1, r2
+        torch.cuda.empty_cache()
+        rec["plain_to_plain"] = e.leg("plain", False)
+        rec["plain_to_gz"] = e.leg("plain", True)
+        rec["bgzf_to_gz"] = e.leg("bgzf", True)
+        rec["bgzf_to_plain"] = e.leg("bgzf", False)
+        rec["bgzf_to_gz_host_parse"] = e.leg("bgzf", True, env={"RD_DEVICE_PARSE": "0"})
+        rec["plain_to_plain_host_parse"] = e.leg("plain", False, env={"RD_DEVICE_PARSE": "0"})
+        rec["gz_to_gz"] = e.leg("gz", True)
+        rec["gz_to_gz_all_cores"] = e.leg("gz", True, threads=usable_cores())
+    print(json.dumps(rec))
+
+
 def main():
-    from ribodetector_amd import detect, synth
     ap = argparse.ArgumentParser()
     ap.add_argument("--reads", type=int, default=4000000)
+    ap.add_argument("--bench-legs", action="store_true", help="the legs of bench.py's timed region (iii), as one JSON (bench.py runs this in a child process)")
+    ap.add_argument("--pairs-per-step", type=int, default=1 << 20)
+    ap.add_argument("--records", type=int, default=1 << 24)
+    ap.add_argument("--read-len", type=int, default=100)
+    ap.add_argument("--max-len", type=int, default=100)
+    ap.add_argument("--single-end", dest="paired", action="store_false")
+    ap.add_argument("--var-len", action="store_true")
+    ap.add_argument("--ensure", default="rrna")
     a = ap.parse_args()
+    if a.bench_legs:
+        return bench_legs(a)
+    from ribodetector_amd import detect, synth
     d = tempfile.mkdtemp(prefix="rde2e", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     files = {}
     for mate, seed in ((1, 1), (2, 2)):

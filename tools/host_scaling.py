@@ -6,7 +6,7 @@ The 8-GPU node of the scaling run gives every rank its own GPU but the same cgro
 over gloo - and records the host side of it: CPU seconds per rank inside the timed region, cores busy, and the ratio device
 path / kernel-only, for bench.py at W = 1, 2, 4, 8 and for the CLI (plain and gz input) at W = 1 and 8. The GPU is shared, so
 reads/s do NOT scale here; what the numbers show is that W x (launch thread + reader + writers) stay below the core budget.
-Writes gpurun_out/r04_host_scaling.json.      python tools/host_scaling.py [--reads 4000000]"""
+Writes gpurun_out/r05_host_scaling.json.      python tools/host_scaling.py [--reads 4000000]"""
 import argparse
 import json
 import os
@@ -38,21 +38,22 @@ def run_bench(world, pairs):
     env = dict(os.environ, RD_DIST_BACKEND="gloo", RD_LOCAL_DEVICE="0", RD_PREFIX_K="12")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
+    full = os.path.join(tempfile.gettempdir(), "rd_hs_full_%d_%d.json" % (os.getpid(), world))
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "6", "--warmup", "2", "--pairs-per-step", str(pairs),
-           "--no-alt", "--no-cpu-baseline", "--no-encoder", "--no-e2e", "--traffic", "off"]
+           "--no-alt", "--no-cpu-baseline", "--no-encoder", "--no-e2e", "--traffic", "off", "--full-out", full]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1800)
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    if r.returncode != 0 or len(lines) != 1:
+    if r.returncode != 0 or not os.path.exists(full):
         return {"error": (r.stdout + r.stderr)[-1500:]}
-    j = json.loads(lines[0])
+    j = json.load(open(full))       # (the full record: the stdout line is the compact one)
+    os.remove(full)
     c = j["config"]
     return {"ranks": world, "pairs_per_step_per_rank": pairs, "reads_per_s_all_ranks_one_gpu": j["value"], "ms_per_step": j["ms_per_step"],
             "device_path_over_kernel_only": c["device_path_over_kernel_only"], "cpu_seconds_per_rank": c["host_cpu_seconds_per_rank_in_timed_region"],
             "host_cores_busy": c["host_cores_busy"], "host_cores_usable": c["host_cores_usable"], "dist_backend": c["dist_backend"]}
 
 
-def run_cli(world, inputs, outdir, tag, threads, shared_decode="1"):
-    outs = [os.path.join(outdir, "%s_w%d_%d.fq" % (tag, world, i)) for i in range(len(inputs))]
+def run_cli(world, inputs, outdir, tag, threads, shared_decode="1", gz_out=False):
+    outs = [os.path.join(outdir, "%s_w%d_%d.fq%s" % (tag, world, i, ".gz" if gz_out else "")) for i in range(len(inputs))]
     base = ["-l", "100", "-i", *inputs, "-o", *outs, "-t", str(threads)] + (["-e", "rrna"] if len(inputs) == 2 else [])
     env = dict(os.environ, RD_PREFIX_K="12", RD_SHARED_DECODE=shared_decode)
     if world == 1:
@@ -66,8 +67,9 @@ def run_cli(world, inputs, outdir, tag, threads, shared_decode="1"):
     dt, cpu = time.perf_counter() - t0, child_cpu() - c0
     if r.returncode != 0:
         return {"error": (r.stdout + r.stderr)[-1500:]}
+    import gzip
     import hashlib
-    sha = [hashlib.sha1(open(o, "rb").read()).hexdigest() for o in outs]
+    sha = [hashlib.sha1((gzip.open if gz_out else open)(o, "rb").read()).hexdigest() for o in outs]      # (of the text)
     for o in outs:
         os.remove(o)
     return {"ranks": world, "threads_flag": threads, "wall_s_whole_process": dt, "cpu_s_all_ranks": cpu, "cores_busy": cpu / dt, "output_sha1": sha}
@@ -77,7 +79,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reads", type=int, default=4000000)
     a = ap.parse_args()
-    from bench import usable_cores
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from e2e_bench import usable_cores
     out = {"host_cores_usable": usable_cores(), "os_cpu_count": os.cpu_count(), "note": "all ranks share ONE GPU (RD_LOCAL_DEVICE=0, gloo): host-side evidence only"}
     out["bench"] = [run_bench(w, 1 << 18) for w in (1, 2, 4, 8)]
     import gzip
@@ -113,10 +116,11 @@ def main():
         torch.cuda.empty_cache()
         out["cli_reads_per_file"] = a.reads
         out["cli"] = {}
-        for tag, ins in (("pe_plain", files), ("pe_gz", [f + ".gz" for f in files]), ("pe_bgzf", [os.path.join(d, "bgzf", os.path.basename(f) + ".gz") for f in files])):
+        bg = [os.path.join(d, "bgzf", os.path.basename(f) + ".gz") for f in files]
+        for tag, ins in (("pe_plain", files), ("pe_gz", [f + ".gz" for f in files]), ("pe_bgzf", bg), ("pe_bgzf_to_gz", bg), ("pe_plain_to_gz", files)):
             rows = []
             for w in (1, 8):
-                rows.append(run_cli(w, ins, d, tag, threads=10 if w == 1 else 2))
+                rows.append(run_cli(w, ins, d, tag, threads=10 if w == 1 else 2, gz_out=tag.endswith("_to_gz")))
             if tag == "pe_gz":     # round-2 behaviour for comparison: every rank inflates and parses the whole stream itself
                 rows.append(dict(run_cli(8, ins, d, tag, threads=2, shared_decode="0"), every_rank_decodes=True))
             same = all("output_sha1" in r for r in rows) and all(r["output_sha1"] == rows[0]["output_sha1"] for r in rows)
@@ -132,7 +136,7 @@ def main():
     finally:
         shutil.rmtree(d, ignore_errors=True)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "r04_host_scaling.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "r05_host_scaling.json"), "w"), indent=1)
     print(json.dumps(out))
 
 
