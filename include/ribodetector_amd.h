@@ -300,6 +300,39 @@ RD_API size_t rd_select_workspace_bytes(int64_t n);
 RD_API int rd_select_pack(const uint8_t *text, int64_t text_bytes, const int64_t *rec_start, const int8_t *labels, int64_t n, int32_t label, uint8_t *out,
                    size_t out_cap, int64_t *info, void *workspace, size_t workspace_bytes, void *stream);
 
+/* ONE DEFLATE stream - a plain .gz, the format sequencers write - inflated on the device (round 5; opt-in: RD_DEVICE_INFLATE=stream).
+ * Replaces, for such files: gzip.open(path, 'rt') of reference data_loader/seq_encoder.py:21-39. The two-pass scheme of pugz (this
+ * build's host reader: csrc/rd_pgzip.h) with one wave per SECTION of `section_bytes` compressed bytes: block starts are searched on the
+ * device, every section is decoded from its start to the next section's start with an unknown window into 16-bit symbols, the windows
+ * are resolved in order and all sections in parallel. The stream arrives in batches:
+ *   comp [dev, 4-byte aligned] holds `valid_bytes` bytes of the file from the batch's first byte (comp_bytes readable); the sections
+ *   cover [0, data_bytes) and one more section behind them is searched for the start the NEXT batch begins with (so valid_bytes >=
+ *   data_bytes + section_bytes unless the file ends; the next batch's buffer starts `data_bytes` further: carry_delta_bits =
+ *   8 * data_bytes). first_start_bit: where the member's first block starts (first batch: behind the gzip header; else ignored and taken
+ *   from `carry` = the state the batch before left [dev]). win_in / win_out [dev] 32 KiB: the text behind the batch before / this one.
+ *   text [dev] receives state->n_text bytes (<= text_cap). state [dev] rd_gzs_state: status RD_GZS_* (MISMATCH: a section did not
+ *   end where the next one starts - nothing speculative is ever accepted; OVERFLOW: a section made more than cap_syms symbols; ...),
+ *   final: the member ended in this batch at bit `end_bit` of comp (its trailer - CRC-32, ISIZE - follows at the next byte boundary: the
+ *   caller compares them with state->crc and total_len). Asynchronous on `stream`. */
+typedef struct rd_gzs_state {
+    uint64_t total_len;
+    int64_t n_text;
+    uint32_t crc, status, final, end_bit, next_start, win_valid, bad_section, n_sections;
+    uint64_t reserved[2];
+} rd_gzs_state;
+#define RD_GZS_OK 0
+#define RD_GZS_DECODE 1
+#define RD_GZS_MISMATCH 2
+#define RD_GZS_OVERFLOW 3
+#define RD_GZS_NOSTOP 4
+#define RD_GZS_WINDOW 5
+#define RD_GZS_TEXTCAP 6
+#define RD_GZS_NOSTART 7
+RD_API size_t rd_gz_stream_workspace_bytes(int64_t data_bytes, int32_t section_bytes, int32_t cap_syms, int64_t text_cap);
+RD_API int rd_gz_stream_inflate(const uint8_t *comp, int64_t comp_bytes, int64_t data_bytes, int64_t valid_bytes, int32_t section_bytes, int32_t cap_syms,
+                         uint32_t first_start_bit, const rd_gzs_state *carry, int64_t carry_delta_bits, int32_t at_eof, const uint8_t *win_in,
+                         uint8_t *win_out, uint8_t *text, int64_t text_cap, rd_gzs_state *state, void *workspace, size_t workspace_bytes, void *stream);
+
 /* n bytes moved by a kernel on `stream` instead of a DMA engine: dst / src [dev, or pinned host memory mapped into the device]. The
  * feeder's H2D of file bytes and the writers' D2H of output bytes use it: an SDMA queue is shared in order with other streams' copies,
  * and a copy that waits for kernels (a label D2H behind two recurrence launches) held a 96 MB H2D back for 60-100 ms. workgroups: 0 = 32. */

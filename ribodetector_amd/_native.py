@@ -25,7 +25,7 @@ SYMBOLS = [
     "rd_pair_fuse", "rd_count_labels", "rd_encode_codes", "rd_encode_onehot_padded", "rd_pack_plan",
     "rd_pack_onehot", "rd_profile_enable", "rd_profile_read", "rd_last_error", "rd_version",
     "rd_gz_workspace_bytes", "rd_gz_out_bound", "rd_gz_compress_selected", "rd_gz_eof_block", "rd_gz_inflate_members",
-    "rd_fastq_index_workspace_bytes", "rd_fastq_index", "rd_fastq_gather", "rd_fastq_sample", "rd_fastq_strip_mark", "rd_select_workspace_bytes", "rd_select_pack", "rd_stream_create", "rd_stream_destroy", "rd_copy_bytes",
+    "rd_fastq_index_workspace_bytes", "rd_fastq_index", "rd_fastq_gather", "rd_fastq_sample", "rd_fastq_strip_mark", "rd_select_workspace_bytes", "rd_select_pack", "rd_stream_create", "rd_stream_destroy", "rd_copy_bytes", "rd_gz_stream_workspace_bytes", "rd_gz_stream_inflate",
 ]
 
 
@@ -97,6 +97,9 @@ def lib():
     L.rd_stream_create.argtypes = [C.c_int, vp, C.c_int, C.c_int, C.POINTER(vp)]
     L.rd_stream_destroy.argtypes = [vp]
     L.rd_copy_bytes.argtypes = [vp, vp, i64, i32, vp]
+    L.rd_gz_stream_workspace_bytes.argtypes = [i64, i32, i32, i64]
+    L.rd_gz_stream_workspace_bytes.restype = sz
+    L.rd_gz_stream_inflate.argtypes = [vp, i64, i64, i64, i32, i32, C.c_uint32, vp, i64, i32, vp, vp, vp, i64, vp, vp, sz, vp]
     L.rd_profile_enable.argtypes = [vp, C.c_int]
     L.rd_profile_read.argtypes = [vp, C.POINTER(i64), C.POINTER(C.c_double)]
     L.rd_last_error.restype = C.c_char_p

@@ -1,0 +1,695 @@
+// rd_inflate_stream.hpp - ONE DEFLATE stream (a plain .gz: what sequencers write) inflated on the device (rd_gzs_* kernels)
+// Part of the single translation unit rd_kernels.hip (included from there, in order); DESIGN.md §3.14 has the numbers.
+//
+// A .gz FASTQ is one DEFLATE stream: a block can be decoded only after everything before it, because matches copy from the previous
+// 32 KiB of output (reference: gzip.open(path, 'rt'), data_loader/seq_encoder.py:21-39). The host reader of this build decodes it with
+// the two-pass scheme of pugz (csrc/rd_pgzip.h; Kerbiriou & Chikhi 2019) on up to 16 cores; here the same scheme runs on the GPU, one
+// WAVE per section of the compressed bytes, with the round-based decoder of rd_inflate_dev.hpp (64 bit positions tried per round):
+//   rd_gzs_search_kernel   section k looks for the first bit position in [k S, (k + 1) S) at which a dynamic-Huffman block starts:
+//                          every lane tests one position per round (BFINAL = 0, BTYPE = 2, HLIT / HDIST in range, a COMPLETE code-length
+//                          code - 1 position in ~2,000 passes), the survivors are validated by the whole wave: complete literal/length
+//                          and distance codes, the block decoded to its end with every literal a text byte, a plausible header behind it;
+//   rd_gzs_decode_kernel   section k is decoded from its start to the start the next section found, with an UNKNOWN window: the
+//                          output is 16-bit symbols, a byte or a marker "byte i of the 32 KiB before this section"; a section that
+//                          does not end exactly where the next one starts poisons the batch (nothing speculative is accepted);
+//   rd_gzs_scan_kernel     symbols per section -> text offsets; the member's end (BFINAL) closes the list;
+//   rd_gzs_window_kernel   in order, one workgroup: the last 32 KiB of every section resolved against the window before it;
+//   rd_gzs_resolve_kernel  all sections in parallel: symbols -> bytes at their offsets in the batch's text;
+//   rd_gzs_crc_kernel / rd_gzs_fold_kernel   CRC-32 per 64 KiB of text, folded into the stream's running CRC (x^(8 n) mod P).
+// The stream's state (window, CRC, length, where the next batch starts) lives in HBM and is carried from batch to batch on the stream.
+#pragma once
+#include "rd_inflate_dev.hpp"
+
+namespace {
+
+constexpr uint32_t GZS_NONE = 0xffffffffu;
+constexpr int GZS_WIN = 32768;
+constexpr uint32_t GZS_MARK = 0x8000u;
+enum { GZS_OK = 0, GZS_DECODE = 1, GZS_MISMATCH = 2, GZS_OVERFLOW = 3, GZS_NOSTOP = 4, GZS_WINDOW = 5, GZS_TEXTCAP = 6, GZS_NOSTART = 7 };
+
+struct GzsSec {            // what the decode of one section left
+    uint32_t n_syms, end_bit, status, final;
+};
+
+struct GzsState {          // = rd_gzs_state of the C ABI (64 bytes), device resident, carried from batch to batch
+    uint64_t total_len;    // bytes of text of the member so far
+    int64_t n_text;        // bytes of text this batch produced
+    uint32_t crc;          // CRC-32 of the member so far
+    uint32_t status;       // GZS_* of this batch (sticky: a failed batch fails the following ones)
+    uint32_t final;        // the member's last block was decoded in this batch
+    uint32_t end_bit;      // ... and ended at this bit of the batch buffer (the 8-byte trailer follows at the next byte boundary)
+    uint32_t next_start;   // where the next batch's first section starts, as a bit position of THIS batch's buffer
+    uint32_t win_valid;    // bytes of the carried window that are text (the member's first 32 KiB have less behind them)
+    uint32_t bad_section;  // first section that failed
+    uint32_t n_sections;   // sections that produced text
+    uint64_t reserved[2];
+};
+static_assert(sizeof(GzsState) == 64 && sizeof(rd_gzs_state) == 64, "rd_gzs_state layout");
+
+__device__ __forceinline__ bool gzs_is_text(uint32_t c) { return (c >= 32u && c < 127u) || c == '\n' || c == '\r' || c == '\t'; }
+
+// DEFLATE blocks from bit position p0 of the stream at inb (4-byte aligned; `limit` readable bytes, `end_bits` valid bits), by one wave.
+//   WRITE: 16-bit symbols to out16[0 .. cap) with an unknown window (markers), until the block boundary `stop_bit` is met exactly
+//          (GZS_MISMATCH when a boundary lies behind it), or the final block ends (fin = true);
+//   !WRITE: validation of a block-start candidate: ONE block, dynamic, complete codes, every literal a text byte.
+// Returns GZS_*; p_end = the bit behind the last block decoded, n_out = symbols.
+constexpr int GZS_VALIDATE_SYMS = 3072;     // a candidate that decodes this many text symbols with complete codes IS a block start
+template <bool WRITE>
+__device__ __forceinline__ int gzs_blocks(GziWave &S, int lane, const uint8_t *__restrict__ inb, int64_t limit, uint32_t end_bits, uint32_t p0, uint32_t stop_bit,
+                          uint16_t *__restrict__ out16, int cap, uint32_t &p_end, int &n_out, bool &fin) {
+    auto load_dw = [&](int k) -> uint32_t {
+        const int64_t b = (int64_t)k * 4;
+        return b + 4 <= limit ? *reinterpret_cast<const uint32_t *>(inb + b) : 0u;
+    };
+    int win = (int)(p0 >> 5);
+    uint32_t cur = load_dw(win + lane), nxt = load_dw(win + GZI_STEP + lane);
+    uint32_t p = p0;
+    int op = 0;
+    int err = GZS_OK;
+    auto ensure = [&](uint32_t q) {
+        while ((int)(q >> 5) - win >= GZI_STEP) {
+            if ((int)(q >> 5) - win >= 2 * GZI_STEP) {
+                win = (int)(q >> 5);
+                cur = load_dw(win + lane);
+            } else {
+                win += GZI_STEP;
+                cur = nxt;
+            }
+            nxt = load_dw(win + GZI_STEP + lane);
+        }
+    };
+    auto peek32 = [&](uint32_t q) -> uint32_t {
+        const int rel = (int)(q >> 5) - win;
+        const uint32_t d0 = gzi_rl(cur, rel), d1 = gzi_rl(cur, rel + 1);
+        return (uint32_t)(((((uint64_t)d1) << 32) | d0) >> (q & 31));
+    };
+    auto peek64 = [&](uint32_t q) -> uint64_t {
+        const int rel = (int)(q >> 5) - win;
+        const uint32_t d0 = gzi_rl(cur, rel), d1 = gzi_rl(cur, rel + 1), d2 = gzi_rl(cur, rel + 2);
+        const uint32_t s = q & 31;
+        const uint32_t lo = (uint32_t)((((uint64_t)d1 << 32) | d0) >> s), hi = (uint32_t)((((uint64_t)d2 << 32) | d1) >> s);
+        return ((uint64_t)hi << 32) | lo;
+    };
+    bool last = false;
+    fin = false;
+    int blocks = 0;
+    while (err == GZS_OK) {
+        if (WRITE) {
+            if (p == stop_bit) break;                                   // exactly where the next section starts: done
+            if (p > stop_bit) { err = GZS_MISMATCH; break; }            // its start was not a block boundary of this stream
+        } else if (blocks == 1) {
+            break;
+        }
+        if (p + 3 > end_bits) { err = WRITE ? GZS_NOSTOP : GZS_DECODE; break; }
+        ensure(p);
+        const uint64_t H = peek64(p);
+        last = (H & 1) != 0;
+        const uint32_t type = (uint32_t)(H >> 1) & 3u;
+        p += 3;
+        ++blocks;
+        if (type == 0) {                                                // stored
+            if (!WRITE) { err = GZS_DECODE; break; }
+            p = (p + 7u) & ~7u;
+            ensure(p);
+            const uint32_t w = peek32(p);
+            const uint32_t ln = w & 0xffffu, nl = w >> 16;
+            p += 32;
+            if ((ln ^ nl) != 0xffffu) { err = GZS_DECODE; break; }
+            const int64_t ib = (int64_t)(p >> 3);
+            if (p + ln * 8 > end_bits) { err = GZS_NOSTOP; break; }
+            if (op + (int)ln > cap) { err = GZS_OVERFLOW; break; }
+            for (int k = lane; k < (int)ln; k += 64) out16[op + k] = inb[ib + k];
+            p += ln * 8; op += (int)ln;
+            if (last) { fin = true; break; }
+            continue;
+        }
+        if (type == 3) { err = GZS_DECODE; break; }
+        int nl, nd;
+        if (type == 1) {                                                // fixed codes
+            if (!WRITE) { err = GZS_DECODE; break; }
+            nl = 288; nd = 30;
+            for (int s = lane; s < 288; s += 64) S.len[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;
+            if (lane < 30) S.len[288 + lane] = 5;
+        } else {
+            nl = (int)((uint32_t)(H >> 3) & 31u) + 257; nd = (int)((uint32_t)(H >> 8) & 31u) + 1;
+            const int nc = (int)((uint32_t)(H >> 13) & 15u) + 4;
+            p += 14;
+            if (nl > 286 || nd > 30) { err = GZS_DECODE; break; }
+            for (int s = lane; s < 320; s += 64) S.len[s] = 0;
+            ensure(p);
+            const uint64_t C = peek64(p);
+            if (lane < nc) S.len[300 + GZ_CLORD[lane]] = (uint8_t)((uint32_t)(C >> (3 * lane)) & 7u);
+            p += 3u * (uint32_t)nc;
+            GziCode cl;
+            {
+                const int L = lane & 15;
+                uint32_t cnt = 0;
+                if (L >= 1 && lane < 16)
+#pragma unroll 1
+                    for (int s = 0; s < 19; ++s) cnt += S.len[300 + s] == L ? 1u : 0u;
+                uint32_t first = 0, offs = 0, code = 0, off = 0;
+                int left = 1;
+                bool over = false;
+                for (int l = 1; l <= 7; ++l) {
+                    const uint32_t c = gzi_rl(cnt, l);
+                    if (L == l) { first = code; offs = off; }
+                    code = (code + c) << 1;
+                    off += c;
+                    left = (left << 1) - (int)c;
+                    over = over || left < 0;
+                }
+                if (__ballot(lane == 1 && (over || (!WRITE && left != 0)))) { err = GZS_DECODE; break; }
+                cl = GziCode{first, lane < 16 ? cnt : 0u, offs};
+                if (lane < 19) {
+                    const int l = S.len[300 + lane];
+                    if (l) {
+                        uint32_t before = 0, o = 0;
+#pragma unroll 1
+                        for (int t = 0; t < 19; ++t) {
+                            const int lt = S.len[300 + t];
+                            before += (t < lane && lt == l) ? 1u : 0u;
+                            o += (lt != 0 && lt < l) ? 1u : 0u;
+                        }
+                        S.dsym[o + before] = (uint16_t)lane;
+                    }
+                }
+            }
+            int i = 0, prev = 0;
+            while (i < nl + nd) {
+                if (p + 14 > end_bits + 64u) { err = GZS_DECODE; break; }
+                ensure(p);
+                int nb = 0;
+                const uint32_t v = peek32(p);
+                const int sym = gzi_decode(v, cl, lane, 0, S.dsym, nb);
+                if (sym < 0) { err = GZS_DECODE; break; }
+                const uint32_t x = v >> nb;
+                int rep = 1, val = sym;
+                if (sym == 16) { if (i == 0) { err = GZS_DECODE; break; } rep = 3 + (int)(x & 3u); val = prev; nb += 2; }
+                else if (sym == 17) { rep = 3 + (int)(x & 7u); val = 0; nb += 3; }
+                else if (sym == 18) { rep = 11 + (int)(x & 127u); val = 0; nb += 7; }
+                p += (uint32_t)nb;
+                if (i + rep > nl + nd) { err = GZS_DECODE; break; }
+                if (lane < rep) S.len[i + lane] = (uint8_t)val;
+                if (lane + 64 < rep) S.len[i + lane + 64] = (uint8_t)val;
+                if (lane + 128 < rep) S.len[i + lane + 128] = (uint8_t)val;
+                i += rep;
+                prev = val;
+            }
+            if (err != GZS_OK) break;
+            if (__builtin_amdgcn_readfirstlane((int)S.len[256]) == 0) { err = GZS_DECODE; break; }
+            if (!WRITE) {
+                // a block START candidate must carry complete codes, as every deflate encoder writes them (a single distance code may
+                // be incomplete; none at all is legal for a block without matches): sum 2^-len == 1
+                uint32_t sl = 0, sd = 0, ndist = 0;
+                for (int s = lane; s < nl; s += 64) { const int l = S.len[s]; sl += l ? (1u << (15 - l)) : 0u; }
+                if (lane < nd) { const int l = S.len[nl + lane]; sd = l ? (1u << (15 - l)) : 0u; ndist = l ? 1u : 0u; }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) { sl += (uint32_t)__shfl_xor((int)sl, o); sd += (uint32_t)__shfl_xor((int)sd, o); ndist += (uint32_t)__shfl_xor((int)ndist, o); }
+                sl = (uint32_t)__builtin_amdgcn_readfirstlane((int)sl);      // (the same in every lane: say so, or the branch - and with it
+                sd = (uint32_t)__builtin_amdgcn_readfirstlane((int)sd);      // every wave-uniform value of the loop - counts as divergent)
+                ndist = (uint32_t)__builtin_amdgcn_readfirstlane((int)ndist);
+                if (sl != (1u << 15) || (ndist > 1 && sd != (1u << 15))) { err = GZS_DECODE; break; }
+            }
+        }
+        GziCode lit, dst;
+        if (!gzi_build(S, nl, nd, lane, lit, dst)) { err = GZS_DECODE; break; }
+        bool eob = false;
+        bool nontext = false;
+        while (!eob && err == GZS_OK) {
+            if (p > end_bits + 64u) { err = WRITE ? GZS_NOSTOP : GZS_DECODE; break; }
+            if (!WRITE && op >= GZS_VALIDATE_SYMS) { fin = true; break; }   // (validation: enough of the block has been seen; fin = "not at its end")
+            ensure(p);
+            uint32_t ent, adv, mres;
+            {
+                const int rel = (int)(p >> 5) - win;
+                const uint32_t d0 = gzi_rl(cur, rel), d1 = gzi_rl(cur, rel + 1), d2 = gzi_rl(cur, rel + 2), d3 = gzi_rl(cur, rel + 3),
+                               d4 = gzi_rl(cur, rel + 4);
+                const uint32_t s = p & 31;
+                const uint32_t A0 = (uint32_t)((((uint64_t)d1 << 32) | d0) >> s), A1 = (uint32_t)((((uint64_t)d2 << 32) | d1) >> s),
+                               A2 = (uint32_t)((((uint64_t)d3 << 32) | d2) >> s), A3 = (uint32_t)((((uint64_t)d4 << 32) | d3) >> s);
+                const bool lowh = lane < 32;
+                const uint32_t x0 = lowh ? A0 : A1, x1 = lowh ? A1 : A2, x2 = lowh ? A2 : A3;
+                const uint32_t sh = (uint32_t)(lane & 31);
+                const uint32_t lo = __builtin_amdgcn_alignbit(x1, x0, sh), hi = __builtin_amdgcn_alignbit(x2, x1, sh);
+                ent = S.llut[lo & ((1u << GZI_LBITS) - 1u)];
+                const uint32_t sym = ent & 511u, cl = ent >> 9;
+                adv = ((ent & 0x100u) == 0 && lane + (int)cl <= 63) ? cl : 0u;
+                const uint32_t ls = sym - 257u, l5 = ls & 31u;
+                const uint32_t le = (l5 < 8u || l5 >= 28u) ? 0u : (l5 >> 2) - 1u;
+                const uint32_t lb = l5 < 8u ? 3u + l5 : l5 >= 28u ? 258u : ((4u + (l5 & 3u)) << le) + 3u;
+                const uint32_t w1 = __builtin_amdgcn_alignbit(hi, lo, cl);
+                const uint32_t len = lb + (w1 & ((1u << le) - 1u));
+                const uint32_t w2 = __builtin_amdgcn_alignbit(hi, lo, cl + le);
+                const uint32_t de = S.dlut[w2 & ((1u << GZI_DBITS) - 1u)];
+                const uint32_t ds = de & 511u, dl = de >> 9;
+                const uint32_t d5 = ds & 31u;
+                const uint32_t dx = d5 < 4u ? 0u : (d5 >> 1) - 1u;
+                const uint32_t db = d5 < 4u ? 1u + d5 : ((2u + (d5 & 1u)) << dx) + 1u;
+                const uint32_t w3 = __builtin_amdgcn_alignbit(hi, lo, cl + le + dl);
+                const uint32_t dist = db + (w3 & ((1u << dx) - 1u));
+                const bool okm = ls < 29u && cl != 0 && dl != 0 && ds < 30u;
+                mres = okm ? (len | (dist << 9) | ((cl + le + dl + dx) << 25)) : 0u;
+            }
+            uint32_t pos = 0;
+            for (;;) {
+                uint64_t M = 0;
+                uint32_t a;
+                do {
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) {
+                        a = gzi_rl(adv, (int)pos);
+                        asm("s_bitset1_b64 %0, %1" : "+s"(M) : "s"(pos));
+                        pos += a;
+                    }
+                } while (a != 0);
+                asm("s_bitset0_b64 %0, %1" : "+s"(M) : "s"(pos));
+                if (M) {
+                    const int n = __builtin_popcountll(M);
+                    if (op + n > cap) { err = GZS_OVERFLOW; break; }
+                    if (WRITE) {
+                        const int r = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(M >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)M, 0u));
+                        if ((M >> lane) & 1) out16[op + r] = (uint16_t)(ent & 0xffu);
+                    } else {
+                        nontext = nontext || (((M >> lane) & 1) && !gzs_is_text(ent & 0xffu));
+                    }
+                    op += n;
+                }
+                const uint32_t e = gzi_rl(ent, (int)pos);
+                int sym = (int)(e & 511u), cl = (int)(e >> 9);
+                if (cl != 0 && sym < 256) break;
+                int len, dist;
+                const uint32_t mr = gzi_rl(mres, (int)pos);
+                if (mr != 0) {
+                    len = (int)(mr & 511u); dist = (int)((mr >> 9) & 0xffffu);
+                    pos += mr >> 25;
+                } else {
+                    if (cl == 0) {
+                        sym = gzi_decode(peek32(p + pos), lit, lane, 0, S.lsym, cl);
+                        if (sym < 0) { err = GZS_DECODE; break; }
+                    }
+                    if (sym < 256) {
+                        if (op >= cap) { err = GZS_OVERFLOW; break; }
+                        if (WRITE) { if (lane == 0) out16[op] = (uint16_t)sym; }
+                        else nontext = nontext || !gzs_is_text((uint32_t)sym);
+                        ++op;
+                        pos += (uint32_t)cl;
+                        if (pos > 53u) break;
+                        continue;
+                    }
+                    if (sym == 256) { pos += (uint32_t)cl; eob = true; break; }
+                    if (sym > 285) { err = GZS_DECODE; break; }
+                    uint64_t B = peek64(p + pos + (uint32_t)cl);
+                    const int ls = sym - 257;
+                    const int le = ls < 8 || ls == 28 ? 0 : (ls >> 2) - 1;
+                    len = (ls < 8 ? 3 + ls : ls == 28 ? 258 : ((4 + (ls & 3)) << le) + 3) + (int)((uint32_t)B & ((1u << le) - 1u));
+                    B >>= le;
+                    int dl = 0;
+                    const int ds = gzi_decode((uint32_t)B, dst, lane, 16, S.dsym, dl);
+                    if (ds < 0 || ds > 29) { err = GZS_DECODE; break; }
+                    B >>= dl;
+                    const int dx = ds < 4 ? 0 : (ds >> 1) - 1;
+                    dist = (ds < 4 ? 1 + ds : ((2 + (ds & 1)) << dx) + 1) + (int)((uint32_t)B & ((1u << dx) - 1u));
+                    pos += (uint32_t)(cl + le + dl + dx);
+                }
+                if (dist > op + GZS_WIN) { err = GZS_DECODE; break; }    // behind the 32 KiB window: not DEFLATE
+                if (op + len > cap) { err = GZS_OVERFLOW; break; }
+                if (WRITE) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    const int j0 = op - dist;                         // (negative: into the unknown window = a marker)
+                    if (dist >= len) {
+                        for (int k = lane; k < len; k += 64) {
+                            const int j = j0 + k;
+                            out16[op + k] = j < 0 ? (uint16_t)(GZS_MARK | (uint32_t)(GZS_WIN + j)) : out16[j];
+                        }
+                    } else if (dist == 1) {
+                        const uint16_t b = j0 < 0 ? (uint16_t)(GZS_MARK | (uint32_t)(GZS_WIN + j0)) : out16[j0];
+                        for (int k = lane; k < len; k += 64) out16[op + k] = b;
+                    } else {
+                        for (int k = lane; k < len; k += 64) {
+                            const int j = j0 + k % dist;
+                            out16[op + k] = j < 0 ? (uint16_t)(GZS_MARK | (uint32_t)(GZS_WIN + j)) : out16[j];
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                }
+                op += len;
+                if (pos > 53u) break;
+            }
+            p += pos;
+        }
+        if (err != GZS_OK) break;
+        if (!WRITE && __ballot(nontext)) { err = GZS_DECODE; break; }
+        if (last) { fin = true; break; }
+    }
+    p_end = p;
+    n_out = op;
+    return err;
+}
+
+// found[k] = the first block start in section k's bits (k = 0: given - the member's first block, or what the batch before found)
+__global__ __launch_bounds__(64 * GZI_WAVES) __attribute__((amdgpu_waves_per_eu(6, 8))) void rd_gzs_search_kernel(
+    const uint8_t *__restrict__ comp, int64_t limit, uint32_t end_bits, uint32_t sec_bits, int nsec, uint32_t first_start, const GzsState *__restrict__ carry,
+    int64_t carry_delta_bits, uint32_t *__restrict__ found) {
+    __shared__ GziSmem SM;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    GziWave &S = SM.w[wave];
+    for (int k = blockIdx.x * GZI_WAVES + wave; k <= nsec; k += gridDim.x * GZI_WAVES) {
+        if (k == 0) {
+            uint32_t st = first_start;
+            if (carry) {
+                const int64_t v = (int64_t)carry->next_start - carry_delta_bits;
+                st = (carry->status != GZS_OK || carry->next_start == GZS_NONE || v < 0) ? GZS_NONE : (uint32_t)v;
+            }
+            if (lane == 0) found[0] = st;
+            continue;
+        }
+        // (the extra section behind the last one looks for the next batch's start in everything the caller sent along)
+        const uint64_t lo64 = (uint64_t)k * sec_bits, hi64 = k == nsec ? (uint64_t)end_bits : lo64 + sec_bits;
+        uint32_t res = GZS_NONE;
+        if (lo64 + 80 < end_bits) {
+            const uint32_t q_end = hi64 + 80 < end_bits ? (uint32_t)hi64 : end_bits - 80u;
+            auto load_dw = [&](int d) -> uint32_t {
+                const int64_t b = (int64_t)d * 4;
+                return b + 4 <= limit ? *reinterpret_cast<const uint32_t *>(comp + b) : 0u;
+            };
+            for (uint32_t q = (uint32_t)lo64; q < q_end && res == GZS_NONE; q += 64) {
+                // lane i: the 96 bits that start at q + i
+                const int d = (int)(q >> 5);
+                const uint32_t mine = load_dw(d + (lane & 7));           // dwords d .. d + 7 (lanes 0-7; the rest mirror them)
+                const uint32_t d0 = gzi_rl(mine, 0), d1 = gzi_rl(mine, 1), d2 = gzi_rl(mine, 2), d3 = gzi_rl(mine, 3), d4 = gzi_rl(mine, 4),
+                               d5 = gzi_rl(mine, 5), d6 = gzi_rl(mine, 6);
+                const uint32_t s = q & 31;
+                const uint32_t A0 = (uint32_t)((((uint64_t)d1 << 32) | d0) >> s), A1 = (uint32_t)((((uint64_t)d2 << 32) | d1) >> s),
+                               A2 = (uint32_t)((((uint64_t)d3 << 32) | d2) >> s), A3 = (uint32_t)((((uint64_t)d4 << 32) | d3) >> s),
+                               A4 = (uint32_t)((((uint64_t)d5 << 32) | d4) >> s), A5 = (uint32_t)((((uint64_t)d6 << 32) | d5) >> s);
+                const bool lowh = lane < 32;
+                const uint32_t x0 = lowh ? A0 : A1, x1 = lowh ? A1 : A2, x2 = lowh ? A2 : A3, x3 = lowh ? A3 : A4;
+                (void)A5;
+                const uint32_t sh = (uint32_t)(lane & 31);
+                const uint32_t w0 = __builtin_amdgcn_alignbit(x1, x0, sh), w1 = __builtin_amdgcn_alignbit(x2, x1, sh),
+                               w2 = __builtin_amdgcn_alignbit(x3, x2, sh);
+                // BFINAL = 0, BTYPE = 2 (bits 1-2 = 0, 1), HLIT <= 29, HDIST <= 29, and a complete code-length code
+                bool ok = (w0 & 7u) == 4u && ((w0 >> 3) & 31u) <= 29u && ((w0 >> 8) & 31u) <= 29u && q + (uint32_t)lane < q_end;
+                const uint32_t nc = ((w0 >> 13) & 15u) + 4u;
+                const uint64_t P = ((uint64_t)(w0 >> 17)) | ((uint64_t)w1 << 15) | ((uint64_t)w2 << 47);
+                uint32_t kraft = 0;
+#pragma unroll
+                for (int c = 0; c < 19; ++c) {
+                    const uint32_t l = (uint32_t)(P >> (3 * c)) & 7u;
+                    kraft += ((uint32_t)c < nc && l) ? (128u >> l) : 0u;
+                }
+                ok = ok && kraft == 128u;
+                uint64_t cand = __ballot(ok);
+                while (cand && res == GZS_NONE) {
+                    const int b = __builtin_ctzll(cand);
+                    cand &= cand - 1;
+                    const uint32_t c0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(q + (uint32_t)b));
+                    uint32_t pe;
+                    int n;
+                    bool fin;
+                    if (gzs_blocks<false>(S, lane, comp, limit, end_bits, c0, GZS_NONE, nullptr, 1 << 30, pe, n, fin) != GZS_OK) continue;
+                    // a plausible header behind it (when the block was seen to its end): not the reserved block type; a dynamic one
+                    // with counts in range
+                    if (!fin && pe + 17 <= end_bits) {
+                        const int dd = (int)(pe >> 5);
+                        const uint32_t e0 = load_dw(dd), e1 = load_dw(dd + 1);
+                        const uint32_t hv = (uint32_t)(((((uint64_t)e1) << 32) | e0) >> (pe & 31));
+                        const uint32_t bt = (hv >> 1) & 3u;
+                        if (bt == 3u || (bt == 2u && (((hv >> 3) & 31u) > 29u || ((hv >> 8) & 31u) > 29u))) continue;
+                    }
+                    res = c0;
+                }
+            }
+        }
+        if (lane == 0) found[k] = res;
+    }
+}
+
+__global__ __launch_bounds__(64 * GZI_WAVES) __attribute__((amdgpu_waves_per_eu(6, 8))) void rd_gzs_decode_kernel(
+    const uint8_t *__restrict__ comp, int64_t limit, uint32_t end_bits, int nsec, const uint32_t *__restrict__ found, uint16_t *__restrict__ syms, int cap,
+    GzsSec *__restrict__ sec) {
+    __shared__ GziSmem SM;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    GziWave &S = SM.w[wave];
+    for (int k = blockIdx.x * GZI_WAVES + wave; k < nsec; k += gridDim.x * GZI_WAVES) {
+        const uint32_t st = (uint32_t)__builtin_amdgcn_readfirstlane((int)found[k]);      // (wave-uniform: bit positions live in SGPRs)
+        GzsSec r{0u, 0u, (uint32_t)GZS_OK, 0u};
+        if (st != GZS_NONE) {
+            uint32_t stop = GZS_NONE;
+            for (int j = k + 1; j <= nsec && stop == GZS_NONE; ++j) stop = (uint32_t)__builtin_amdgcn_readfirstlane((int)found[j]);
+            uint32_t pe = st;
+            int n = 0;
+            bool fin = false;
+            const int e = gzs_blocks<true>(S, lane, comp, limit, end_bits, st, stop, syms + (size_t)k * (size_t)cap, cap, pe, n, fin);
+            r = GzsSec{(uint32_t)n, pe, (uint32_t)e, fin ? 1u : 0u};
+        }
+        if (lane == 0) sec[k] = r;
+    }
+}
+
+// one thread: the sections that make up the batch's text, in order - up to the member's end; offsets; the batch's verdict
+__global__ void rd_gzs_scan_kernel(const GzsSec *__restrict__ sec, const uint32_t *__restrict__ found, int nsec, int at_eof, int64_t text_cap,
+                                   int64_t *__restrict__ off, int32_t *__restrict__ wslot, int32_t *__restrict__ plist, GzsState *__restrict__ st,
+                                   const GzsState *__restrict__ carry) {
+    GzsState s;
+    s.total_len = carry ? carry->total_len : 0;
+    s.crc = carry ? carry->crc : 0;
+    s.win_valid = carry ? carry->win_valid : 0;
+    s.status = carry ? carry->status : (uint32_t)GZS_OK;
+    s.final = 0; s.end_bit = 0; s.next_start = GZS_NONE; s.bad_section = GZS_NONE; s.n_sections = 0; s.n_text = 0; s.reserved[0] = s.reserved[1] = 0;
+    int64_t o = 0;
+    int slot = 0;
+    bool done = false;
+    if (found[0] == GZS_NONE && s.status == GZS_OK) { s.status = GZS_NOSTART; s.bad_section = 0; }
+    for (int k = 0; k < nsec; ++k) {
+        off[k] = o;
+        wslot[k] = slot;
+        if (done || s.status != GZS_OK || found[k] == GZS_NONE) continue;
+        const GzsSec r = sec[k];
+        if (r.status != GZS_OK) { s.status = r.status; s.bad_section = (uint32_t)k; continue; }
+        o += r.n_syms;
+        plist[slot] = k;
+        ++slot;
+        ++s.n_sections;
+        if (r.final) { done = true; s.final = 1; s.end_bit = r.end_bit; }
+    }
+    off[nsec] = o;
+    wslot[nsec] = slot;
+    if (s.status == GZS_OK && o > text_cap) s.status = GZS_TEXTCAP;
+    if (s.status == GZS_OK && !done) {
+        // the stream goes on: the next batch starts where this batch's last section stopped = the start the extra section found
+        s.next_start = found[nsec];
+        if (s.next_start == GZS_NONE) { s.status = at_eof ? GZS_NOSTOP : GZS_NOSTART; s.bad_section = (uint32_t)nsec; }   // at EOF: the member never ended
+    }
+    s.n_text = s.status == GZS_OK ? o : 0;
+    *st = s;
+}
+
+// one workgroup, the sections in order: windows[slot + 1] = the 32 KiB of text behind section `slot` (windows[0] = the carried one).
+// Thread t owns window bytes [32 t, 32 t + 32): the 32 symbols they come from (the section's last 32 Ki symbols) are fetched one
+// section AHEAD (they do not depend on the window), resolved through the window in LDS, written back 32 bytes at a time.
+__global__ __launch_bounds__(1024) void rd_gzs_window_kernel(const uint16_t *__restrict__ syms, int cap, const GzsSec *__restrict__ sec, const int32_t *__restrict__ plist,
+                                                             const int32_t *__restrict__ wslot, int nsec, GzsState *__restrict__ st, const uint8_t *__restrict__ win_in,
+                                                             uint8_t *__restrict__ windows, uint8_t *__restrict__ win_out) {
+    __shared__ __attribute__((aligned(16))) uint8_t W[2][GZS_WIN];
+    __shared__ int s_bad;
+    const int tid = threadIdx.x;
+    if (st->status != GZS_OK) return;
+    for (int i = tid; i < GZS_WIN; i += 1024) {
+        const uint8_t b = win_in ? win_in[i] : 0;
+        W[0][i] = b;
+        windows[i] = b;
+    }
+    if (tid == 0) s_bad = 0;
+    int cur = 0;
+    uint32_t valid = st->win_valid;                 // bytes at the END of the window that are text
+    const int nslots = wslot[nsec];
+    u32x4 pre[4];                                   // the 32 symbols of this thread for the section about to be processed
+    auto fetch = [&](int slot) {
+        if (slot >= nslots) return;
+        const int k = plist[slot];
+        const int n = (int)sec[k].n_syms;
+        if (n < GZS_WIN) return;                    // (short section: the slow path reads its symbols itself)
+        const uint8_t *src = reinterpret_cast<const uint8_t *>(syms + (size_t)k * (size_t)cap + (size_t)(n - GZS_WIN) + (size_t)tid * 32);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) __builtin_memcpy(&pre[q], src + 16 * q, 16);
+    };
+    fetch(0);
+    __syncthreads();
+    bool bad = false;
+    for (int slot = 0; slot < nslots; ++slot) {
+        const int k = plist[slot];
+        const int n = (int)sec[k].n_syms;
+        const uint8_t *Wp = W[cur];
+        uint8_t *Wn = W[cur ^ 1];
+        uint8_t *gdst = windows + (size_t)(slot + 1) * GZS_WIN;
+        if (n >= GZS_WIN) {
+            u32x4 now[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) now[q] = pre[q];
+            fetch(slot + 1);                        // the next section's symbols travel while this one is resolved
+            uint32_t out[8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t two = now[q][j];
+                    uint32_t packed = 0;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const uint32_t sy = (two >> (16 * h)) & 0xffffu;
+                        uint32_t b = sy;
+                        if (sy & GZS_MARK) {
+                            const uint32_t w = sy & 0x7fffu;
+                            bad = bad || w < (uint32_t)GZS_WIN - valid;
+                            b = Wp[w];
+                        }
+                        packed |= (b & 0xffu) << (8 * h);
+                    }
+                    const int pos = q * 8 + j * 2;          // byte index within the thread's 32
+                    out[pos >> 2] = (pos & 2) ? (out[pos >> 2] | (packed << 16)) : packed;
+                }
+            }
+            u32x4 o0 = {out[0], out[1], out[2], out[3]}, o1 = {out[4], out[5], out[6], out[7]};
+            *reinterpret_cast<u32x4 *>(Wn + tid * 32) = o0;
+            *reinterpret_cast<u32x4 *>(Wn + tid * 32 + 16) = o1;
+            *reinterpret_cast<u32x4 *>(gdst + tid * 32) = o0;
+            *reinterpret_cast<u32x4 *>(gdst + tid * 32 + 16) = o1;
+        } else {
+            const uint16_t *sy = syms + (size_t)k * (size_t)cap;
+            for (int i = tid; i < GZS_WIN; i += 1024) {
+                uint8_t b;
+                if (i >= GZS_WIN - n) {
+                    const uint32_t s = sy[i - (GZS_WIN - n)];
+                    if (s & GZS_MARK) {
+                        const uint32_t w = s & 0x7fffu;
+                        bad = bad || w < (uint32_t)GZS_WIN - valid;
+                        b = Wp[w];
+                    } else {
+                        b = (uint8_t)s;
+                    }
+                } else {
+                    b = Wp[i + n];
+                }
+                Wn[i] = b;
+                gdst[i] = b;
+            }
+            fetch(slot + 1);
+        }
+        __syncthreads();
+        valid = valid + (uint32_t)n > (uint32_t)GZS_WIN ? (uint32_t)GZS_WIN : valid + (uint32_t)n;
+        cur ^= 1;
+    }
+    if (bad) s_bad = 1;
+    __syncthreads();
+    for (int i = tid; i < GZS_WIN; i += 1024) win_out[i] = W[cur][i];
+    if (tid == 0) {
+        st->win_valid = valid;
+        if (s_bad) st->status = GZS_WINDOW;          // (markers of the LAST 32 KiB only; the member's CRC covers the rest)
+    }
+}
+
+constexpr int GZS_RTILE = 8192;     // symbols per workgroup of the resolve pass
+__global__ __launch_bounds__(256) void rd_gzs_resolve_kernel(const uint16_t *__restrict__ syms, int cap, const GzsSec *__restrict__ sec, const uint32_t *__restrict__ found,
+                                                            const int64_t *__restrict__ off, const int32_t *__restrict__ wslot, int tiles_per_sec,
+                                                            const uint8_t *__restrict__ windows, GzsState *__restrict__ st, uint8_t *__restrict__ text) {
+    const int k = blockIdx.x / tiles_per_sec, t = blockIdx.x % tiles_per_sec;
+    if (st->status != GZS_OK && st->status != GZS_WINDOW) return;
+    if (found[k] == GZS_NONE || wslot[k + 1] == wslot[k]) return;       // a section that is not part of the text
+    const int n = (int)sec[k].n_syms;
+    const int i0 = t * GZS_RTILE;
+    if (i0 >= n) return;
+    const uint16_t *sy = syms + (size_t)k * (size_t)cap;
+    const uint8_t *W = windows + (size_t)wslot[k] * GZS_WIN;
+    uint8_t *dst = text + off[k];
+    const int i1 = i0 + GZS_RTILE < n ? i0 + GZS_RTILE : n;
+    for (int i = i0 + (int)threadIdx.x; i < i1; i += 256) {
+        const uint32_t s = sy[i];
+        dst[i] = (s & GZS_MARK) ? W[s & 0x7fffu] : (uint8_t)s;
+    }
+}
+
+// CRC-32 of every 64 KiB tile of the batch's text (one wave per tile, 1 KiB per lane)
+constexpr int GZS_CTILE = 65536;
+__global__ __launch_bounds__(256) void rd_gzs_crc_kernel(const uint8_t *__restrict__ text, const GzsState *__restrict__ st, uint32_t *__restrict__ tile_crc) {
+    __shared__ uint32_t tab[256];
+    {
+        uint32_t c = threadIdx.x;
+        for (int b = 0; b < 8; ++b) c = (c & 1) ? (c >> 1) ^ 0xedb88320u : c >> 1;
+        tab[threadIdx.x] = c;
+    }
+    __syncthreads();
+    const int64_t n = st->status == GZS_OK ? st->n_text : 0;
+    const int lane = threadIdx.x & 63;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t t0 = tile * GZS_CTILE;
+    if (t0 >= n) return;
+    const int len = (int)(n - t0 < GZS_CTILE ? n - t0 : GZS_CTILE);
+    const uint8_t *p = text + t0;
+    const int per = 1024;
+    const int b0 = lane * per < len ? lane * per : len, b1 = b0 + per < len ? b0 + per : len;
+    uint32_t c = 0xffffffffu;
+    for (int b = b0; b < b1; ++b) c = tab[(c ^ p[b]) & 0xffu] ^ (c >> 8);
+    c = ~c;
+    if (b1 == b0) c = 0;
+    c = gz_multmodp(gz_x8n((uint32_t)(len - b1)), c);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c ^= (uint32_t)__shfl_xor((int)c, o);
+    if (lane == 0) tile_crc[tile] = c;
+}
+
+// the tile CRCs folded into the stream's running CRC: crc(A || B) = crc(A) x^(8 |B|) + crc(B) (mod P). One wave: lane l folds its
+// run of tiles, then the 64 partial results are folded in order.
+__global__ __launch_bounds__(64) void rd_gzs_fold_kernel(const uint32_t *__restrict__ tile_crc, GzsState *__restrict__ st) {
+    if (st->status != GZS_OK) return;
+    const int lane = threadIdx.x;
+    const int64_t n = st->n_text;
+    const int64_t ntiles = (n + GZS_CTILE - 1) / GZS_CTILE;
+    const int64_t per = (ntiles + 63) / 64;
+    const int64_t t0 = lane * per < ntiles ? lane * per : ntiles, t1 = t0 + per < ntiles ? t0 + per : ntiles;
+    const uint32_t xfull = gz_x8n(GZS_CTILE);
+    uint32_t c = 0;
+    uint64_t bytes = 0;
+    for (int64_t t = t0; t < t1; ++t) {
+        const int64_t len = n - t * GZS_CTILE < GZS_CTILE ? n - t * GZS_CTILE : GZS_CTILE;
+        c = gz_multmodp(len == GZS_CTILE ? xfull : gz_x8n((uint32_t)len), c) ^ tile_crc[t];
+        bytes += (uint64_t)len;
+    }
+    // x^(8 bytes) of this lane's run, by the bits of `bytes` (it can exceed 2^32 in principle; a batch is far below)
+    const uint32_t xr = gz_x8n((uint32_t)bytes);
+    uint32_t crc = st->crc;
+    for (int l = 0; l < 64; ++l) {
+        const uint32_t cl = (uint32_t)__builtin_amdgcn_readlane((int)c, l), xl = (uint32_t)__builtin_amdgcn_readlane((int)xr, l);
+        const uint32_t has = (uint32_t)__builtin_amdgcn_readlane((int)(t1 > t0 ? 1 : 0), l);
+        if (has) crc = gz_multmodp(xl, crc) ^ cl;
+    }
+    if (lane == 0) {
+        st->crc = crc;
+        st->total_len += (uint64_t)n;
+    }
+}
+
+struct GzsPlan {
+    int nsec, tiles_per_sec, ctiles;
+    size_t found_bytes, sec_bytes, off_bytes, wslot_bytes, plist_bytes, crc_bytes, windows_bytes, syms_bytes, total;
+};
+GzsPlan gzs_plan(int64_t data_bytes, int32_t section_bytes, int32_t cap_syms, int64_t text_cap) {
+    GzsPlan p;
+    p.nsec = (int)((data_bytes + section_bytes - 1) / section_bytes);
+    if (p.nsec < 1) p.nsec = 1;
+    p.tiles_per_sec = (cap_syms + GZS_RTILE - 1) / GZS_RTILE;
+    p.ctiles = (int)((text_cap + GZS_CTILE - 1) / GZS_CTILE) + 1;
+    auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+    p.found_bytes = al((size_t)(p.nsec + 1) * 4);
+    p.sec_bytes = al((size_t)p.nsec * sizeof(GzsSec));
+    p.off_bytes = al((size_t)(p.nsec + 1) * 8);
+    p.wslot_bytes = al((size_t)(p.nsec + 1) * 4);
+    p.plist_bytes = al((size_t)(p.nsec + 1) * 4);
+    p.crc_bytes = al((size_t)p.ctiles * 4);
+    p.windows_bytes = al((size_t)(p.nsec + 1) * GZS_WIN);
+    p.syms_bytes = al((size_t)p.nsec * (size_t)cap_syms * 2);
+    p.total = p.found_bytes + p.sec_bytes + p.off_bytes + p.wslot_bytes + p.plist_bytes + p.crc_bytes + p.windows_bytes + p.syms_bytes;
+    return p;
+}
+
+}  // namespace

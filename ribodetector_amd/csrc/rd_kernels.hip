@@ -36,6 +36,7 @@
 #include "rd_encode.hpp"
 #include "rd_deflate.hpp"
 #include "rd_inflate_dev.hpp"
+#include "rd_inflate_stream.hpp"
 #include "rd_fastq_index.hpp"
 
 // ================================================================================================
@@ -642,6 +643,49 @@ int rd_gz_inflate_members(const uint8_t *comp, int64_t comp_bytes, const rd_gz_m
     if (grid > 65536) grid = 65536;
     hipLaunchKernelGGL(rd_gz_inflate_kernel, dim3((unsigned)grid), dim3(64 * GZI_WAVES), 0, (hipStream_t)stream, comp, comp_bytes,
                        (const GzMemberIn *)members, n, text, text_bytes, status);
+    RD_HIP(hipGetLastError());
+    return RD_OK;
+}
+
+// ---- one DEFLATE stream inflated on the device (rd_inflate_stream.hpp) ----------------------------------------------------------------------
+size_t rd_gz_stream_workspace_bytes(int64_t data_bytes, int32_t section_bytes, int32_t cap_syms, int64_t text_cap) {
+    if (data_bytes < 0 || section_bytes < 1024 || cap_syms < 1024 || text_cap < 0) return 0;
+    return gzs_plan(data_bytes, section_bytes, cap_syms, text_cap).total;
+}
+
+int rd_gz_stream_inflate(const uint8_t *comp, int64_t comp_bytes, int64_t data_bytes, int64_t valid_bytes, int32_t section_bytes, int32_t cap_syms,
+                         uint32_t first_start_bit, const rd_gzs_state *carry, int64_t carry_delta_bits, int32_t at_eof, const uint8_t *win_in,
+                         uint8_t *win_out, uint8_t *text, int64_t text_cap, rd_gzs_state *state, void *workspace, size_t workspace_bytes, void *stream) {
+    if (!comp || !win_out || !text || !state || !workspace) RD_FAIL(RD_E_INVALID, "rd_gz_stream_inflate: null pointer");
+    if (((uintptr_t)comp & 3) || ((uintptr_t)workspace & 255)) RD_FAIL(RD_E_INVALID, "rd_gz_stream_inflate: comp must be 4-byte aligned, workspace 256-byte aligned");
+    if (data_bytes <= 0 || valid_bytes < data_bytes || comp_bytes < valid_bytes || valid_bytes >= (1LL << 28) || section_bytes < 1024 || (section_bytes & 3) ||
+        cap_syms < 1024 || text_cap < 0)
+        RD_FAIL(RD_E_INVALID, "rd_gz_stream_inflate: bad sizes (a batch holds < 256 MiB of compressed bytes)");
+    const GzsPlan p = gzs_plan(data_bytes, section_bytes, cap_syms, text_cap);
+    if (workspace_bytes < p.total) RD_FAIL(RD_E_WORKSPACE, "rd_gz_stream_inflate: workspace too small: %zu < %zu", workspace_bytes, p.total);
+    char *w = (char *)workspace;
+    uint32_t *found = (uint32_t *)w; w += p.found_bytes;
+    GzsSec *sec = (GzsSec *)w; w += p.sec_bytes;
+    int64_t *off = (int64_t *)w; w += p.off_bytes;
+    int32_t *wslot = (int32_t *)w; w += p.wslot_bytes;
+    int32_t *plist = (int32_t *)w; w += p.plist_bytes;
+    uint32_t *tcrc = (uint32_t *)w; w += p.crc_bytes;
+    uint8_t *windows = (uint8_t *)w; w += p.windows_bytes;
+    uint16_t *syms = (uint16_t *)w;
+    hipStream_t st = (hipStream_t)stream;
+    const uint32_t end_bits = (uint32_t)(valid_bytes * 8), sec_bits = (uint32_t)section_bytes * 8u;
+    GzsState *S = (GzsState *)state;
+    const GzsState *C = (const GzsState *)carry;
+    hipLaunchKernelGGL(rd_gzs_search_kernel, dim3((unsigned)((p.nsec + 1 + GZI_WAVES - 1) / GZI_WAVES)), dim3(64 * GZI_WAVES), 0, st, comp, comp_bytes, end_bits, sec_bits,
+                       p.nsec, first_start_bit, C, carry_delta_bits, found);
+    hipLaunchKernelGGL(rd_gzs_decode_kernel, dim3((unsigned)((p.nsec + GZI_WAVES - 1) / GZI_WAVES)), dim3(64 * GZI_WAVES), 0, st, comp, comp_bytes, end_bits, p.nsec, found,
+                       syms, (int)cap_syms, sec);
+    hipLaunchKernelGGL(rd_gzs_scan_kernel, dim3(1), dim3(1), 0, st, sec, found, p.nsec, (int)at_eof, text_cap, off, wslot, plist, S, C);
+    hipLaunchKernelGGL(rd_gzs_window_kernel, dim3(1), dim3(1024), 0, st, syms, (int)cap_syms, sec, plist, wslot, p.nsec, S, win_in, windows, win_out);
+    hipLaunchKernelGGL(rd_gzs_resolve_kernel, dim3((unsigned)(p.nsec * p.tiles_per_sec)), dim3(256), 0, st, syms, (int)cap_syms, sec, found, off, wslot, p.tiles_per_sec,
+                       windows, S, text);
+    hipLaunchKernelGGL(rd_gzs_crc_kernel, dim3((unsigned)((p.ctiles + 3) / 4)), dim3(256), 0, st, text, S, tcrc);
+    hipLaunchKernelGGL(rd_gzs_fold_kernel, dim3(1), dim3(64), 0, st, tcrc, S);
     RD_HIP(hipGetLastError());
     return RD_OK;
 }

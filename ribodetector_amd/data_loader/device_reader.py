@@ -39,17 +39,28 @@ FQ_ERRORS = {1: "FASTQ record does not start with '@'",
              4: "the batch before this one could not be framed", 5: "more lines than the line table holds"}
 
 
-def device_parse_wanted(path, fmt=None):
-    """FASTQ input, a GPU, and RD_DEVICE_PARSE != 0: plain files and .gz files made of size-carrying members (BGZF)"""
+def device_ingest_kind(path, fmt=None):
+    """how the device reader would take this input: "plain" | "bgzf" (members that carry their size: inflated one wave per member) |
+    "stream" (any other gzip file - one DEFLATE stream, what sequencers write: the two-pass decoder of csrc/rd_inflate_stream.hpp;
+    opt-in with RD_DEVICE_INFLATE=stream) | None (FASTA, no GPU, RD_DEVICE_PARSE=0, RD_DEVICE_INFLATE=0 for .gz)"""
     if os.environ.get("RD_DEVICE_PARSE", "1") == "0" or not torch.cuda.is_available():
-        return False
+        return None
     from . import fastx_parser as fx
     fmt = fmt or fx.get_seq_format(path)
     if not fmt.startswith("fq"):
-        return False
+        return None
     if fmt.endswith("gz"):
-        return fx.device_inflate_wanted(path)
-    return not fx.file_info(path)[1]          # (a gzip file under a plain name goes to the host reader, which sniffs the magic)
+        if fx.device_inflate_wanted(path):
+            return "bgzf"
+        if os.environ.get("RD_DEVICE_INFLATE", "auto") == "stream" and fx.file_info(path)[1] and gz.is_member_indexed(path) is None:
+            return "stream"
+        return None
+    return None if fx.file_info(path)[1] else "plain"      # (a gzip file under a plain name goes to the host reader, which sniffs the magic)
+
+
+def device_parse_wanted(path, fmt=None):
+    """FASTQ input, a GPU, and RD_DEVICE_PARSE != 0: plain files, BGZF files, and (RD_DEVICE_INFLATE=stream) single-stream .gz files"""
+    return device_ingest_kind(path, fmt) is not None
 
 
 class DeviceChunk:
@@ -317,7 +328,9 @@ class DeviceFeeder:
             return
         self._ready.set()
         try:
-            if self.compressed:
+            if self.compressed == "stream":
+                self._run_stream()
+            elif self.compressed:
                 self._run_bgzf()
             else:
                 self._run_plain()
@@ -396,6 +409,100 @@ class DeviceFeeder:
                 if have < want:
                     break
                 batch = min(2 * batch, self.PLAIN_BATCH)
+
+    def _run_stream(self):
+        """ONE gzip member decoded on the device (gz.DeviceStreamGunzip): batches of compressed bytes, two in flight; a batch's text
+        length is known only when its 64-byte state has arrived, so its records are framed one batch behind the submission. What
+        follows the member in the file (further members; zero padding) goes to zlib on the host, in order."""
+        tm = self.stage_s
+        dsg = gz.DeviceStreamGunzip(self.device, self.stream)
+        span = dsg.BATCH + dsg.SLACK + 8192
+        pinned = [torch.empty(span, dtype=torch.uint8, pin_memory=True) for _ in range(self.SLOTS + 1)]
+        views = [t.numpy() for t in pinned]
+        free = list(range(len(pinned)))
+        fd = os.open(self.path, os.O_RDONLY)
+        try:
+            size = os.fstat(fd).st_size
+            hl = gz.gzip_header_len(os.pread(fd, 1 << 16, 0))
+            if hl is None:
+                raise ValueError("Compressed file ended before the end-of-stream marker was reached")
+            pos, first, batch = 0, hl * 8, min(self.FIRST, dsg.BATCH)
+            flight = deque()                                  # (ticket, text, pinned slot, file offset of the batch)
+            member_end = None
+
+            def finish_one():
+                nonlocal member_end
+                tk, text, slot, at = flight.popleft()
+                t0 = time.perf_counter()
+                r = dsg.finish(tk)
+                tm["wait_slot"] += time.perf_counter() - t0
+                free.append(slot)
+                if member_end is not None:
+                    return True                               # (a batch submitted behind the member's last one: nothing of it is used)
+                if r["status"]:
+                    raise ValueError("%s (device stream decoder, section %d of the batch at byte %d; RD_DEVICE_INFLATE=0 reads the file with "
+                                     "the host's decoders)" % (gz.GZS_ERRORS.get(r["status"], "error %d" % r["status"]), r["bad_section"], at))
+                if r["final"]:
+                    end = at + (r["end_bit"] + 7) // 8
+                    tr = os.pread(fd, 8, end)
+                    if len(tr) < 8:
+                        raise ValueError("Compressed file ended before the end-of-stream marker was reached")
+                    if int.from_bytes(tr[:4], "little") != r["crc"]:
+                        raise ValueError("CRC check failed")
+                    if int.from_bytes(tr[4:], "little") != (r["total_len"] & 0xffffffff):
+                        raise ValueError("Incorrect length of data produced")
+                    member_end = end + 8
+                b = self.ix.index(text, PAD, PAD + r["n_text"])
+                tm["batches"] += 1
+                tm["bytes"] += r["n_text"]
+                return self._put(b)
+
+            while not self._stop and member_end is None:
+                data = min(batch, size - pos)
+                if data <= 0:
+                    break
+                valid = min(data + dsg.SLACK, size - pos)
+                at_eof = pos + valid >= size
+                t0 = time.perf_counter()
+                while len(flight) >= self.SLOTS:
+                    if not finish_one():
+                        return
+                if member_end is not None:
+                    break
+                slot = free.pop()
+                t1 = time.perf_counter()
+                have = 0
+                while have < valid:
+                    k = os.preadv(fd, [memoryview(views[slot])[have:valid]], pos + have)
+                    if k <= 0:
+                        raise ValueError("Compressed file ended before the end-of-stream marker was reached")
+                    have += k
+                t2 = time.perf_counter()
+                text = self.ix.alloc_text(dsg.text_cap(data))
+                tk = dsg.submit(pinned[slot], valid, data, first, at_eof, text[PAD:])
+                flight.append((tk, text, slot, pos))
+                tm["read"] += t2 - t1
+                tm["submit"] += time.perf_counter() - t2
+                pos += data
+                first = 0xffffffff                              # (from the second batch on: where the batch before said)
+                batch = min(2 * batch, dsg.BATCH)
+                if at_eof and pos >= size:
+                    break
+            while flight:
+                if not finish_one():
+                    return
+            if member_end is None:
+                if not self._stop:
+                    raise ValueError("Compressed file ended before the end-of-stream marker was reached")
+                return
+            if member_end < size:            # further members, or padding: the host's zlib, behind the batches in flight
+                with open(self.path, "rb", buffering=0) as fh:
+                    fh.seek(member_end)
+                    rest = fh.read(1 << 16)
+                    if rest.strip(b"\0"):
+                        self._host_tail(fh, rest)
+        finally:
+            os.close(fd)
 
     def _host_tail(self, fh, data):
         """the rest of a file whose members stop carrying their size (`cat a.bgzf.gz b.gz` is a legal .gz): zlib, member after member,
@@ -516,8 +623,8 @@ def get_seq_chunks_device(seq_file, chunk_size=1048576, byte_range=None, first_c
     from . import fastx_parser as fx
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     torch.cuda.set_device(device)
-    fmt = fx.get_seq_format(seq_file)
-    compressed = fmt.endswith("gz")
+    kind = device_ingest_kind(seq_file)
+    compressed = "stream" if kind == "stream" else fx.get_seq_format(seq_file).endswith("gz")
     span = None
     if isinstance(byte_range, fx.BgzfRange):
         a, b = byte_range

@@ -268,3 +268,99 @@ class DeviceGunzip:
         self.submit(buf, nbytes, n, out_bytes, slot=0)
         self.finish(0)
         return self._slots[0].text_dev[:out_bytes]
+
+
+# ---- ONE DEFLATE stream inflated on the device (csrc/rd_inflate_stream.hpp; opt-in: RD_DEVICE_INFLATE=stream) ------------------------------
+
+GZS_ERRORS = {1: "invalid deflate data", 2: "a section did not end where the next one starts", 3: "a section produced more symbols than its slot holds",
+              4: "Compressed file ended before the end-of-stream marker was reached", 5: "invalid distance too far back",
+              6: "the batch produced more text than its buffer holds", 7: "no block start found where the stream goes on"}
+
+
+def gzip_header_len(buf):
+    """length of the RFC 1952 member header at the start of `buf` (bytes-like); None if more bytes are needed; ValueError if it is none"""
+    b = bytes(buf[:10])
+    if len(b) < 10:
+        return None
+    if b[0] != 0x1f or b[1] != 0x8b:
+        raise ValueError("Not a gzipped file (%r)" % b[:2])
+    if b[2] != 8:
+        raise ValueError("Unknown compression method")
+    flg, p = b[3], 10
+    if flg & 4:
+        if len(buf) < p + 2:
+            return None
+        p += 2 + (buf[p] | (buf[p + 1] << 8))
+    for bit in (8, 16):
+        if flg & bit:
+            while True:
+                if p >= len(buf):
+                    return None
+                p += 1
+                if buf[p - 1] == 0:
+                    break
+    if flg & 2:
+        p += 2
+    return p if p <= len(buf) else None
+
+
+class DeviceStreamGunzip:
+    """The batches of ONE gzip member through C ABI rd_gz_stream_inflate: submit() queues a batch - its compressed bytes (pinned host
+    memory) to HBM by a copy kernel, block-start search, section decode, window chain, resolve, CRC - and returns a ticket; finish()
+    sleeps until the batch's 64-byte state has arrived and returns it. The stream's state (window, CRC, length, where the next batch
+    starts) is carried on the device from one submit() to the next."""
+
+    SECTION = 16 << 10          # compressed bytes per section = per wave
+    BATCH = 64 << 20            # compressed bytes per batch (its sections); the bytes behind them are searched for the next batch's start
+    SLACK = 256 << 10           # ... this many (a block start every 10-60 KB in zlib / pigz output)
+    CAP_RATIO = 24              # symbols a section may produce per compressed byte (FASTQ: 4-5; a section also takes over its
+                                # successors that hold no block start)
+    TEXT_RATIO = 12             # text bytes a batch may produce per compressed byte
+
+    def __init__(self, device, stream):
+        import os
+        self.device, self.stream = torch.device(device), stream
+        self.carry = self.win = None
+        self._ws = None
+        if os.environ.get("RD_GZS_BATCH"):            # (experiments: compressed bytes per batch)
+            self.BATCH = int(os.environ["RD_GZS_BATCH"])
+
+    def text_cap(self, data_bytes):
+        return int(data_bytes) * self.TEXT_RATIO + (1 << 20)
+
+    def submit(self, src, valid_bytes, data_bytes, first_start_bit, at_eof, text_out):
+        """src: pinned uint8 tensor holding valid_bytes bytes of the file from the batch's first byte; the sections cover
+        [0, data_bytes); text_out: device uint8 tensor that receives the text"""
+        lib = N.lib()
+        cap_syms = self.SECTION * self.CAP_RATIO
+        with torch.cuda.device(self.device), torch.cuda.stream(self.stream):
+            comp = torch.empty(((valid_bytes + 4096 + 255) // 256) * 256, dtype=torch.uint8, device=self.device)
+            N.copy_bytes(comp, src, valid_bytes, self.stream)
+            comp[valid_bytes:valid_bytes + 4096].zero_()
+            need = int(lib.rd_gz_stream_workspace_bytes(data_bytes, self.SECTION, cap_syms, text_out.numel()))
+            if self._ws is None or self._ws.numel() < need:
+                self._ws = None
+                self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            state = torch.zeros(8, dtype=torch.int64, device=self.device)
+            win_out = torch.empty(32768, dtype=torch.uint8, device=self.device)
+            N.check(lib.rd_gz_stream_inflate(N.ptr(comp), comp.numel(), int(data_bytes), int(valid_bytes), self.SECTION, cap_syms,
+                                             int(first_start_bit) & 0xffffffff, N.ptr(self.carry), int(self._delta_bits) if self.carry is not None else 0,
+                                             1 if at_eof else 0, N.ptr(self.win), N.ptr(win_out), N.ptr(text_out), text_out.numel(), N.ptr(state),
+                                             N.ptr(self._ws), self._ws.numel(), C.c_void_p(self.stream.cuda_stream)), "rd_gz_stream_inflate")
+            host = torch.empty(64, dtype=torch.uint8, pin_memory=True)
+            N.copy_bytes(host, state.view(torch.uint8), 64, self.stream, workgroups=1)
+            ev = N.new_event()
+            ev.record(self.stream)
+        self.carry, self.win, self._delta_bits = state, win_out, int(data_bytes) * 8
+        return {"host": host, "event": ev, "keep": (comp, state, win_out)}
+
+    @staticmethod
+    def finish(ticket):
+        """-> dict(total_len, n_text, crc, status, final, end_bit, next_start, bad_section, n_sections)"""
+        import numpy as np
+        N.wait_event(ticket["event"])
+        h = ticket["host"].numpy()
+        q = h.view(np.uint64)
+        d = h.view(np.uint32)
+        return {"total_len": int(q[0]), "n_text": int(h.view(np.int64)[1]), "crc": int(d[4]), "status": int(d[5]), "final": int(d[6]), "end_bit": int(d[7]),
+                "next_start": int(d[8]), "win_valid": int(d[9]), "bad_section": int(d[10]), "n_sections": int(d[11])}
