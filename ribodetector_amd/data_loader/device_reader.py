@@ -63,6 +63,10 @@ def device_parse_wanted(path, fmt=None):
     return device_ingest_kind(path, fmt) is not None
 
 
+class _StreamFallback(Exception):
+    """the device stream decoder gives the file back before it has delivered anything"""
+
+
 class DeviceChunk:
     """A chunk of n records whose text and index live in HBM. The attribute names follow fastx_parser.Chunk where the meaning is the
     same: seq_len (len() = n), verbatim, release; `dev` = (text, seq_off, seq_len, rec_start) device tensors, `ready` = the event
@@ -422,87 +426,101 @@ class DeviceFeeder:
         free = list(range(len(pinned)))
         fd = os.open(self.path, os.O_RDONLY)
         try:
-            size = os.fstat(fd).st_size
-            hl = gz.gzip_header_len(os.pread(fd, 1 << 16, 0))
-            if hl is None:
-                raise ValueError("Compressed file ended before the end-of-stream marker was reached")
-            pos, first, batch = 0, hl * 8, min(self.FIRST, dsg.BATCH)
-            flight = deque()                                  # (ticket, text, pinned slot, file offset of the batch)
-            member_end = None
-
-            def finish_one():
-                nonlocal member_end
-                tk, text, slot, at = flight.popleft()
-                t0 = time.perf_counter()
-                r = dsg.finish(tk)
-                tm["wait_slot"] += time.perf_counter() - t0
-                free.append(slot)
-                if member_end is not None:
-                    return True                               # (a batch submitted behind the member's last one: nothing of it is used)
-                if r["status"]:
-                    raise ValueError("%s (device stream decoder, section %d of the batch at byte %d; RD_DEVICE_INFLATE=0 reads the file with "
-                                     "the host's decoders)" % (gz.GZS_ERRORS.get(r["status"], "error %d" % r["status"]), r["bad_section"], at))
-                if r["final"]:
-                    end = at + (r["end_bit"] + 7) // 8
-                    tr = os.pread(fd, 8, end)
-                    if len(tr) < 8:
-                        raise ValueError("Compressed file ended before the end-of-stream marker was reached")
-                    if int.from_bytes(tr[:4], "little") != r["crc"]:
-                        raise ValueError("CRC check failed")
-                    if int.from_bytes(tr[4:], "little") != (r["total_len"] & 0xffffffff):
-                        raise ValueError("Incorrect length of data produced")
-                    member_end = end + 8
-                b = self.ix.index(text, PAD, PAD + r["n_text"])
-                tm["batches"] += 1
-                tm["bytes"] += r["n_text"]
-                return self._put(b)
-
-            while not self._stop and member_end is None:
-                data = min(batch, size - pos)
-                if data <= 0:
-                    break
-                valid = min(data + dsg.SLACK, size - pos)
-                at_eof = pos + valid >= size
-                t0 = time.perf_counter()
-                while len(flight) >= self.SLOTS:
-                    if not finish_one():
-                        return
-                if member_end is not None:
-                    break
-                slot = free.pop()
-                t1 = time.perf_counter()
-                have = 0
-                while have < valid:
-                    k = os.preadv(fd, [memoryview(views[slot])[have:valid]], pos + have)
-                    if k <= 0:
-                        raise ValueError("Compressed file ended before the end-of-stream marker was reached")
-                    have += k
-                t2 = time.perf_counter()
-                text = self.ix.alloc_text(dsg.text_cap(data))
-                tk = dsg.submit(pinned[slot], valid, data, first, at_eof, text[PAD:])
-                flight.append((tk, text, slot, pos))
-                tm["read"] += t2 - t1
-                tm["submit"] += time.perf_counter() - t2
-                pos += data
-                first = 0xffffffff                              # (from the second batch on: where the batch before said)
-                batch = min(2 * batch, dsg.BATCH)
-                if at_eof and pos >= size:
-                    break
-            while flight:
-                if not finish_one():
-                    return
-            if member_end is None:
-                if not self._stop:
-                    raise ValueError("Compressed file ended before the end-of-stream marker was reached")
-                return
-            if member_end < size:            # further members, or padding: the host's zlib, behind the batches in flight
+            try:
+                self._stream_batches(fd, dsg, pinned, views, free, tm)
+            except _StreamFallback as e:
+                tm["fallback"] = str(e)
+                self.stream.synchronize()
                 with open(self.path, "rb", buffering=0) as fh:
-                    fh.seek(member_end)
-                    rest = fh.read(1 << 16)
-                    if rest.strip(b"\0"):
-                        self._host_tail(fh, rest)
+                    self._host_tail(fh, b"")
         finally:
             os.close(fd)
+
+    def _stream_batches(self, fd, dsg, pinned, views, free, tm):
+        size = os.fstat(fd).st_size
+        hl = gz.gzip_header_len(os.pread(fd, 1 << 16, 0))
+        if hl is None:
+            raise ValueError("Compressed file ended before the end-of-stream marker was reached")
+        pos, first, batch = 0, hl * 8, min(self.FIRST, dsg.BATCH)
+        flight = deque()                                  # (ticket, text, pinned slot, file offset of the batch)
+        member_end = None
+
+        def finish_one():
+            nonlocal member_end
+            tk, text, slot, at = flight.popleft()
+            t0 = time.perf_counter()
+            r = dsg.finish(tk)
+            tm["wait_slot"] += time.perf_counter() - t0
+            free.append(slot)
+            if member_end is not None:
+                return True                               # (a batch submitted behind the member's last one: nothing of it is used)
+            if r["status"]:
+                if at == 0:
+                    # the member's FIRST batch: nothing has been delivered yet, so the whole file can still go to zlib on the host -
+                    # what is not text (no block start passes the search: one wave would have to decode everything), what
+                    # compresses 100:1, and damaged files, whose error messages are then zlib's
+                    raise _StreamFallback(gz.GZS_ERRORS.get(r["status"], "error %d" % r["status"]))
+                raise ValueError("%s (device stream decoder, section %d of the batch at byte %d; RD_DEVICE_INFLATE=0 reads the file with "
+                                 "the host's decoders)" % (gz.GZS_ERRORS.get(r["status"], "error %d" % r["status"]), r["bad_section"], at))
+            if r["final"]:
+                end = at + (r["end_bit"] + 7) // 8
+                tr = os.pread(fd, 8, end)
+                if len(tr) < 8:
+                    raise ValueError("Compressed file ended before the end-of-stream marker was reached")
+                if int.from_bytes(tr[:4], "little") != r["crc"]:
+                    raise ValueError("CRC check failed")
+                if int.from_bytes(tr[4:], "little") != (r["total_len"] & 0xffffffff):
+                    raise ValueError("Incorrect length of data produced")
+                member_end = end + 8
+            b = self.ix.index(text, PAD, PAD + r["n_text"])
+            tm["batches"] += 1
+            tm["bytes"] += r["n_text"]
+            return self._put(b)
+
+        while not self._stop and member_end is None:
+            data = min(batch, size - pos)
+            if data <= 0:
+                break
+            valid = min(data + dsg.SLACK, size - pos)
+            at_eof = pos + valid >= size
+            t0 = time.perf_counter()
+            while len(flight) >= self.SLOTS:
+                if not finish_one():
+                    return
+            if member_end is not None:
+                break
+            slot = free.pop()
+            t1 = time.perf_counter()
+            have = 0
+            while have < valid:
+                k = os.preadv(fd, [memoryview(views[slot])[have:valid]], pos + have)
+                if k <= 0:
+                    raise ValueError("Compressed file ended before the end-of-stream marker was reached")
+                have += k
+            t2 = time.perf_counter()
+            text = self.ix.alloc_text(dsg.text_cap(data))
+            tk = dsg.submit(pinned[slot], valid, data, first, at_eof, text[PAD:])
+            flight.append((tk, text, slot, pos))
+            tm["read"] += t2 - t1
+            tm["submit"] += time.perf_counter() - t2
+            pos += data
+            first = 0xffffffff                              # (from the second batch on: where the batch before said)
+            batch = min(2 * batch, dsg.BATCH)
+            if at_eof and pos >= size:
+                break
+        while flight:
+            if not finish_one():
+                return
+        if member_end is None:
+            if not self._stop:
+                raise ValueError("Compressed file ended before the end-of-stream marker was reached")
+            return
+        if member_end < size:            # further members, or padding: the host's zlib, behind the batches in flight
+            with open(self.path, "rb", buffering=0) as fh:
+                fh.seek(member_end)
+                rest = fh.read(1 << 16)
+                if rest.strip(b"\0"):
+                    self._host_tail(fh, rest)
 
     def _host_tail(self, fh, data):
         """the rest of a file whose members stop carrying their size (`cat a.bgzf.gz b.gz` is a legal .gz): zlib, member after member,
@@ -516,6 +534,9 @@ class DeviceFeeder:
                     if inside:
                         raise ValueError("Compressed file ended before the end-of-stream marker was reached")
                     return
+            if not inside and not data.strip(b"\0"):       # zero padding behind the last member (Python's gzip module skips it too)
+                data = b""
+                continue
             try:
                 out = d.decompress(data, 16 << 20)          # (at most 16 MB of text per call)
             except zlib.error as e:

@@ -508,3 +508,33 @@ def test_cli_device_resident_ingest_writes_the_same_files(tmp_path, paired, ensu
             assert len(pr.ingest) == len(inputs) and all(v["path"] == "device" and v["feeder"]["batches"] >= 1 for v in pr.ingest.values())
             if kind == "crlf":
                 assert all(v["indexer"]["stripped"] >= 1 for v in pr.ingest.values())
+
+
+def test_cli_single_stream_gz_inflated_on_the_device(tmp_path, monkeypatch):
+    """RD_DEVICE_INFLATE=stream: a plain .gz (one DEFLATE stream - what sequencers write) is decoded by the two-pass device decoder
+    (csrc/rd_inflate_stream.hpp), its text framed and classified where it lands: the files of the default route (the host's parallel
+    decoder), the same counts, and no host reader involved"""
+    import gzip as gzmod
+    from ribodetector_amd import detect, synth
+    n = 120000
+    ins = []
+    for m in range(2):
+        a, o, _ = synth.reads_numpy(n, (40, 140), seed=90 + m, rrna_frac=0.3)
+        p = str(tmp_path / ("r_%d.fq" % (m + 1)))
+        synth.write_fastq(p, a, o, m + 1)
+        with open(p, "rb") as fi, gzmod.open(p + ".gz", "wb", compresslevel=6) as fo:
+            fo.write(fi.read())
+        ins.append(p + ".gz")
+
+    def run(tag):
+        outs = [str(tmp_path / ("%s.non%d.fq.gz" % (tag, e))) for e in range(2)]
+        rrs = [str(tmp_path / ("%s.rr%d.fq" % (tag, e))) for e in range(2)]
+        pr = detect.main(["-l", "100", "-i", *ins, "-o", *outs, "-r", *rrs, "-e", "rrna", "--chunk_size", "8", "-m", "3"])
+        return pr, [_read(f) for f in outs + rrs]
+    monkeypatch.delenv("RD_DEVICE_INFLATE", raising=False)
+    p0, want = run("host")
+    assert not p0.ingest
+    monkeypatch.setenv("RD_DEVICE_INFLATE", "stream")
+    p1, got = run("dev")
+    assert got == want and (p1.num_read, p1.num_rrna, p1.num_nonrrna) == (p0.num_read, p0.num_rrna, p0.num_nonrrna) == (n, p0.num_rrna, n - p0.num_rrna)
+    assert len(p1.ingest) == 2 and all(v["path"] == "device" and "fallback" not in v["feeder"] for v in p1.ingest.values())

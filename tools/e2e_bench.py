@@ -363,6 +363,7 @@ def bench_legs(a):
         rec["plain_to_plain_host_parse"] = e.leg("plain", False, env={"RD_DEVICE_PARSE": "0"})
         rec["gz_to_gz"] = e.leg("gz", True)
         rec["gz_to_gz_all_cores"] = e.leg("gz", True, threads=usable_cores())
+        rec["gz_to_gz_device_stream"] = e.leg("gz", True, env={"RD_DEVICE_INFLATE": "stream"})      # the single stream decoded on the GPU (opt-in)
     print(json.dumps(rec))
 
 
