@@ -1,0 +1,108 @@
+#!/usr/bin/env python
+"""The device-ingest kernels on one 2^20-record batch of FASTQ text (218 B per record, the text the CLI's e2e legs read): time by
+events on the launch stream, achieved GB/s against the 8 TB/s of HBM (PCIe for the copy kernels).
+    rd_fastq_index   (begin, count, scan, fill, check, verdict, sample)   algorithmic bytes: the text once + 4 B per line
+    rd_fastq_gather  (the whole batch into a chunk)                        the text read + written, 20 B of index per record
+    rd_select_pack   (both label files)                                    the text read + written
+    rd_copy_bytes    pinned -> HBM and back                                PCIe
+    rd_gz_stream_inflate  (the same text as ONE zlib level-6 stream)       text out; per-kernel split in the rocprofv3 table
+python tools/fq_bench.py [--records 1048576] [--out file.json] [--no-stream]"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import zlib
+
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
+import numpy as np      # noqa: E402
+import torch            # noqa: E402
+from ribodetector_amd import _native as N, gz, synth      # noqa: E402
+from ribodetector_amd.data_loader import device_reader as dr      # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--records", type=int, default=1 << 20)
+    ap.add_argument("--out", default=None)
+    ap.add_argument("--no-stream", action="store_true")
+    ap.add_argument("--reps", type=int, default=10)
+    a = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    n = a.records
+    arena, off, lens = synth.reads_torch(n, 100, seed=1, device=dev)
+    text = synth.fastq_image_torch(arena, off, lens, mate=1)
+    tb = int(text.numel())
+    st = torch.cuda.current_stream(dev)
+    L = N.lib()
+    ix = dr.FastqIndexer(dev, st)
+
+    def timed(fn, reps=a.reps):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+    out = {"records": n, "text_bytes": tb, "hbm_peak_GBps": 8000.0, "kernels": {}}
+
+    def put(name, ms, nbytes, what, peak=8000.0):
+        out["kernels"][name] = {"ms": ms, "GBps": nbytes / ms / 1e6, "frac_of_peak": nbytes / ms / 1e6 / peak, "algorithmic_bytes": what}
+    buf = ix.alloc_text(tb)
+    buf[dr.PAD:dr.PAD + tb] = text
+    batch = [None]
+
+    def do_index():
+        ix.prev = None
+        batch[0] = ix.index(buf, dr.PAD, dr.PAD + tb, final=True, chain=False)
+    ms = timed(do_index)
+    b = ix.finish(batch[0])
+    assert b.n == n and b.status == 0, (b.n, b.status)
+    put("rd_fastq_index", ms, tb + 16 * n, "text once + 4 B per line")
+    ms = timed(lambda: ix.gather([(b, 0, n)]))
+    put("rd_fastq_gather", ms, 2 * tb + 20 * n, "text read + written, 20 B of index per record")
+    ch = ix.gather([(b, 0, n)])
+    lab = (torch.arange(n, device=dev) % 50 == 0).to(torch.int8)
+    ds = gz.DeviceSelect(dev)
+    ms = timed(lambda: [ds.pack_selected(ch.dev[0], ch.dev[3], lab, v, slot=v) for v in (0, 1)])
+    put("rd_select_pack (both label files)", ms, 2 * tb + 2 * 9 * n, "text read + written, 9 B of index per record and file")
+    pin = torch.empty(tb, dtype=torch.uint8, pin_memory=True)
+    pin.copy_(text)
+    dst = torch.empty(tb, dtype=torch.uint8, device=dev)
+    ms = timed(lambda: N.copy_bytes(dst, pin, tb, st))
+    put("rd_copy_bytes pinned -> HBM", ms, tb, "the bytes (PCIe 5 x16: 64 GB/s)", peak=64.0)
+    ms = timed(lambda: N.copy_bytes(pin, dst, tb, st))
+    put("rd_copy_bytes HBM -> pinned", ms, tb, "the bytes (PCIe 5 x16: 64 GB/s)", peak=64.0)
+    ms = timed(lambda: dst.copy_(pin, non_blocking=True))
+    put("hipMemcpyAsync pinned -> HBM (SDMA, for comparison)", ms, tb, "the bytes", peak=64.0)
+    if not a.no_stream:
+        raw = text.cpu().numpy().tobytes()
+        co = zlib.compressobj(6, zlib.DEFLATED, 31)
+        blob = co.compress(raw) + co.flush()
+        dsg = gz.DeviceStreamGunzip(dev, st)
+        dsg.BATCH = max(dsg.BATCH, (len(blob) + dsg.SECTION) // dsg.SECTION * dsg.SECTION)
+        src = torch.from_numpy(np.frombuffer(blob, dtype=np.uint8).copy()).pin_memory()
+        tx = torch.empty(dsg.text_cap(len(blob)), dtype=torch.uint8, device=dev)
+        hl = gz.gzip_header_len(blob)
+        res = [None]
+
+        def do_stream():
+            dsg.carry = dsg.win = None
+            res[0] = dsg.submit(src, len(blob), len(blob), hl * 8, True, tx)
+        ms = timed(do_stream, reps=5)
+        r = dsg.finish(res[0])
+        assert r["status"] == 0 and r["final"] and r["n_text"] == tb and r["crc"] == (zlib.crc32(raw) & 0xffffffff), r
+        put("rd_gz_stream_inflate (zlib level 6, one batch of %d sections)" % r["n_sections"], ms, tb, "text produced")
+        out["stream"] = {"compressed_bytes": len(blob), "sections": r["n_sections"], "section_bytes": dsg.SECTION}
+    s = json.dumps(out)
+    if a.out:
+        open(a.out, "w").write(json.dumps(out, indent=1))
+    print(s)
+
+
+if __name__ == "__main__":
+    main()

@@ -62,7 +62,8 @@ def main():
                     print("%-72s %-28s n=%-6d mean=%.6g" % (k, c, len(v), sum(v) / len(v)))
     # achieved HBM bandwidth per kernel: encoders (run 'encoders' + enc_pmc_*) and the recurrence (pe100 + pmc_*)
     table = {}
-    for tr, f, w in (("encoders", "enc_pmc_FETCH_SIZE", "enc_pmc_WRITE_SIZE"), ("pe100", "pmc_FETCH_SIZE", "pmc_WRITE_SIZE")):
+    for tr, f, w in (("encoders", "enc_pmc_FETCH_SIZE", "enc_pmc_WRITE_SIZE"), ("pe100", "pmc_FETCH_SIZE", "pmc_WRITE_SIZE"),
+                      ("fq", "fq_pmc_FETCH_SIZE", "fq_pmc_WRITE_SIZE")):
         if tr not in traces or f not in ctrs or w not in ctrs:
             continue
         for k, v in traces[tr].items():

@@ -41,10 +41,14 @@ python $R/tools/gz_bench.py --inflate-sweep --out $O/${TAG}_gz_bench.json > /dev
 for c in FETCH_SIZE WRITE_SIZE; do pmc gz_pmc_$c $c -- python $R/tools/gz_bench.py; done
 pmc gz_pmc_sq SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY -- python $R/tools/gz_bench.py
 pmc gz_pmc_lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS -- python $R/tools/gz_bench.py
+# 5. device ingest (round 5): FASTQ index / gather / select / copy kernels and the single-stream inflate on a 2^20-record batch
+stats fq python $R/tools/fq_bench.py
+python $R/tools/fq_bench.py --out $O/${TAG}_fq_bench.json > /dev/null 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do pmc fq_pmc_$c $c -- python $R/tools/fq_bench.py --no-stream --reps 2; done
 python $R/tools/prof_summarize.py --tag $TAG --out $O /tmp/p_$TAG > $O/${TAG}_summary.txt 2>&1
 cd $R
 T0=$(date +%s)
-(timeout 900 python bench.py 2>/dev/null | grep "^{") > $O/${TAG}_bench.json
+(timeout 900 python bench.py --full-out $O/${TAG}_bench_full.json 2>/dev/null | grep "^{") > $O/${TAG}_bench.json
 echo "default bench.py wall seconds: $(( $(date +%s) - T0 ))" >> $O/${TAG}_summary.txt
 rm -f $O/*.log
 ls -la $O
