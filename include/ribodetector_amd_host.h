@@ -100,6 +100,9 @@ RD_API int rd_reader_feed_end(rd_reader *r, const char *error);
  * waits inside rd_reader_feed (which then returns -1) and fails every later feed call; nothing is freed. The owner then JOINS its
  * feeder threads and only then calls rd_reader_close (which frees the reader: no thread may still be inside a feed call). */
 RD_API int rd_reader_feed_abort(rd_reader *r);
+/* FASTA only: the fed text is a share of a stream that continues behind it (another rank reads on): the share's last record is
+ * yielded even when its sequence is empty - the reference yields a record at the NEXT header (fastx_parser.py:39-55) */
+RD_API int rd_reader_set_flush_empty_tail(rd_reader *r, int on);
 
 /* Walk gzip members that carry their own size - BGZF ('B','C') and this library's writer ('R','D') - without decoding them: one
  * entry per non-empty member (layout = rd_gz_member of include/ribodetector_amd.h), offsets relative to in_base / out_base.

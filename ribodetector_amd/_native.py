@@ -160,7 +160,7 @@ def ptr(t):
 HOST_LIB_PATH = os.path.join(_HERE, "csrc", "librd_host.so")
 HOST_SYMBOLS = ["rd_reader_open", "rd_reader_close", "rd_reader_next", "rd_host_file_info", "rd_host_find_record_start",
                 "rd_host_count_records", "rd_host_skip_records", "rd_reader_open_range", "rd_writer_open", "rd_writer_write_selected",
-                "rd_writer_write_members", "rd_writer_close", "rd_reader_open_feed", "rd_reader_feed", "rd_reader_feed_end", "rd_reader_feed_abort", "rd_writer_write_text", "rd_writer_set_eof_marker", "rd_host_gz_index", "rd_writer_threads", "rd_host_last_error", "rd_host_set_threads", "rd_host_set_gz_threads", "rd_host_gunzip", "rd_host_gunzip_parallel"]
+                "rd_writer_write_members", "rd_writer_close", "rd_reader_open_feed", "rd_reader_feed", "rd_reader_feed_end", "rd_reader_feed_abort", "rd_reader_set_flush_empty_tail", "rd_writer_write_text", "rd_writer_set_eof_marker", "rd_host_gz_index", "rd_writer_threads", "rd_host_last_error", "rd_host_set_threads", "rd_host_set_gz_threads", "rd_host_gunzip", "rd_host_gunzip_parallel"]
 _host = None
 
 
@@ -186,6 +186,7 @@ def host_lib():
     L.rd_reader_feed.argtypes = [vp, vp, i64]
     L.rd_reader_feed_end.argtypes = [vp, C.c_char_p]
     L.rd_reader_feed_abort.argtypes = [vp]
+    L.rd_reader_set_flush_empty_tail.argtypes = [vp, C.c_int]
     L.rd_writer_write_text.argtypes = [vp, vp, i64]
     L.rd_writer_set_eof_marker.argtypes = [vp, C.c_int]
     L.rd_host_gz_index.argtypes = [vp, i64, i64, i64, vp, i64, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]

@@ -713,6 +713,14 @@ int rd_reader_open_feed(int format, rd_reader **out) {
     return 0;
 }
 
+// FASTA, a feed reader over a SHARE of a stream that goes on behind it (a rank's members of a BGZF file): the share's last record is
+// followed by another rank's header, so it is yielded even with an empty sequence (rd_reader_open_range does the same for byte ranges)
+int rd_reader_set_flush_empty_tail(rd_reader *r, int on) {
+    if (!r) RDH_FAIL("rd_reader_set_flush_empty_tail: null reader");
+    r->flush_empty_tail = on != 0;
+    return 0;
+}
+
 int rd_reader_feed(rd_reader *r, const uint8_t *bytes, int64_t len) {
     if (!r || !r->feed || len < 0 || (!bytes && len)) RDH_FAIL("rd_reader_feed: not a feed reader, or bad argument");
     rd_feed *f = r->feed;

@@ -563,6 +563,8 @@ class NativeReader:
             a, b = byte_range
             c0, c1, drop = byte_range.view.file_span(a, b)
             N.host_check(N.host_lib().rd_reader_open_feed(f, C.byref(self.h)), "rd_reader_open_feed")
+            if f == 1 and b < byte_range.view.size:      # FASTA share that ends before the stream does: its last record counts even if empty
+                N.host_lib().rd_reader_set_flush_empty_tail(self.h, 1)
             self._feeder = _DeviceInflateFeeder(path, self.h, span=(c0, c1, drop, b - a), device=device)
         elif byte_range is None and fmt.endswith("gz") and device_inflate_wanted(path):
             # a .gz whose members say how long they are (BGZF; this build's own outputs): the members are inflated on the GPU and the
@@ -710,8 +712,9 @@ class BgzfView:
 
     WINDOW = 1 << 18
 
-    def __init__(self, path, index=None):
+    def __init__(self, path, index=None, fasta=None):
         self.path = str(path)
+        self.fasta = get_seq_format(path).startswith("fa") if fasta is None else bool(fasta)      # records start with '>' lines
         if index is None:
             index = self.build_index(self.path)
         self.comp_off, self.comp_len, self.out_off = index      # per non-empty member: file offset / size; text offsets (n + 1 entries)
@@ -786,7 +789,10 @@ class BgzfView:
             return self.size
         line = pos if self.text(pos - 1, pos) == b"\n" else self._next_line(pos)
         while line < self.size:
-            if self.text(line, line + 1) == b"@":
+            if self.fasta:
+                if self.text(line, line + 1) == b">":
+                    return line
+            elif self.text(line, line + 1) == b"@":
                 l2 = self._next_line(self._next_line(line))
                 if l2 < self.size and self.text(l2, l2 + 1) == b"+":
                     return line
@@ -794,6 +800,15 @@ class BgzfView:
         return self.size
 
     def skip_records(self, start, k):
+        if self.fasta:           # from one header line to the next, k times (rd_host_skip_records, format 1)
+            at = int(start)
+            for _ in range(int(k)):
+                if at >= self.size:
+                    break
+                at = self._next_line(at)
+                while at < self.size and self.text(at, at + 1) != b">":
+                    at = self._next_line(at)
+            return min(at, self.size)
         at, left = int(start), 4 * int(k)
         while left > 0 and at < self.size:
             w = np.frombuffer(self.text(at, at + (4 << 20)), dtype=np.uint8)
@@ -808,23 +823,31 @@ class BgzfView:
         start, end = max(0, int(start)), min(self.size, int(end))
         if end <= start:
             return 0
+        if self.fasta:                      # lines that start with '>' (start is a line start: a record boundary or 0)
+            return self._count_newlines(start, end, headers=True)
         lines = self._count_newlines(start, end)
         if self.text(end - 1, end) != b"\n":
             lines += 1                      # last line without terminator
         return lines // 4
 
-    def _count_newlines(self, a, b):
+    def _count_newlines(self, a, b, headers=False):
+        """newlines in [a, b) - or (headers) the lines of it that start with '>' (a is a line start)"""
         m0, m1 = self._member_of(a), self._member_of(b - 1)
         import torch
         if not torch.cuda.is_available():
-            total = 0
+            total, prev_nl = 0, True
             for m in range(m0, m1 + 1, 64):
                 lo, hi = int(self.out_off[m]), int(self.out_off[min(m + 64, m1 + 1)])
-                total += self.text(max(a, lo), min(b, hi)).count(b"\n")
+                t = self.text(max(a, lo), min(b, hi))
+                if headers:
+                    total += t.count(b"\n>") + (1 if t[:1] == b">" and (max(a, lo) == a or prev_nl) else 0)
+                    prev_nl = t[-1:] == b"\n" if t else prev_nl
+                else:
+                    total += t.count(b"\n")
             return total
         from .. import gz
         dg = gz.DeviceGunzip(torch.device("cuda", torch.cuda.current_device()))
-        total, m = 0, m0
+        total, m, prev_nl = 0, m0, True
         hdr = 64                                               # bytes read in front of a member's DEFLATE data: its gzip header
         with open(self.path, "rb") as fh:
             while m <= m1:
@@ -843,7 +866,13 @@ class BgzfView:
                 text = dg.inflate(buf, len(buf), e - m, ob)
                 lo = max(a, int(self.out_off[m])) - int(self.out_off[m])
                 hi = min(b, int(self.out_off[e])) - int(self.out_off[m])
-                total += int((text[lo:hi] == 10).sum())
+                if headers:         # '>' behind a '\n'; the window's first byte is a line start at `a`, else iff the batch before ended a line
+                    w = text[lo:hi]
+                    first = True if max(a, int(self.out_off[m])) == a else prev_nl
+                    total += int(((w[1:] == 62) & (w[:-1] == 10)).sum()) + (1 if hi > lo and first and bool(w[0] == 62) else 0)
+                    prev_nl = bool(w[-1] == 10) if hi > lo else prev_nl
+                else:
+                    total += int((text[lo:hi] == 10).sum())
                 m = e
         return total
 

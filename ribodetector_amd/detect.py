@@ -465,7 +465,7 @@ class Predictor:
         # ... and BGZF FASTQ inputs likewise: their members are independent, so every rank inflates (on its own GPU), parses, classifies
         # and writes the members of its share (positions in the decompressed stream, fx.BgzfView). RD_BGZF_SHARD=0: one decoding rank
         bgzf = (self.multi and not plain and os.environ.get("RD_BGZF_SHARD", "1") != "0"
-                and all(fx.get_seq_format(p) == "fqgz" and fx.bgzf_all_the_way(p) and fx.device_inflate_wanted(p) for p in self.input))
+                and all(fx.get_seq_format(p) in ("fqgz", "fagz") and fx.bgzf_all_the_way(p) and fx.device_inflate_wanted(p) for p in self.input))
         views = None
         if bgzf:                    # the member index: rank 0 walks the headers, the others receive the three arrays per file
             import torch.distributed as dist

@@ -708,3 +708,35 @@ def test_feed_reader_equals_the_file_reader(tmp_path):
     cut = raw.index(b"\n@", len(raw) // 2) + 1
     got, err = run([cut], error=b"gzip member 7: CRC check failed")
     assert err == "gzip member 7: CRC check failed" and b"".join(g[0] for g in got) == raw[:cut]
+
+
+def test_bgzf_view_on_fasta_gives_the_plain_files_answers(tmp_path):
+    """BGZF FASTA (round 5): records start at '>' lines; multi-line sequences, blank lines, an empty-sequence record. The view's
+    find_record_start / count_records / skip_records equal the librd_host.so helpers on the plain file"""
+    rng = np.random.default_rng(8)
+    recs = []
+    for i in range(3000):
+        L = int(rng.choice([0, 5, 60, 61, 200, 700]))
+        seq = "".join(rng.choice(list("ACGTN"), L))
+        lines = [seq[k:k + 60] for k in range(0, L, 60)]
+        recs.append(">seq%d some description\n" % i + "".join(l + "\n" for l in lines) + ("\n" if i % 97 == 0 else ""))
+    raw = "".join(recs).encode()
+    plain, gzp = str(tmp_path / "x.fasta"), str(tmp_path / "x.fasta.gz")
+    open(plain, "wb").write(raw)
+    _bgzf_file(plain, gzp, 3000)
+    v = fx.BgzfView(gzp)
+    assert v.fasta and v.size == len(raw)
+    for pos in list(rng.integers(0, v.size, 60)) + [0, 1, v.size - 1, v.size]:
+        assert v.find_record_start(pos) == fx.find_record_start(plain, pos), pos
+    for _ in range(25):
+        a = fx.find_record_start(plain, int(rng.integers(0, v.size)))
+        b = fx.find_record_start(plain, int(rng.integers(a, v.size + 1)))
+        assert v.count_records(a, b) == fx.count_records(plain, a, b), (a, b)
+        k = int(rng.integers(0, 500))
+        assert v.skip_records(a, k) == fx.skip_records(plain, a, k), (a, k)
+    # the ranges of 1 ... 5 ranks are the plain file's
+    for world in (1, 2, 3, 5):
+        for r in range(world):
+            got = fx.plan_ranges([gzp], r, world, views=[fx.BgzfView(gzp)])
+            want = fx.plan_ranges([plain], r, world)
+            assert tuple(got[0]) == tuple(want[0])

@@ -538,3 +538,42 @@ def test_cli_single_stream_gz_inflated_on_the_device(tmp_path, monkeypatch):
     p1, got = run("dev")
     assert got == want and (p1.num_read, p1.num_rrna, p1.num_nonrrna) == (p0.num_read, p0.num_rrna, p0.num_nonrrna) == (n, p0.num_rrna, n - p0.num_rrna)
     assert len(p1.ingest) == 2 and all(v["path"] == "device" and "fallback" not in v["feeder"] for v in p1.ingest.values())
+
+
+def test_cli_bgzf_fasta_is_sharded_across_ranks(tmp_path):
+    """round 5: a BGZF FASTA input is cut at '>' records in its decompressed stream like a BGZF FASTQ at '@' records: every rank
+    inflates the members of its share on its GPU, parses (host parser: FASTA), classifies and writes its part; same files as one rank -
+    multi-line sequences, an empty-sequence record at a cut included"""
+    import re
+    import socket
+    import subprocess
+    import sys
+    from ribodetector_amd import detect, synth
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    n = 6000
+    a, o, _ = synth.reads_numpy(n, (40, 260), seed=61, rrna_frac=0.3)
+    b = a.tobytes()
+    with open(str(tmp_path / "p.fasta"), "wb") as fh:
+        for i in range(n):
+            s = b[o[i]:o[i + 1]] if i % 500 else b""                     # (every 500th record has no sequence at all)
+            fh.write(b">seq%d\n" % i + b"".join(s[k:k + 70] + b"\n" for k in range(0, len(s), 70)))
+    inp = str(tmp_path / "in.fasta.gz")
+    _bgzf(str(tmp_path / "p.fasta"), inp)
+    one = [str(tmp_path / "one.non.fa"), str(tmp_path / "one.rr.fa.gz")]
+    p = detect.main(["-l", "100", "-i", inp, "-o", one[0], "-r", one[1], "--chunk_size", "1", "-m", "3"])
+    for world in (2, 3):
+        two = [str(tmp_path / ("w%d.non.fa" % world)), str(tmp_path / ("w%d.rr.fa.gz" % world))]
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        env = dict(os.environ, RD_DIST_BACKEND="gloo", RD_LOCAL_DEVICE="0", PYTHONPATH=root)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), "-m", "ribodetector_amd.detect", "-l", "100", "-i", inp, "-o", two[0], "-r", two[1], "--chunk_size", "1", "-m", "3"]
+        r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        for x, y in zip(one, two):
+            assert _read(x) == _read(y) and len(_read(x)) > 0
+        rows = re.findall(r"Rank (\d) parses (\d+) bytes of (\d+) \(decompressed; BGZF members\)", r.stdout + r.stderr)
+        assert len(rows) == world and sum(int(x[1]) for x in rows) == os.path.getsize(str(tmp_path / "p.fasta"))
+    assert p.num_read > 0

@@ -113,6 +113,34 @@ class E2E:
     def close(self):
         shutil.rmtree(self.dir, ignore_errors=True)
 
+    def save(self):
+        """what a child process needs to run legs on these files (E2E.from_dir)"""
+        with open(os.path.join(self.dir, "e2e_meta.json"), "w") as fh:
+            json.dump({"L": self.L, "ensure": self.ensure, "n": self.n, "files": self.files, "how": self.how, "plain_bytes": self.plain_bytes}, fh)
+
+    @classmethod
+    def from_dir(cls, d):
+        m = json.load(open(os.path.join(d, "e2e_meta.json")))
+        e = cls.__new__(cls)
+        e.dir, e.L, e.ensure, e.n, e.files, e.how, e.plain_bytes = d, m["L"], m["ensure"], m["n"], m["files"], m["how"], m["plain_bytes"]
+        e.torch = e.synth = e.lens = e.dev = None
+        return e
+
+    def leg_in_child(self, in_kind="plain", out_gz=False, timed_calls=3, threads=None, env=None):
+        """the same leg in a process of its own - what a CLI invocation is. (In a process that has already made a dozen calls the HIP
+        runtime's helper thread spins a full core through every later call: BGZF -> gz read 1.3 host cores as the 7th leg of one process,
+        0.6 as the first.)"""
+        import subprocess
+        self.inputs(in_kind)
+        self.save()
+        cmd = [sys.executable, os.path.abspath(__file__), "--one-leg", self.dir, "--in-kind", in_kind, "--timed-calls", str(timed_calls)] + (
+            ["--out-gz"] if out_gz else []) + (["--threads", str(threads)] if threads else []) + [a for k, v in (env or {}).items() for a in ("--env", "%s=%s" % (k, v))]
+        r = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        lines = [l for l in r.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not lines:
+            raise RuntimeError("e2e leg %s -> %s failed (rc %d): %s" % (in_kind, "gz" if out_gz else "plain", r.returncode, r.stderr.decode(errors="replace")[-400:]))
+        return json.loads(lines[-1])
+
     def __enter__(self):
         return self
 
@@ -354,16 +382,20 @@ def bench_legs(a):
     arenas = [cat(r1, rep)] + ([cat(r2, rep)] if paired else [])
     with E2E(torch, synth, arenas, offs_l, lens.repeat(rep * nslices), a.max_len, a.ensure) as e:
         del arenas, r1, r2
+        e.inputs("bgzf")
+        e.inputs("gz")
+        e.lens = None
         torch.cuda.empty_cache()
-        rec["plain_to_plain"] = e.leg("plain", False)
-        rec["plain_to_gz"] = e.leg("plain", True)
-        rec["bgzf_to_gz"] = e.leg("bgzf", True)
-        rec["bgzf_to_plain"] = e.leg("bgzf", False)
-        rec["bgzf_to_gz_host_parse"] = e.leg("bgzf", True, env={"RD_DEVICE_PARSE": "0"})
-        rec["plain_to_plain_host_parse"] = e.leg("plain", False, env={"RD_DEVICE_PARSE": "0"})
-        rec["gz_to_gz"] = e.leg("gz", True)
-        rec["gz_to_gz_all_cores"] = e.leg("gz", True, threads=usable_cores())
-        rec["gz_to_gz_device_stream"] = e.leg("gz", True, env={"RD_DEVICE_INFLATE": "stream"})      # the single stream decoded on the GPU (opt-in)
+        leg = e.leg_in_child            # every leg in a process of its own (the input files are built once, here)
+        rec["plain_to_plain"] = leg("plain", False)
+        rec["plain_to_gz"] = leg("plain", True)
+        rec["bgzf_to_gz"] = leg("bgzf", True)
+        rec["bgzf_to_plain"] = leg("bgzf", False)
+        rec["bgzf_to_gz_host_parse"] = leg("bgzf", True, env={"RD_DEVICE_PARSE": "0"})
+        rec["plain_to_plain_host_parse"] = leg("plain", False, env={"RD_DEVICE_PARSE": "0"})
+        rec["gz_to_gz"] = leg("gz", True)
+        rec["gz_to_gz_all_cores"] = leg("gz", True, threads=usable_cores())
+        rec["gz_to_gz_device_stream"] = leg("gz", True, env={"RD_DEVICE_INFLATE": "stream"})      # the single stream decoded on the GPU (opt-in)
     print(json.dumps(rec))
 
 
@@ -378,7 +410,18 @@ def main():
     ap.add_argument("--single-end", dest="paired", action="store_false")
     ap.add_argument("--var-len", action="store_true")
     ap.add_argument("--ensure", default="rrna")
+    ap.add_argument("--one-leg", default=None, metavar="DIR", help=argparse.SUPPRESS)      # child of E2E.leg_in_child
+    ap.add_argument("--in-kind", default="plain", help=argparse.SUPPRESS)
+    ap.add_argument("--out-gz", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--timed-calls", type=int, default=3, help=argparse.SUPPRESS)
+    ap.add_argument("--threads", type=int, default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--env", action="append", default=[], help=argparse.SUPPRESS)
     a = ap.parse_args()
+    if a.one_leg:
+        import ribodetector_amd      # noqa: F401  (before torch: the runtime knobs of ribodetector_amd/__init__.py)
+        e = E2E.from_dir(a.one_leg)
+        print(json.dumps(e.leg(a.in_kind, a.out_gz, timed_calls=a.timed_calls, threads=a.threads, env=dict(x.split("=", 1) for x in a.env))))
+        return
     if a.bench_legs:
         return bench_legs(a)
     from ribodetector_amd import detect, synth
