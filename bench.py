@@ -159,8 +159,8 @@ def e2e_legs(args, P, RL, MAXLEN, paired):
     1.3 host cores here, 0.6 in a process of its own).
     one_step_batch: the batch of one step (the pipeline-fill-bound point), one call after a warm one. Then every flow on files of
     --e2e-records records (default 16 Mi: >= 1 s of CLI per call), median of three calls after a warm one: plain -> plain, plain -> gz,
-    BGZF -> gz / plain (text stays on the device), the same two through the host parser, gz -> gz (one member per file; -t 10, -t = cores,
-    and with the stream decoded on the GPU: RD_DEVICE_INFLATE=stream)."""
+    BGZF -> gz / plain (text stays on the device), the same two through the host parser, gz -> gz (one member per file: the stream decoded on the GPU; and by
+    the host's decoders with -t 10 / -t = cores: RD_DEVICE_INFLATE=members)."""
     cmd = [sys.executable, os.path.join(ROOT, "tools", "e2e_bench.py"), "--bench-legs", "--pairs-per-step", str(P), "--records", str(args.e2e_records),
            "--read-len", str(RL), "--max-len", str(MAXLEN), "--ensure", args.ensure] + ([] if paired else ["--single-end"]) + (
                ["--var-len"] if args.workload == "var300" else [])

@@ -300,7 +300,7 @@ RD_API size_t rd_select_workspace_bytes(int64_t n);
 RD_API int rd_select_pack(const uint8_t *text, int64_t text_bytes, const int64_t *rec_start, const int8_t *labels, int64_t n, int32_t label, uint8_t *out,
                    size_t out_cap, int64_t *info, void *workspace, size_t workspace_bytes, void *stream);
 
-/* ONE DEFLATE stream - a plain .gz, the format sequencers write - inflated on the device (round 5; opt-in: RD_DEVICE_INFLATE=stream).
+/* ONE DEFLATE stream - a plain .gz, the format sequencers write - inflated on the device (round 5; the CLI's default for such FASTQ, RD_DEVICE_INFLATE=members keeps the host's decoders).
  * Replaces, for such files: gzip.open(path, 'rt') of reference data_loader/seq_encoder.py:21-39. The two-pass scheme of pugz (this
  * build's host reader: csrc/rd_pgzip.h) with one wave per SECTION of `section_bytes` compressed bytes: block starts are searched on the
  * device, every section is decoded from its start to the next section's start with an unknown window into 16-bit symbols, the windows

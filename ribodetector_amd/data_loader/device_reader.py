@@ -42,7 +42,8 @@ FQ_ERRORS = {1: "FASTQ record does not start with '@'",
 def device_ingest_kind(path, fmt=None):
     """how the device reader would take this input: "plain" | "bgzf" (members that carry their size: inflated one wave per member) |
     "stream" (any other gzip file - one DEFLATE stream, what sequencers write: the two-pass decoder of csrc/rd_inflate_stream.hpp;
-    opt-in with RD_DEVICE_INFLATE=stream) | None (FASTA, no GPU, RD_DEVICE_PARSE=0, RD_DEVICE_INFLATE=0 for .gz)"""
+    RD_DEVICE_INFLATE=members keeps such files with the host's decoders) | None (FASTA, no GPU, RD_DEVICE_PARSE=0,
+    RD_DEVICE_INFLATE=0 for .gz)"""
     if os.environ.get("RD_DEVICE_PARSE", "1") == "0" or not torch.cuda.is_available():
         return None
     from . import fastx_parser as fx
@@ -52,7 +53,7 @@ def device_ingest_kind(path, fmt=None):
     if fmt.endswith("gz"):
         if fx.device_inflate_wanted(path):
             return "bgzf"
-        if os.environ.get("RD_DEVICE_INFLATE", "auto") == "stream" and fx.file_info(path)[1] and gz.is_member_indexed(path) is None:
+        if os.environ.get("RD_DEVICE_INFLATE", "auto") not in ("0", "members") and fx.file_info(path)[1] and gz.is_member_indexed(path) is None:
             return "stream"
         return None
     return None if fx.file_info(path)[1] else "plain"      # (a gzip file under a plain name goes to the host reader, which sniffs the magic)
@@ -444,6 +445,7 @@ class DeviceFeeder:
         pos, first, batch = 0, hl * 8, min(self.FIRST, dsg.BATCH)
         flight = deque()                                  # (ticket, text, pinned slot, file offset of the batch)
         member_end = None
+        good = {}                                         # what the last good batch left: where the stream goes on, window, CRC, length
 
         def finish_one():
             nonlocal member_end
@@ -460,8 +462,14 @@ class DeviceFeeder:
                     # what is not text (no block start passes the search: one wave would have to decode everything), what
                     # compresses 100:1, and damaged files, whose error messages are then zlib's
                     raise _StreamFallback(gz.GZS_ERRORS.get(r["status"], "error %d" % r["status"]))
-                raise ValueError("%s (device stream decoder, section %d of the batch at byte %d; RD_DEVICE_INFLATE=0 reads the file with "
-                                 "the host's decoders)" % (gz.GZS_ERRORS.get(r["status"], "error %d" % r["status"]), r["bad_section"], at))
+                # a later batch: the text before it has been delivered, so the REST of the member is decoded by zlib on the host from the
+                # bit this batch was to start at, with the window the batch before left as its dictionary (slow - one core - but the
+                # same text, and zlib's messages for real damage); the batches in flight behind it are dropped
+                tm["resumed_on_host"] = "%s at byte %d" % (gz.GZS_ERRORS.get(r["status"], "error %d" % r["status"]), at)
+                while flight:
+                    dsg.finish(flight.popleft()[0])
+                member_end = self._resume_on_host(fd, size, good["abs_next"], good["win"], good["win_valid"], good["crc"], good["total_len"])
+                return not self._stop
             if r["final"]:
                 end = at + (r["end_bit"] + 7) // 8
                 tr = os.pread(fd, 8, end)
@@ -472,6 +480,7 @@ class DeviceFeeder:
                 if int.from_bytes(tr[4:], "little") != (r["total_len"] & 0xffffffff):
                     raise ValueError("Incorrect length of data produced")
                 member_end = end + 8
+            good.update(abs_next=at * 8 + r["next_start"], win=tk["keep"][2], win_valid=r["win_valid"], crc=r["crc"], total_len=r["total_len"])
             b = self.ix.index(text, PAD, PAD + r["n_text"])
             tm["batches"] += 1
             tm["bytes"] += r["n_text"]
@@ -521,6 +530,60 @@ class DeviceFeeder:
                 rest = fh.read(1 << 16)
                 if rest.strip(b"\0"):
                     self._host_tail(fh, rest)
+
+    def _resume_on_host(self, fd, size, start_bit, win_dev, win_valid, crc, total_len):
+        """the rest of a gzip member from absolute bit `start_bit` of the file, by zlib: the compressed bytes are shifted to a byte
+        boundary piece by piece (DEFLATE packs bits LSB first), the 32 KiB window the device decoder left is the preset dictionary.
+        Returns the file offset behind the member's trailer (CRC-32 and ISIZE are checked against the carried values + this text)."""
+        import zlib
+        window = win_dev.cpu().numpy().tobytes()[32768 - min(int(win_valid), 32768):]
+        d = zlib.decompressobj(-15, zdict=window) if window else zlib.decompressobj(-15)
+        k, pos = start_bit & 7, start_bit >> 3
+        fed = 0
+        PIECE = 4 << 20
+        while not d.eof:
+            raw = os.pread(fd, PIECE + 1, pos)
+            if len(raw) == 0 or self._stop:
+                if self._stop:
+                    return None
+                raise ValueError("Compressed file ended before the end-of-stream marker was reached")
+            arr = np.frombuffer(raw, dtype=np.uint8)
+            n = len(arr) - 1 if len(arr) == PIECE + 1 else len(arr)
+            if k:
+                nxt = np.concatenate([arr[1:], np.zeros(1, np.uint8)])[:n] if len(arr) != PIECE + 1 else arr[1:n + 1]
+                piece = ((arr[:n] >> k) | ((nxt.astype(np.uint16) << (8 - k)) & 0xff).astype(np.uint8)).tobytes()
+            else:
+                piece = arr[:n].tobytes()
+            pos += n
+            data = piece
+            while data and not d.eof:
+                try:
+                    out = d.decompress(data, 16 << 20)
+                except zlib.error as e:
+                    raise ValueError(str(e))
+                # (at the end of the stream CPython puts the bytes behind it into unused_data AND leaves them in unconsumed_tail)
+                fed += len(data) - (len(d.unused_data) if d.eof else len(d.unconsumed_tail))
+                data = d.unconsumed_tail
+                if out:
+                    crc = zlib.crc32(out, crc)
+                    total_len += len(out)
+                    src = torch.from_numpy(np.frombuffer(out, dtype=np.uint8).copy()).pin_memory()
+                    b = self._submit_text(src, len(out), None)
+                    b.orig = src
+                    if not self._put(b):
+                        return None
+        # the member's trailer starts at the byte boundary behind its last bit: zlib says how many (shifted) bytes it consumed, the last
+        # of them partly - two candidates unless the stream was byte aligned; CRC-32 and ISIZE say which
+        base = (start_bit >> 3) + fed
+        for end in ((base,) if k == 0 else (base, base + 1)):
+            tr = os.pread(fd, 8, end)
+            if len(tr) == 8 and int.from_bytes(tr[:4], "little") == (crc & 0xffffffff) and int.from_bytes(tr[4:], "little") == (total_len & 0xffffffff):
+                return end + 8
+        if os.environ.get("RD_FEED_TRACE"):
+            import sys
+            sys.stderr.write("resume: start_bit %d k %d fed %d crc %08x len %d; trailers %s\n" % (
+                start_bit, k, fed, crc & 0xffffffff, total_len, [os.pread(fd, 8, e).hex() for e in (base - 1, base, base + 1)]))
+        raise ValueError("CRC check failed")
 
     def _host_tail(self, fh, data):
         """the rest of a file whose members stop carrying their size (`cat a.bgzf.gz b.gz` is a legal .gz): zlib, member after member,

@@ -270,7 +270,7 @@ class DeviceGunzip:
         return self._slots[0].text_dev[:out_bytes]
 
 
-# ---- ONE DEFLATE stream inflated on the device (csrc/rd_inflate_stream.hpp; opt-in: RD_DEVICE_INFLATE=stream) ------------------------------
+# ---- ONE DEFLATE stream inflated on the device (csrc/rd_inflate_stream.hpp; RD_DEVICE_INFLATE=members: off) ------------------------------
 
 GZS_ERRORS = {1: "invalid deflate data", 2: "a section did not end where the next one starts", 3: "a section produced more symbols than its slot holds",
               4: "Compressed file ended before the end-of-stream marker was reached", 5: "invalid distance too far back",

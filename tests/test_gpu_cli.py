@@ -511,7 +511,7 @@ def test_cli_device_resident_ingest_writes_the_same_files(tmp_path, paired, ensu
 
 
 def test_cli_single_stream_gz_inflated_on_the_device(tmp_path, monkeypatch):
-    """RD_DEVICE_INFLATE=stream: a plain .gz (one DEFLATE stream - what sequencers write) is decoded by the two-pass device decoder
+    """the default since round 5: a plain .gz (one DEFLATE stream - what sequencers write) is decoded by the two-pass device decoder
     (csrc/rd_inflate_stream.hpp), its text framed and classified where it lands: the files of the default route (the host's parallel
     decoder), the same counts, and no host reader involved"""
     import gzip as gzmod
@@ -531,10 +531,10 @@ def test_cli_single_stream_gz_inflated_on_the_device(tmp_path, monkeypatch):
         rrs = [str(tmp_path / ("%s.rr%d.fq" % (tag, e))) for e in range(2)]
         pr = detect.main(["-l", "100", "-i", *ins, "-o", *outs, "-r", *rrs, "-e", "rrna", "--chunk_size", "8", "-m", "3"])
         return pr, [_read(f) for f in outs + rrs]
-    monkeypatch.delenv("RD_DEVICE_INFLATE", raising=False)
+    monkeypatch.setenv("RD_DEVICE_INFLATE", "members")          # the round-4 route: BGZF members on the GPU, a single stream on the host
     p0, want = run("host")
     assert not p0.ingest
-    monkeypatch.setenv("RD_DEVICE_INFLATE", "stream")
+    monkeypatch.delenv("RD_DEVICE_INFLATE")                     # the default since round 5
     p1, got = run("dev")
     assert got == want and (p1.num_read, p1.num_rrna, p1.num_nonrrna) == (p0.num_read, p0.num_rrna, p0.num_nonrrna) == (n, p0.num_rrna, n - p0.num_rrna)
     assert len(p1.ingest) == 2 and all(v["path"] == "device" and "fallback" not in v["feeder"] for v in p1.ingest.values())

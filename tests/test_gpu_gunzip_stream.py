@@ -1,4 +1,4 @@
-"""ONE DEFLATE stream inflated on the device (C ABI rd_gz_stream_inflate, csrc/rd_inflate_stream.hpp; opt-in RD_DEVICE_INFLATE=stream) and
+"""ONE DEFLATE stream inflated on the device (C ABI rd_gz_stream_inflate, csrc/rd_inflate_stream.hpp; RD_DEVICE_INFLATE=members keeps the host's) and
 the reader path built on it (data_loader/device_reader.py: DeviceFeeder._run_stream).
 
 What it replaces for plain .gz files - the format sequencers write: gzip.open(path, 'rt') of the reference
@@ -200,3 +200,29 @@ def test_c_abi_argument_errors():
     assert L.rd_gz_stream_inflate(None, 0, 0, 0, 16384, 1 << 16, 0, None, 0, 0, None, None, None, 0, None, None, 0, None) != 0 and b"null" in L.rd_last_error()
     assert L.rd_gz_stream_inflate(N.ptr(t), 1 << 16, 1 << 16, 1 << 15, 16384, 1 << 16, 0, None, 0, 1, None, N.ptr(t), N.ptr(t), 1 << 16, N.ptr(t), N.ptr(t), 1 << 16, None) != 0
     assert L.rd_gz_stream_workspace_bytes(-1, 16384, 1 << 16, 0) == 0 and L.rd_gz_stream_workspace_bytes(1 << 20, 16384, 1 << 16, 1 << 23) > (1 << 20) // 16384 * (1 << 17)
+
+
+def test_reader_resumes_on_the_host_behind_a_batch_it_cannot_take(tmp_path, fastq, monkeypatch):
+    """FASTQ, then 36 MB of one record repeated (250:1: a section outgrows its slot), then FASTQ again - ONE member. The batches in
+    front are decoded on the device and delivered; from the batch that fails on, zlib continues at that batch's first bit (the
+    compressed bytes shifted to a byte boundary) with the window the device left as its dictionary; trailer checked; same text"""
+    from ribodetector_amd import gz
+    from ribodetector_amd.data_loader import device_reader as dr
+    monkeypatch.setenv("RD_DEVICE_INFLATE", "stream")
+    monkeypatch.setattr(dr.DeviceFeeder, "FIRST", 1 << 18)
+    monkeypatch.setattr(gz.DeviceStreamGunzip, "BATCH", 1 << 20)
+    rep = b"@read\nACGTACGTACGTACGTACGTACGTACGTACGTACGTACGTACGTACGT\n+\nIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIII\n" * 350000
+    data = fastq + rep + fastq_bytes(8000, seed=9)
+    for flags, tail in ((0, b""), (8, member(b"@x\nAC\n+\nII\n", 6) + bytes(100))):
+        p = str(tmp_path / "mixed.fastq.gz")
+        open(p, "wb").write(member(data, 6, flags=flags) + tail)
+        st = {}
+        got = _reader_text(p, chunk=50000, stats=st)
+        assert got == data + (b"@x\nAC\n+\nII\n" if tail else b""), (len(got), len(data))
+        assert "resumed_on_host" in st["feeder"] and "fallback" not in st["feeder"] and st["feeder"]["batches"] >= 3, st["feeder"]
+    # damage behind the point of resumption is zlib's to report
+    blob = bytearray(member(data, 6))
+    blob[-3000] ^= 0x10
+    open(p, "wb").write(bytes(blob))
+    with pytest.raises(ValueError):
+        _reader_text(p, chunk=50000)

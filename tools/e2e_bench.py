@@ -393,9 +393,9 @@ def bench_legs(a):
         rec["bgzf_to_plain"] = leg("bgzf", False)
         rec["bgzf_to_gz_host_parse"] = leg("bgzf", True, env={"RD_DEVICE_PARSE": "0"})
         rec["plain_to_plain_host_parse"] = leg("plain", False, env={"RD_DEVICE_PARSE": "0"})
-        rec["gz_to_gz"] = leg("gz", True)
-        rec["gz_to_gz_all_cores"] = leg("gz", True, threads=usable_cores())
-        rec["gz_to_gz_device_stream"] = leg("gz", True, env={"RD_DEVICE_INFLATE": "stream"})      # the single stream decoded on the GPU (opt-in)
+        rec["gz_to_gz"] = leg("gz", True)                                    # the single stream decoded on the GPU (the default since round 5)
+        rec["gz_to_gz_host_inflate"] = leg("gz", True, env={"RD_DEVICE_INFLATE": "members"})                 # ... by the host's parallel decoder, -t 10
+        rec["gz_to_gz_host_inflate_all_cores"] = leg("gz", True, threads=usable_cores(), env={"RD_DEVICE_INFLATE": "members"})
     print(json.dumps(rec))
 
 
