@@ -335,7 +335,8 @@ RD_API int rd_gz_stream_inflate(const uint8_t *comp, int64_t comp_bytes, int64_t
 
 /* n bytes moved by a kernel on `stream` instead of a DMA engine: dst / src [dev, or pinned host memory mapped into the device]. The
  * feeder's H2D of file bytes and the writers' D2H of output bytes use it: an SDMA queue is shared in order with other streams' copies,
- * and a copy that waits for kernels (a label D2H behind two recurrence launches) held a 96 MB H2D back for 60-100 ms. workgroups: 0 = 32. */
+ * and a copy that waits for kernels (a label D2H behind two recurrence launches) held a 96 MB H2D back for 60-100 ms. workgroups (of 1,024 threads): 0 = 8 - few and fat, because a
+ * workgroup that copies keeps its CU from the recurrence kernel for as long as the copy runs. */
 RD_API int rd_copy_bytes(void *dst, const void *src, int64_t n, int32_t workgroups, void *stream);
 
 /* A HIP stream whose kernels run on a subset of the compute units (hipExtStreamCreateWithCUMask): cu_mask [host] uint32[words], bit i =

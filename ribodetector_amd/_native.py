@@ -146,6 +146,7 @@ def copy_bytes(dst, src, nbytes, stream, workgroups=0):
             dst[:nbytes].copy_(src[:nbytes], non_blocking=True)
         return
     dev = dst.device if dst.is_cuda else src.device
+    workgroups = workgroups or int(os.environ.get("RD_COPY_WGS", "0"))
     with torch.cuda.device(dev):
         check(lib().rd_copy_bytes(C.c_void_p(dst.data_ptr()), C.c_void_p(src.data_ptr()), int(nbytes), int(workgroups), C.c_void_p(stream.cuda_stream)),
               "rd_copy_bytes")

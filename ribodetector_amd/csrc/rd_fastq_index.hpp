@@ -290,9 +290,11 @@ __global__ __launch_bounds__(FQ_THREADS) void rd_fq_sample_kernel(const int32_t 
 // bytes moved by a kernel instead of a DMA engine: dst / src are device memory or pinned host memory (mapped into the device's address
 // space). hipMemcpyAsync between pinned memory and HBM goes to an SDMA queue that other streams' copies share IN ORDER - a 96 MB H2D of
 // the feeder was seen waiting 60-100 ms behind a label D2H that itself waited for two recurrence launches; a kernel on the feeder's own
-// stream waits for nothing but a free workgroup slot (~1 ms). 64 bytes per thread and trip keep ~50 GB/s of PCIe busy from 32 workgroups.
-__global__ __launch_bounds__(FQ_THREADS) void rd_copy_kernel(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src, int64_t n) {
-    const int64_t gtid = (int64_t)blockIdx.x * FQ_THREADS + threadIdx.x, stride = (int64_t)gridDim.x * FQ_THREADS;
+// stream waits for nothing but a free workgroup slot (~1 ms). 64 bytes per thread and trip keep ~55 GB/s of PCIe busy from 8 workgroups.
+constexpr int COPY_THREADS = 1024;   // FEW, fat workgroups: a workgroup that copies holds its CU from the recurrence kernel for as long as the copy runs (that kernel's
+                                     // waves take whole SIMDs); 8 x 1,024 threads keep as many bytes in flight as 32 x 256 did, on 8 CUs instead of 32
+__global__ __launch_bounds__(COPY_THREADS) void rd_copy_kernel(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src, int64_t n) {
+    const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t head = (16 - ((uintptr_t)dst & 15)) & 15;                 // bytes before dst's first 16-byte boundary
     if (gtid < head && gtid < n) dst[gtid] = src[gtid];
     const int64_t body = n > head ? (n - head) / 16 : 0;                    // 16-byte pieces, aligned at dst

@@ -714,10 +714,10 @@ int rd_stream_destroy(void *stream) {
 int rd_copy_bytes(void *dst, const void *src, int64_t n, int32_t workgroups, void *stream) {
     if (n < 0 || (n > 0 && (!dst || !src))) RD_FAIL(RD_E_INVALID, "rd_copy_bytes: bad argument");
     if (n == 0) return RD_OK;
-    int64_t grid = workgroups > 0 ? workgroups : 32;
-    const int64_t need = n / (16 * FQ_THREADS) + 1;
+    int64_t grid = workgroups > 0 ? workgroups : 8;
+    const int64_t need = n / (16 * COPY_THREADS) + 1;
     if (grid > need) grid = need;
-    hipLaunchKernelGGL(rd_copy_kernel, dim3((unsigned)grid), dim3(FQ_THREADS), 0, (hipStream_t)stream, (uint8_t *)dst, (const uint8_t *)src, n);
+    hipLaunchKernelGGL(rd_copy_kernel, dim3((unsigned)grid), dim3(COPY_THREADS), 0, (hipStream_t)stream, (uint8_t *)dst, (const uint8_t *)src, n);
     RD_HIP(hipGetLastError());
     return RD_OK;
 }

@@ -386,16 +386,17 @@ def bench_legs(a):
         e.inputs("gz")
         e.lens = None
         torch.cuda.empty_cache()
-        leg = e.leg_in_child            # every leg in a process of its own (the input files are built once, here)
-        rec["plain_to_plain"] = leg("plain", False)
-        rec["plain_to_gz"] = leg("plain", True)
-        rec["bgzf_to_gz"] = leg("bgzf", True)
-        rec["bgzf_to_plain"] = leg("bgzf", False)
-        rec["bgzf_to_gz_host_parse"] = leg("bgzf", True, env={"RD_DEVICE_PARSE": "0"})
-        rec["plain_to_plain_host_parse"] = leg("plain", False, env={"RD_DEVICE_PARSE": "0"})
-        rec["gz_to_gz"] = leg("gz", True)                                    # the single stream decoded on the GPU (the default since round 5)
-        rec["gz_to_gz_host_inflate"] = leg("gz", True, env={"RD_DEVICE_INFLATE": "members"})                 # ... by the host's parallel decoder, -t 10
-        rec["gz_to_gz_host_inflate_all_cores"] = leg("gz", True, threads=usable_cores(), env={"RD_DEVICE_INFLATE": "members"})
+        xenv = dict(kv.split("=", 1) for kv in a.env)                        # (--env K=V: the same for every leg - A/B runs)
+        legs = {"plain_to_plain": ("plain", False, None, {}), "plain_to_gz": ("plain", True, None, {}), "bgzf_to_gz": ("bgzf", True, None, {}),
+                "bgzf_to_plain": ("bgzf", False, None, {}), "bgzf_to_gz_host_parse": ("bgzf", True, None, {"RD_DEVICE_PARSE": "0"}),
+                "plain_to_plain_host_parse": ("plain", False, None, {"RD_DEVICE_PARSE": "0"}),
+                "gz_to_gz": ("gz", True, None, {}),                                                    # the single stream decoded on the GPU (the default since round 5)
+                "gz_to_gz_host_inflate": ("gz", True, None, {"RD_DEVICE_INFLATE": "members"}),          # ... by the host's parallel decoder, -t 10
+                "gz_to_gz_host_inflate_all_cores": ("gz", True, usable_cores(), {"RD_DEVICE_INFLATE": "members"})}
+        want = [k for k in (a.legs.split(",") if a.legs else legs) if k]
+        for k in want:                  # every leg in a process of its own (the input files are built once, here)
+            kind, out_gz, threads, env = legs[k]
+            rec[k] = e.leg_in_child(kind, out_gz, threads=threads, env=dict(env, **xenv))
     print(json.dumps(rec))
 
 
@@ -410,6 +411,7 @@ def main():
     ap.add_argument("--single-end", dest="paired", action="store_false")
     ap.add_argument("--var-len", action="store_true")
     ap.add_argument("--ensure", default="rrna")
+    ap.add_argument("--legs", default=None, help="with --bench-legs: only these legs (comma-separated names)")
     ap.add_argument("--one-leg", default=None, metavar="DIR", help=argparse.SUPPRESS)      # child of E2E.leg_in_child
     ap.add_argument("--in-kind", default="plain", help=argparse.SUPPRESS)
     ap.add_argument("--out-gz", action="store_true", help=argparse.SUPPRESS)

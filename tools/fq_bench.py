@@ -77,6 +77,11 @@ def main():
     put("rd_copy_bytes pinned -> HBM", ms, tb, "the bytes (PCIe 5 x16: 64 GB/s)", peak=64.0)
     ms = timed(lambda: N.copy_bytes(pin, dst, tb, st))
     put("rd_copy_bytes HBM -> pinned", ms, tb, "the bytes (PCIe 5 x16: 64 GB/s)", peak=64.0)
+    for wgs in (1, 2, 4, 16, 32):      # (default 8: above) workgroups of 1,024 threads - how few CUs keep the link busy
+        ms = timed(lambda: N.copy_bytes(dst, pin, tb, st, workgroups=wgs))
+        put("rd_copy_bytes pinned -> HBM, %d workgroups" % wgs, ms, tb, "the bytes", peak=64.0)
+        ms = timed(lambda: N.copy_bytes(pin, dst, tb, st, workgroups=wgs))
+        put("rd_copy_bytes HBM -> pinned, %d workgroups" % wgs, ms, tb, "the bytes", peak=64.0)
     ms = timed(lambda: dst.copy_(pin, non_blocking=True))
     put("hipMemcpyAsync pinned -> HBM (SDMA, for comparison)", ms, tb, "the bytes", peak=64.0)
     if not a.no_stream:
