@@ -33,19 +33,18 @@ constexpr int GZ_MEMBER = 65280;                       // input bytes per member
 constexpr int GZ_NQ = 16, GZ_PART = GZ_MEMBER / GZ_NQ;      // waves per member; each parses its own part 
 constexpr int GZ_THREADS = 64 * GZ_NQ;
 constexpr int GZ_SEED = 512;                                   // bytes of the part before that a wave's table starts with
-constexpr int GZ_CRCB = 64;                                    // bytes per thread in the CRC pass (GZ_CRCB * GZ_THREADS >= GZ_MEMBER)
-static_assert(GZ_CRCB * GZ_THREADS >= GZ_MEMBER && GZ_MEMBER % (4 * GZ_NQ) == 0 && GZ_PART + GZ_SEED < (1 << 14) && GZ_SEED % 64 == 0, "deflate kernel geometry");
-constexpr int GZ_HBITS = 8, GZ_WAYS = 8;                // 256 buckets of the 8 nearest earlier positions per wave
+constexpr int GZ_CRCB = 68;                                    // bytes per thread in the CRC pass: the threads of waves 1 .. 15 (wave 0 builds the tree meanwhile)
+static_assert(GZ_CRCB * (GZ_THREADS - 64) >= GZ_MEMBER && GZ_CRCB % 4 == 0 && GZ_MEMBER % (4 * GZ_NQ) == 0 && GZ_PART + GZ_SEED < (1 << 13) && GZ_SEED % 64 == 0, "deflate kernel geometry");
+constexpr int GZ_HBITS = 9, GZ_WAYS = 4;                // 512 buckets of the 4 nearest earlier positions per wave
+// a table entry, 16 bits: 2 more hash bits | 1 bit that only an EMPTY way has set | 13 bits of position in the part (+ 1)
+constexpr uint32_t GZ_EMPTY = 0x2000u, GZ_EMPTY2 = GZ_EMPTY | (GZ_EMPTY << 16), GZ_POSM = 0x1fffu;
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 constexpr int GZ_MINM = 8, GZ_MINRUN = 6, GZ_MAXM = 258, GZ_CAP = 16;
 constexpr int GZ_SLOT = 65536;                         // output bytes reserved per member (BGZF: total block size <= 65536)
 constexpr int GZ_HDR = 18, GZ_TRL = 8;
 constexpr int GZ_NSYM = 320;                           // 0..285 literal/length symbols, 286..315 distance symbols
 constexpr int GZ_MAX_GRID = 512;
 
-__constant__ uint16_t GZ_LBASE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
-__constant__ uint8_t GZ_LEXTRA[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-__constant__ uint16_t GZ_DBASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
-__constant__ uint8_t GZ_DEXTRA[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
 __constant__ uint8_t GZ_CLORD[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 // x^(2^i) mod P of the (reflected) CRC-32 polynomial: zlib's x2n_table
 __constant__ uint32_t GZ_X2N[32] = {0x40000000u, 0x20000000u, 0x08000000u, 0x00800000u, 0x00008000u, 0xedb88320u, 0xb1e6b092u, 0xa06a2517u,
@@ -180,7 +179,7 @@ __global__ __launch_bounds__(256) void rd_gz_pack_kernel(const uint8_t *__restri
 // ------------------------------------------------------------------------------------------------
 struct __attribute__((aligned(16))) GzSmem {
     uint32_t text[(GZ_MEMBER + 16) / 4];      // the member's bytes (+ zero pad); after the parse: the output (header, deflate data, trailer)
-    u32x4 tab[GZ_NQ][1 << GZ_HBITS];          // per wave: hash -> the 8 nearest earlier positions in its part (+ 1), 16 bits each, nearest first
+    u32x2 tab[GZ_NQ][1 << GZ_HBITS];          // per wave: hash -> the 4 nearest earlier positions in its part (+ 1), 16 bits each, nearest first
     uint32_t hist[GZ_NQ][GZ_NSYM / 2];        // per wave: symbol counts of its part, two 16-bit counters per word (a part has < 2^16 tokens)
     uint32_t freq[GZ_NSYM];
     uint8_t lens[GZ_NSYM];
@@ -188,16 +187,17 @@ struct __attribute__((aligned(16))) GzSmem {
     uint32_t clfreq[19];
     uint8_t cllen[19];
     uint16_t clcode[19];
+    alignas(16) uint32_t key[288];                        // tree scratch: (frequency << 9) | symbol of the used symbols, 0xffffffff for the others (16-byte aligned: see below)
+    uint32_t cw[GZ_NSYM];                     // code | length << 16 (what the emission looks up: one LDS read per code)
     uint16_t order[288];                      // tree scratch: used symbols by (frequency, symbol)
     uint32_t w[576];
     uint16_t parent[576];
     uint8_t depth[576];
     uint32_t crc_tab[256];
-    uint8_t lsym[256];                        // match length - 3 -> length symbol - 257
-    uint8_t dsym[512];                        // zlib's _dist_code
     uint64_t litmask[GZ_NQ][(GZ_PART + 63) / 64];   // per strip: which positions became literals
     uint32_t scan[GZ_NQ];
     uint32_t blc[16];                         // leaves per code length (tree scratch)
+    uint32_t wcnt[5][16];                     // symbols per code length in each wave of symbols (canonical codes)
     uint32_t qbits[GZ_NQ], qtok[GZ_NQ];
     uint32_t crc;
     int used, hlit, hdist, hclen;
@@ -225,8 +225,11 @@ __device__ __forceinline__ int gz_min64(int v) {   // wave minimum (uniform)
     v = min(v, gz_dpp<DPP_ROW_MIRROR>(v));
     return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
-__device__ __forceinline__ int gz_max64_of_groups(int v) {   // wave maximum of a value that is already uniform within groups of 8
-    v = max(v, gz_dpp<DPP_ROW_MIRROR>(v));
+__device__ __forceinline__ int gz_min16(int v) {   // minimum over each row of 16 lanes, in all of them
+    v = gz_min8(v);
+    return min(v, gz_dpp<DPP_ROW_MIRROR>(v));
+}
+__device__ __forceinline__ int gz_max64_of_rows(int v) {   // wave maximum of a value that is already uniform within rows of 16
     return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 __device__ __forceinline__ uint32_t gz_wave_scan(uint32_t x) {   // inclusive prefix sum over the 64 lanes
@@ -245,6 +248,38 @@ __device__ __forceinline__ uint32_t gz_ld32(const uint32_t *T, int i) {   // 4 b
     const uint32_t *q = T + (i >> 2);
     return __builtin_amdgcn_alignbyte(q[1], q[0], (uint32_t)(i & 3));
 }
+
+// 16 bytes at byte offset i (any alignment): five dwords requested together (one LDS round trip), shifted into place
+__device__ __forceinline__ void gz_ld128(const uint32_t *T, int i, uint32_t &w0, uint32_t &w1, uint32_t &w2, uint32_t &w3) {
+    const uint32_t *q = T + (i >> 2);
+    const uint32_t a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3], a4 = q[4], sh = (uint32_t)(i & 3);
+    w0 = __builtin_amdgcn_alignbyte(a1, a0, sh);
+    w1 = __builtin_amdgcn_alignbyte(a2, a1, sh);
+    w2 = __builtin_amdgcn_alignbyte(a3, a2, sh);
+    w3 = __builtin_amdgcn_alignbyte(a4, a3, sh);
+}
+
+// length 3..258 -> length symbol - 257; distance 1..32768 -> distance symbol (RFC 1951 3.2.5: groups of four / two codes per extra-bit
+// count, so the symbol is the position of the leading bit and the bits behind it; a few VALU instructions instead of a table in LDS -
+// a dependent round trip per token)
+__device__ __forceinline__ int gz_len_sym(int L) {
+    const int l = L - 3;
+    const int e = 29 - __clz(l | 8);
+    const int s = 4 * (e + 1) + ((l >> e) & 3);
+    return l < 8 ? l : l == 255 ? 28 : s;
+}
+__device__ __forceinline__ int gz_dist_sym(int D) {
+    const int d = D - 1;
+    const int e = 30 - __clz(d | 4);
+    const int s = 2 * (e + 1) + ((d >> e) & 1);
+    return d < 4 ? d : s;
+}
+
+// extra bits behind a length / distance symbol (RFC 1951 3.2.5 as arithmetic: a __constant__ table indexed per lane is a vector
+// load from memory); the extra VALUE is the low bits of (length - 3) / (distance - 1): every symbol's base is a
+// multiple of its range there
+__device__ __forceinline__ int gz_len_extra(int ls) { return (ls < 8 || ls == 28) ? 0 : (ls >> 2) - 1; }
+__device__ __forceinline__ int gz_dist_extra(int ds) { return ds < 4 ? 0 : (ds >> 1) - 1; }
 
 __device__ __forceinline__ uint32_t gz_multmodp(uint32_t a, uint32_t b) {   // zlib's multmodp: a(x) b(x) mod P, reflected
     uint32_t m = 1u << 31, p = 0;
@@ -283,7 +318,7 @@ __device__ __forceinline__ uint32_t gz_scan_wg(uint32_t v, uint32_t *sh, uint32_
     return base + inc - v;
 }
 
-__device__ __forceinline__ void gz_or_bits(uint32_t *out, uint32_t bitpos, uint64_t bits, int nb) {   // nb <= 48
+__device__ __forceinline__ void gz_or_bits(uint32_t *out, uint32_t bitpos, uint64_t bits, int nb) {   // nb <= 64: up to three words
     if (nb <= 0) return;
     const uint32_t sh = bitpos & 31u;
     uint32_t *w = out + (bitpos >> 5);
@@ -294,15 +329,34 @@ __device__ __forceinline__ void gz_or_bits(uint32_t *out, uint32_t bitpos, uint6
     if (rest >> 32) atomicOr(w + 2, (uint32_t)(rest >> 32));
 }
 
+#ifdef RD_DIAG
+// diagnostic build only: cycles per stage of the member loop, summed per workgroup (tools/gz_bench.py --stages)
+__device__ unsigned long long *g_gz_prof = nullptr;
+#define GZ_STAMP(k)                                                                                         \
+    do {                                                                                                    \
+        if (g_gz_prof && threadIdx.x == 0) {                                                                \
+            const unsigned long long now_ = clock64();                                                      \
+            atomicAdd(&g_gz_prof[k], now_ - stamp_);                                                        \
+            stamp_ = now_;                                                                                  \
+        }                                                                                                   \
+    } while (0)
+#define GZ_STAMP_ARG , unsigned long long &stamp_
+#define GZ_STAMP_PASS , stamp_
+#else
+#define GZ_STAMP(k) do { } while (0)
+#define GZ_STAMP_ARG
+#define GZ_STAMP_PASS
+#endif
+
 // Code lengths of an alphabet of N symbols (frequencies in LDS), at most MAXB bits: rank sort of the used symbols (all threads), then
 // one thread: two-queue merge, depths, zlib's repair of the lengths beyond MAXB, the rarest leaves get the longest codes; canonical
 // codes (bit-reversed: DEFLATE sends Huffman codes MSB first) by all threads. Called by all GZ_THREADS threads.
-template <int N, int MAXB>
-__device__ void gz_huff(GzSmem &S, uint32_t *freq, uint8_t *lens, uint16_t *codes) {
+template <int N, int MAXB, class Side>
+__device__ void gz_huff(GzSmem &S, uint32_t *freq, uint8_t *lens, uint16_t *codes, Side side GZ_STAMP_ARG) {
+    static_assert(N <= 288 && N <= GZ_THREADS, "gz_huff: one symbol per thread");
     const int tid = threadIdx.x;
-    const int i0 = tid, i1 = tid + GZ_THREADS;
-    const uint32_t f0 = i0 < N ? freq[i0] : 0, f1 = i1 < N ? freq[i1] : 0;
-    int used = __syncthreads_count(f0 != 0) + __syncthreads_count(f1 != 0);
+    GZ_STAMP(4);
+    int used = __syncthreads_count(tid < N && freq[tid] != 0);
     if (used < 2) {   // at least two codes (zlib build_tree): a decoder never sees a 0-bit code
         if (tid == 0)
             for (int i = 0; used < 2 && i < N; ++i)
@@ -310,23 +364,26 @@ __device__ void gz_huff(GzSmem &S, uint32_t *freq, uint8_t *lens, uint16_t *code
         used = 2;
         __syncthreads();
     }
-    if (i0 < N) lens[i0] = 0;
-    if (i1 < N) lens[i1] = 0;
-#pragma unroll
-    for (int rep = 0; rep < 2; ++rep) {
-        const int i = rep ? i1 : i0;
-        const uint32_t f = i < N ? freq[i] : 0;
-        if (f) {
-            int r = 0;
-            for (int j = 0; j < N; ++j) {
-                const uint32_t g = freq[j];
-                r += (g != 0 && (g < f || (g == f && j < i))) ? 1 : 0;
-            }
-            S.order[r] = (uint16_t)i;
-            S.w[r] = f;
+    // rank sort of the used symbols by (frequency, symbol): one key per symbol ((f << 9) | symbol: a member holds < 2^17 tokens),
+    // every thread counts the keys below its own - four keys per LDS read, a compare and an add-with-carry per key
+    const uint32_t f = tid < N ? freq[tid] : 0u;
+    const uint32_t mykey = f ? (f << 9) | (uint32_t)tid : 0xffffffffu;
+    if (tid < 288) S.key[tid] = mykey;
+    if (tid < N) lens[tid] = 0;
+    __syncthreads();
+    if (f) {
+        const u32x4 *k4 = reinterpret_cast<const u32x4 *>(S.key);
+        int r = 0;
+#pragma unroll 6
+        for (int j = 0; j < (N + 3) / 4; ++j) {
+            const u32x4 k = k4[j];
+            r += (k.x < mykey ? 1 : 0) + (k.y < mykey ? 1 : 0) + (k.z < mykey ? 1 : 0) + (k.w < mykey ? 1 : 0);
         }
+        S.order[r] = (uint16_t)tid;
+        S.w[r] = f;
     }
     __syncthreads();
+    GZ_STAMP(11);   // rank sort
     if (tid == 0) {
         const int ns = used;
         int a = 0, b = ns, nn = ns;
@@ -341,8 +398,12 @@ __device__ void gz_huff(GzSmem &S, uint32_t *freq, uint8_t *lens, uint16_t *code
         }
         // depths of the INTERNAL nodes only (each hangs below a node made later): the leaves - most of the nodes - take theirs from
         // their parents in parallel below, and are counted and given their lengths in parallel too
+        GZ_STAMP(12);   // merge
         S.depth[nn - 1] = 0;
         for (int i = nn - 2; i >= ns; --i) S.depth[i] = (uint8_t)(S.depth[S.parent[i]] + 1);   // (<= 287: fits)
+        GZ_STAMP(13);   // depths of the internal nodes
+    } else if (tid >= 64) {
+        side();   // (the waves that only wait for the merge: work that depends on nothing here - the member's CRC)
     }
     if (tid <= MAXB) S.blc[tid] = 0;
     __syncthreads();
@@ -396,43 +457,41 @@ __device__ void gz_huff(GzSmem &S, uint32_t *freq, uint8_t *lens, uint16_t *code
         lens[S.order[tid]] = (uint8_t)len;
     }
     __syncthreads();
-    // canonical codes
+    // canonical codes (N <= GZ_THREADS: symbol = thread): code = sum over shorter lengths l of count(l) 2^(L - l) + rank among the
+    // symbols of the same length - the rank from one ballot per length (this wave) and the earlier waves' counts, the counts per
+    // length are S.blc (a loop over all symbols per symbol was 286 dependent LDS reads)
+    static_assert(N <= GZ_THREADS && (N + 63) / 64 <= 5 && MAXB <= 15, "gz_huff: one symbol per thread, five waves of symbols");
+    {
+        const int lane = tid & 63, wv = tid >> 6;
+        const int L = tid < N ? (int)lens[tid] : 0;
+        uint32_t same_before = 0, mine = 0;
+        if (wv * 64 < N) {
 #pragma unroll
-    for (int rep = 0; rep < 2; ++rep) {
-        const int i = rep ? i1 : i0;
-        if (i < N) {
-            const int L = lens[i];
+            for (int l = 1; l <= MAXB; ++l) {
+                const uint64_t b = __ballot(L == l);
+                same_before = L == l ? (uint32_t)__popcll(b & ((1ull << lane) - 1ull)) : same_before;
+                mine = lane == l ? (uint32_t)__popcll(b) : mine;
+            }
+            if (lane >= 1 && lane <= MAXB) S.wcnt[wv][lane] = mine;
+        }
+        __syncthreads();
+        if (tid < N) {
             uint32_t code = 0;
             if (L) {
-                uint32_t cnt_shorter = 0, same_before = 0;   // code = sum over shorter lengths l of count(l) 2^(L-l)  +  rank among equals
-                for (int j = 0; j < N; ++j) {
-                    const int lj = lens[j];
-                    if (lj && lj < L) cnt_shorter += 1u << (L - lj);
-                    same_before += (lj == L && j < i) ? 1u : 0u;
-                }
+                uint32_t cnt_shorter = 0;
+#pragma unroll
+                for (int l = 1; l < MAXB; ++l) cnt_shorter += l < L ? S.blc[l] << (L - l) : 0u;
+                for (int v = 0; v < wv; ++v) same_before += S.wcnt[v][L];
                 code = cnt_shorter + same_before;
                 code = __brev(code) >> (32 - L);
             }
-            codes[i] = (uint16_t)code;
+            codes[tid] = (uint16_t)code;
         }
     }
     __syncthreads();
+    GZ_STAMP(14);   // leaf lengths, repair, canonical codes
 }
 
-#ifdef RD_DIAG
-// diagnostic build only: cycles per stage of the member loop, summed per workgroup (tools/gz_bench.py --stages)
-__device__ unsigned long long *g_gz_prof = nullptr;
-#define GZ_STAMP(k)                                                                                         \
-    do {                                                                                                    \
-        if (g_gz_prof && threadIdx.x == 0) {                                                                \
-            const unsigned long long now_ = clock64();                                                      \
-            atomicAdd(&g_gz_prof[k], now_ - stamp_);                                                        \
-            stamp_ = now_;                                                                                  \
-        }                                                                                                   \
-    } while (0)
-#else
-#define GZ_STAMP(k) do { } while (0)
-#endif
 
 // plain: the selected records of the chunk as one stream (info[1] bytes); member m = bytes [65280 m, ...). toks: 65,280 words of
 // scratch per workgroup. slots: GZ_SLOT bytes per member; msize[m] = the member's size.
@@ -449,17 +508,12 @@ __global__ __launch_bounds__(GZ_THREADS) void rd_gz_deflate_kernel(const uint8_t
             uint32_t c = (uint32_t)tid;
             for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0xedb88320u : c >> 1;
             S.crc_tab[tid] = c;
-            int ls = 28;
-            while (GZ_LBASE[ls] > tid + 3) --ls;
-            S.lsym[tid] = (uint8_t)(tid + 3 == 258 ? 28 : ls);
-        }
-        for (int k = tid; k < 512; k += GZ_THREADS) {
-            const int d = k < 256 ? k + 1 : ((k - 256) << 7) + 1;   // a distance of the range the entry stands for
-            int ds = 29;
-            while (GZ_DBASE[ds] > d) --ds;
-            S.dsym[k] = (uint8_t)ds;
         }
     }
+    // x^(8 (bytes of a FULL member behind this thread's piece)) mod P, once: every member but a file's last is full, and the
+    // exponentiation (up to eleven 32-step multiplications) was most of the CRC stage's time
+    const int crc_b0 = GZ_CRCB * (tid - 64);      // (this thread's piece of a member: threads 64 ..)
+    const uint32_t x8n_full = tid >= 64 && crc_b0 < GZ_MEMBER ? gz_x8n((uint32_t)(GZ_MEMBER - (crc_b0 + GZ_CRCB < GZ_MEMBER ? crc_b0 + GZ_CRCB : GZ_MEMBER))) : 0u;
     uint32_t *mytoks = toks + (size_t)blockIdx.x * GZ_MEMBER;
     for (int64_t m = blockIdx.x; m < nmem; m += gridDim.x) {
         const int len = (int)(total - m * GZ_MEMBER < GZ_MEMBER ? total - m * GZ_MEMBER : GZ_MEMBER);
@@ -467,37 +521,34 @@ __global__ __launch_bounds__(GZ_THREADS) void rd_gz_deflate_kernel(const uint8_t
 #ifdef RD_DIAG
         unsigned long long stamp_ = clock64();
 #endif
-        {   // member -> LDS (dword loads: plain is 256-byte aligned and GZ_MEMBER a multiple of 4), zero pad; tables cleared
-            const uint32_t *src = reinterpret_cast<const uint32_t *>(plain + m * GZ_MEMBER);
-            const int nw = (len + 3) >> 2;
-            for (int k = tid; k < (GZ_MEMBER + 16) / 4; k += GZ_THREADS) {
-                uint32_t v = 0;
-                if (k < nw) {
-                    v = src[k];
-                    if (4 * k + 4 > len) v &= 0xffffffffu >> (8 * (4 * k + 4 - len));
+        {   // member -> LDS (16-byte loads: plain is 256-byte aligned and GZ_MEMBER a multiple of 16), zero pad; tables cleared
+            const u32x4 *src4 = reinterpret_cast<const u32x4 *>(plain + m * GZ_MEMBER);
+            u32x4 *t4 = reinterpret_cast<u32x4 *>(S.text);
+            for (int k = tid; k < (GZ_MEMBER + 16) / 16; k += GZ_THREADS) {
+                u32x4 v = {0u, 0u, 0u, 0u};
+                const int b = 16 * k;
+                if (b + 16 <= len) {
+                    v = src4[k];
+                } else if (b < len) {            // (the last vector of a file's last member: dwords, the bytes behind the end masked)
+                    const uint32_t *s32 = reinterpret_cast<const uint32_t *>(src4 + k);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (b + 4 * j < len) {
+                            uint32_t w = s32[j];
+                            if (b + 4 * j + 4 > len) w &= 0xffffffffu >> (8 * (b + 4 * j + 4 - len));
+                            v[j] = w;
+                        }
                 }
-                S.text[k] = v;
+                t4[k] = v;
             }
-            for (int k = tid; k < GZ_NQ * (1 << GZ_HBITS); k += GZ_THREADS) (&S.tab[0][0])[k] = u32x4{0u, 0u, 0u, 0u};
-            for (int k = tid; k < GZ_NQ * (GZ_NSYM / 2); k += GZ_THREADS) (&S.hist[0][0])[k] = 0;
+            static_assert(sizeof(S.tab) % 16 == 0 && sizeof(S.hist) % 16 == 0, "tables are cleared 16 bytes at a time");
+            u32x4 *tab4 = reinterpret_cast<u32x4 *>(&S.tab[0][0]), *hist4 = reinterpret_cast<u32x4 *>(&S.hist[0][0]);
+            for (int k = tid; k < (int)(sizeof(S.tab) / 16); k += GZ_THREADS) tab4[k] = u32x4{GZ_EMPTY2, GZ_EMPTY2, GZ_EMPTY2, GZ_EMPTY2};
+            for (int k = tid; k < (int)(sizeof(S.hist) / 16); k += GZ_THREADS) hist4[k] = u32x4{0u, 0u, 0u, 0u};
             if (tid == 0) S.crc = 0;
         }
         __syncthreads();
         GZ_STAMP(0);   // load
-        // ---- CRC-32: thread t takes bytes [GZ_CRCB t, GZ_CRCB (t + 1)), the pieces are combined with x^(8 bytes after) mod P ------------
-        if (GZ_CRCB * tid < len) {
-            const int b0 = GZ_CRCB * tid, b1 = b0 + GZ_CRCB < len ? b0 + GZ_CRCB : len;
-            uint32_t c = 0xffffffffu;
-            for (int b = b0; b < b1; b += 4) {
-                const uint32_t v = S.text[b >> 2];
-                const int nb = b1 - b < 4 ? b1 - b : 4;
-                for (int k = 0; k < nb; ++k) c = S.crc_tab[(c ^ (v >> (8 * k))) & 0xffu] ^ (c >> 8);
-            }
-            c = ~c;
-            c = gz_multmodp(gz_x8n((uint32_t)(len - b1)), c);
-            atomicXor(&S.crc, c);
-        }
-        GZ_STAMP(1);   // crc (thread 0's share)
         // ---- parse: wave w, part w ---------------------------------------------------------------------------------------------------
         const int q0 = wave * GZ_PART, q1 = len < q0 + GZ_PART ? len : q0 + GZ_PART;
         uint32_t *qt = mytoks + q0;
@@ -515,9 +566,8 @@ __global__ __launch_bounds__(GZ_THREADS) void rd_gz_deflate_kernel(const uint8_t
                     const uint32_t hh = ((w0 * 0x9E3779B1u) ^ (w1 * 0x85EBCA77u)) * 0xC2B2AE3Du;
                     const uint32_t h = hh >> (32 - GZ_HBITS);
                     const uint32_t tag = ((hh >> (30 - GZ_HBITS)) & 3u) << 14;
-                    const u32x4 ent = S.tab[wave][h];
-                    S.tab[wave][h] = u32x4{(ent.x << 16) | tag | (uint32_t)(p - qb + 1), (ent.y << 16) | (ent.x >> 16), (ent.z << 16) | (ent.y >> 16),
-                                           (ent.w << 16) | (ent.z >> 16)};
+                    const u32x2 ent = S.tab[wave][h];
+                    S.tab[wave][h] = u32x2{(ent.x << 16) | tag | (uint32_t)(p - qb + 1), (ent.y << 16) | (ent.x >> 16)};
                 }
             }
         for (int s0 = q0; s0 < q1; s0 += 64) {
@@ -527,40 +577,57 @@ __global__ __launch_bounds__(GZ_THREADS) void rd_gz_deflate_kernel(const uint8_t
             const int lim = q1 - p < GZ_MAXM ? q1 - p : GZ_MAXM;
             const bool hv = in && p + 8 <= q1;
             const int pl = in ? p : s0;                 // (lanes past the part's end load somewhere harmless)
-            const uint32_t w0 = gz_ld32(S.text, pl), w1 = gz_ld32(S.text, pl + 4);
+            uint32_t w0, w1, w2, w3;                    // the 16 bytes at the position
+            gz_ld128(S.text, pl, w0, w1, w2, w3);
             const uint32_t hh = ((w0 * 0x9E3779B1u) ^ (w1 * 0x85EBCA77u)) * 0xC2B2AE3Du;
             const uint32_t h = hh >> (32 - GZ_HBITS);
-            const uint32_t tag = ((hh >> (30 - GZ_HBITS)) & 3u) << 14;   // two more hash bits ride in the entry (a position needs 14 bits):
+            const uint32_t tag = ((hh >> (30 - GZ_HBITS)) & 3u) << 14;   // two more hash bits ride in the entry (a position needs 13 bits):
                                                                         // three of four hash collisions are rejected without touching the text
-            // Per lane: the bucket's 8 candidates (the 8 nearest earlier positions with this hash, nearest first), the first 8 bytes of
-            // all of them and the byte before the position fetched TOGETHER (one LDS round trip; most candidates are hash collisions and
-            // end there), the survivors compared over 8 more bytes: a length CAPPED at 16 per lane - all the lazy rule needs (zlib level
-            // 5 does not look for a better match behind one of 16+ either). Exact lengths are found later, for the CHOSEN matches only.
-            const u32x4 ent = hv ? S.tab[wave][h] : u32x4{0u, 0u, 0u, 0u};
+            // Per lane: the bucket's 4 candidates (the 4 nearest earlier positions with this hash, nearest first) compared over their
+            // first 16 bytes: a length CAPPED at 16 per lane - all the lazy rule needs (zlib level 5 does not look for a better match
+            // behind one of 16+ either). Exact lengths are found later, for the CHOSEN matches only.
+            // (Round 5: 512 x 4 instead of 256 x 8 - the compares are VALU-bound, not latency-bound, and this stage was 47 % of the
+            // kernel: half the compares for +0.5 % of size on sequencer-like FASTQ, nothing on the bench's; tools/gzdev_model.c.)
+            const u32x2 ent = hv ? S.tab[wave][h] : u32x2{GZ_EMPTY2, GZ_EMPTY2};
             int Lc = 0, Dc = 0;        // capped length and distance of the lane's best candidate
             uint32_t full = 0;         // ways whose first 16 bytes agree (bit 8: the run candidate): their exact length is still open
             if (carry < 64) {          // (else every position of the strip lies inside a match: nothing to find, only to insert)
-                const uint32_t w2 = gz_ld32(S.text, pl + 8), w3 = gz_ld32(S.text, pl + 12);
-                // straight-line on purpose: a branch per way would serialise eight LDS round trips; every way loads 16 bytes (five dwords)
-                // from its candidate - or, when the way is empty or its tag differs, from the lane's own position (consecutive lanes,
-                // consecutive addresses: no bank conflicts) - and the outcome is folded in with selects
+                // All loads BEFORE any compare: every way requests 16 bytes (five dwords) from its candidate - or, when the way is empty
+                // or its tag differs, from the lane's own position (consecutive lanes, consecutive addresses: no bank conflicts) - and
+                // the empty asm keeps the compiler from sinking the loads into per-way branches (dependent LDS round trips).
+                const uint32_t tagw = tag | (tag << 16);
+                const uint32_t y[2] = {ent.x ^ tagw, ent.y ^ tagw};      // a way passes when its tag bits and its empty bit are all 0 here
+                uint32_t d[GZ_WAYS][5];
+                int cs[GZ_WAYS];
+                bool oks[GZ_WAYS];
 #pragma unroll
-                for (int wy = 0; wy < GZ_WAYS; ++wy) {
-                    const uint32_t e16 = (ent[wy >> 1] >> (16 * (wy & 1))) & 0xffffu;
-                    const uint32_t c16 = e16 & 0x3fffu;
-                    const bool ok = c16 != 0 && (e16 & 0xc000u) == tag;
-                    const int c = ok ? qb + (int)c16 - 1 : pl;
-                    const uint32_t *cq = S.text + (c >> 2);
-                    const uint32_t sh = (uint32_t)(c & 3);
-                    const uint32_t d0 = cq[0], d1 = cq[1], d2 = cq[2], d3 = cq[3], d4 = cq[4];
-                    const uint32_t x0 = __builtin_amdgcn_alignbyte(d1, d0, sh) ^ w0, x1 = __builtin_amdgcn_alignbyte(d2, d1, sh) ^ w1;
-                    const uint32_t x2 = __builtin_amdgcn_alignbyte(d3, d2, sh) ^ w2, x3 = __builtin_amdgcn_alignbyte(d4, d3, sh) ^ w3;
-                    const int k = (!ok || (x0 | x1)) ? 0 : x2 ? 8 + (__builtin_ctz(x2) >> 3) : x3 ? 12 + (__builtin_ctz(x3) >> 3) : GZ_CAP;
-                    full |= (k == GZ_CAP ? 1u : 0u) << wy;
-                    const bool better = k > Lc;
-                    Dc = better ? p - c : Dc;
-                    Lc = better ? k : Lc;
+                for (int u = 0; u < GZ_WAYS; ++u) {
+                    oks[u] = (y[u >> 1] & (0xe000u << (16 * (u & 1)))) == 0;
+                    const int c13 = (int)((ent[u >> 1] >> (16 * (u & 1))) & GZ_POSM);
+                    cs[u] = oks[u] ? qb - 1 + c13 : pl;
+                    const uint32_t *cq = S.text + (cs[u] >> 2);
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) d[u][j] = cq[j];
                 }
+                asm volatile("" ::"v"(d[0][0]), "v"(d[0][1]), "v"(d[0][2]), "v"(d[0][3]), "v"(d[0][4]), "v"(d[1][0]), "v"(d[1][1]), "v"(d[1][2]),
+                             "v"(d[1][3]), "v"(d[1][4]), "v"(d[2][0]), "v"(d[2][1]), "v"(d[2][2]), "v"(d[2][3]), "v"(d[2][4]), "v"(d[3][0]),
+                             "v"(d[3][1]), "v"(d[3][2]), "v"(d[3][3]), "v"(d[3][4]));
+                uint32_t key = 0;      // (capped length << 2) | (3 - way): the longest, the nearest on ties
+#pragma unroll
+                for (int u = 0; u < GZ_WAYS; ++u) {
+                    const uint32_t sh = (uint32_t)(cs[u] & 3);
+                    const uint32_t x0 = __builtin_amdgcn_alignbyte(d[u][1], d[u][0], sh) ^ w0, x1 = __builtin_amdgcn_alignbyte(d[u][2], d[u][1], sh) ^ w1;
+                    const uint32_t x2 = __builtin_amdgcn_alignbyte(d[u][3], d[u][2], sh) ^ w2, x3 = __builtin_amdgcn_alignbyte(d[u][4], d[u][3], sh) ^ w3;
+                    // the first byte of 8..15 that differs: lowest set bit of x3:x2 (no set bit: 0xffffffff from both, capped below)
+                    const uint32_t fb = min((uint32_t)__builtin_ffs((int)x2) - 1u, ((uint32_t)__builtin_ffs((int)x3) - 1u) | 32u);
+                    const uint32_t kt = 8u + min(fb >> 3, 8u);
+                    const uint32_t k = (oks[u] && !(x0 | x1)) ? kt : 0u;
+                    full |= (k >> 4) << u;
+                    key = max(key, (k << 2) | (uint32_t)(3 - u));
+                }
+                Lc = (int)(key >> 2);
+                const uint32_t bw = 3u - (key & 3u);
+                Dc = p - (qb - 1 + (int)(((bw & 2u ? ent.y : ent.x) >> (16 * (bw & 1u))) & GZ_POSM));
                 const uint32_t splat = (uint32_t)tb[pl > q0 ? pl - 1 : pl] * 0x01010101u;
                 if (in && p > q0 && lim >= GZ_MINRUN && w0 == splat && (w1 & 0xffffu) == (splat & 0xffffu)) {   // a run of 6+
                     const uint32_t y1 = w1 ^ splat, y2 = w2 ^ splat, y3 = w3 ^ splat;
@@ -572,8 +639,7 @@ __global__ __launch_bounds__(GZ_THREADS) void rd_gz_deflate_kernel(const uint8_t
             }
             // insert: the occupants from before this strip move one way down (lanes of this strip with the same hash differ only in the
             // low half of .x: whichever of them wins the store leaves a valid bucket)
-            if (hv) S.tab[wave][h] = u32x4{(ent.x << 16) | tag | (uint32_t)(p - qb + 1), (ent.y << 16) | (ent.x >> 16), (ent.z << 16) | (ent.y >> 16),
-                                           (ent.w << 16) | (ent.z >> 16)};
+            if (hv) S.tab[wave][h] = u32x2{(ent.x << 16) | tag | (uint32_t)(p - qb + 1), (ent.y << 16) | (ent.x >> 16)};
             GZ_STAMP(8);    // strip: per-lane candidates + insert
             if (carry >= n) {
                 if (lane == 0) S.litmask[wave][(s0 - q0) >> 6] = 0;
@@ -596,32 +662,31 @@ __global__ __launch_bounds__(GZ_THREADS) void rd_gz_deflate_kernel(const uint8_t
                 int bestL = __builtin_amdgcn_readlane(Lc, f), bestD = __builtin_amdgcn_readlane(Dc, f);
                 const uint32_t fullf = (uint32_t)__builtin_amdgcn_readlane((int)full, f);
                 if (fullf) {
-                    // the exact length of lane f's match, by the whole wave: 8 lanes per way, each comparing 4 bytes - 32 bytes per way
-                    // and round (a match of 258 in eight rounds, the common ones in one or two)
+                    // the exact length of lane f's match, by the whole wave
                     const int pf = s0 + f, limf = q1 - pf < GZ_MAXM ? q1 - pf : GZ_MAXM;
                     const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)ent.x, f), e1 = (uint32_t)__builtin_amdgcn_readlane((int)ent.y, f);
-                    const uint32_t e2 = (uint32_t)__builtin_amdgcn_readlane((int)ent.z, f), e3 = (uint32_t)__builtin_amdgcn_readlane((int)ent.w, f);
                     bestL = 0;
                     if (fullf & 0xffu) {
-                        const int way = lane >> 3, sub = lane & 7;
-                        const uint32_t ew = way < 2 ? e0 : way < 4 ? e1 : way < 6 ? e2 : e3;
+                        // 16 lanes per way, each comparing 4 bytes - 64 bytes per way and round (a match of 258 in four rounds)
+                        const int way = lane >> 4, sub = lane & 15;
+                        const uint32_t ew = way < 2 ? e0 : e1;
                         const bool act = (fullf >> way) & 1u;
-                        const int c = act ? qb + (int)((ew >> (16 * (way & 1))) & 0x3fffu) - 1 : pf;
+                        const int c = act ? qb + (int)((ew >> (16 * (way & 1))) & GZ_POSM) - 1 : pf;
                         int glen = act ? limf : 0;
                         bool open = act;
-                        for (int base = GZ_CAP; base < limf; base += 32) {
+                        for (int base = GZ_CAP; base < limf; base += 64) {
                             if (!__ballot(open)) break;
                             const int o = base + 4 * sub;
                             uint32_t x = 0;
                             if (open && o < limf) x = gz_ld32(S.text, pf + o) ^ gz_ld32(S.text, c + o);
-                            const int cand = gz_min8(x ? o + (__builtin_ctz(x) >> 3) : 0x7fffffff);
+                            const int cand = gz_min16(x ? o + (__builtin_ctz(x) >> 3) : 0x7fffffff);
                             if (open && cand != 0x7fffffff) { glen = cand < limf ? cand : limf; open = false; }
                         }
-                        const int key = gz_max64_of_groups((glen << 3) | (7 - way));   // longest; the nearest on ties
-                        const int bw = 7 - (key & 7);
-                        const uint32_t eb = bw < 2 ? e0 : bw < 4 ? e1 : bw < 6 ? e2 : e3;
-                        bestL = key >> 3;
-                        bestD = pf - (qb + (int)((eb >> (16 * (bw & 1))) & 0x3fffu) - 1);
+                        const int key = gz_max64_of_rows((glen << 2) | (3 - way));   // longest; the nearest on ties
+                        const int bw = 3 - (key & 3);
+                        const uint32_t eb = bw < 2 ? e0 : e1;
+                        bestL = key >> 2;
+                        bestD = pf - (qb + (int)((eb >> (16 * (bw & 1))) & GZ_POSM) - 1);
                     }
                     if (fullf >> 8) {   // the run: the first byte from pf + 16 on that differs from the byte before pf
                         const uint32_t sp = (uint32_t)tb[pf - 1] * 0x01010101u;
@@ -648,8 +713,8 @@ __global__ __launch_bounds__(GZ_THREADS) void rd_gz_deflate_kernel(const uint8_t
                 const int idx = __popcll(sel & ((1ull << lane) - 1));
                 qt[ntok + idx] = ismatch ? ((uint32_t)L << 16) | (uint32_t)D : byte;
                 if (ismatch) {
-                    gz_count(S.hist[wave], 257 + S.lsym[L - 3]);
-                    gz_count(S.hist[wave], 286 + S.dsym[D <= 256 ? D - 1 : 256 + ((D - 1) >> 7)]);
+                    gz_count(S.hist[wave], 257 + gz_len_sym(L));
+                    gz_count(S.hist[wave], 286 + gz_dist_sym(D));
                 }
             }
             // literal counts: not here (64 lanes adding to the same few counters - A, C, G, T ... - every strip); the strip leaves the mask
@@ -684,8 +749,26 @@ __global__ __launch_bounds__(GZ_THREADS) void rd_gz_deflate_kernel(const uint8_t
             S.freq[s] = f;
         }
         __syncthreads();
-        gz_huff<286, 15>(S, S.freq, S.lens, S.codes);
-        gz_huff<30, 15>(S, S.freq + 286, S.lens + 286, S.codes + 286);
+        // ---- CRC-32: thread 64 + t takes bytes [GZ_CRCB t, GZ_CRCB (t + 1)), the pieces are combined with x^(8 bytes after) mod P; run by
+        // waves 1 .. 15 while wave 0's first thread merges the literal/length tree (gz_huff's side work)
+        auto crc_side = [&]() {
+            if (crc_b0 < len) {
+                const int b0 = crc_b0, b1 = b0 + GZ_CRCB < len ? b0 + GZ_CRCB : len;
+                uint32_t c = 0xffffffffu;
+                for (int b = b0; b < b1; b += 4) {
+                    const uint32_t v = S.text[b >> 2];
+                    const int nb = b1 - b < 4 ? b1 - b : 4;
+                    for (int k = 0; k < nb; ++k) c = S.crc_tab[(c ^ (v >> (8 * k))) & 0xffu] ^ (c >> 8);
+                }
+                c = ~c;
+                c = gz_multmodp(len == GZ_MEMBER ? x8n_full : gz_x8n((uint32_t)(len - b1)), c);
+                atomicXor(&S.crc, c);
+            }
+        };
+        auto no_side = []() {};
+        gz_huff<286, 15>(S, S.freq, S.lens, S.codes, crc_side GZ_STAMP_PASS);
+        gz_huff<30, 15>(S, S.freq + 286, S.lens + 286, S.codes + 286, no_side GZ_STAMP_PASS);
+        for (int k = tid; k < 316; k += GZ_THREADS) S.cw[k] = (uint32_t)S.codes[k] | ((uint32_t)S.lens[k] << 16);
         if (tid == 0) {
             int hlit = 286, hdist = 30;
             while (hlit > 257 && S.lens[hlit - 1] == 0) --hlit;
@@ -704,7 +787,7 @@ __global__ __launch_bounds__(GZ_THREADS) void rd_gz_deflate_kernel(const uint8_t
             if (sq[rep] >= 0) atomicAdd(&S.clfreq[sq[rep]], 1u);
         }
         __syncthreads();
-        gz_huff<19, 7>(S, S.clfreq, S.cllen, S.clcode);
+        gz_huff<19, 7>(S, S.clfreq, S.cllen, S.clcode, no_side GZ_STAMP_PASS);
         if (tid == 0) {
             int hclen = 19;
             while (hclen > 4 && S.cllen[GZ_CLORD[hclen - 1]] == 0) --hclen;
@@ -714,7 +797,7 @@ __global__ __launch_bounds__(GZ_THREADS) void rd_gz_deflate_kernel(const uint8_t
         {
             uint32_t b = 0;
             for (int s = lane; s < GZ_NSYM; s += 64) {
-                const uint32_t extra = s >= 286 ? GZ_DEXTRA[s - 286 < 30 ? s - 286 : 0] : s >= 257 ? GZ_LEXTRA[s - 257] : 0;
+                const uint32_t extra = s >= 286 ? (uint32_t)gz_dist_extra(s - 286 < 30 ? s - 286 : 0) : s >= 257 ? (uint32_t)gz_len_extra(s - 257) : 0u;
                 if (s < 316) b += gz_counted(S.hist[wave], s) * (S.lens[s] + extra);
             }
             b = gz_wave_scan(b);
@@ -771,36 +854,66 @@ __global__ __launch_bounds__(GZ_THREADS) void rd_gz_deflate_kernel(const uint8_t
         if (tid < hclen) gz_or_bits(out, B0 + 17 + 3 * tid, S.cllen[GZ_CLORD[tid]], 3);
         if (sq[0] >= 0) gz_or_bits(out, B0 + 17 + 3 * hclen + ex0, S.clcode[sq[0]], (int)c0);
         if (sq[1] >= 0) gz_or_bits(out, B0 + 17 + 3 * hclen + ex1, S.clcode[sq[1]], (int)c1);
-        {   // tokens of this wave's part
+        {   // tokens of this wave's part: FOUR per lane and trip (one 16-byte load from the scratch, requested a trip ahead; one prefix sum per
+            // 256 tokens; the four code words of a lane go out as one bit string when they fit). A trip is VALU-bound (sixteen waves code
+            // at once): requesting the tokens four trips ahead, or right behind the parse, changes nothing (measured, round 5).
             uint32_t bit = B0 + hdr_bits;
             for (int v = 0; v < wave; ++v) bit += S.qbits[v];
-            const int nt = (int)S.qtok[wave];
-            for (int t0 = 0; t0 < nt; t0 += 64) {
-                const int t = t0 + lane;
-                uint64_t bits = 0;
-                int nb = 0;
-                if (t < nt) {
-                    const uint32_t tv = qt[t];
-                    const uint32_t L = tv >> 16;
-                    if (L) {
-                        const uint32_t D = tv & 0xffffu;
-                        const int ls = S.lsym[L - 3], ds = S.dsym[D <= 256 ? D - 1 : 256 + ((D - 1) >> 7)];
-                        bits = S.codes[257 + ls];
-                        nb = S.lens[257 + ls];
-                        bits |= (uint64_t)(L - GZ_LBASE[ls]) << nb;
-                        nb += GZ_LEXTRA[ls];
-                        bits |= (uint64_t)S.codes[286 + ds] << nb;
-                        nb += S.lens[286 + ds];
-                        bits |= (uint64_t)(D - GZ_DBASE[ds]) << nb;
-                        nb += GZ_DEXTRA[ds];
-                    } else {
-                        bits = S.codes[tv];
-                        nb = S.lens[tv];
+            const int nt = ntok;
+            auto trip = [&](const u32x4 tv4, const int t) {
+                uint64_t bits[4];
+                int nb[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    bits[j] = 0;
+                    nb[j] = 0;
+                    if (t + j < nt) {
+                        const uint32_t tv = tv4[j];
+                        const uint32_t L = tv >> 16;
+                        if (L) {
+                            const uint32_t D = tv & 0xffffu;
+                            const int ls = gz_len_sym((int)L), ds = gz_dist_sym((int)D);
+                            const uint32_t lw = S.cw[257 + ls], dw = S.cw[286 + ds];
+                            const int le = gz_len_extra(ls), de = gz_dist_extra(ds);
+                            uint64_t b = lw & 0xffffu;
+                            int n = (int)(lw >> 16);
+                            b |= (uint64_t)((L - 3u) & ((1u << le) - 1u)) << n;
+                            n += le;
+                            b |= (uint64_t)(dw & 0xffffu) << n;
+                            n += (int)(dw >> 16);
+                            b |= (uint64_t)((D - 1u) & ((1u << de) - 1u)) << n;
+                            n += de;
+                            bits[j] = b;
+                            nb[j] = n;
+                        } else {
+                            const uint32_t cw = S.cw[tv];
+                            bits[j] = cw & 0xffffu;
+                            nb[j] = (int)(cw >> 16);
+                        }
                     }
                 }
-                const uint32_t inc = gz_wave_scan((uint32_t)nb);
-                gz_or_bits(out, bit + inc - (uint32_t)nb, bits, nb);
+                const int sum = nb[0] + nb[1] + nb[2] + nb[3];
+                const uint32_t inc = gz_wave_scan((uint32_t)sum);
+                const uint32_t at = bit + inc - (uint32_t)sum;
+                if (sum <= 64) {                     // (four literals: 8-36 bits)
+                    const uint64_t all = bits[0] | (nb[0] < 64 ? bits[1] << nb[0] : 0ull) | (nb[0] + nb[1] < 64 ? bits[2] << (nb[0] + nb[1]) : 0ull) |
+                                         (nb[0] + nb[1] + nb[2] < 64 ? bits[3] << (nb[0] + nb[1] + nb[2]) : 0ull);
+                    gz_or_bits(out, at, all, sum);
+                } else {
+                    gz_or_bits(out, at, bits[0], nb[0]);
+                    gz_or_bits(out, at + (uint32_t)nb[0], bits[1], nb[1]);
+                    gz_or_bits(out, at + (uint32_t)(nb[0] + nb[1]), bits[2], nb[2]);
+                    gz_or_bits(out, at + (uint32_t)(nb[0] + nb[1] + nb[2]), bits[3], nb[3]);
+                }
                 bit += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+            };
+            const u32x4 *qt4 = reinterpret_cast<const u32x4 *>(qt);      // (16-byte aligned: GZ_PART and GZ_MEMBER are multiples of 4 words)
+            u32x4 tv_next = 4 * lane < nt ? qt4[lane] : u32x4{0u, 0u, 0u, 0u};
+            for (int t0 = 0; t0 < nt; t0 += 256) {
+                const int t = t0 + 4 * lane;
+                const u32x4 tv4 = tv_next;
+                if (t + 256 < nt) tv_next = qt4[(t + 256) >> 2];
+                trip(tv4, t);
             }
         }
         __syncthreads();

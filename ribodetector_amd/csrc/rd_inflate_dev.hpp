@@ -164,6 +164,18 @@ __device__ __forceinline__ int gzi_decode(uint32_t v, const GziCode &c, int lane
     return __builtin_amdgcn_readfirstlane((int)syms[idx]);
 }
 
+#ifdef RD_DIAG
+// diagnostic build only: cycles per stage of a wave's member loop (tools/gz_bench.py --stages): g_gz_prof[16 ...]
+#define GZI_T(k)                                       \
+    do {                                               \
+        const unsigned long long n_ = clock64();       \
+        acc_[k] += n_ - t_;                            \
+        t_ = n_;                                       \
+    } while (0)
+#else
+#define GZI_T(k) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(64 * GZI_WAVES) __attribute__((amdgpu_waves_per_eu(6, 8))) void rd_gz_inflate_kernel(const uint8_t *__restrict__ comp, int64_t comp_bytes, const GzMemberIn *__restrict__ mem,
                                                                        int64_t nmem, uint8_t *__restrict__ text, int64_t text_bytes,
                                                                        uint32_t *__restrict__ status) {
@@ -178,6 +190,9 @@ __global__ __launch_bounds__(64 * GZI_WAVES) __attribute__((amdgpu_waves_per_eu(
     __syncthreads();      // (the only barrier: from here on every wave is on its own)
     for (int64_t m = (int64_t)blockIdx.x * GZI_WAVES + wave; m < nmem; m += (int64_t)gridDim.x * GZI_WAVES) {
         const GzMemberIn me = mem[m];
+#ifdef RD_DIAG
+        unsigned long long acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_ = clock64();
+#endif
         const int in_len = me.in_len, out_len = me.out_len;
         if (me.in_off < 0 || in_len < 0 || in_len > (1 << 28) || me.in_off + in_len + 8 > comp_bytes || me.out_off < 0 || out_len < 0 || me.out_off + out_len > text_bytes) {
             if (lane == 0) status[m] = GZI_MEMBER;
@@ -321,7 +336,9 @@ __global__ __launch_bounds__(64 * GZI_WAVES) __attribute__((amdgpu_waves_per_eu(
                 if (__builtin_amdgcn_readfirstlane((int)S.len[256]) == 0) { err = GZI_BAD_LENGTHS; break; }   // no end-of-block code
             }
             GziCode lit, dst;
+            GZI_T(0);   // block header, code lengths
             if (!gzi_build(S, nl, nd, lane, lit, dst)) { err = GZI_BAD_LENGTHS; break; }
+            GZI_T(1);   // tables
             // ---- the block's symbols: 64 bit positions per round --------------------------------------------------------------------
             bool eob = false;
             while (!eob && err == GZI_OK) {
@@ -363,6 +380,7 @@ __global__ __launch_bounds__(64 * GZI_WAVES) __attribute__((amdgpu_waves_per_eu(
                     const bool okm = ls < 29u && cl != 0 && dl != 0 && ds < 30u;
                     mres = okm ? (len | (dist << 9) | ((cl + le + dl + dx) << 25)) : 0u;     // 9 + 16 + 6 bits
                 }
+                GZI_T(2);   // round: the 64 positions' table entries
                 uint32_t pos = 0;                                        // bits behind p
                 for (;;) {
                     // the chain of literal starts from pos: four hops per test (a stop is sticky: its advance is 0)
@@ -384,6 +402,7 @@ __global__ __launch_bounds__(64 * GZI_WAVES) __attribute__((amdgpu_waves_per_eu(
                         if ((M >> lane) & 1) out[op + r] = (uint8_t)ent;
                         op += n;
                     }
+                    GZI_T(3);   // walk + literal stores
                     // ---- what stopped the walk at p + pos ---------------------------------------------------------------------------
                     const uint32_t e = gzi_rl(ent, (int)pos);
                     int sym = (int)(e & 511u), cl = (int)(e >> 9);
@@ -436,11 +455,13 @@ __global__ __launch_bounds__(64 * GZI_WAVES) __attribute__((amdgpu_waves_per_eu(
                     }
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     op += len;
+                    GZI_T(4);   // match
                     if (pos > 53u) break;                                // (what is left of the 64 positions is not worth a walk)
                 }
                 p += pos;
             }
         }
+        GZI_T(5);   // (what the stamps above left out)
         if (err == GZI_OK && p > end_bits) err = GZI_TRUNCATED;
         if (err == GZI_OK && op != out_len) err = GZI_SIZE;
         if (err == GZI_OK) {   // CRC-32 of the member (trailer: CRC-32, ISIZE little-endian right behind the DEFLATE data)
@@ -468,6 +489,11 @@ __global__ __launch_bounds__(64 * GZI_WAVES) __attribute__((amdgpu_waves_per_eu(
             for (int q = 0; q < 4; ++q) want |= (uint32_t)tr[q] << (8 * q);
             if (c != want) err = GZI_CRC;
         }
+        GZI_T(6);   // CRC
+#ifdef RD_DIAG
+        if (g_gz_prof && lane == 0)
+            for (int k = 0; k < 7; ++k) atomicAdd(&g_gz_prof[16 + k], acc_[k]);
+#endif
         if (lane == 0) status[m] = (uint32_t)err;
     }
 }

@@ -820,8 +820,8 @@ int rd_select_pack(const uint8_t *text, int64_t text_bytes, const int64_t *rec_s
 }
 
 #ifdef RD_DIAG
-// diagnostic build only (not in include/ribodetector_amd.h): [dev] uint64[8] that receives the cycles per stage of rd_gz_deflate_kernel
-int rd_gz_diag_set_profile(unsigned long long *dev_buf) {
+// diagnostic build only (not in include/ribodetector_amd.h): [dev] uint64[32] that receives the cycles per stage of rd_gz_deflate_kernel ([0..15]) and rd_gz_inflate_kernel ([16..31])
+RD_API int rd_gz_diag_set_profile(unsigned long long *dev_buf) {
     RD_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_gz_prof), &dev_buf, sizeof(dev_buf)));
     return RD_OK;
 }

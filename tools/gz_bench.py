@@ -33,7 +33,7 @@ def main():
     if a.stages:
         import ctypes as C
         from ribodetector_amd import _native as N
-        prof = torch.zeros(16, dtype=torch.int64, device=dev)
+        prof = torch.zeros(32, dtype=torch.int64, device=dev)
         N.check(N.lib().rd_gz_diag_set_profile(C.c_void_p(prof.data_ptr())), "rd_gz_diag_set_profile")
     arena, off, lens = synth.reads_torch(n, 100, seed=2000, device=dev)
     rec = {"records": n}
@@ -72,8 +72,11 @@ def main():
             st = prof.cpu().tolist()
             prof.zero_()
             tot = float(sum(st)) or 1.0
-            names = ("load", "crc_thread0", "parse_rest", "wait_slowest_wave", "codes", "emit", "copy", "-", "strip_candidates", "strip_walk", "strip_tokens")
-            rec.setdefault("stages", {})[name] = {k: round(x / tot, 4) for k, x in zip(names, st[:11]) if k != "-"}
+            names = ("load", "crc_thread0", "parse_rest", "wait_slowest_wave", "codes_rest", "emit", "copy", "-", "strip_candidates", "strip_walk", "strip_tokens",
+                     "huff_rank_sort", "huff_merge", "huff_node_depths", "huff_lengths_codes")
+            rec.setdefault("stages", {})[name] = {k: round(x / tot, 4) for k, x in zip(names, st[:15]) if k != "-"}
+            rec.setdefault("stage_cycles_per_member", {})[name] = {k: round(x / (reps + 1) / max(1, sum(int(-(-int(o[1][1]) // 65280)) for o in outs.values())))
+                                                                   for k, x in zip(names, st[:15]) if k != "-"}
         comp = sum(int(outs[lab][1][0]) for lab in (0, 1))
         plain = sum(int(outs[lab][1][1]) for lab in (0, 1))
         assert plain == int(text.numel())
@@ -103,6 +106,13 @@ def main():
             ims = a0.elapsed_time(a1) / 5
             ok = bool((du._status[:nm] == 0).all())
             inf = {"members": nm, "compressed_bytes": consumed, "text_bytes": ob, "ms": ims, "GB_per_s_of_text": ob / ims / 1e6, "all_members_ok": ok}
+            if prof is not None:      # the inflate kernel's own stamps (per wave = per member): g_gz_prof[16 ...]
+                ist = prof.cpu().tolist()[16:23]
+                prof.zero_()
+                itot = float(sum(ist)) or 1.0
+                inames = ("header_code_lengths", "tables", "round_lookup", "walk_literals", "match", "rest", "crc")
+                inf["stages"] = {k: round(x / itot, 4) for k, x in zip(inames, ist)}
+                inf["stage_cycles_per_member"] = {k: round(x / 6 / max(1, nm)) for k, x in zip(inames, ist)}
             # how the rate depends on the members in flight (one wave each): the same members 1/4 ... 4 times in one launch
             import numpy as np
             mt = du._mem_dev[: nm * 24].cpu().numpy().view(np.dtype([("i", "<i8"), ("o", "<i8"), ("il", "<i4"), ("ol", "<i4")]))

@@ -6,7 +6,7 @@
 // header, BGZF framing) in a form that zlib's inflate checks on this machine. The kernel follows the same steps:
 //
 //   member  = 65,280 input bytes (BGZF's block size: the output is a valid BGZF file), one workgroup;
-//   part    = 4,080 bytes (a sixteenth), one wave: its own hash table (seeded with the last 512 bytes of the part before) of 256 buckets x the 8 nearest earlier positions (8-byte hashes; matches
+//   part    = 4,080 bytes (a sixteenth), one wave: its own hash table (seeded with the last 512 bytes of the part before) of 512 buckets x the 4 nearest earlier positions (8-byte hashes; matches
 //             of 8+ bytes only: on FASTQ the shorter ones cost more bits than the 2-bit literals they replace - measured here);
 //   strip   = 64 consecutive positions, one per lane: every lane hashes its position, looks its candidate up (positions before the
 //             strip), also tries distance 1 (runs), measures the match; then all 64 positions are inserted (the highest lane wins a
@@ -22,7 +22,7 @@
 #include <zlib.h>
 
 #ifndef HBITS
-#define HBITS 8
+#define HBITS 9
 #endif
 #ifndef HBYTES
 #define HBYTES 8
@@ -34,7 +34,7 @@
 #define NQ 16
 #endif
 #ifndef NWAYS
-#define NWAYS 8
+#define NWAYS 4
 #endif
 #ifndef SEED
 #define SEED 512   /* bytes of the part before that a part's table starts with */
