@@ -244,6 +244,17 @@ __device__ __forceinline__ uint32_t gz_wave_scan(uint32_t x) {   // inclusive pr
     return t + (row == 0 ? 0u : row == 1 ? r0 : row == 2 ? r0 + r1 : r0 + r1 + r2);
 }
 
+// hash of the 8 bytes at a position: ONE 32-bit multiply (quarter rate on the vector unit: the three of rounds 4-5 were a twelfth of a
+// strip's compare stage); bucket = the top GZ_HBITS bits, the entry's tag = the two bits below them. tools/gzdev_model.c: the size is
+// the same or a hair smaller than with the three-multiply mix.
+__device__ __forceinline__ uint32_t gz_hash(uint32_t w0, uint32_t w1) { return (w0 ^ __builtin_amdgcn_alignbit(w1, w1, 17)) * 0x9E3779B1u; }
+// position of the lowest set bit; 0xffffffff for 0 (what v_ffbl_b32 returns: the C builtins make a select around it)
+__device__ __forceinline__ uint32_t gz_ffbl(uint32_t x) {
+    uint32_t r;
+    asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
 __device__ __forceinline__ uint32_t gz_ld32(const uint32_t *T, int i) {   // 4 bytes at byte offset i (any alignment)
     const uint32_t *q = T + (i >> 2);
     return __builtin_amdgcn_alignbyte(q[1], q[0], (uint32_t)(i & 3));
@@ -386,14 +397,34 @@ __device__ void gz_huff(GzSmem &S, uint32_t *freq, uint8_t *lens, uint16_t *code
     GZ_STAMP(11);   // rank sort
     if (tid == 0) {
         const int ns = used;
+        // two-queue merge (leaves in rank order, internal nodes in the order they are made). The next four of either queue wait in
+        // registers: a pick costs no LDS round trip (it was three per node: heads, heads again, the two weights), the refill is
+        // requested four picks ahead. 0xffffffff = nothing there (weights stay below 2^18).
+        constexpr uint32_t NONE = 0xffffffffu;
         int a = 0, b = ns, nn = ns;
+        uint32_t A0 = S.w[0], A1 = S.w[1], A2 = 2 < ns ? S.w[2] : NONE, A3 = 3 < ns ? S.w[3] : NONE;   // leaves a .. a + 3 (ns >= 2)
+        uint32_t B0 = NONE, B1 = NONE, B2 = NONE, B3 = NONE;                                              // internal nodes b .. b + 3
         while (nn < 2 * ns - 1) {
-            int pick0, pick1;
-            if (a < ns && (b >= nn || S.w[a] <= S.w[b])) pick0 = a++; else pick0 = b++;
-            if (a < ns && (b >= nn || S.w[a] <= S.w[b])) pick1 = a++; else pick1 = b++;
-            S.w[nn] = S.w[pick0] + S.w[pick1];
-            S.parent[pick0] = (uint16_t)nn;
-            S.parent[pick1] = (uint16_t)nn;
+            uint32_t sum = 0;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                int pick;
+                if (A0 <= B0) {      // (a tie goes to the leaf, as in zlib's order of equal weights; both empty cannot happen)
+                    pick = a++;
+                    sum += A0;
+                    A0 = A1; A1 = A2; A2 = A3;
+                    A3 = a + 3 < ns ? S.w[a + 3] : NONE;
+                } else {
+                    pick = b++;
+                    sum += B0;
+                    B0 = B1; B1 = B2; B2 = B3;
+                    B3 = b + 3 < nn ? S.w[b + 3] : NONE;
+                }
+                S.parent[pick] = (uint16_t)nn;
+            }
+            S.w[nn] = sum;
+            const int d = nn - b;    // the new node's place in the window of internal nodes (beyond it: read back when the window gets there)
+            B0 = d == 0 ? sum : B0; B1 = d == 1 ? sum : B1; B2 = d == 2 ? sum : B2; B3 = d == 3 ? sum : B3;
             ++nn;
         }
         // depths of the INTERNAL nodes only (each hangs below a node made later): the leaves - most of the nodes - take theirs from
@@ -563,7 +594,7 @@ __global__ __launch_bounds__(GZ_THREADS) void rd_gz_deflate_kernel(const uint8_t
                 const int p = s0 + lane;
                 if (p < q0) {
                     const uint32_t w0 = gz_ld32(S.text, p), w1 = gz_ld32(S.text, p + 4);
-                    const uint32_t hh = ((w0 * 0x9E3779B1u) ^ (w1 * 0x85EBCA77u)) * 0xC2B2AE3Du;
+                    const uint32_t hh = gz_hash(w0, w1);
                     const uint32_t h = hh >> (32 - GZ_HBITS);
                     const uint32_t tag = ((hh >> (30 - GZ_HBITS)) & 3u) << 14;
                     const u32x2 ent = S.tab[wave][h];
@@ -579,7 +610,7 @@ __global__ __launch_bounds__(GZ_THREADS) void rd_gz_deflate_kernel(const uint8_t
             const int pl = in ? p : s0;                 // (lanes past the part's end load somewhere harmless)
             uint32_t w0, w1, w2, w3;                    // the 16 bytes at the position
             gz_ld128(S.text, pl, w0, w1, w2, w3);
-            const uint32_t hh = ((w0 * 0x9E3779B1u) ^ (w1 * 0x85EBCA77u)) * 0xC2B2AE3Du;
+            const uint32_t hh = gz_hash(w0, w1);
             const uint32_t h = hh >> (32 - GZ_HBITS);
             const uint32_t tag = ((hh >> (30 - GZ_HBITS)) & 3u) << 14;   // two more hash bits ride in the entry (a position needs 13 bits):
                                                                         // three of four hash collisions are rejected without touching the text
@@ -619,7 +650,7 @@ __global__ __launch_bounds__(GZ_THREADS) void rd_gz_deflate_kernel(const uint8_t
                     const uint32_t x0 = __builtin_amdgcn_alignbyte(d[u][1], d[u][0], sh) ^ w0, x1 = __builtin_amdgcn_alignbyte(d[u][2], d[u][1], sh) ^ w1;
                     const uint32_t x2 = __builtin_amdgcn_alignbyte(d[u][3], d[u][2], sh) ^ w2, x3 = __builtin_amdgcn_alignbyte(d[u][4], d[u][3], sh) ^ w3;
                     // the first byte of 8..15 that differs: lowest set bit of x3:x2 (no set bit: 0xffffffff from both, capped below)
-                    const uint32_t fb = min((uint32_t)__builtin_ffs((int)x2) - 1u, ((uint32_t)__builtin_ffs((int)x3) - 1u) | 32u);
+                    const uint32_t fb = min(gz_ffbl(x2), gz_ffbl(x3) | 32u);
                     const uint32_t kt = 8u + min(fb >> 3, 8u);
                     const uint32_t k = (oks[u] && !(x0 | x1)) ? kt : 0u;
                     full |= (k >> 4) << u;

@@ -64,8 +64,8 @@ static int dist_sym(int d) {
 
 static uint32_t load32(const uint8_t *p) { uint32_t v; memcpy(&v, p, 4); return v; }
 static int hash4(uint32_t v) { return (int)((v * 2654435761u) >> (32 - HBITS)); }
-static int hashn(const uint8_t *p) {   // the kernel's hash: two dwords, 32-bit multiplies
-    if (HBYTES == 8) { const uint32_t a = load32(p), b = load32(p + 4); return (int)((((a * 0x9E3779B1u) ^ (b * 0x85EBCA77u)) * 0xC2B2AE3Du) >> (32 - HBITS)); }
+static int hashn(const uint8_t *p) {   // the kernel's hash (gz_hash): two dwords, one 32-bit multiply
+    if (HBYTES == 8) { const uint32_t a = load32(p), b = load32(p + 4); return (int)(((a ^ ((b << 15) | (b >> 17))) * 0x9E3779B1u) >> (32 - HBITS)); }
     uint64_t v = 0; memcpy(&v, p, HBYTES); return (int)((v * 0x9E3779B97F4A7C15ull) >> (64 - HBITS));
 }
 
