@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--records", type=int, default=1 << 20)
     ap.add_argument("--out", default=None)
     ap.add_argument("--inflate-sweep", action="store_true", help="also time the inflate kernel with 1/4 ... 4 times the members in one launch")
+    ap.add_argument("--zlib-members", action="store_true", help="also time the inflate kernel on BGZF members made by zlib level 6 (what bgzip writes: many short matches)")
     ap.add_argument("--stages", action="store_true", help="with RD_HIP_LIB=.../librd_hip_diag.so: cycles per stage of the deflate kernel")
     a = ap.parse_args()
     import numpy as np
@@ -140,6 +141,36 @@ def main():
                 sweep["%d_members" % (take * reps_k)] = {"ms": round(kms, 3), "GB_per_s_of_text": round(nbytes / kms / 1e6, 1), "ok": bool((stt == 0).all())}
             if sweep:
                 inf["members_in_flight_sweep"] = sweep
+            if a.zlib_members:        # the same text as bgzip would write it: zlib level 6 members of 65,280 bytes (host-made, ~10 s)
+                import struct
+                raw = text[: min(int(text.numel()), 3500 * 65280)].cpu().numpy().tobytes()
+                parts = []
+                for o in range(0, len(raw), 65280):
+                    blk = raw[o:o + 65280]
+                    co = zlib.compressobj(6, zlib.DEFLATED, -15)
+                    body = co.compress(blk) + co.flush()
+                    parts.append(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", len(body) + 25) + body + struct.pack("<II", zlib.crc32(blk) & 0xffffffff, len(blk)))
+                zb = np.frombuffer(b"".join(parts), dtype=np.uint8).copy()
+                nmz, consz, obz, _ = du.index(zb, len(zb))
+                du.inflate(zb, consz, nmz, obz)
+                if prof is not None:
+                    prof.zero_()
+                a0.record()
+                for _ in range(5):
+                    N.check(lib.rd_gz_inflate_members(N.ptr(du._comp_dev), consz, N.ptr(du._mem_dev), nmz, N.ptr(du._text_dev), obz, N.ptr(du._status),
+                                                      C.c_void_p(st.cuda_stream)), "rd_gz_inflate_members")
+                a1.record()
+                torch.cuda.synchronize()
+                zms = a0.elapsed_time(a1) / 5
+                same = bool((du._text_dev[:obz].cpu().numpy().tobytes() == raw))
+                inf["zlib6_members"] = {"members": nmz, "compressed_bytes": consz, "text_bytes": obz, "ms": zms, "GB_per_s_of_text": obz / zms / 1e6,
+                                        "all_members_ok": bool((du._status[:nmz] == 0).all()), "text_identical": same}
+                if prof is not None:
+                    ist = prof.cpu().tolist()[16:23]
+                    prof.zero_()
+                    itot = float(sum(ist)) or 1.0
+                    inf["zlib6_members"]["stages"] = {k: round(x / itot, 4) for k, x in zip(inames, ist)}
+                    inf["zlib6_members"]["stage_cycles_per_member"] = {k: round(x / 5 / max(1, nmz)) for k, x in zip(inames, ist)}
         except Exception as e:      # noqa: BLE001
             inf = {"error": repr(e)}
         rec[name] = {"records": nr, "text_bytes": int(text.numel()), "device_gzip_bytes": comp, "ratio": int(text.numel()) / comp, "device_inflate": inf,
