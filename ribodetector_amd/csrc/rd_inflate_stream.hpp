@@ -175,6 +175,10 @@ __device__ __forceinline__ int gzs_blocks(GziWave &S, int lane, const uint8_t *_
                 }
             }
             int i = 0, prev = 0;
+            // what is left of the two codes' space (units of 2^-15): a length set that over-subscribes its code is rejected where it does
+            // - a bit position that is NOT a block start (the search tries ~60 per section that pass the filter of the code-length code)
+            // gives itself away within a few symbols instead of after 316 of them and the table build's counting
+            int left_l = 1 << 15, left_d = 1 << 15;
             while (i < nl + nd) {
                 if (p + 14 > end_bits + 64u) { err = GZS_DECODE; break; }
                 ensure(p);
@@ -189,6 +193,12 @@ __device__ __forceinline__ int gzs_blocks(GziWave &S, int lane, const uint8_t *_
                 else if (sym == 18) { rep = 11 + (int)(x & 127u); val = 0; nb += 7; }
                 p += (uint32_t)nb;
                 if (i + rep > nl + nd) { err = GZS_DECODE; break; }
+                if (val) {
+                    const int in_l = i >= nl ? 0 : (i + rep <= nl ? rep : nl - i);      // symbols of the run in the literal/length code
+                    left_l -= in_l << (15 - val);
+                    left_d -= (rep - in_l) << (15 - val);
+                    if ((left_l | left_d) < 0) { err = GZS_DECODE; break; }
+                }
                 if (lane < rep) S.len[i + lane] = (uint8_t)val;
                 if (lane + 64 < rep) S.len[i + lane + 64] = (uint8_t)val;
                 if (lane + 128 < rep) S.len[i + lane + 128] = (uint8_t)val;
@@ -351,8 +361,15 @@ __global__ __launch_bounds__(64 * GZI_WAVES) __attribute__((amdgpu_waves_per_eu(
     const uint8_t *__restrict__ comp, int64_t limit, uint32_t end_bits, uint32_t sec_bits, int nsec, uint32_t first_start, const GzsState *__restrict__ carry,
     int64_t carry_delta_bits, uint32_t *__restrict__ found) {
     __shared__ GziSmem SM;
+    __shared__ uint8_t KT[512];       // three code-length-code lengths (3 bits each) -> the sum of their 2^(7 - length), 0 for length 0
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     GziWave &S = SM.w[wave];
+    for (int e = threadIdx.x; e < 512; e += 64 * GZI_WAVES) {
+        uint32_t t = 0;
+        for (int j = 0; j < 3; ++j) { const uint32_t l = ((uint32_t)e >> (3 * j)) & 7u; t += l ? (128u >> l) : 0u; }
+        KT[e] = (uint8_t)t;
+    }
+    __syncthreads();
     for (int k = blockIdx.x * GZI_WAVES + wave; k <= nsec; k += gridDim.x * GZI_WAVES) {
         if (k == 0) {
             uint32_t st = first_start;
@@ -372,12 +389,20 @@ __global__ __launch_bounds__(64 * GZI_WAVES) __attribute__((amdgpu_waves_per_eu(
                 const int64_t b = (int64_t)d * 4;
                 return b + 4 <= limit ? *reinterpret_cast<const uint32_t *>(comp + b) : 0u;
             };
+            // the section's bits pass through one register, 64 dwords at a time (one coalesced load per 57 dwords = 28 trips; a load of
+            // eight dwords per trip put a memory round trip into every one of a wave's 2,048 trips)
+            int wbase = (int)((uint32_t)lo64 >> 5);
+            uint32_t wcur = load_dw(wbase + lane);
             for (uint32_t q = (uint32_t)lo64; q < q_end && res == GZS_NONE; q += 64) {
                 // lane i: the 96 bits that start at q + i
                 const int d = (int)(q >> 5);
-                const uint32_t mine = load_dw(d + (lane & 7));           // dwords d .. d + 7 (lanes 0-7; the rest mirror them)
-                const uint32_t d0 = gzi_rl(mine, 0), d1 = gzi_rl(mine, 1), d2 = gzi_rl(mine, 2), d3 = gzi_rl(mine, 3), d4 = gzi_rl(mine, 4),
-                               d5 = gzi_rl(mine, 5), d6 = gzi_rl(mine, 6);
+                if (d - wbase > 64 - 7) {
+                    wbase = d;
+                    wcur = load_dw(wbase + lane);
+                }
+                const int rel = d - wbase;
+                const uint32_t d0 = gzi_rl(wcur, rel), d1 = gzi_rl(wcur, rel + 1), d2 = gzi_rl(wcur, rel + 2), d3 = gzi_rl(wcur, rel + 3),
+                               d4 = gzi_rl(wcur, rel + 4), d5 = gzi_rl(wcur, rel + 5), d6 = gzi_rl(wcur, rel + 6);
                 const uint32_t s = q & 31;
                 const uint32_t A0 = (uint32_t)((((uint64_t)d1 << 32) | d0) >> s), A1 = (uint32_t)((((uint64_t)d2 << 32) | d1) >> s),
                                A2 = (uint32_t)((((uint64_t)d3 << 32) | d2) >> s), A3 = (uint32_t)((((uint64_t)d4 << 32) | d3) >> s),
@@ -391,13 +416,12 @@ __global__ __launch_bounds__(64 * GZI_WAVES) __attribute__((amdgpu_waves_per_eu(
                 // BFINAL = 0, BTYPE = 2 (bits 1-2 = 0, 1), HLIT <= 29, HDIST <= 29, and a complete code-length code
                 bool ok = (w0 & 7u) == 4u && ((w0 >> 3) & 31u) <= 29u && ((w0 >> 8) & 31u) <= 29u && q + (uint32_t)lane < q_end;
                 const uint32_t nc = ((w0 >> 13) & 15u) + 4u;
-                const uint64_t P = ((uint64_t)(w0 >> 17)) | ((uint64_t)w1 << 15) | ((uint64_t)w2 << 47);
-                uint32_t kraft = 0;
-#pragma unroll
-                for (int c = 0; c < 19; ++c) {
-                    const uint32_t l = (uint32_t)(P >> (3 * c)) & 7u;
-                    kraft += ((uint32_t)c < nc && l) ? (128u >> l) : 0u;
-                }
+                // (the nc fields of 3 bits, three at a time through a 512-entry table of their 2^(7 - length) sums: 7 LDS reads instead
+                // of 19 shift / mask / compare / select / add steps - the trip is VALU-bound when four waves share a SIMD)
+                const uint64_t P = (((uint64_t)(w0 >> 17)) | ((uint64_t)w1 << 15) | ((uint64_t)w2 << 47)) & ((1ull << (3u * nc)) - 1ull);
+                const uint32_t Plo = (uint32_t)P, Pmi = (uint32_t)(P >> 27), Phi = (uint32_t)(P >> 54);
+                const uint32_t kraft = (uint32_t)KT[Plo & 511u] + KT[(Plo >> 9) & 511u] + KT[(Plo >> 18) & 511u] + KT[Pmi & 511u] + KT[(Pmi >> 9) & 511u] +
+                                       KT[(Pmi >> 18) & 511u] + KT[Phi & 7u];
                 ok = ok && kraft == 128u;
                 uint64_t cand = __ballot(ok);
                 while (cand && res == GZS_NONE) {
