@@ -54,7 +54,7 @@ struct __attribute__((aligned(16))) GziWave {
     uint8_t len[320];       // code lengths being read
 };
 struct __attribute__((aligned(16))) GziSmem {
-    uint32_t crc_tab[256];
+    uint32_t crc_tab[4][256];       // crc_tab[k][b]: the CRC of byte b followed by k zero bytes (slicing-by-4)
     GziWave w[GZI_WAVES];
 };
 
@@ -185,9 +185,14 @@ __global__ __launch_bounds__(64 * GZI_WAVES) __attribute__((amdgpu_waves_per_eu(
     {
         uint32_t c = threadIdx.x;
         for (int b = 0; b < 8; ++b) c = (c & 1) ? (c >> 1) ^ 0xedb88320u : c >> 1;
-        SM.crc_tab[threadIdx.x] = c;
+        SM.crc_tab[0][threadIdx.x] = c;
+        __syncthreads();
+        for (int k = 1; k < 4; ++k) {
+            c = (c >> 8) ^ SM.crc_tab[0][c & 0xffu];
+            SM.crc_tab[k][threadIdx.x] = c;
+        }
     }
-    __syncthreads();      // (the only barrier: from here on every wave is on its own)
+    __syncthreads();      // (the last barrier: from here on every wave is on its own)
     for (int64_t m = (int64_t)blockIdx.x * GZI_WAVES + wave; m < nmem; m += (int64_t)gridDim.x * GZI_WAVES) {
         const GzMemberIn me = mem[m];
 #ifdef RD_DIAG
@@ -470,15 +475,17 @@ __global__ __launch_bounds__(64 * GZI_WAVES) __attribute__((amdgpu_waves_per_eu(
             const int b0 = lane * per < out_len ? lane * per : out_len, b1 = b0 + per < out_len ? b0 + per : out_len;
             uint32_t c = 0xffffffffu;
             int b = b0;
-            for (; b + 4 <= b1; b += 4) {
-                uint32_t w;
-                __builtin_memcpy(&w, out + b, 4);
-                c = SM.crc_tab[(c ^ w) & 0xffu] ^ (c >> 8);
-                c = SM.crc_tab[(c ^ (w >> 8)) & 0xffu] ^ (c >> 8);
-                c = SM.crc_tab[(c ^ (w >> 16)) & 0xffu] ^ (c >> 8);
-                c = SM.crc_tab[(c ^ (w >> 24)) & 0xffu] ^ (c >> 8);
+            // bytes up to a 16-byte boundary, then 16 bytes per load and four table reads per dword that do not wait for each other
+            for (; b < b1 && ((reinterpret_cast<uintptr_t>(out) + (uintptr_t)b) & 15) != 0; ++b) c = SM.crc_tab[0][(c ^ out[b]) & 0xffu] ^ (c >> 8);
+            for (; b + 16 <= b1; b += 16) {
+                const u32x4 v = *reinterpret_cast<const u32x4 *>(out + b);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t x = c ^ v[j];
+                    c = SM.crc_tab[3][x & 0xffu] ^ SM.crc_tab[2][(x >> 8) & 0xffu] ^ SM.crc_tab[1][(x >> 16) & 0xffu] ^ SM.crc_tab[0][x >> 24];
+                }
             }
-            for (; b < b1; ++b) c = SM.crc_tab[(c ^ out[b]) & 0xffu] ^ (c >> 8);
+            for (; b < b1; ++b) c = SM.crc_tab[0][(c ^ out[b]) & 0xffu] ^ (c >> 8);
             c = ~c;
             if (b1 == b0) c = 0;
             c = gz_multmodp(gz_x8n((uint32_t)(out_len - b1)), c);

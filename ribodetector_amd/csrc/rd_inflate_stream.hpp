@@ -633,14 +633,22 @@ __global__ __launch_bounds__(256) void rd_gzs_resolve_kernel(const uint16_t *__r
     }
 }
 
-// CRC-32 of every 64 KiB tile of the batch's text (one wave per tile, 1 KiB per lane)
+// CRC-32 of every 64 KiB tile of the batch's text (one wave per tile, 1 KiB per lane): 16 bytes per load, four bytes per step
+// (slicing-by-4: four independent table reads per dword instead of four dependent ones). Round 5: the byte-at-a-time form - a
+// global byte load per lane and step, the lanes 1 KiB apart - took 2.1 ms per 300 MB batch.
 constexpr int GZS_CTILE = 65536;
 __global__ __launch_bounds__(256) void rd_gzs_crc_kernel(const uint8_t *__restrict__ text, const GzsState *__restrict__ st, uint32_t *__restrict__ tile_crc) {
-    __shared__ uint32_t tab[256];
+    __shared__ uint32_t tab[4][256];      // tab[k][b]: the CRC of byte b followed by k zero bytes
     {
         uint32_t c = threadIdx.x;
         for (int b = 0; b < 8; ++b) c = (c & 1) ? (c >> 1) ^ 0xedb88320u : c >> 1;
-        tab[threadIdx.x] = c;
+        tab[0][threadIdx.x] = c;
+        __syncthreads();
+        uint32_t v = c;
+        for (int k = 1; k < 4; ++k) {
+            v = (v >> 8) ^ tab[0][v & 0xffu];
+            tab[k][threadIdx.x] = v;
+        }
     }
     __syncthreads();
     const int64_t n = st->status == GZS_OK ? st->n_text : 0;
@@ -653,7 +661,18 @@ __global__ __launch_bounds__(256) void rd_gzs_crc_kernel(const uint8_t *__restri
     const int per = 1024;
     const int b0 = lane * per < len ? lane * per : len, b1 = b0 + per < len ? b0 + per : len;
     uint32_t c = 0xffffffffu;
-    for (int b = b0; b < b1; ++b) c = tab[(c ^ p[b]) & 0xffu] ^ (c >> 8);
+    int b = b0;
+    if ((reinterpret_cast<uintptr_t>(p) & 15) == 0) {                   // (b0 is a multiple of 1,024)
+        for (; b + 16 <= b1; b += 16) {
+            const u32x4 v = *reinterpret_cast<const u32x4 *>(p + b);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t x = c ^ v[j];
+                c = tab[3][x & 0xffu] ^ tab[2][(x >> 8) & 0xffu] ^ tab[1][(x >> 16) & 0xffu] ^ tab[0][x >> 24];
+            }
+        }
+    }
+    for (; b < b1; ++b) c = tab[0][(c ^ p[b]) & 0xffu] ^ (c >> 8);
     c = ~c;
     if (b1 == b0) c = 0;
     c = gz_multmodp(gz_x8n((uint32_t)(len - b1)), c);
