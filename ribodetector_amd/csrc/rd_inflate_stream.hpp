@@ -449,7 +449,9 @@ __global__ __launch_bounds__(64 * GZI_WAVES) __attribute__((amdgpu_waves_per_eu(
     }
 }
 
-__global__ __launch_bounds__(64 * GZI_WAVES) __attribute__((amdgpu_waves_per_eu(6, 8))) void rd_gzs_decode_kernel(
+// (8 waves per SIMD = 64 VGPRs: the same time alone - a wave is a latency chain -, and beside the recurrence kernel the sections' workgroups
+// pack eight to a CU instead of seven: a CU that holds one of them holds no recurrence workgroup)
+__global__ __launch_bounds__(64 * GZI_WAVES) __attribute__((amdgpu_waves_per_eu(8, 8))) void rd_gzs_decode_kernel(
     const uint8_t *__restrict__ comp, int64_t limit, uint32_t end_bits, int nsec, const uint32_t *__restrict__ found, uint16_t *__restrict__ syms, int cap,
     GzsSec *__restrict__ sec) {
     __shared__ GziSmem SM;
