@@ -292,6 +292,28 @@ RD_API int rd_fastq_gather(const uint8_t *text, const int32_t *line_end, const r
 RD_API int rd_fastq_sample(const int32_t *line_end, const rd_fq_summary *summary, int64_t every, int32_t *samples, int64_t cap, void *stream);
 RD_API int rd_fastq_strip_mark(const uint8_t *text, const int32_t *line_end, const rd_fq_summary *summary, int64_t max_lines, uint8_t *del, void *stream);
 
+/* FASTA records on the device (round 5). Replaces the FASTA half of the parser for text that lies in HBM (reference
+ * data_loader/fastx_parser.py:39-55: every line strip()-ed, blank lines skipped, '>' starts a record, the other lines of a record joined
+ * and upper-cased; a record is yielded at the next header, at the end of the file only if its sequence is not empty) together with the
+ * writer's '\n'.join(record) + '\n' (detect.py:489-492). A FASTA record is not a verbatim range of its file, so the batch is
+ * RE-WRITTEN: norm [dev, norm_cap bytes, 16-byte aligned] receives header '\n' SEQUENCE '\n' per record (what the host reader puts into
+ * its chunk buffer), rec_tab [dev] int64[cap_records] the offset in `norm` where record r starts (entry n_records = the end),
+ * hdr_tab [dev] int32[cap_records] the length of its header line. text / pad / end / prev_text / prev / final / line_end / cap_lines /
+ * summary as rd_fastq_index (the batches of a stream chain the same way: the carry is the raw text from the last header line on - that
+ * record is complete only in a final batch); summary->reserved = the bytes of `norm` that belong to records; status RD_FQ_LINES also
+ * when norm_cap or cap_records is too small (norm_cap >= window + lines, cap_records >= lines + 1 is always enough), RD_FA_LEADING:
+ * sequence lines in front of the first header (the reference glues them to the first record) - not framed here, the host reader takes
+ * such a file. rd_fasta_gather / rd_fasta_sample: as rd_fastq_gather / rd_fastq_sample, over `norm` and the two tables. */
+#define RD_FA_LEADING 6
+RD_API size_t rd_fasta_index_workspace_bytes(int64_t text_end, int64_t cap_lines);
+RD_API int rd_fasta_index(uint8_t *text, int64_t pad, int64_t end, const uint8_t *prev_text, const rd_fq_summary *prev, int32_t final, int32_t *line_end,
+                   int64_t cap_lines, uint8_t *norm, int64_t norm_cap, int64_t *rec_tab, int32_t *hdr_tab, int64_t cap_records, rd_fq_summary *summary,
+                   void *workspace, size_t workspace_bytes, void *stream);
+RD_API int rd_fasta_gather(const uint8_t *norm, const int64_t *rec_tab, const int32_t *hdr_tab, const rd_fq_summary *summary, int64_t rec_lo, int64_t rec_hi,
+                    int64_t max_bytes, uint8_t *out_text, int64_t out_cap, const int64_t *cursor_in, int64_t *cursor_out, int64_t *rec_start,
+                    int64_t *seq_off, int32_t *seq_len, void *stream);
+RD_API int rd_fasta_sample(const int64_t *rec_tab, const rd_fq_summary *summary, int64_t every, int32_t *samples, int64_t cap, void *stream);
+
 /* The records of a chunk that carry one label as ONE contiguous text in `out` [dev, 16-byte aligned], in input order - what the
  * reference's writer joins on the host (detect.py:485-492: fh.write('\n'.join(selected) + '\n')) - for plain (uncompressed) outputs of
  * chunks whose text lives on the device; arguments as rd_gz_compress_selected. info [dev] int64[4]: info[1] = bytes written,

@@ -25,7 +25,7 @@ SYMBOLS = [
     "rd_pair_fuse", "rd_count_labels", "rd_encode_codes", "rd_encode_onehot_padded", "rd_pack_plan",
     "rd_pack_onehot", "rd_profile_enable", "rd_profile_read", "rd_last_error", "rd_version",
     "rd_gz_workspace_bytes", "rd_gz_out_bound", "rd_gz_compress_selected", "rd_gz_eof_block", "rd_gz_inflate_members",
-    "rd_fastq_index_workspace_bytes", "rd_fastq_index", "rd_fastq_gather", "rd_fastq_sample", "rd_fastq_strip_mark", "rd_select_workspace_bytes", "rd_select_pack", "rd_stream_create", "rd_stream_destroy", "rd_copy_bytes", "rd_gz_stream_workspace_bytes", "rd_gz_stream_inflate",
+    "rd_fastq_index_workspace_bytes", "rd_fastq_index", "rd_fastq_gather", "rd_fastq_sample", "rd_fastq_strip_mark", "rd_fasta_index_workspace_bytes", "rd_fasta_index", "rd_fasta_gather", "rd_fasta_sample", "rd_select_workspace_bytes", "rd_select_pack", "rd_stream_create", "rd_stream_destroy", "rd_copy_bytes", "rd_gz_stream_workspace_bytes", "rd_gz_stream_inflate",
 ]
 
 
@@ -91,6 +91,11 @@ def lib():
     L.rd_fastq_gather.argtypes = [vp, vp, vp, i64, i64, i64, vp, i64, vp, vp, vp, vp, vp, vp]
     L.rd_fastq_strip_mark.argtypes = [vp, vp, vp, i64, vp, vp]
     L.rd_fastq_sample.argtypes = [vp, vp, i64, vp, i64, vp]
+    L.rd_fasta_index_workspace_bytes.argtypes = [i64, i64]
+    L.rd_fasta_index_workspace_bytes.restype = sz
+    L.rd_fasta_index.argtypes = [vp, i64, i64, vp, vp, i32, vp, i64, vp, i64, vp, vp, i64, vp, vp, sz, vp]
+    L.rd_fasta_gather.argtypes = [vp, vp, vp, vp, i64, i64, i64, vp, i64, vp, vp, vp, vp, vp, vp]
+    L.rd_fasta_sample.argtypes = [vp, vp, i64, vp, i64, vp]
     L.rd_select_workspace_bytes.argtypes = [i64]
     L.rd_select_workspace_bytes.restype = sz
     L.rd_select_pack.argtypes = [vp, i64, vp, vp, i64, i32, vp, sz, vp, vp, sz, vp]

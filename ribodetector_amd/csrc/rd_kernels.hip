@@ -38,6 +38,7 @@
 #include "rd_inflate_dev.hpp"
 #include "rd_inflate_stream.hpp"
 #include "rd_fastq_index.hpp"
+#include "rd_fasta_index.hpp"
 
 // ================================================================================================
 // C ABI
@@ -783,6 +784,69 @@ int rd_fastq_strip_mark(const uint8_t *text, const int32_t *line_end, const rd_f
     int64_t grid = max_lines / FQ_THREADS + 1;
     if (grid > 4096) grid = 4096;
     hipLaunchKernelGGL(rd_fq_strip_mark_kernel, dim3((unsigned)grid), dim3(FQ_THREADS), 0, (hipStream_t)stream, text, line_end, (const FqSummary *)summary, del);
+    RD_HIP(hipGetLastError());
+    return RD_OK;
+}
+
+size_t rd_fasta_index_workspace_bytes(int64_t text_end, int64_t cap_lines) {
+    if (text_end < 0 || text_end >= 0x7fffffffLL || cap_lines < 0) return 0;
+    return fa_plan(text_end, cap_lines).total;
+}
+
+int rd_fasta_index(uint8_t *text, int64_t pad, int64_t end, const uint8_t *prev_text, const rd_fq_summary *prev, int32_t final, int32_t *line_end,
+                   int64_t cap_lines, uint8_t *norm, int64_t norm_cap, int64_t *rec_tab, int32_t *hdr_tab, int64_t cap_records, rd_fq_summary *summary,
+                   void *workspace, size_t workspace_bytes, void *stream) {
+    if (!text || !line_end || !norm || !rec_tab || !hdr_tab || !summary || !workspace) RD_FAIL(RD_E_INVALID, "rd_fasta_index: null pointer");
+    if (pad < 0 || end < pad || end >= 0x7fffffffLL - 64 || cap_lines < 0 || norm_cap < 0 || cap_records < 1)
+        RD_FAIL(RD_E_INVALID, "rd_fasta_index: bad pad / end / cap_lines / norm_cap / cap_records (a batch buffer is < 2 GiB)");
+    if ((prev == nullptr) != (prev_text == nullptr)) RD_FAIL(RD_E_INVALID, "rd_fasta_index: prev and prev_text go together");
+    if (((uintptr_t)text & 63) || ((uintptr_t)workspace & 255) || ((uintptr_t)norm & 15))
+        RD_FAIL(RD_E_INVALID, "rd_fasta_index: text must be 64-byte aligned, workspace 256-byte aligned, norm 16-byte aligned");
+    const FaPlan p = fa_plan(end, cap_lines);
+    if (workspace_bytes < p.total) RD_FAIL(RD_E_WORKSPACE, "rd_fasta_index: workspace too small: %zu < %zu", workspace_bytes, p.total);
+    hipStream_t st = (hipStream_t)stream;
+    char *ws = (char *)workspace;
+    uint32_t *tiles = (uint32_t *)ws;
+    int32_t *info_a = (int32_t *)(ws + p.a_off);
+    uint32_t *info_k = (uint32_t *)(ws + p.k_off);
+    unsigned long long *blk = (unsigned long long *)(ws + p.blk_off);
+    FaScratch *sc = (FaScratch *)(ws + p.sc_off);
+    FqSummary *sum = (FqSummary *)summary;
+    hipLaunchKernelGGL(rd_fq_begin_kernel, dim3(1), dim3(FQ_THREADS), 0, st, text, pad, end, prev_text, (const FqSummary *)prev, (int)final, sum);
+    hipLaunchKernelGGL(rd_fq_count_kernel, dim3(p.fq.ntiles), dim3(FQ_THREADS), 0, st, text, sum, tiles);
+    hipLaunchKernelGGL(rd_fq_scan_kernel, dim3(1), dim3(FQ_THREADS), 0, st, tiles, p.fq.ntiles, sum, cap_lines);
+    hipLaunchKernelGGL(rd_fq_fill_kernel, dim3(p.fq.ntiles), dim3(FQ_THREADS), 0, st, text, sum, tiles, line_end);
+    hipLaunchKernelGGL(rd_fa_init_kernel, dim3(1), dim3(FQ_THREADS), 0, st, sc);
+    hipLaunchKernelGGL(rd_fa_lines_kernel, dim3(p.nblk), dim3(FQ_THREADS), 0, st, text, line_end, sum, info_a, info_k, blk, sc);
+    hipLaunchKernelGGL(rd_fa_base_kernel, dim3(1), dim3(FQ_THREADS), 0, st, blk, line_end, sum, sc, (int)final, norm_cap, cap_records);
+    hipLaunchKernelGGL(rd_fa_emit_kernel, dim3(p.nblk), dim3(FQ_THREADS), 0, st, text, info_a, info_k, blk, sum, sc, (int)final, norm, rec_tab, hdr_tab);
+    RD_HIP(hipGetLastError());
+    return RD_OK;
+}
+
+int rd_fasta_gather(const uint8_t *norm, const int64_t *rec_tab, const int32_t *hdr_tab, const rd_fq_summary *summary, int64_t rec_lo, int64_t rec_hi,
+                    int64_t max_bytes, uint8_t *out_text, int64_t out_cap, const int64_t *cursor_in, int64_t *cursor_out, int64_t *rec_start,
+                    int64_t *seq_off, int32_t *seq_len, void *stream) {
+    if (!norm || !rec_tab || !hdr_tab || !summary || !out_text || !cursor_in || !cursor_out || !rec_start || !seq_off || !seq_len)
+        RD_FAIL(RD_E_INVALID, "rd_fasta_gather: null pointer");
+    if (rec_lo < 0 || rec_hi < rec_lo || max_bytes < 0 || out_cap < 0 || cursor_in == cursor_out) RD_FAIL(RD_E_INVALID, "rd_fasta_gather: bad range");
+    if ((uintptr_t)out_text & 15) RD_FAIL(RD_E_INVALID, "rd_fasta_gather: out_text must be 16-byte aligned");
+    int64_t grid = max_bytes / (16 * FQ_THREADS * 4) + 1;
+    const int64_t grid_r = (rec_hi - rec_lo) / FQ_THREADS + 1;
+    if (grid < grid_r) grid = grid_r;
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(rd_fa_gather_kernel, dim3((unsigned)grid), dim3(FQ_THREADS), 0, (hipStream_t)stream, norm, rec_tab, hdr_tab, (const FqSummary *)summary,
+                       rec_lo, rec_hi, out_text, out_cap, cursor_in, cursor_out, rec_start, seq_off, seq_len);
+    RD_HIP(hipGetLastError());
+    return RD_OK;
+}
+
+int rd_fasta_sample(const int64_t *rec_tab, const rd_fq_summary *summary, int64_t every, int32_t *samples, int64_t cap, void *stream) {
+    if (!rec_tab || !summary || !samples || every < 1 || cap < 0) RD_FAIL(RD_E_INVALID, "rd_fasta_sample: bad argument");
+    if (cap == 0) return RD_OK;
+    int64_t grid = cap / FQ_THREADS + 1;
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(rd_fa_sample_kernel, dim3((unsigned)grid), dim3(FQ_THREADS), 0, (hipStream_t)stream, rec_tab, (const FqSummary *)summary, every, samples, cap);
     RD_HIP(hipGetLastError());
     return RD_OK;
 }

@@ -14,7 +14,8 @@ so the host moves compressed bytes (or the file's bytes once, in and out) and a 
 those of csrc/rd_host.cpp's reader (tests/test_gpu_device_reader.py holds the two to each other and to the reference's parser):
 every line rstrip()-ed (a batch with trailing whitespace - CR LF files - is stripped on the device and indexed again), header must
 start with '@', last line may lack its newline, fewer than four blank trailing lines tolerated.
-RD_DEVICE_PARSE=0 keeps the host parser; FASTA always uses it.
+RD_DEVICE_PARSE=0 keeps the host parser. FASTA (one rank): FastaIndexer - the batch is re-written as header / joined upper-case sequence
+(fastx_parser.py:39-55) by rd_fasta_index and indexed there; RD_DEVICE_FASTA=0 or a file that starts with sequence lines: the host parser.
 """
 import ctypes as C
 import os
@@ -33,7 +34,8 @@ PAD = 16 << 20                 # bytes in front of a batch's new text: room for 
 LINE_DIV = 4                   # the line table of a batch holds window / LINE_DIV lines (a FASTQ line of reads is >= 4 bytes; a batch of
                                # shorter lines overflows it, is framed again with a full-size table, and so are the batches chained to it)
 EVERY = 4096                   # one record-offset sample per EVERY records travels to the host with the summary: bounds a chunk's bytes
-FQ_ERRORS = {1: "FASTQ record does not start with '@'",
+FQ_ERRORS = {6: "sequence lines in front of the first FASTA header (RD_DEVICE_FASTA=0 reads such a file with the host parser)",
+             1: "FASTQ record does not start with '@'",
              2: "truncated FASTQ record at end of file (number of lines is not a multiple of 4)",
              3: "a FASTQ record longer than %d bytes: set RD_DEVICE_PARSE=0 (the host parser has no record-size limit)" % PAD,
              4: "the batch before this one could not be framed", 5: "more lines than the line table holds"}
@@ -49,7 +51,10 @@ def device_ingest_kind(path, fmt=None):
     from . import fastx_parser as fx
     fmt = fmt or fx.get_seq_format(path)
     if not fmt.startswith("fq"):
-        return None
+        # FASTA (round 5: rd_fasta_index): on the device when the file starts with a header line - sequence in front of the first
+        # header (the reference glues it to the first record) is the host reader's case; RD_DEVICE_FASTA=0 keeps the host parser
+        if os.environ.get("RD_DEVICE_FASTA", "1") == "0" or not _fasta_starts_with_header(path, fmt.endswith("gz")):
+            return None
     if fmt.endswith("gz"):
         if fx.device_inflate_wanted(path):
             return "bgzf"
@@ -62,6 +67,22 @@ def device_ingest_kind(path, fmt=None):
 def device_parse_wanted(path, fmt=None):
     """FASTQ input, a GPU, and RD_DEVICE_PARSE != 0: plain files, BGZF files, and (RD_DEVICE_INFLATE=stream) single-stream .gz files"""
     return device_ingest_kind(path, fmt) is not None
+
+
+def _fasta_starts_with_header(path, gzipped):
+    """the first byte that is not whitespace is '>' (or there is none)"""
+    try:
+        if gzipped:
+            import gzip
+            with gzip.open(path, "rb") as fh:
+                head = fh.read(1 << 16)
+        else:
+            with open(path, "rb") as fh:
+                head = fh.read(1 << 16)
+    except (OSError, EOFError, ValueError):
+        return False                     # (the host reader reports what is wrong with the file)
+    head = head.lstrip()
+    return head[:1] == b">" if head else True
 
 
 class _StreamFallback(Exception):
@@ -95,13 +116,13 @@ class DeviceChunk:
 
 class _Batch:
     __slots__ = ("text", "line_end", "summary", "host", "event", "slot", "gz_slot", "n", "begin", "end", "consumed", "status", "dirty",
-                 "bad_record", "n_lines", "final", "orig", "samples", "samples_host", "args", "chain")
+                 "bad_record", "n_lines", "final", "orig", "samples", "samples_host", "args", "chain", "norm", "rec_tab", "hdr_tab", "norm_end")
 
     def bytes_bound(self, lo, hi):
         """an upper bound (tight within 2 * EVERY records) of the text bytes of records [lo, hi)"""
         s = self.samples_host
         k1 = -(-hi // EVERY)
-        top = int(s[k1]) if k1 * EVERY <= self.n and k1 < len(s) else self.consumed
+        top = int(s[k1]) if k1 * EVERY <= self.n and k1 < len(s) else (self.consumed if getattr(self, "norm", None) is None else self.norm_end)
         return top - int(s[lo // EVERY])
 
 
@@ -241,6 +262,95 @@ class FastqIndexer:
         return DeviceChunk(n, text, rs, so, sl, ready, total)
 
 
+LINE_DIV_FA = 16              # FASTA: the line table of a batch holds window / 16 lines (shorter lines on average: framed again, full size)
+
+
+class FastaIndexer(FastqIndexer):
+    """rd_fasta_index / rd_fasta_gather behind the interface of FastqIndexer: a batch of FASTA text is RE-WRITTEN on the device into
+    `norm` (header, newline, the record's sequence lines joined and upper-cased, newline - fastx_parser.py:39-55 and the writer's join) and
+    indexed there (rec_tab / hdr_tab); the carry of a batch is the raw text from its last header line on. No strip pass: strip() is
+    part of the re-writing."""
+
+    def index(self, text, start, end, final=False, chain=True, prev=None, full_table=False):
+        b = _Batch()
+        if prev is None and chain:
+            prev = self.prev
+        with torch.cuda.device(self.device), torch.cuda.stream(self.stream):
+            window = (end - start) + (PAD if prev is not None else 0)
+            cap_lines = (window + 2) if full_table else (window // LINE_DIV_FA + 4096)
+            cap_rec = cap_lines + 2
+            norm_cap = ((window + cap_lines + 64 + 255) // 256) * 256
+            b.text = text
+            b.line_end = torch.empty(cap_lines, dtype=torch.int32, device=self.device)
+            b.norm = torch.empty(norm_cap, dtype=torch.uint8, device=self.device)
+            b.rec_tab = torch.empty(cap_rec, dtype=torch.int64, device=self.device)
+            b.hdr_tab = torch.empty(cap_rec, dtype=torch.int32, device=self.device)
+            ns = cap_rec // EVERY + 3
+            meta = torch.empty(64 + 4 * ns, dtype=torch.uint8, device=self.device)
+            meta_host = torch.empty(64 + 4 * ns, dtype=torch.uint8, pin_memory=True)
+            b.summary, b.samples = meta[:64].view(torch.int64), meta[64:].view(torch.int32)
+            b.host, b.samples_host = meta_host[:64].view(torch.int64), meta_host[64:].view(torch.int32)
+            ws = torch.empty(max(int(self.lib.rd_fasta_index_workspace_bytes(end, cap_lines)), 256), dtype=torch.uint8, device=self.device)
+            N.check(self.lib.rd_fasta_index(N.ptr(text), int(start), int(end), N.ptr(prev[0]) if prev is not None else None,
+                                            N.ptr(prev[1]) if prev is not None else None, 1 if final else 0, N.ptr(b.line_end), cap_lines,
+                                            N.ptr(b.norm), norm_cap, N.ptr(b.rec_tab), N.ptr(b.hdr_tab), cap_rec, N.ptr(b.summary), N.ptr(ws),
+                                            ws.numel(), self._sp()), "rd_fasta_index")
+            N.check(self.lib.rd_fasta_sample(N.ptr(b.rec_tab), N.ptr(b.summary), EVERY, N.ptr(b.samples), ns, self._sp()), "rd_fasta_sample")
+            N.copy_bytes(meta_host, meta, meta.numel(), self.stream, workgroups=4)
+            b.event = N.new_event()
+            b.event.record(self.stream)
+        b.final, b.orig, b.slot, b.gz_slot, b.n = final, None, None, None, None
+        b.args, b.chain = (start, end, final), (text, b.summary)
+        if chain:
+            self.prev = (text, b.summary)
+        self.stats["batches"] += 1
+        return b
+
+    @staticmethod
+    def _read(b):
+        FastqIndexer._read(b)
+        b.norm_end = int(b.host.numpy()[7])
+
+    def finish(self, b):
+        self.wait(b)
+        self._read(b)
+        if b.status in (4, 5) and b.chain is not None:       # (as FastqIndexer.finish: the tables were too small, or the batch chains to one)
+            self.stats["reframed"] += 1
+            start, end, final = b.args
+            nb = self.index(b.text, start, end, final=final, chain=False, prev=self.last_good, full_table=True)
+            self.stats["batches"] -= 1
+            self.wait(nb)
+            self._read(nb)
+            for k in ("line_end", "summary", "host", "samples", "samples_host", "begin", "end", "consumed", "n", "n_lines", "status", "dirty",
+                      "bad_record", "chain", "norm", "rec_tab", "hdr_tab", "norm_end"):
+                setattr(b, k, getattr(nb, k))
+        if b.chain is not None:
+            self.last_good = b.chain
+        return b
+
+    def gather(self, pieces):
+        n = sum(hi - lo for _, lo, hi in pieces)
+        cap = sum(b.bytes_bound(lo, hi) for b, lo, hi in pieces)
+        with torch.cuda.device(self.device), torch.cuda.stream(self.stream):
+            text = torch.empty(((cap + 255) // 256) * 256 + 256, dtype=torch.uint8, device=self.device)
+            rs = torch.empty(n + 1, dtype=torch.int64, device=self.device)
+            so = torch.empty(n, dtype=torch.int64, device=self.device)
+            sl = torch.empty(n, dtype=torch.int32, device=self.device)
+            cursor = torch.zeros(len(pieces) + 1, dtype=torch.int64, device=self.device)
+            at = 0
+            for i, (b, lo, hi) in enumerate(pieces):
+                N.check(self.lib.rd_fasta_gather(N.ptr(b.norm), N.ptr(b.rec_tab), N.ptr(b.hdr_tab), N.ptr(b.summary), lo, hi, b.bytes_bound(lo, hi),
+                                                 N.ptr(text), text.numel(), C.c_void_p(cursor.data_ptr() + 8 * i), C.c_void_p(cursor.data_ptr() + 8 * (i + 1)),
+                                                 C.c_void_p(rs.data_ptr() + 8 * at), C.c_void_p(so.data_ptr() + 8 * at),
+                                                 C.c_void_p(sl.data_ptr() + 4 * at), self._sp()), "rd_fasta_gather")
+                at += hi - lo
+            total = torch.empty(1, dtype=torch.int64, pin_memory=True)
+            N.copy_bytes(total.view(torch.uint8), cursor[len(pieces):].view(torch.uint8), 8, self.stream, workgroups=1)
+            ready = torch.cuda.Event()
+            ready.record(self.stream)
+        return DeviceChunk(n, text, rs, so, sl, ready, total)
+
+
 class DeviceFeeder:
     """The producer thread of one input file: file bytes -> batches on the GPU (H2D, members inflated where the file is BGZF, records
     framed), two batches in flight; next_batch() hands them over in order, finished."""
@@ -252,10 +362,11 @@ class DeviceFeeder:
     PLAIN_FIRST = 12 << 20
     SLOTS = 2
 
-    def __init__(self, path, device, compressed, span=None, byte_range=None):
+    def __init__(self, path, device, compressed, span=None, byte_range=None, fasta=False):
         """compressed: the file is BGZF (span = (first file byte, one past the last, text bytes to drop in front, text bytes to
         deliver) for a rank's share, fastx_parser.BgzfView.file_span); else plain text (byte_range = (start, end), record-aligned)"""
         self.path, self.device, self.compressed, self.span, self.byte_range = str(path), torch.device(device), compressed, span, byte_range
+        self.fasta = bool(fasta)
         self._stop = False
         self.out = queue.Queue(maxsize=self.SLOTS)
         self.slot_free = queue.Queue()
@@ -326,7 +437,7 @@ class DeviceFeeder:
             torch.cuda.set_device(self.device)          # the current device is per thread (and defaults to 0)
             self.stream = gz.acquire_stream(self.device, priority=-1)
             self.dg = gz.DeviceGunzip(self.device, slots=self.SLOTS, stream=self.stream)
-            self.ix = FastqIndexer(self.device, self.stream)
+            self.ix = (FastaIndexer if self.fasta else FastqIndexer)(self.device, self.stream)
         except BaseException as e:      # noqa: BLE001
             self._init_err = e
             self._ready.set()
@@ -714,7 +825,7 @@ def get_seq_chunks_device(seq_file, chunk_size=1048576, byte_range=None, first_c
         a, b = byte_range
         c0, c1, drop = byte_range.view.file_span(a, b)
         span, byte_range = (c0, c1, drop, b - a), None
-    feeder = DeviceFeeder(seq_file, device, compressed, span=span, byte_range=byte_range)
+    feeder = DeviceFeeder(seq_file, device, compressed, span=span, byte_range=byte_range, fasta=fx.get_seq_format(seq_file).startswith("fa"))
     want = chunk_size if not first_chunk else max(1, min(int(first_chunk), chunk_size))
     sched = list(schedule) if schedule else None
     pend = deque()                   # [batch, next record]

@@ -183,6 +183,14 @@ def test_cli_fasta_and_cpu_semantics(tmp_path, oracle):
         assert p.num_rrna == int(lab.sum())
         want = "".join(">seq%d some text\n%s\n" % (i, seqs[i]) for i in np.flatnonzero(lab == 0))
         assert _read(out) == want
+        assert p.ingest["in.fa"]["path"] == "device"      # (round 5: FASTA is re-written and indexed on the GPU, rd_fasta_index)
+    os.environ["RD_DEVICE_FASTA"] = "0"                   # the host parser: the same file
+    try:
+        out = str(tmp_path / "out_host.fa")
+        p = detect.main(["-l", "100", "-i", inp, "-o", out])
+        assert p.ingest.get("in.fa", {}).get("path") != "device" and _read(out) == _read(str(tmp_path / "out_gpu.fa"))
+    finally:
+        del os.environ["RD_DEVICE_FASTA"]
 
 
 def _bgzf(src, dst):

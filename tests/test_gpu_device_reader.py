@@ -284,3 +284,98 @@ def test_short_lines_overflow_the_line_table_and_are_framed_again(tmp_path, smal
         assert st["indexer"]["reframed"] >= (1 if first > 100000 else 3), st
         assert b"".join(d[0] for d in dev) == text
         _same(_host_chunks(p, 7000), dev)
+
+
+# ---- FASTA on the device (rd_fasta_index / rd_fasta_gather; reference data_loader/fastx_parser.py:39-55) -----------------------------------
+
+def _fuzz_fasta(rng, nrec):
+    """FASTA as files have it: multi-line sequences of every width, lower case, CR LF, indented lines, blank lines anywhere, records
+    without a sequence, headers with blanks, '>' inside lines, a last line without its newline"""
+    crlf = rng.random() < 0.25
+    nl = b"\r\n" if crlf else b"\n"
+    out = []
+    if rng.random() < 0.2:
+        out.append(nl * int(rng.integers(1, 3)) if rng.random() < 0.5 else b"  \t" + nl)      # blank lines in front of the first header
+    for i in range(nrec):
+        hdr = (b"  " if rng.random() < 0.05 else b"") + b">s%d" % i + (b" some text > here" if rng.random() < 0.3 else b"") + (b" \t" if rng.random() < 0.1 else b"")
+        out.append(hdr + nl)
+        L = int(rng.choice([0, 0, 1, 7, 60, 100, 151, 1000]))
+        seq = bytes(rng.choice(list(b"ACGTNacgtnRYKM"), L).astype(np.uint8))
+        width = int(rng.choice([1, 10, 60, 70, 80, 100000]))
+        for o in range(0, L, width):
+            line = seq[o:o + width]
+            if rng.random() < 0.03:
+                line = b" " + line + b"\t"
+            out.append(line + nl)
+            if rng.random() < 0.03:
+                out.append(nl)                                     # a blank line inside a sequence
+        if rng.random() < 0.05:
+            out.append(nl)
+    text = b"".join(out)
+    if text and rng.random() < 0.25:
+        text = text[:-len(nl)]
+    return text
+
+
+def test_fasta_reference_parser_text(golden, tmp_path, small_batches):
+    """tests/golden/parser.json: the FASTA text the reference's own seq_parser was run on - the device's records are the reference's"""
+    g = golden.json("parser")
+    text = g["fasta_text"].encode()
+    want = "".join("\n".join(r) + "\n" for r in g["fasta_records"])
+    p = str(tmp_path / "ref.fasta")
+    open(p, "wb").write(text)
+    for first, full in ((1 << 20, 1 << 20), (64, 64), (7, 13), (1, 1)):
+        small_batches(first, full)
+        dev = _dev_chunks(p, 1000)
+        assert b"".join(d[0] for d in dev).decode() == want
+        rs, so, sl = dev[0][1], dev[0][2], dev[0][3]
+        for i, r in enumerate(g["fasta_records"]):
+            assert dev[0][0][rs[i]:rs[i + 1]].decode() == "\n".join(r) + "\n" and dev[0][0][so[i]:so[i] + sl[i]].decode() == r[1]
+        _same(_host_chunks(p, 1000), dev)
+
+
+def test_fasta_fuzz_plain_and_bgzf_against_the_host_reader(tmp_path, small_batches):
+    """300 files: the device's FASTA chunks == the host reader's (normalised text, rec_start, seq_off, seq_len), plain and BGZF, small
+    random batch and chunk sizes: the carry (the raw text from the last header line on) is exercised at every offset"""
+    rng = np.random.default_rng(12)
+    n_files = 0
+    for it in range(150):
+        nrec = int(rng.choice([0, 1, 2, 3, 5, 17, 100, 400]))
+        text = _fuzz_fasta(rng, nrec)
+        first = int(rng.choice([1, 3, 50, 700, 5000, 1 << 20]))
+        small_batches(first, max(first, int(rng.choice([1, 9, 333, 4096, 1 << 20]))), members=int(rng.choice([1, 2, 7, 4096])))
+        chunk, fc = int(rng.choice([1, 2, 7, 64, 1000, 100000])), (None if rng.random() < 0.5 else int(rng.choice([1, 5, 100])))
+        p = str(tmp_path / "f.fasta")
+        open(p, "wb").write(text)
+        host = _host_chunks(p, chunk, fc)
+        pz = str(tmp_path / "f.fasta.gz")
+        open(pz, "wb").write(_bgzf(text, block=int(rng.choice([40, 700, 65280])), rng=rng if rng.random() < 0.5 else None))
+        for q in (p, pz):
+            _same(host, _dev_chunks(q, chunk, fc))
+            n_files += 1
+    assert n_files == 300
+
+
+def test_fasta_large_file_and_what_stays_with_the_host(tmp_path):
+    from ribodetector_amd import synth
+    from ribodetector_amd.data_loader import device_reader as dr
+    arena, off, lens = synth.reads_numpy(300000, (40, 150), seed=5)
+    p = str(tmp_path / "big.fasta")
+    with open(p, "wb") as fh:                      # 60-column FASTA
+        for i in range(len(lens)):
+            s = arena[off[i]:off[i] + lens[i]].tobytes()
+            fh.write(b">read%d\n" % i + b"\n".join(s[o:o + 60] for o in range(0, len(s), 60)) + b"\n")
+    st = {}
+    dev = _dev_chunks(p, 100000, first=1 << 15, stats=st)
+    assert [len(d[3]) for d in dev] == [32768, 65536, 100000, 100000, 1696] and st["feeder"]["batches"] >= 2
+    _same(_host_chunks(p, 100000, 1 << 15), dev)
+    assert dr.device_ingest_kind(p) == "plain"
+    # sequence in front of the first header: the reference glues it to the first record - the host reader's case
+    q = str(tmp_path / "lead.fasta")
+    open(q, "wb").write(b"ACGT\n>r1\nGG\n")
+    assert dr.device_ingest_kind(q) is None
+    os.environ["RD_DEVICE_FASTA"] = "0"
+    try:
+        assert dr.device_ingest_kind(p) is None
+    finally:
+        del os.environ["RD_DEVICE_FASTA"]

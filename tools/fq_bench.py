@@ -70,6 +70,27 @@ def main():
     ds = gz.DeviceSelect(dev)
     ms = timed(lambda: [ds.pack_selected(ch.dev[0], ch.dev[3], lab, v, slot=v) for v in (0, 1)])
     put("rd_select_pack (both label files)", ms, 2 * tb + 2 * 9 * n, "text read + written, 9 B of index per record and file")
+    # FASTA (rd_fasta_index: the batch re-written as header / joined upper-case sequence): the same reads as 60-column FASTA
+    nfa = min(n, 1 << 18)
+    a_np, o_np = arena.cpu().numpy(), off.cpu().numpy()
+    fa = b"".join(b">read%d\n" % i + b"\n".join(a_np[o_np[i]:o_np[i] + 100].tobytes()[q:q + 60] for q in (0, 60)) + b"\n" for i in range(nfa))
+    fa = fa * (n // nfa)
+    fb = len(fa)
+    fx_ = dr.FastaIndexer(dev, st)
+    fbuf = fx_.alloc_text(fb)
+    fbuf[dr.PAD:dr.PAD + fb] = torch.from_numpy(np.frombuffer(fa, dtype=np.uint8).copy()).to(dev)
+    fbatch = [None]
+
+    def do_fa():
+        fx_.prev = None
+        fbatch[0] = fx_.index(fbuf, dr.PAD, dr.PAD + fb, final=True, chain=False)
+    ms = timed(do_fa)
+    fbt = fx_.finish(fbatch[0])
+    assert fbt.n == n and fbt.status == 0, (fbt.n, fbt.status)
+    put("rd_fasta_index (60-column FASTA, %d lines)" % (3 * n), ms, 2 * fb, "text read + re-written")
+    ms = timed(lambda: fx_.gather([(fbt, 0, n)]))
+    put("rd_fasta_gather", ms, 2 * fbt.norm_end + 20 * n, "normalised text read + written, 20 B of index per record")
+    del fbuf, fbt, fbatch
     pin = torch.empty(tb, dtype=torch.uint8, pin_memory=True)
     pin.copy_(text)
     dst = torch.empty(tb, dtype=torch.uint8, device=dev)
