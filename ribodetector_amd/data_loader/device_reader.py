@@ -37,7 +37,7 @@ EVERY = 4096                   # one record-offset sample per EVERY records trav
 FQ_ERRORS = {6: "sequence lines in front of the first FASTA header (RD_DEVICE_FASTA=0 reads such a file with the host parser)",
              1: "FASTQ record does not start with '@'",
              2: "truncated FASTQ record at end of file (number of lines is not a multiple of 4)",
-             3: "a FASTQ record longer than %d bytes: set RD_DEVICE_PARSE=0 (the host parser has no record-size limit)" % PAD,
+             3: "a record longer than %d bytes: set RD_DEVICE_PARSE=0 (the host parser has no record-size limit)" % PAD,
              4: "the batch before this one could not be framed", 5: "more lines than the line table holds"}
 
 

@@ -379,3 +379,31 @@ def test_fasta_large_file_and_what_stays_with_the_host(tmp_path):
         assert dr.device_ingest_kind(p) is None
     finally:
         del os.environ["RD_DEVICE_FASTA"]
+
+
+def test_fasta_single_stream_gz_and_a_record_longer_than_the_pad(tmp_path, small_batches):
+    """a FASTA .gz that is ONE gzip stream goes through the stream decoder and the same re-writing; a record that does not fit the carry
+    pad is refused with the way out named"""
+    import gzip
+    from ribodetector_amd.data_loader import device_reader as dr
+    rng = np.random.default_rng(21)
+    text = _fuzz_fasta(rng, 3000)
+    if not text.lstrip().startswith(b">"):
+        text = b">first\n" + text
+    p, pz = str(tmp_path / "s.fasta"), str(tmp_path / "s.fasta.gz")
+    open(p, "wb").write(text)
+    with gzip.open(pz, "wb", compresslevel=6) as fh:
+        fh.write(text)
+    host = _host_chunks(p, 700)
+    assert dr.device_ingest_kind(pz) in ("stream", None)
+    _same(host, _dev_chunks(pz, 700))
+    small_batches(1000, 1000)
+    pad = dr.PAD
+    try:
+        dr.PAD = 4096
+        q = str(tmp_path / "long.fasta")
+        open(q, "wb").write(b">a\nACGT\n>long\n" + b"ACGT" * 3000 + b"\n>b\nGG\n")
+        with pytest.raises(ValueError, match="RD_DEVICE_PARSE=0"):
+            _dev_chunks(q, 1000)
+    finally:
+        dr.PAD = pad
