@@ -27,6 +27,7 @@ namespace {
 constexpr int FA_LINES = 8;                              // lines per thread
 constexpr int FA_BLOCK = FQ_THREADS * FA_LINES;          // 2,048 lines per workgroup
 constexpr unsigned long long FA_NONE = ~0ull;
+constexpr int FA_LONG = 512;                             // bytes from which a line is copied by its workgroup instead of its thread
 
 struct FaScratch {            // device scratch of one rd_fasta_index call (64 bytes)
     unsigned long long first_hdr, first_seq;   // index of the first header line / sequence line (FA_NONE: none)
@@ -119,9 +120,13 @@ __global__ __launch_bounds__(FQ_THREADS) void rd_fa_emit_kernel(const uint8_t *_
                                                                const FaScratch *__restrict__ sc, int final, uint8_t *__restrict__ norm,
                                                                int64_t *__restrict__ rec_start, int32_t *__restrict__ hdr_len) {
     __shared__ int64_t sh[4];
+    __shared__ int n_long;                               // lines of FA_LONG bytes or more are copied by the whole workgroup (long reads on
+    __shared__ int64_t long_dst[FA_BLOCK];               // one line: a thread of its own would walk megabytes byte by byte)
+    __shared__ int32_t long_src[FA_BLOCK], long_len[FA_BLOCK];
     if (sum->status != RD_FQ_OK) return;
     const int64_t L = sum->n_lines;
     if ((int64_t)blockIdx.x * FA_BLOCK >= L) return;
+    if (threadIdx.x == 0) n_long = 0;
     const int64_t j0 = (int64_t)blockIdx.x * FA_BLOCK + (int64_t)threadIdx.x * FA_LINES;
     const int64_t m = (int64_t)(sc->total >> 32), T = (int64_t)(sc->total & 0xffffffffull);
     int a[FA_LINES];
@@ -151,7 +156,12 @@ __global__ __launch_bounds__(FQ_THREADS) void rd_fa_emit_kernel(const uint8_t *_
         if (kind == 1) {
             if (P >= 0) norm[P] = '\n';
             uint8_t *d = norm + P + 1;
-            for (int q = 0; q < len; ++q) d[q] = src[q];
+            if (len >= FA_LONG) {
+                const int at = atomicAdd(&n_long, 1);
+                long_dst[at] = P + 1; long_src[at] = a[k]; long_len[at] = len;                 // (a header: copied as it is)
+            } else {
+                for (int q = 0; q < len; ++q) d[q] = src[q];
+            }
             d[len] = '\n';
             rec_start[hidx] = P + 1;
             hdr_len[hidx] = len;
@@ -172,11 +182,28 @@ __global__ __launch_bounds__(FQ_THREADS) void rd_fa_emit_kernel(const uint8_t *_
             E += (1ull << 32) + (unsigned long long)len + 2ull;
         } else if (kind == 2) {
             uint8_t *d = norm + P;
-            for (int q = 0; q < len; ++q) {
-                const unsigned c = src[q];
-                d[q] = (uint8_t)((c >= 'a' && c <= 'z') ? c - 32 : c);
+            if (len >= FA_LONG) {
+                const int at = atomicAdd(&n_long, 1);
+                long_dst[at] = P; long_src[at] = a[k]; long_len[at] = -len;                    // (negative: a sequence line, upper-cased)
+            } else {
+                for (int q = 0; q < len; ++q) {
+                    const unsigned c = src[q];
+                    d[q] = (uint8_t)((c >= 'a' && c <= 'z') ? c - 32 : c);
+                }
             }
             E += (unsigned long long)len;
+        }
+    }
+    __syncthreads();
+    const int nl = n_long;
+    for (int i = 0; i < nl; ++i) {
+        const bool up = long_len[i] < 0;
+        const int len = up ? -long_len[i] : long_len[i];
+        const uint8_t *src = text + long_src[i];
+        uint8_t *d = norm + long_dst[i];
+        for (int q = threadIdx.x; q < len; q += FQ_THREADS) {
+            const unsigned c = src[q];
+            d[q] = (uint8_t)((up && c >= 'a' && c <= 'z') ? c - 32 : c);
         }
     }
 }

@@ -299,7 +299,7 @@ def _fuzz_fasta(rng, nrec):
     for i in range(nrec):
         hdr = (b"  " if rng.random() < 0.05 else b"") + b">s%d" % i + (b" some text > here" if rng.random() < 0.3 else b"") + (b" \t" if rng.random() < 0.1 else b"")
         out.append(hdr + nl)
-        L = int(rng.choice([0, 0, 1, 7, 60, 100, 151, 1000]))
+        L = int(rng.choice([0, 0, 1, 7, 60, 100, 151, 511, 512, 1000, 2500]))      # (lines of 512+ bytes are copied by a workgroup)
         seq = bytes(rng.choice(list(b"ACGTNacgtnRYKM"), L).astype(np.uint8))
         width = int(rng.choice([1, 10, 60, 70, 80, 100000]))
         for o in range(0, L, width):
