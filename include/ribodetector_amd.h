@@ -300,7 +300,8 @@ RD_API int rd_fastq_strip_mark(const uint8_t *text, const int32_t *line_end, con
  * its chunk buffer), rec_tab [dev] int64[cap_records] the offset in `norm` where record r starts (entry n_records = the end),
  * hdr_tab [dev] int32[cap_records] the length of its header line. text / pad / end / prev_text / prev / final / line_end / cap_lines /
  * summary as rd_fastq_index (the batches of a stream chain the same way: the carry is the raw text from the last header line on - that
- * record is complete only in a final batch); summary->reserved = the bytes of `norm` that belong to records; status RD_FQ_LINES also
+ * record is complete only in a final batch; final = 2: the stream is a SHARE of a file that goes on behind it - its last record counts
+ * even without a sequence, which final = 1, the end of the file, drops like the reference); summary->reserved = the bytes of `norm` that belong to records; status RD_FQ_LINES also
  * when norm_cap or cap_records is too small (norm_cap >= window + lines, cap_records >= lines + 1 is always enough), RD_FA_LEADING:
  * sequence lines in front of the first header (the reference glues them to the first record) - not framed here, the host reader takes
  * such a file. rd_fasta_gather / rd_fasta_sample: as rd_fastq_gather / rd_fastq_sample, over `norm` and the two tables. */

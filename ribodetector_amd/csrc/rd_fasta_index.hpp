@@ -170,9 +170,10 @@ __global__ __launch_bounds__(FQ_THREADS) void rd_fa_emit_kernel(const uint8_t *_
                     const int64_t seq_bytes = T - 1 - (P + 1 + len + 1);
                     rec_start[m] = T;
                     norm[T - 1] = '\n';
-                    sum->n_records = seq_bytes > 0 ? m : m - 1;      // (the reference drops a last record without a sequence)
+                    const bool keep = seq_bytes > 0 || final == 2;   // (the reference drops a last record without a sequence at the end of the
+                    sum->n_records = keep ? m : m - 1;               // FILE; final == 2: the end of a rank's share, the file goes on)
                     sum->consumed = sum->end;
-                    sum->reserved = seq_bytes > 0 ? T : P + 1;         // bytes of `norm` that belong to records
+                    sum->reserved = keep ? T : P + 1;                  // bytes of `norm` that belong to records
                 } else {
                     sum->n_records = m - 1;
                     sum->consumed = a[k];

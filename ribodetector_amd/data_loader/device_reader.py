@@ -14,7 +14,7 @@ so the host moves compressed bytes (or the file's bytes once, in and out) and a 
 those of csrc/rd_host.cpp's reader (tests/test_gpu_device_reader.py holds the two to each other and to the reference's parser):
 every line rstrip()-ed (a batch with trailing whitespace - CR LF files - is stripped on the device and indexed again), header must
 start with '@', last line may lack its newline, fewer than four blank trailing lines tolerated.
-RD_DEVICE_PARSE=0 keeps the host parser. FASTA (one rank): FastaIndexer - the batch is re-written as header / joined upper-case sequence
+RD_DEVICE_PARSE=0 keeps the host parser. FASTA: FastaIndexer - the batch is re-written as header / joined upper-case sequence
 (fastx_parser.py:39-55) by rd_fasta_index and indexed there; RD_DEVICE_FASTA=0 or a file that starts with sequence lines: the host parser.
 """
 import ctypes as C
@@ -269,7 +269,9 @@ class FastaIndexer(FastqIndexer):
     """rd_fasta_index / rd_fasta_gather behind the interface of FastqIndexer: a batch of FASTA text is RE-WRITTEN on the device into
     `norm` (header, newline, the record's sequence lines joined and upper-cased, newline - fastx_parser.py:39-55 and the writer's join) and
     indexed there (rec_tab / hdr_tab); the carry of a batch is the raw text from its last header line on. No strip pass: strip() is
-    part of the re-writing."""
+    part of the re-writing. keep_empty_tail: the stream is a rank's share of a file that goes on behind it (its last record counts even
+    without a sequence; the end of the FILE drops such a record, like the reference)."""
+    keep_empty_tail = False
 
     def index(self, text, start, end, final=False, chain=True, prev=None, full_table=False):
         b = _Batch()
@@ -292,8 +294,8 @@ class FastaIndexer(FastqIndexer):
             b.host, b.samples_host = meta_host[:64].view(torch.int64), meta_host[64:].view(torch.int32)
             ws = torch.empty(max(int(self.lib.rd_fasta_index_workspace_bytes(end, cap_lines)), 256), dtype=torch.uint8, device=self.device)
             N.check(self.lib.rd_fasta_index(N.ptr(text), int(start), int(end), N.ptr(prev[0]) if prev is not None else None,
-                                            N.ptr(prev[1]) if prev is not None else None, 1 if final else 0, N.ptr(b.line_end), cap_lines,
-                                            N.ptr(b.norm), norm_cap, N.ptr(b.rec_tab), N.ptr(b.hdr_tab), cap_rec, N.ptr(b.summary), N.ptr(ws),
+                                            N.ptr(prev[1]) if prev is not None else None, (2 if self.keep_empty_tail else 1) if final else 0,
+                                            N.ptr(b.line_end), cap_lines, N.ptr(b.norm), norm_cap, N.ptr(b.rec_tab), N.ptr(b.hdr_tab), cap_rec, N.ptr(b.summary), N.ptr(ws),
                                             ws.numel(), self._sp()), "rd_fasta_index")
             N.check(self.lib.rd_fasta_sample(N.ptr(b.rec_tab), N.ptr(b.summary), EVERY, N.ptr(b.samples), ns, self._sp()), "rd_fasta_sample")
             N.copy_bytes(meta_host, meta, meta.numel(), self.stream, workgroups=4)
@@ -362,11 +364,11 @@ class DeviceFeeder:
     PLAIN_FIRST = 12 << 20
     SLOTS = 2
 
-    def __init__(self, path, device, compressed, span=None, byte_range=None, fasta=False):
+    def __init__(self, path, device, compressed, span=None, byte_range=None, fasta=False, keep_empty_tail=False):
         """compressed: the file is BGZF (span = (first file byte, one past the last, text bytes to drop in front, text bytes to
         deliver) for a rank's share, fastx_parser.BgzfView.file_span); else plain text (byte_range = (start, end), record-aligned)"""
         self.path, self.device, self.compressed, self.span, self.byte_range = str(path), torch.device(device), compressed, span, byte_range
-        self.fasta = bool(fasta)
+        self.fasta, self.keep_empty_tail = bool(fasta), bool(keep_empty_tail)
         self._stop = False
         self.out = queue.Queue(maxsize=self.SLOTS)
         self.slot_free = queue.Queue()
@@ -438,6 +440,8 @@ class DeviceFeeder:
             self.stream = gz.acquire_stream(self.device, priority=-1)
             self.dg = gz.DeviceGunzip(self.device, slots=self.SLOTS, stream=self.stream)
             self.ix = (FastaIndexer if self.fasta else FastqIndexer)(self.device, self.stream)
+            if self.fasta:
+                self.ix.keep_empty_tail = self.keep_empty_tail
         except BaseException as e:      # noqa: BLE001
             self._init_err = e
             self._ready.set()
@@ -821,11 +825,16 @@ def get_seq_chunks_device(seq_file, chunk_size=1048576, byte_range=None, first_c
     kind = device_ingest_kind(seq_file)
     compressed = "stream" if kind == "stream" else fx.get_seq_format(seq_file).endswith("gz")
     span = None
+    keep_tail = False            # a share that ends before the file does (FASTA: its last record counts even without a sequence)
     if isinstance(byte_range, fx.BgzfRange):
         a, b = byte_range
         c0, c1, drop = byte_range.view.file_span(a, b)
+        keep_tail = b < byte_range.view.size
         span, byte_range = (c0, c1, drop, b - a), None
-    feeder = DeviceFeeder(seq_file, device, compressed, span=span, byte_range=byte_range, fasta=fx.get_seq_format(seq_file).startswith("fa"))
+    elif byte_range is not None:
+        keep_tail = int(byte_range[1]) < os.path.getsize(seq_file)
+    feeder = DeviceFeeder(seq_file, device, compressed, span=span, byte_range=byte_range, fasta=fx.get_seq_format(seq_file).startswith("fa"),
+                          keep_empty_tail=keep_tail)
     want = chunk_size if not first_chunk else max(1, min(int(first_chunk), chunk_size))
     sched = list(schedule) if schedule else None
     pend = deque()                   # [batch, next record]

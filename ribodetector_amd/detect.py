@@ -377,11 +377,7 @@ class Predictor:
     def _device_parse(self, path):
         """does this input's text stay on the device? FASTQ, plain or BGZF, when every record a rank reads is a record it classifies
         (one rank, or the sharded parse) - under the label gather the chunk's lengths are needed on the host for the shard bounds"""
-        if not ((not self.multi or self.sharded_parse) and dr.device_parse_wanted(path)):
-            return False
-        # FASTA on the device (round 5) frames a whole stream: a rank's SHARE of a FASTA file keeps the host reader (its last record may be
-        # one without a sequence, which only the end of the FILE drops: rd_reader_set_flush_empty_tail)
-        return not (self.multi and fx.get_seq_format(path).startswith("fa"))
+        return (not self.multi or self.sharded_parse) and dr.device_parse_wanted(path)
 
     def _shared_decode(self):
         """several ranks of ONE node on gzip input: rank 0 inflates and parses the stream once into shared memory (fx.ShmArena)

@@ -407,3 +407,18 @@ def test_fasta_single_stream_gz_and_a_record_longer_than_the_pad(tmp_path, small
             _dev_chunks(q, 1000)
     finally:
         dr.PAD = pad
+
+
+def test_fasta_share_keeps_its_last_record_without_a_sequence(tmp_path):
+    """a rank's share of a FASTA file that goes on behind it: the share's last record counts even when it has no sequence (the next
+    rank starts with the next header); the end of the FILE drops such a record, like the reference - both as the host reader does"""
+    from ribodetector_amd.data_loader import fastx_parser as fx
+    text = b">a\nAC\n>b\n>c\nGG\n>z\n"
+    p = str(tmp_path / "s.fasta")
+    open(p, "wb").write(text)
+    cut = text.index(b">c")
+    for rng_ in ((0, cut), (cut, len(text)), None):
+        host = [(c.buf[c.rec_start[0]:c.rec_start[-1]].tobytes(), np.asarray(c.seq_len)) for c in fx.get_seq_chunks(p, chunk_size=100, byte_range=rng_)]
+        dev = _dev_chunks(p, 100, byte_range=rng_)
+        assert [h[0] for h in host] == [d[0] for d in dev] and all(np.array_equal(h[1], d[3]) for h, d in zip(host, dev)), rng_
+    assert _dev_chunks(p, 100, byte_range=(0, cut))[0][0] == b">a\nAC\n>b\n\n" and _dev_chunks(p, 100)[0][0] == b">a\nAC\n>b\n\n>c\nGG\n"
