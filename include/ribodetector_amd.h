@@ -302,10 +302,10 @@ RD_API int rd_fastq_strip_mark(const uint8_t *text, const int32_t *line_end, con
  * summary as rd_fastq_index (the batches of a stream chain the same way: the carry is the raw text from the last header line on - that
  * record is complete only in a final batch; final = 2: the stream is a SHARE of a file that goes on behind it - its last record counts
  * even without a sequence, which final = 1, the end of the file, drops like the reference); summary->reserved = the bytes of `norm` that belong to records; status RD_FQ_LINES also
- * when norm_cap or cap_records is too small (norm_cap >= window + lines, cap_records >= lines + 1 is always enough), RD_FA_LEADING:
- * sequence lines in front of the first header (the reference glues them to the first record) - not framed here, the host reader takes
- * such a file. rd_fasta_gather / rd_fasta_sample: as rd_fastq_gather / rd_fastq_sample, over `norm` and the two tables. */
-#define RD_FA_LEADING 6
+ * when norm_cap or cap_records is too small (norm_cap >= window + lines + 2, cap_records >= lines + 2 is always enough). Sequence lines
+ * in front of the first header (a malformed file) become part of the first record's sequence, a stream without any header ONE record with
+ * an empty header line - what the reference's parser yields. rd_fasta_gather / rd_fasta_sample: as rd_fastq_gather / rd_fastq_sample,
+ * over `norm` and the two tables. */
 RD_API size_t rd_fasta_index_workspace_bytes(int64_t text_end, int64_t cap_lines);
 RD_API int rd_fasta_index(uint8_t *text, int64_t pad, int64_t end, const uint8_t *prev_text, const rd_fq_summary *prev, int32_t final, int32_t *line_end,
                    int64_t cap_lines, uint8_t *norm, int64_t norm_cap, int64_t *rec_tab, int32_t *hdr_tab, int64_t cap_records, rd_fq_summary *summary,

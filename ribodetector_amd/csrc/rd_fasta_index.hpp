@@ -17,8 +17,10 @@
 //                        batch: the record it starts is complete only in a final batch - otherwise it is the carry of the next one
 //   rd_fa_gather_kernel  records [lo, hi) of a batch's `norm` -> a chunk (text + rec_start / seq_off / seq_len), like rd_fq_gather_kernel
 // A line contributes: header = 1 ('\n' that closes the record before; the very first lands at position -1 and is not written) + its
-// bytes + 1; sequence = its bytes; blank = 0. Sequence lines IN FRONT of the first header (the reference glues them to the first
-// record's sequence) are not framed here: RD_FA_LEADING, and the caller hands the file to the host reader before anything is delivered.
+// bytes + 1; sequence = its bytes; blank = 0. Sequence lines IN FRONT of the first header (a malformed file): the reference glues them
+// to the first record's sequence, and yields them under an EMPTY header when the file has no header at all - so do the kernels: the
+// first header's bytes go to position 0 and the lines in front of it behind them; without any header the stream's end makes one record
+// with an empty header line (until then everything is carried).
 #pragma once
 #include "rd_fastq_index.hpp"
 
@@ -32,7 +34,8 @@ constexpr int FA_LONG = 512;                             // bytes from which a l
 struct FaScratch {            // device scratch of one rd_fasta_index call (64 bytes)
     unsigned long long first_hdr, first_seq;   // index of the first header line / sequence line (FA_NONE: none)
     unsigned long long total;                  // headers << 32 | bytes of `norm` (with the closing '\n' of every header, the first included)
-    unsigned long long reserved[5];
+    unsigned long long leading;                // sequence lines in front of the first header
+    unsigned long long reserved[4];
 };
 
 __device__ __forceinline__ void fa_line(const uint8_t *__restrict__ text, const int32_t *__restrict__ line_end, int64_t j, int64_t begin, int &a, int &len, int &kind) {
@@ -77,7 +80,8 @@ __global__ __launch_bounds__(FQ_THREADS) void rd_fa_lines_kernel(const uint8_t *
 
 // one workgroup: blk[] -> exclusive bases in place; totals; what can be said about the batch before a line is copied
 __global__ __launch_bounds__(FQ_THREADS) void rd_fa_base_kernel(unsigned long long *__restrict__ blk, const int32_t *__restrict__ line_end, FqSummary *__restrict__ sum,
-                                                               FaScratch *__restrict__ sc, int final, int64_t norm_cap, int64_t cap_records) {
+                                                               FaScratch *__restrict__ sc, int final, int64_t norm_cap, int64_t cap_records,
+                                                               uint8_t *__restrict__ norm, int64_t *__restrict__ rec_start, int32_t *__restrict__ hdr_len) {
     __shared__ int64_t sh[4];
     __shared__ int64_t run_s;
     if (sum->status != RD_FQ_OK) return;
@@ -100,13 +104,27 @@ __global__ __launch_bounds__(FQ_THREADS) void rd_fa_base_kernel(unsigned long lo
         const unsigned long long tot = (unsigned long long)run_s;
         const int64_t m = (int64_t)(tot >> 32), bytes = (int64_t)(tot & 0xffffffffull);
         sc->total = tot;
+        sc->leading = (sc->first_seq != FA_NONE && sc->first_seq < sc->first_hdr) ? 1ull : 0ull;
         sum->reserved = 0;
-        if (sc->first_seq != FA_NONE && sc->first_seq < sc->first_hdr) {
-            sum->status = RD_FA_LEADING;        // sequence in front of the first header (or a file without any): the host reader's case
-            sum->n_records = 0;
-        } else if (bytes > norm_cap || m + 1 > cap_records) {
+        if (bytes + 2 > norm_cap || m + 2 > cap_records) {
             sum->status = RD_FQ_LINES;          // the caller's buffers are too small for this batch: framed again with full-size ones
             sum->n_records = 0;
+        } else if (m == 0 && sc->first_seq != FA_NONE) {
+            // sequence lines and no header: carried until one arrives; at the end of the stream they are ONE record with an empty header
+            // line (the reference's `yield header, seq` with header == ''): rd_fa_emit_kernel writes the lines from position 1 on
+            if (final) {
+                norm[0] = '\n';
+                norm[bytes + 1] = '\n';
+                rec_start[0] = 0;
+                rec_start[1] = bytes + 2;
+                hdr_len[0] = 0;
+                sum->n_records = 1;
+                sum->consumed = sum->end;
+                sum->reserved = bytes + 2;
+            } else {
+                sum->n_records = 0;
+                sum->consumed = sum->begin;
+            }
         } else if (m == 0) {                    // nothing but blank lines
             sum->n_records = 0;
             sum->consumed = final ? sum->end : (L ? (int64_t)line_end[L - 1] + 1 : sum->begin);
@@ -129,6 +147,12 @@ __global__ __launch_bounds__(FQ_THREADS) void rd_fa_emit_kernel(const uint8_t *_
     if (threadIdx.x == 0) n_long = 0;
     const int64_t j0 = (int64_t)blockIdx.x * FA_BLOCK + (int64_t)threadIdx.x * FA_LINES;
     const int64_t m = (int64_t)(sc->total >> 32), T = (int64_t)(sc->total & 0xffffffffull);
+    // sequence lines in front of the first header: that header's bytes go first (position -1 like every first header), the lines behind
+    // them; no header at all: the lines start at position 1, behind the empty header line rd_fa_base_kernel wrote
+    const bool leading = sc->leading != 0 && m > 0;
+    const int64_t fh = leading ? (int64_t)sc->first_hdr : -1;
+    const int64_t len_h0 = leading ? (int64_t)(info_k[fh] & 0x3fffffffu) : 0;
+    const int64_t virt = m == 0 ? 2 : 0;
     int a[FA_LINES];
     uint32_t lk[FA_LINES];
     unsigned long long s = 0;
@@ -151,7 +175,9 @@ __global__ __launch_bounds__(FQ_THREADS) void rd_fa_emit_kernel(const uint8_t *_
         const int64_t j = j0 + k;
         if (j >= L) break;
         const int len = (int)(lk[k] & 0x3fffffffu), kind = (int)(lk[k] >> 30);
-        const int64_t P = (int64_t)(E & 0xffffffffull) - 1, hidx = (int64_t)(E >> 32);
+        int64_t P = (int64_t)(E & 0xffffffffull) - 1 + virt;
+        const int64_t hidx = (int64_t)(E >> 32);
+        if (leading && j <= fh) P = j == fh ? -1 : P + len_h0 + 2;
         const uint8_t *src = text + a[k];
         if (kind == 1) {
             if (P >= 0) norm[P] = '\n';
@@ -176,7 +202,7 @@ __global__ __launch_bounds__(FQ_THREADS) void rd_fa_emit_kernel(const uint8_t *_
                     sum->reserved = keep ? T : P + 1;                  // bytes of `norm` that belong to records
                 } else {
                     sum->n_records = m - 1;
-                    sum->consumed = a[k];
+                    sum->consumed = leading && hidx == 0 ? sum->begin : a[k];     // (the lines in front of the first header travel with it)
                     sum->reserved = P + 1;
                 }
             }

@@ -818,7 +818,7 @@ int rd_fasta_index(uint8_t *text, int64_t pad, int64_t end, const uint8_t *prev_
     hipLaunchKernelGGL(rd_fq_fill_kernel, dim3(p.fq.ntiles), dim3(FQ_THREADS), 0, st, text, sum, tiles, line_end);
     hipLaunchKernelGGL(rd_fa_init_kernel, dim3(1), dim3(FQ_THREADS), 0, st, sc);
     hipLaunchKernelGGL(rd_fa_lines_kernel, dim3(p.nblk), dim3(FQ_THREADS), 0, st, text, line_end, sum, info_a, info_k, blk, sc);
-    hipLaunchKernelGGL(rd_fa_base_kernel, dim3(1), dim3(FQ_THREADS), 0, st, blk, line_end, sum, sc, (int)final, norm_cap, cap_records);
+    hipLaunchKernelGGL(rd_fa_base_kernel, dim3(1), dim3(FQ_THREADS), 0, st, blk, line_end, sum, sc, (int)final, norm_cap, cap_records, norm, rec_tab, hdr_tab);
     hipLaunchKernelGGL(rd_fa_emit_kernel, dim3(p.nblk), dim3(FQ_THREADS), 0, st, text, info_a, info_k, blk, sum, sc, (int)final, norm, rec_tab, hdr_tab);
     RD_HIP(hipGetLastError());
     return RD_OK;

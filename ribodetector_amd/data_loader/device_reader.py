@@ -15,7 +15,7 @@ those of csrc/rd_host.cpp's reader (tests/test_gpu_device_reader.py holds the tw
 every line rstrip()-ed (a batch with trailing whitespace - CR LF files - is stripped on the device and indexed again), header must
 start with '@', last line may lack its newline, fewer than four blank trailing lines tolerated.
 RD_DEVICE_PARSE=0 keeps the host parser. FASTA: FastaIndexer - the batch is re-written as header / joined upper-case sequence
-(fastx_parser.py:39-55) by rd_fasta_index and indexed there; RD_DEVICE_FASTA=0 or a file that starts with sequence lines: the host parser.
+(fastx_parser.py:39-55) by rd_fasta_index and indexed there; RD_DEVICE_FASTA=0: the host parser.
 """
 import ctypes as C
 import os
@@ -34,8 +34,7 @@ PAD = 16 << 20                 # bytes in front of a batch's new text: room for 
 LINE_DIV = 4                   # the line table of a batch holds window / LINE_DIV lines (a FASTQ line of reads is >= 4 bytes; a batch of
                                # shorter lines overflows it, is framed again with a full-size table, and so are the batches chained to it)
 EVERY = 4096                   # one record-offset sample per EVERY records travels to the host with the summary: bounds a chunk's bytes
-FQ_ERRORS = {6: "sequence lines in front of the first FASTA header (RD_DEVICE_FASTA=0 reads such a file with the host parser)",
-             1: "FASTQ record does not start with '@'",
+FQ_ERRORS = {1: "FASTQ record does not start with '@'",
              2: "truncated FASTQ record at end of file (number of lines is not a multiple of 4)",
              3: "a record longer than %d bytes: set RD_DEVICE_PARSE=0 (the host parser has no record-size limit)" % PAD,
              4: "the batch before this one could not be framed", 5: "more lines than the line table holds"}
@@ -51,9 +50,8 @@ def device_ingest_kind(path, fmt=None):
     from . import fastx_parser as fx
     fmt = fmt or fx.get_seq_format(path)
     if not fmt.startswith("fq"):
-        # FASTA (round 5: rd_fasta_index): on the device when the file starts with a header line - sequence in front of the first
-        # header (the reference glues it to the first record) is the host reader's case; RD_DEVICE_FASTA=0 keeps the host parser
-        if os.environ.get("RD_DEVICE_FASTA", "1") == "0" or not _fasta_starts_with_header(path, fmt.endswith("gz")):
+        # FASTA (round 5: rd_fasta_index re-writes and indexes the batch on the device); RD_DEVICE_FASTA=0 keeps the host parser
+        if os.environ.get("RD_DEVICE_FASTA", "1") == "0":
             return None
     if fmt.endswith("gz"):
         if fx.device_inflate_wanted(path):
@@ -67,22 +65,6 @@ def device_ingest_kind(path, fmt=None):
 def device_parse_wanted(path, fmt=None):
     """FASTQ input, a GPU, and RD_DEVICE_PARSE != 0: plain files, BGZF files, and (RD_DEVICE_INFLATE=stream) single-stream .gz files"""
     return device_ingest_kind(path, fmt) is not None
-
-
-def _fasta_starts_with_header(path, gzipped):
-    """the first byte that is not whitespace is '>' (or there is none)"""
-    try:
-        if gzipped:
-            import gzip
-            with gzip.open(path, "rb") as fh:
-                head = fh.read(1 << 16)
-        else:
-            with open(path, "rb") as fh:
-                head = fh.read(1 << 16)
-    except (OSError, EOFError, ValueError):
-        return False                     # (the host reader reports what is wrong with the file)
-    head = head.lstrip()
-    return head[:1] == b">" if head else True
 
 
 class _StreamFallback(Exception):
@@ -281,7 +263,7 @@ class FastaIndexer(FastqIndexer):
             window = (end - start) + (PAD if prev is not None else 0)
             cap_lines = (window + 2) if full_table else (window // LINE_DIV_FA + 4096)
             cap_rec = cap_lines + 2
-            norm_cap = ((window + cap_lines + 64 + 255) // 256) * 256
+            norm_cap = ((window + cap_lines + 66 + 255) // 256) * 256
             b.text = text
             b.line_end = torch.empty(cap_lines, dtype=torch.int32, device=self.device)
             b.norm = torch.empty(norm_cap, dtype=torch.uint8, device=self.device)

@@ -743,21 +743,18 @@ def test_bgzf_view_on_fasta_gives_the_plain_files_answers(tmp_path):
 
 
 def test_device_ingest_choice_for_fasta(tmp_path, monkeypatch):
-    """which FASTA files the device reader (round 5: rd_fasta_index) would take: those that start with a header line; never without a
-    GPU, never with RD_DEVICE_FASTA=0 (the rest of the decision needs no GPU and is tested here)"""
-    import gzip
+    """which FASTA files the device reader (round 5: rd_fasta_index) would take: all of them when there is a GPU, none with
+    RD_DEVICE_FASTA=0 or RD_DEVICE_PARSE=0 (the decision needs no GPU and is tested here)"""
     from ribodetector_amd.data_loader import device_reader as dr
-    a, b, c = str(tmp_path / "a.fasta"), str(tmp_path / "b.fa"), str(tmp_path / "c.fasta.gz")
-    open(a, "wb").write(b"\n  \n>r1\nACGT\n")
-    open(b, "wb").write(b"ACGT\n>r1\nGG\n")
-    with gzip.open(c, "wb") as fh:
-        fh.write(b">r1\nACGT\n")
-    assert dr._fasta_starts_with_header(a, False) and not dr._fasta_starts_with_header(b, False) and dr._fasta_starts_with_header(c, True)
-    assert dr._fasta_starts_with_header(str(tmp_path / "missing.fa"), False) is False
+    a = str(tmp_path / "a.fasta")
+    open(a, "wb").write(b">r1\nACGT\n")
     import torch
     if not torch.cuda.is_available():
         assert dr.device_ingest_kind(a) is None
     monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
-    assert dr.device_ingest_kind(a) == "plain" and dr.device_ingest_kind(b) is None
+    assert dr.device_ingest_kind(a) == "plain"
     monkeypatch.setenv("RD_DEVICE_FASTA", "0")
+    assert dr.device_ingest_kind(a) is None
+    monkeypatch.delenv("RD_DEVICE_FASTA")
+    monkeypatch.setenv("RD_DEVICE_PARSE", "0")
     assert dr.device_ingest_kind(a) is None

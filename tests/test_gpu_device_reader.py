@@ -296,6 +296,9 @@ def _fuzz_fasta(rng, nrec):
     out = []
     if rng.random() < 0.2:
         out.append(nl * int(rng.integers(1, 3)) if rng.random() < 0.5 else b"  \t" + nl)      # blank lines in front of the first header
+    if rng.random() < 0.15:                                # sequence lines in front of the first header (the reference glues them to the
+        for _ in range(int(rng.integers(1, 4))):           # first record; a file without any header: one record with an empty header)
+            out.append(bytes(rng.choice(list(b"ACGTacgt"), int(rng.integers(1, 90))).astype(np.uint8)) + nl)
     for i in range(nrec):
         hdr = (b"  " if rng.random() < 0.05 else b"") + b">s%d" % i + (b" some text > here" if rng.random() < 0.3 else b"") + (b" \t" if rng.random() < 0.1 else b"")
         out.append(hdr + nl)
@@ -370,10 +373,13 @@ def test_fasta_large_file_and_what_stays_with_the_host(tmp_path):
     assert [len(d[3]) for d in dev] == [32768, 65536, 100000, 100000, 1696] and st["feeder"]["batches"] >= 2
     _same(_host_chunks(p, 100000, 1 << 15), dev)
     assert dr.device_ingest_kind(p) == "plain"
-    # sequence in front of the first header: the reference glues it to the first record - the host reader's case
+    # sequence in front of the first header: the reference glues it to the first record; no header at all: one record, empty header
     q = str(tmp_path / "lead.fasta")
-    open(q, "wb").write(b"ACGT\n>r1\nGG\n")
-    assert dr.device_ingest_kind(q) is None
+    open(q, "wb").write(b"ACGT\nac\n>r1\nGG\n>r2\nT\n")
+    assert dr.device_ingest_kind(q) == "plain" and _dev_chunks(q, 10)[0][0] == b">r1\nACGTACGG\n>r2\nT\n"
+    open(q, "wb").write(b"ACGT\n\nac\n")
+    assert _dev_chunks(q, 10)[0][0] == b"\nACGTAC\n"
+    _same(_host_chunks(q, 10), _dev_chunks(q, 10))
     os.environ["RD_DEVICE_FASTA"] = "0"
     try:
         assert dr.device_ingest_kind(p) is None
@@ -388,8 +394,6 @@ def test_fasta_single_stream_gz_and_a_record_longer_than_the_pad(tmp_path, small
     from ribodetector_amd.data_loader import device_reader as dr
     rng = np.random.default_rng(21)
     text = _fuzz_fasta(rng, 3000)
-    if not text.lstrip().startswith(b">"):
-        text = b">first\n" + text
     p, pz = str(tmp_path / "s.fasta"), str(tmp_path / "s.fasta.gz")
     open(p, "wb").write(text)
     with gzip.open(pz, "wb", compresslevel=6) as fh:
