@@ -25,6 +25,7 @@
 //   rd_encode_* / rd_pack_onehot       standalone encoder kernels (reference tensor layouts), HBM-bound
 //   rd_pair_fuse_kernel, rd_count_kernel
 //   rd_gz_*                            records of one label -> gzip (BGZF) members on the device (rd_deflate.hpp)
+//   rd_fq_* / rd_fa_*                  FASTQ records framed, FASTA batches re-written and indexed in HBM (rd_fastq_index.hpp, rd_fasta_index.hpp)
 #include <stdlib.h>
 #include "rd_common.hpp"
 #include "rd_prep.hpp"
