@@ -244,7 +244,7 @@ class FastqIndexer:
         return DeviceChunk(n, text, rs, so, sl, ready, total)
 
 
-LINE_DIV_FA = 16              # FASTA: the line table of a batch holds window / 16 lines (shorter lines on average: framed again, full size)
+LINE_DIV_FA = 8               # FASTA: the line table of a batch holds window / 8 lines (shorter lines on average - reads under 14 bases: framed again, full size)
 
 
 class FastaIndexer(FastqIndexer):

@@ -426,3 +426,17 @@ def test_fasta_share_keeps_its_last_record_without_a_sequence(tmp_path):
         dev = _dev_chunks(p, 100, byte_range=rng_)
         assert [h[0] for h in host] == [d[0] for d in dev] and all(np.array_equal(h[1], d[3]) for h, d in zip(host, dev)), rng_
     assert _dev_chunks(p, 100, byte_range=(0, cut))[0][0] == b">a\nAC\n>b\n\n" and _dev_chunks(p, 100)[0][0] == b">a\nAC\n>b\n\n>c\nGG\n"
+
+
+def test_fasta_short_lines_overflow_the_tables_and_are_framed_again(tmp_path, small_batches):
+    """FASTA whose lines average under 8 bytes (the line / record tables of a batch hold window / 8 entries): the batch - and what was
+    chained to it - is framed again with full-size tables"""
+    text = b"".join((b">\nA\n" if i % 3 else b">r%d\nac\nG\n" % i) for i in range(60000))
+    p = str(tmp_path / "tiny.fasta")
+    open(p, "wb").write(text)
+    for first, full in ((1 << 20, 1 << 20), (30000, 50000)):
+        small_batches(first, full)
+        st = {}
+        dev = _dev_chunks(p, 7000, stats=st)
+        assert st["indexer"]["reframed"] >= 1, st
+        _same(_host_chunks(p, 7000), dev)
