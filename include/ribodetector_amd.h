@@ -356,6 +356,29 @@ RD_API int rd_gz_stream_inflate(const uint8_t *comp, int64_t comp_bytes, int64_t
                          uint32_t first_start_bit, const rd_gzs_state *carry, int64_t carry_delta_bits, int32_t at_eof, const uint8_t *win_in,
                          uint8_t *win_out, uint8_t *text, int64_t text_cap, rd_gzs_state *state, void *workspace, size_t workspace_bytes, void *stream);
 
+/* Round 6 - a RANGE of such a stream decoded before the text in front of it is known: what lets the ranks of a node share ONE .gz
+ * (rank r decodes the compressed bytes [r S / W, (r + 1) S / W) on its own GPU while rank r - 1 still decodes its share). Replaces, for W > 1,
+ * the same gzip.open(path, 'rt') of reference data_loader/seq_encoder.py:21-39,75-87 that every rank would otherwise repeat (or one rank
+ * perform for all). rd_gz_range_decode is rd_gz_stream_inflate up to the window chain, which runs on SYMBOLS: sym_text [dev, 16-byte
+ * aligned] receives state->n_text 16-bit symbols - a byte, or 0x8000 | i = "byte i of the 32 KiB in front of the RANGE" - and map_out [dev]
+ * uint16[32768] the 32 KiB behind the batch in the same form: the range's MAP so far. Batches of a range chain through carry / map_in (both
+ * null for its first batch). first_start_bit = RD_GZS_SEARCH: the range starts inside the stream, its first block start is searched like
+ * every section's (state->reserved[0] = the bit found: it must equal the next_start the range before reports, nothing speculative is
+ * accepted); a rank whose range holds the gzip header passes the bit behind it. state: as above, crc / total_len / win_valid untouched.
+ * The ranks exchange their maps, apply them in rank order on the host (window[r + 1][i] = map[r][i] is a byte ? it : window[r][map[r][i] &
+ * 0x7fff]) and call rd_gz_range_resolve per batch: text [dev, 16-byte aligned] = the n symbols as bytes, window [dev] uint8[32768] the
+ * 32 KiB in front of the range of which the LAST win_valid bytes are text of the member (a marker in front of them: state->status =
+ * RD_GZS_WINDOW); state [dev, zeroed by the caller before the range's first call] accumulates crc / total_len over the calls (CRC-32 of the
+ * range's text alone: the ranks' values are combined like zlib's crc32_combine and compared with the member's trailer). */
+#define RD_GZS_SEARCH 0xfffffffeu
+RD_API size_t rd_gz_range_workspace_bytes(int64_t data_bytes, int32_t section_bytes, int32_t cap_syms, int64_t text_cap);
+RD_API int rd_gz_range_decode(const uint8_t *comp, int64_t comp_bytes, int64_t data_bytes, int64_t valid_bytes, int32_t section_bytes, int32_t cap_syms,
+                       uint32_t first_start_bit, const rd_gzs_state *carry, int64_t carry_delta_bits, int32_t at_eof, const uint16_t *map_in, uint16_t *map_out,
+                       uint16_t *sym_text, int64_t text_cap, rd_gzs_state *state, void *workspace, size_t workspace_bytes, void *stream);
+RD_API size_t rd_gz_range_resolve_workspace_bytes(int64_t n);
+RD_API int rd_gz_range_resolve(const uint16_t *sym_text, int64_t n, const uint8_t *window, uint32_t win_valid, uint8_t *text, rd_gzs_state *state, void *workspace,
+                        size_t workspace_bytes, void *stream);
+
 /* n bytes moved by a kernel on `stream` instead of a DMA engine: dst / src [dev, or pinned host memory mapped into the device]. The
  * feeder's H2D of file bytes and the writers' D2H of output bytes use it: an SDMA queue is shared in order with other streams' copies,
  * and a copy that waits for kernels (a label D2H behind two recurrence launches) held a 96 MB H2D back for 60-100 ms. workgroups (of 1,024 threads): 0 = 8 - few and fat, because a

@@ -26,6 +26,7 @@ SYMBOLS = [
     "rd_pack_onehot", "rd_profile_enable", "rd_profile_read", "rd_last_error", "rd_version",
     "rd_gz_workspace_bytes", "rd_gz_out_bound", "rd_gz_compress_selected", "rd_gz_eof_block", "rd_gz_inflate_members",
     "rd_fastq_index_workspace_bytes", "rd_fastq_index", "rd_fastq_gather", "rd_fastq_sample", "rd_fastq_strip_mark", "rd_fasta_index_workspace_bytes", "rd_fasta_index", "rd_fasta_gather", "rd_fasta_sample", "rd_select_workspace_bytes", "rd_select_pack", "rd_stream_create", "rd_stream_destroy", "rd_copy_bytes", "rd_gz_stream_workspace_bytes", "rd_gz_stream_inflate",
+    "rd_gz_range_workspace_bytes", "rd_gz_range_decode", "rd_gz_range_resolve_workspace_bytes", "rd_gz_range_resolve",
 ]
 
 
@@ -105,6 +106,12 @@ def lib():
     L.rd_gz_stream_workspace_bytes.argtypes = [i64, i32, i32, i64]
     L.rd_gz_stream_workspace_bytes.restype = sz
     L.rd_gz_stream_inflate.argtypes = [vp, i64, i64, i64, i32, i32, C.c_uint32, vp, i64, i32, vp, vp, vp, i64, vp, vp, sz, vp]
+    L.rd_gz_range_workspace_bytes.argtypes = [i64, i32, i32, i64]
+    L.rd_gz_range_workspace_bytes.restype = sz
+    L.rd_gz_range_decode.argtypes = [vp, i64, i64, i64, i32, i32, C.c_uint32, vp, i64, i32, vp, vp, vp, i64, vp, vp, sz, vp]
+    L.rd_gz_range_resolve_workspace_bytes.argtypes = [i64]
+    L.rd_gz_range_resolve_workspace_bytes.restype = sz
+    L.rd_gz_range_resolve.argtypes = [vp, i64, vp, C.c_uint32, vp, vp, vp, sz, vp]
     L.rd_profile_enable.argtypes = [vp, C.c_int]
     L.rd_profile_read.argtypes = [vp, C.POINTER(i64), C.POINTER(C.c_double)]
     L.rd_last_error.restype = C.c_char_p

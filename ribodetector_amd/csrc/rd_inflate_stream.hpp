@@ -23,6 +23,7 @@
 namespace {
 
 constexpr uint32_t GZS_NONE = 0xffffffffu;
+constexpr uint32_t GZS_SEARCH = 0xfffffffeu;     // first_start_bit of a RANGE that begins inside the stream: section 0 looks for its start like the others
 constexpr int GZS_WIN = 32768;
 constexpr uint32_t GZS_MARK = 0x8000u;
 enum { GZS_OK = 0, GZS_DECODE = 1, GZS_MISMATCH = 2, GZS_OVERFLOW = 3, GZS_NOSTOP = 4, GZS_WINDOW = 5, GZS_TEXTCAP = 6, GZS_NOSTART = 7 };
@@ -371,7 +372,7 @@ __global__ __launch_bounds__(64 * GZI_WAVES) __attribute__((amdgpu_waves_per_eu(
     }
     __syncthreads();
     for (int k = blockIdx.x * GZI_WAVES + wave; k <= nsec; k += gridDim.x * GZI_WAVES) {
-        if (k == 0) {
+        if (k == 0 && !(carry == nullptr && first_start == GZS_SEARCH)) {
             uint32_t st = first_start;
             if (carry) {
                 const int64_t v = (int64_t)carry->next_start - carry_delta_bits;
@@ -476,7 +477,7 @@ __global__ __launch_bounds__(64 * GZI_WAVES) __attribute__((amdgpu_waves_per_eu(
 // one thread: the sections that make up the batch's text, in order - up to the member's end; offsets; the batch's verdict
 __global__ void rd_gzs_scan_kernel(const GzsSec *__restrict__ sec, const uint32_t *__restrict__ found, int nsec, int at_eof, int64_t text_cap,
                                    int64_t *__restrict__ off, int32_t *__restrict__ wslot, int32_t *__restrict__ plist, GzsState *__restrict__ st,
-                                   const GzsState *__restrict__ carry) {
+                                   const GzsState *__restrict__ carry, int search0) {
     GzsState s;
     s.total_len = carry ? carry->total_len : 0;
     s.crc = carry ? carry->crc : 0;
@@ -486,11 +487,14 @@ __global__ void rd_gzs_scan_kernel(const GzsSec *__restrict__ sec, const uint32_
     int64_t o = 0;
     int slot = 0;
     bool done = false;
-    if (found[0] == GZS_NONE && s.status == GZS_OK) { s.status = GZS_NOSTART; s.bad_section = 0; }
+    // (search0: the batch opens a RANGE of the stream - the sections in front of its first block start belong to the range before)
+    if (!search0 && found[0] == GZS_NONE && s.status == GZS_OK) { s.status = GZS_NOSTART; s.bad_section = 0; }
+    uint32_t first = GZS_NONE;
     for (int k = 0; k < nsec; ++k) {
         off[k] = o;
         wslot[k] = slot;
         if (done || s.status != GZS_OK || found[k] == GZS_NONE) continue;
+        if (first == GZS_NONE) first = found[k];
         const GzsSec r = sec[k];
         if (r.status != GZS_OK) { s.status = r.status; s.bad_section = (uint32_t)k; continue; }
         o += r.n_syms;
@@ -501,6 +505,8 @@ __global__ void rd_gzs_scan_kernel(const GzsSec *__restrict__ sec, const uint32_
     }
     off[nsec] = o;
     wslot[nsec] = slot;
+    if (search0 && first == GZS_NONE && s.status == GZS_OK) { s.status = GZS_NOSTART; s.bad_section = 0; }
+    s.reserved[0] = first;                      // the bit this batch's text starts at (a range's first batch: what its search found)
     if (s.status == GZS_OK && o > text_cap) s.status = GZS_TEXTCAP;
     if (s.status == GZS_OK && !done) {
         // the stream goes on: the next batch starts where this batch's last section stopped = the start the extra section found
@@ -635,6 +641,147 @@ __global__ __launch_bounds__(256) void rd_gzs_resolve_kernel(const uint16_t *__r
     }
 }
 
+// ---- a RANGE of the stream decoded before the text in front of it is known (round 6: one .gz shared by the ranks of a node) -----------------
+// Rank r of W decodes the compressed bytes [r S / W, (r + 1) S / W) of ONE DEFLATE stream on its own GPU while rank r - 1 is still decoding
+// its share: the 32 KiB of text in front of the range are not known yet. Everything above works without them up to the window chain;
+// here the chain is run on SYMBOLS - a window entry is a byte or a marker "byte i of the window the RANGE started with" (markers compose:
+// a marker into the previous section's window is replaced by that window's entry, itself a byte or a marker) - and the batch's text is
+// written as 16-bit symbols of the same kind (sym_text). The last window of the range, in that form, is the range's MAP: the window
+// behind it as a function of the window in front of it, 64 KiB. The ranks exchange their maps, apply them in rank order (W - 1 gathers of
+// 32 Ki entries) and every rank then turns its symbols into bytes (rd_gzs_symtext_kernel): no rank ever waits for another one's decode.
+
+// one workgroup, the sections in order (the kernel above on 16-bit entries): windows16[slot + 1] = the 32 Ki symbols behind section `slot`,
+// windows16[0] = map_in (what the batch before left; null: the identity - the batch opens the range). Thread t owns entries [32 t, 32 t + 32);
+// ONE LDS window of 64 KiB: the new entries wait in registers for the barrier behind the reads of the old ones.
+__global__ __launch_bounds__(1024) void rd_gzs_symwin_kernel(const uint16_t *__restrict__ syms, int cap, const GzsSec *__restrict__ sec, const int32_t *__restrict__ plist,
+                                                             const int32_t *__restrict__ wslot, int nsec, const GzsState *__restrict__ st, const uint16_t *__restrict__ map_in,
+                                                             uint16_t *__restrict__ windows16, uint16_t *__restrict__ map_out) {
+    __shared__ __attribute__((aligned(16))) uint16_t W[GZS_WIN];
+    const int tid = threadIdx.x;
+    if (st->status != GZS_OK) return;
+    for (int i = tid; i < GZS_WIN; i += 1024) {
+        const uint16_t b = map_in ? map_in[i] : (uint16_t)(GZS_MARK | (uint32_t)i);
+        W[i] = b;
+        windows16[i] = b;
+    }
+    const int nslots = wslot[nsec];
+    u32x4 pre[4];                                   // the 32 symbols of this thread for the section about to be processed
+    auto fetch = [&](int slot) {
+        if (slot >= nslots) return;
+        const int k = plist[slot];
+        const int n = (int)sec[k].n_syms;
+        if (n < GZS_WIN) return;
+        const uint8_t *src = reinterpret_cast<const uint8_t *>(syms + (size_t)k * (size_t)cap + (size_t)(n - GZS_WIN) + (size_t)tid * 32);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) __builtin_memcpy(&pre[q], src + 16 * q, 16);
+    };
+    fetch(0);
+    __syncthreads();
+    for (int slot = 0; slot < nslots; ++slot) {
+        const int k = plist[slot];
+        const int n = (int)sec[k].n_syms;
+        uint32_t out[16];                           // this thread's 32 new entries, two per dword
+        if (n >= GZS_WIN) {
+            u32x4 now[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) now[q] = pre[q];
+            fetch(slot + 1);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t two = now[q][j];
+                    uint32_t lo = two & 0xffffu, hi = two >> 16;
+                    if (lo & GZS_MARK) lo = W[lo & 0x7fffu];
+                    if (hi & GZS_MARK) hi = W[hi & 0x7fffu];
+                    out[q * 4 + j] = lo | (hi << 16);
+                }
+            }
+        } else {
+            const uint16_t *sy = syms + (size_t)k * (size_t)cap;
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                const int i = tid * 32 + j;
+                uint32_t b;
+                if (i >= GZS_WIN - n) {
+                    b = sy[i - (GZS_WIN - n)];
+                    if (b & GZS_MARK) b = W[b & 0x7fffu];
+                } else {
+                    b = W[i + n];
+                }
+                out[j >> 1] = (j & 1) ? (out[j >> 1] | (b << 16)) : b;
+            }
+            fetch(slot + 1);
+        }
+        __syncthreads();                            // every read of the old window is over
+        uint16_t *gdst = windows16 + (size_t)(slot + 1) * GZS_WIN + tid * 32;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const u32x4 o = {out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]};
+            *reinterpret_cast<u32x4 *>(W + tid * 32 + 8 * q) = o;
+            *reinterpret_cast<u32x4 *>(gdst + 8 * q) = o;
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < GZS_WIN; i += 1024) map_out[i] = W[i];
+}
+
+// all sections in parallel: symbols -> symbols whose markers point into the RANGE's first window, at their offsets in the batch's text
+__global__ __launch_bounds__(256) void rd_gzs_resolve16_kernel(const uint16_t *__restrict__ syms, int cap, const GzsSec *__restrict__ sec, const uint32_t *__restrict__ found,
+                                                              const int64_t *__restrict__ off, const int32_t *__restrict__ wslot, int tiles_per_sec,
+                                                              const uint16_t *__restrict__ windows16, const GzsState *__restrict__ st, uint16_t *__restrict__ sym_text) {
+    const int k = blockIdx.x / tiles_per_sec, t = blockIdx.x % tiles_per_sec;
+    if (st->status != GZS_OK) return;
+    if (found[k] == GZS_NONE || wslot[k + 1] == wslot[k]) return;
+    const int n = (int)sec[k].n_syms;
+    const int i0 = t * GZS_RTILE;
+    if (i0 >= n) return;
+    const uint16_t *sy = syms + (size_t)k * (size_t)cap;
+    const uint16_t *W = windows16 + (size_t)wslot[k] * GZS_WIN;
+    uint16_t *dst = sym_text + off[k];
+    const int i1 = i0 + GZS_RTILE < n ? i0 + GZS_RTILE : n;
+    for (int i = i0 + (int)threadIdx.x; i < i1; i += 256) {
+        const uint32_t s = sy[i];
+        dst[i] = (s & GZS_MARK) ? W[s & 0x7fffu] : (uint16_t)s;
+    }
+}
+
+// the range's symbols -> bytes, once the window in front of the range is known (`valid` = how many of its LAST bytes are text of the member:
+// a marker in front of them is a distance too far back); st: n_text = n for the CRC kernels behind this one, status GZS_WINDOW on such a marker
+__global__ __launch_bounds__(256) void rd_gzs_symtext_kernel(const uint16_t *__restrict__ sym_text, int64_t n, const uint8_t *__restrict__ win, uint32_t valid,
+                                                            uint8_t *__restrict__ text, GzsState *__restrict__ st) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) st->n_text = n;
+    bool bad = false;
+    const uint32_t lowest = (uint32_t)GZS_WIN - (valid > (uint32_t)GZS_WIN ? (uint32_t)GZS_WIN : valid);
+    const int64_t n8 = n / 8;
+    for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < n8; g += (int64_t)gridDim.x * 256) {
+        const u32x4 v = *reinterpret_cast<const u32x4 *>(sym_text + g * 8);
+        uint32_t o[2] = {0u, 0u};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            uint32_t s = (v[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+            if (s & GZS_MARK) {
+                const uint32_t w = s & 0x7fffu;
+                bad = bad || w < lowest;
+                s = w < lowest ? 0u : win[w];
+            }
+            o[j >> 2] |= (s & 0xffu) << (8 * (j & 3));
+        }
+        *reinterpret_cast<uint2 *>(text + g * 8) = make_uint2(o[0], o[1]);
+    }
+    if (blockIdx.x == 0 && (int64_t)threadIdx.x < n - n8 * 8) {
+        const int64_t i = n8 * 8 + threadIdx.x;
+        uint32_t s = sym_text[i];
+        if (s & GZS_MARK) {
+            const uint32_t w = s & 0x7fffu;
+            bad = bad || w < lowest;
+            s = w < lowest ? 0u : win[w];
+        }
+        text[i] = (uint8_t)s;
+    }
+    if (__ballot(bad) && (threadIdx.x & 63) == 0) atomicMax(&st->status, (uint32_t)GZS_WINDOW);
+}
+
 // CRC-32 of every 64 KiB tile of the batch's text (one wave per tile, 1 KiB per lane): 16 bytes per load, four bytes per step
 // (slicing-by-4: four independent table reads per dword instead of four dependent ones). Round 5: the byte-at-a-time form - a
 // global byte load per lane and step, the lanes 1 KiB apart - took 2.1 ms per 300 MB batch.
@@ -718,7 +865,7 @@ struct GzsPlan {
     int nsec, tiles_per_sec, ctiles;
     size_t found_bytes, sec_bytes, off_bytes, wslot_bytes, plist_bytes, crc_bytes, windows_bytes, syms_bytes, total;
 };
-GzsPlan gzs_plan(int64_t data_bytes, int32_t section_bytes, int32_t cap_syms, int64_t text_cap) {
+GzsPlan gzs_plan(int64_t data_bytes, int32_t section_bytes, int32_t cap_syms, int64_t text_cap, bool sym = false) {
     GzsPlan p;
     p.nsec = (int)((data_bytes + section_bytes - 1) / section_bytes);
     if (p.nsec < 1) p.nsec = 1;
@@ -731,7 +878,7 @@ GzsPlan gzs_plan(int64_t data_bytes, int32_t section_bytes, int32_t cap_syms, in
     p.wslot_bytes = al((size_t)(p.nsec + 1) * 4);
     p.plist_bytes = al((size_t)(p.nsec + 1) * 4);
     p.crc_bytes = al((size_t)p.ctiles * 4);
-    p.windows_bytes = al((size_t)(p.nsec + 1) * GZS_WIN);
+    p.windows_bytes = al((size_t)(p.nsec + 1) * GZS_WIN * (sym ? 2 : 1));      // (range mode: 16-bit entries)
     p.syms_bytes = al((size_t)p.nsec * (size_t)cap_syms * 2);
     p.total = p.found_bytes + p.sec_bytes + p.off_bytes + p.wslot_bytes + p.plist_bytes + p.crc_bytes + p.windows_bytes + p.syms_bytes;
     return p;

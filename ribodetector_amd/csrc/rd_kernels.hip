@@ -682,12 +682,76 @@ int rd_gz_stream_inflate(const uint8_t *comp, int64_t comp_bytes, int64_t data_b
                        p.nsec, first_start_bit, C, carry_delta_bits, found);
     hipLaunchKernelGGL(rd_gzs_decode_kernel, dim3((unsigned)((p.nsec + GZI_WAVES - 1) / GZI_WAVES)), dim3(64 * GZI_WAVES), 0, st, comp, comp_bytes, end_bits, p.nsec, found,
                        syms, (int)cap_syms, sec);
-    hipLaunchKernelGGL(rd_gzs_scan_kernel, dim3(1), dim3(1), 0, st, sec, found, p.nsec, (int)at_eof, text_cap, off, wslot, plist, S, C);
+    hipLaunchKernelGGL(rd_gzs_scan_kernel, dim3(1), dim3(1), 0, st, sec, found, p.nsec, (int)at_eof, text_cap, off, wslot, plist, S, C, 0);
     hipLaunchKernelGGL(rd_gzs_window_kernel, dim3(1), dim3(1024), 0, st, syms, (int)cap_syms, sec, plist, wslot, p.nsec, S, win_in, windows, win_out);
     hipLaunchKernelGGL(rd_gzs_resolve_kernel, dim3((unsigned)(p.nsec * p.tiles_per_sec)), dim3(256), 0, st, syms, (int)cap_syms, sec, found, off, wslot, p.tiles_per_sec,
                        windows, S, text);
     hipLaunchKernelGGL(rd_gzs_crc_kernel, dim3((unsigned)((p.ctiles + 3) / 4)), dim3(256), 0, st, text, S, tcrc);
     hipLaunchKernelGGL(rd_gzs_fold_kernel, dim3(1), dim3(64), 0, st, tcrc, S);
+    RD_HIP(hipGetLastError());
+    return RD_OK;
+}
+
+// ---- a range of one DEFLATE stream: symbols first, bytes once the window in front of the range is known (rd_inflate_stream.hpp) -----------
+size_t rd_gz_range_workspace_bytes(int64_t data_bytes, int32_t section_bytes, int32_t cap_syms, int64_t text_cap) {
+    if (data_bytes < 0 || section_bytes < 1024 || cap_syms < 1024 || text_cap < 0) return 0;
+    return gzs_plan(data_bytes, section_bytes, cap_syms, text_cap, true).total;
+}
+
+int rd_gz_range_decode(const uint8_t *comp, int64_t comp_bytes, int64_t data_bytes, int64_t valid_bytes, int32_t section_bytes, int32_t cap_syms,
+                       uint32_t first_start_bit, const rd_gzs_state *carry, int64_t carry_delta_bits, int32_t at_eof, const uint16_t *map_in, uint16_t *map_out,
+                       uint16_t *sym_text, int64_t text_cap, rd_gzs_state *state, void *workspace, size_t workspace_bytes, void *stream) {
+    if (!comp || !map_out || !sym_text || !state || !workspace) RD_FAIL(RD_E_INVALID, "rd_gz_range_decode: null pointer");
+    if (((uintptr_t)comp & 3) || ((uintptr_t)workspace & 255) || ((uintptr_t)sym_text & 15))
+        RD_FAIL(RD_E_INVALID, "rd_gz_range_decode: comp must be 4-byte aligned, sym_text 16-byte aligned, workspace 256-byte aligned");
+    if (data_bytes <= 0 || valid_bytes < data_bytes || comp_bytes < valid_bytes || valid_bytes >= (1LL << 28) || section_bytes < 1024 || (section_bytes & 3) ||
+        cap_syms < 1024 || text_cap < 0)
+        RD_FAIL(RD_E_INVALID, "rd_gz_range_decode: bad sizes (a batch holds < 256 MiB of compressed bytes)");
+    if ((carry == nullptr) != (map_in == nullptr)) RD_FAIL(RD_E_INVALID, "rd_gz_range_decode: carry and map_in go together (both null: the range's first batch)");
+    const GzsPlan p = gzs_plan(data_bytes, section_bytes, cap_syms, text_cap, true);
+    if (workspace_bytes < p.total) RD_FAIL(RD_E_WORKSPACE, "rd_gz_range_decode: workspace too small: %zu < %zu", workspace_bytes, p.total);
+    char *w = (char *)workspace;
+    uint32_t *found = (uint32_t *)w; w += p.found_bytes;
+    GzsSec *sec = (GzsSec *)w; w += p.sec_bytes;
+    int64_t *off = (int64_t *)w; w += p.off_bytes;
+    int32_t *wslot = (int32_t *)w; w += p.wslot_bytes;
+    int32_t *plist = (int32_t *)w; w += p.plist_bytes;
+    w += p.crc_bytes;
+    uint16_t *windows16 = (uint16_t *)w; w += p.windows_bytes;
+    uint16_t *syms = (uint16_t *)w;
+    hipStream_t st = (hipStream_t)stream;
+    const uint32_t end_bits = (uint32_t)(valid_bytes * 8), sec_bits = (uint32_t)section_bytes * 8u;
+    GzsState *S = (GzsState *)state;
+    const GzsState *C = (const GzsState *)carry;
+    const int search0 = (C == nullptr && first_start_bit == GZS_SEARCH) ? 1 : 0;
+    hipLaunchKernelGGL(rd_gzs_search_kernel, dim3((unsigned)((p.nsec + 1 + GZI_WAVES - 1) / GZI_WAVES)), dim3(64 * GZI_WAVES), 0, st, comp, comp_bytes, end_bits, sec_bits,
+                       p.nsec, first_start_bit, C, carry_delta_bits, found);
+    hipLaunchKernelGGL(rd_gzs_decode_kernel, dim3((unsigned)((p.nsec + GZI_WAVES - 1) / GZI_WAVES)), dim3(64 * GZI_WAVES), 0, st, comp, comp_bytes, end_bits, p.nsec, found,
+                       syms, (int)cap_syms, sec);
+    hipLaunchKernelGGL(rd_gzs_scan_kernel, dim3(1), dim3(1), 0, st, sec, found, p.nsec, (int)at_eof, text_cap, off, wslot, plist, S, C, search0);
+    hipLaunchKernelGGL(rd_gzs_symwin_kernel, dim3(1), dim3(1024), 0, st, syms, (int)cap_syms, sec, plist, wslot, p.nsec, S, map_in, windows16, map_out);
+    hipLaunchKernelGGL(rd_gzs_resolve16_kernel, dim3((unsigned)(p.nsec * p.tiles_per_sec)), dim3(256), 0, st, syms, (int)cap_syms, sec, found, off, wslot, p.tiles_per_sec,
+                       windows16, S, sym_text);
+    RD_HIP(hipGetLastError());
+    return RD_OK;
+}
+
+size_t rd_gz_range_resolve_workspace_bytes(int64_t n) { return n < 0 ? 0 : ((size_t)(n / GZS_CTILE + 2) * 4 + 255) / 256 * 256; }
+
+int rd_gz_range_resolve(const uint16_t *sym_text, int64_t n, const uint8_t *window, uint32_t win_valid, uint8_t *text, rd_gzs_state *state, void *workspace,
+                        size_t workspace_bytes, void *stream) {
+    if (n < 0 || !state || (n > 0 && (!sym_text || !text || !workspace))) RD_FAIL(RD_E_INVALID, "rd_gz_range_resolve: bad argument");
+    if (win_valid > 0 && !window) RD_FAIL(RD_E_INVALID, "rd_gz_range_resolve: win_valid > 0 needs a window");
+    if (((uintptr_t)sym_text & 15) || ((uintptr_t)text & 15)) RD_FAIL(RD_E_INVALID, "rd_gz_range_resolve: sym_text and text must be 16-byte aligned");
+    if (workspace_bytes < rd_gz_range_resolve_workspace_bytes(n)) RD_FAIL(RD_E_WORKSPACE, "rd_gz_range_resolve: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    GzsState *S = (GzsState *)state;
+    int64_t grid = n / (8 * 256 * 4) + 1;
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(rd_gzs_symtext_kernel, dim3((unsigned)grid), dim3(256), 0, st, sym_text, n, window, win_valid, text, S);
+    const int ctiles = (int)((n + GZS_CTILE - 1) / GZS_CTILE) + 1;
+    hipLaunchKernelGGL(rd_gzs_crc_kernel, dim3((unsigned)((ctiles + 3) / 4)), dim3(256), 0, st, text, S, (uint32_t *)workspace);
+    hipLaunchKernelGGL(rd_gzs_fold_kernel, dim3(1), dim3(64), 0, st, (const uint32_t *)workspace, S);
     RD_HIP(hipGetLastError());
     return RD_OK;
 }

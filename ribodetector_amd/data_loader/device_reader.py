@@ -808,6 +808,10 @@ def get_seq_chunks_device(seq_file, chunk_size=1048576, byte_range=None, first_c
     compressed = "stream" if kind == "stream" else fx.get_seq_format(seq_file).endswith("gz")
     span = None
     keep_tail = False            # a share that ends before the file does (FASTA: its last record counts even without a sequence)
+    from . import gz_shard
+    resident = byte_range if isinstance(byte_range, gz_shard.ResidentRange) else None
+    if resident is not None:     # a rank's share of a single-stream .gz, decoded and framed already (gz_shard.prepare)
+        byte_range = None
     if isinstance(byte_range, fx.BgzfRange):
         a, b = byte_range
         c0, c1, drop = byte_range.view.file_span(a, b)
@@ -815,8 +819,12 @@ def get_seq_chunks_device(seq_file, chunk_size=1048576, byte_range=None, first_c
         span, byte_range = (c0, c1, drop, b - a), None
     elif byte_range is not None:
         keep_tail = int(byte_range[1]) < os.path.getsize(seq_file)
-    feeder = DeviceFeeder(seq_file, device, compressed, span=span, byte_range=byte_range, fasta=fx.get_seq_format(seq_file).startswith("fa"),
-                          keep_empty_tail=keep_tail)
+    if resident is not None:
+        feeder = gz_shard.ResidentFeeder(resident)
+    else:
+        feeder = DeviceFeeder(seq_file, device, compressed, span=span, byte_range=byte_range, fasta=fx.get_seq_format(seq_file).startswith("fa"),
+                              keep_empty_tail=keep_tail)
+    skip_left = resident.skip if resident is not None else 0      # (mate files: the records in front of the ranks' common cut went to the rank before)
     want = chunk_size if not first_chunk else max(1, min(int(first_chunk), chunk_size))
     sched = list(schedule) if schedule else None
     pend = deque()                   # [batch, next record]
@@ -838,9 +846,11 @@ def get_seq_chunks_device(seq_file, chunk_size=1048576, byte_range=None, first_c
                 if b.status:             # a malformed record: the chunks in front of it are delivered, then the error
                     err, eof, framing = ValueError(FQ_ERRORS.get(b.status, "FASTQ framing error %d" % b.status)), True, True
                     good = min(b.n, b.bad_record) if b.status == 1 and b.bad_record >= 0 else (b.n if b.status == 2 else 0)
-                if good > 0:
-                    pend.append([b, 0, good])
-                    avail += good
+                drop = min(skip_left, good)
+                skip_left -= drop
+                if good > drop:
+                    pend.append([b, drop, good])
+                    avail += good - drop
             if avail == 0 or (framing and avail < want):
                 # (the host reader meets a malformed record while it fills a chunk and fails that call: the records it had gathered for
                 # THAT chunk are not delivered, csrc/rd_host.cpp rd_reader_next - the same chunks come out of both readers)

@@ -482,22 +482,38 @@ class Predictor:
                 bgzf = False
             else:
                 views = [fx.BgzfView(p, index=i) for p, i in zip(self.input, idx[0])]
-        self.sharded_parse = self.multi and (plain or bgzf)
+        def all_gather(obj):
+            import torch.distributed as dist
+            out = [None] * self.world
+            dist.all_gather_object(out, obj)
+            return out
+        # ... and single-stream .gz inputs (what sequencers write; round 6): every rank decodes its own compressed range on its own GPU -
+        # symbols first, bytes once the ranks have exchanged the 64 KiB maps of their ranges (data_loader/gz_shard.py). What the device
+        # decoder does not take (or RD_GZ_SHARD=0) stays with the one-decode path below.
+        gzr = None
+        if (self.multi and not plain and not bgzf and os.environ.get("RD_GZ_SHARD", "1") != "0"
+                and all(dr.device_ingest_kind(p) == "stream" for p in self.input)):
+            from .data_loader import gz_shard
+            t0 = time.perf_counter()
+            gzr, why = gz_shard.prepare(self.input, self.rank, self.world, self.device, [fx.get_seq_format(p).startswith("fa") for p in self.input],
+                                        all_gather, rdist.shift_to_prev)
+            if gzr is None and self.rank == 0:
+                self.logger.info('{}: one rank decodes'.format(why))
+            self.gz_shard_s = time.perf_counter() - t0
+        self.sharded_parse = self.multi and (plain or bgzf or gzr is not None)
         self.bytes_parsed = None
         if self.sharded_parse:
-            import torch.distributed as dist
-
-            def all_gather(obj):
-                out = [None] * self.world
-                dist.all_gather_object(out, obj)
-                return out
-            self._ranges = fx.plan_ranges(self.input, self.rank, self.world, all_gather, views=views)
+            if gzr is not None:
+                self._ranges = gzr
+            else:
+                self._ranges = fx.plan_ranges(self.input, self.rank, self.world, all_gather, views=views)
             self.bytes_parsed = [e - b for b, e in self._ranges]
             totals = [v.size for v in views] if views else [fx.file_info(p)[0] for p in self.input]
             for r, bp in enumerate(all_gather(self.bytes_parsed)):
                 if self.rank == 0:
                     self.logger.info('Rank {} parses {} bytes of {}{}'.format(
-                        r, ", ".join(str(b) for b in bp), ", ".join(str(t) for t in totals), " (decompressed; BGZF members)" if bgzf else ""))
+                        r, ", ".join(str(b) for b in bp), ", ".join(str(t) for t in totals),
+                        " (decompressed; BGZF members)" if bgzf else " (compressed; ranges of one DEFLATE stream)" if gzr is not None else ""))
         def part(path):
             if not self.sharded_parse:
                 return path

@@ -158,3 +158,26 @@ def reduce_counts(counts, group=None):
         else:
             dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
     return counts
+
+
+def shift_to_prev(buf, group=None):
+    """every rank r > 0 sends `buf` (uint8 tensor, device or host; None = nothing) to rank r - 1; returns what rank r + 1 sent (uint8
+    tensor - device memory under nccl, host memory under gloo - or None). The mate records in front of a rank's common cut travel this
+    way to the rank before (data_loader/gz_shard.py): one all-gather of the sizes, then one send / receive pair per boundary."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    n = int(buf.numel()) if buf is not None else 0
+    sizes = all_gather_sizes([n], group=group)[:, 0].tolist()
+    on_host = dist.get_backend(group) == "gloo"
+    ops, recv, keep = [], None, None
+    if rank > 0 and n > 0:
+        keep = buf.cpu().contiguous() if on_host else buf.contiguous()
+        ops.append(dist.P2POp(dist.isend, keep, rank - 1, group))
+    if rank + 1 < world and sizes[rank + 1] > 0:
+        recv = torch.empty(int(sizes[rank + 1]), dtype=torch.uint8, device="cpu" if on_host else torch.device("cuda", torch.cuda.current_device()))
+        ops.append(dist.P2POp(dist.irecv, recv, rank + 1, group))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    return recv

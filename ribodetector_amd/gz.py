@@ -364,3 +364,108 @@ class DeviceStreamGunzip:
         d = h.view(np.uint32)
         return {"total_len": int(q[0]), "n_text": int(h.view(np.int64)[1]), "crc": int(d[4]), "status": int(d[5]), "final": int(d[6]), "end_bit": int(d[7]),
                 "next_start": int(d[8]), "win_valid": int(d[9]), "bad_section": int(d[10]), "n_sections": int(d[11])}
+
+
+# ---- a RANGE of one DEFLATE stream: every rank of a node decodes its own part of ONE .gz (csrc/rd_inflate_stream.hpp, round 6) ---------
+
+GZS_SEARCH = 0xfffffffe        # first_start_bit of a range that begins inside the stream (include/ribodetector_amd.h RD_GZS_SEARCH)
+
+
+class DeviceRangeGunzip(DeviceStreamGunzip):
+    """The batches of a RANGE of a gzip member through C ABI rd_gz_range_decode: as DeviceStreamGunzip, but the 32 KiB in front of the
+    range need not be known - a batch's text comes back as 16-bit symbols (a byte, or 0x8000 | i = byte i of the window in front of the
+    RANGE) and `self.map` is the window behind the batches so far in the same form. resolve() turns a batch's symbols into bytes once
+    the window is known (data_loader/gz_shard.py: the ranks exchange their maps)."""
+
+    def __init__(self, device, stream):
+        super().__init__(device, stream)
+        self.map = None
+        self._rws = None
+
+    def submit(self, src, valid_bytes, data_bytes, first_start_bit, at_eof):
+        lib = N.lib()
+        cap_syms = self.SECTION * self.CAP_RATIO
+        text_cap = self.text_cap(data_bytes)
+        with torch.cuda.device(self.device), torch.cuda.stream(self.stream):
+            comp = torch.empty(((valid_bytes + 4096 + 255) // 256) * 256, dtype=torch.uint8, device=self.device)
+            N.copy_bytes(comp, src, valid_bytes, self.stream)
+            comp[valid_bytes:valid_bytes + 4096].zero_()
+            sym = torch.empty(text_cap, dtype=torch.int16, device=self.device)
+            need = int(lib.rd_gz_range_workspace_bytes(data_bytes, self.SECTION, cap_syms, text_cap))
+            if self._ws is None or self._ws.numel() < need:
+                self._ws = None
+                self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            state = torch.zeros(8, dtype=torch.int64, device=self.device)
+            map_out = torch.empty(32768, dtype=torch.int16, device=self.device)
+            N.check(lib.rd_gz_range_decode(N.ptr(comp), comp.numel(), int(data_bytes), int(valid_bytes), self.SECTION, cap_syms,
+                                           int(first_start_bit) & 0xffffffff, N.ptr(self.carry), int(self._delta_bits) if self.carry is not None else 0,
+                                           1 if at_eof else 0, N.ptr(self.map), N.ptr(map_out), N.ptr(sym), text_cap, N.ptr(state),
+                                           N.ptr(self._ws), self._ws.numel(), C.c_void_p(self.stream.cuda_stream)), "rd_gz_range_decode")
+            host = torch.empty(64, dtype=torch.uint8, pin_memory=True)
+            N.copy_bytes(host, state.view(torch.uint8), 64, self.stream, workgroups=1)
+            ev = N.new_event()
+            ev.record(self.stream)
+        self.carry, self.map, self._delta_bits = state, map_out, int(data_bytes) * 8
+        return {"host": host, "event": ev, "keep": (comp, state, map_out), "sym": sym}
+
+    @staticmethod
+    def finish(ticket):
+        import numpy as np
+        r = DeviceStreamGunzip.finish(ticket)
+        r["first_start"] = int(ticket["host"].numpy().view(np.uint64)[6])       # the bit the batch's text starts at (0xffffffff: none)
+        return r
+
+    def resolve(self, sym, n, window, win_valid, text_out, rstate):
+        """text_out[:n] = the n symbols of `sym` as bytes; window: device uint8[32768] (None when win_valid == 0: the member starts with
+        the range); rstate: device int64[8], zeroed before the range's first batch - accumulates the CRC-32 and length of the range's
+        text; a marker in front of the window's valid bytes sets its status word"""
+        lib = N.lib()
+        with torch.cuda.device(self.device), torch.cuda.stream(self.stream):
+            need = int(lib.rd_gz_range_resolve_workspace_bytes(n))
+            if self._rws is None or self._rws.numel() < need:
+                self._rws = None
+                self._rws = torch.empty(max(need, 1 << 16), dtype=torch.uint8, device=self.device)
+            N.check(lib.rd_gz_range_resolve(N.ptr(sym), int(n), N.ptr(window), int(win_valid), N.ptr(text_out), N.ptr(rstate), N.ptr(self._rws),
+                                            self._rws.numel(), C.c_void_p(self.stream.cuda_stream)), "rd_gz_range_resolve")
+
+
+def apply_map(m, window):
+    """the window behind a range = its map applied to the window in front of it (numpy: m uint16[32768], window uint8[32768])"""
+    import numpy as np
+    m = np.asarray(m).view(np.uint16)
+    return np.where(m & 0x8000, window[m & 0x7fff], (m & 0xff).astype(np.uint8)).astype(np.uint8)
+
+
+def crc32_combine(crc1, crc2, len2):
+    """CRC-32 of A || B from crc32(A), crc32(B), len(B) - zlib's crc32_combine (it is not exposed by Python's zlib module)"""
+    if len2 <= 0:
+        return crc1 & 0xffffffff
+
+    def times(mat, vec):
+        s, i = 0, 0
+        while vec:
+            if vec & 1:
+                s ^= mat[i]
+            vec >>= 1
+            i += 1
+        return s
+
+    def square(mat):
+        return [times(mat, mat[n]) for n in range(32)]
+    odd = [0xedb88320] + [1 << n for n in range(31)]       # the operator for one zero bit
+    even = square(odd)                                      # two
+    odd = square(even)                                      # four
+    while True:
+        even = square(odd)                                  # first pass: one zero byte
+        if len2 & 1:
+            crc1 = times(even, crc1)
+        len2 >>= 1
+        if not len2:
+            break
+        odd = square(even)
+        if len2 & 1:
+            crc1 = times(odd, crc1)
+        len2 >>= 1
+        if not len2:
+            break
+    return (crc1 ^ crc2) & 0xffffffff
