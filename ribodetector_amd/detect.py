@@ -500,6 +500,9 @@ class Predictor:
             if gzr is None and self.rank == 0:
                 self.logger.info('{}: one rank decodes'.format(why))
             self.gz_shard_s = time.perf_counter() - t0
+            if gzr is not None:                      # (every rank says so itself: the line is what shows that no rank read another's bytes)
+                self.logger.info('Rank {} decoded {} compressed bytes into {} bytes of text on {} in {:.2f} s'.format(
+                    self.rank, ", ".join(str(x.comp_bytes) for x in gzr), ", ".join(str(x.stats["text_bytes"]) for x in gzr), self.device, self.gz_shard_s))
         self.sharded_parse = self.multi and (plain or bgzf or gzr is not None)
         self.bytes_parsed = None
         if self.sharded_parse:

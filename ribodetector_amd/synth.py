@@ -72,24 +72,26 @@ def write_fastq_realistic(path, arena, offsets, mate=1, seed=0):
     """4-line FASTQ shaped like sequencer output for the host-side benchmarks: Illumina-style headers
     (@A00123:45:HXXXXXXX:lane:tile:x:y mate:N:0:index) and NovaSeq-like binned qualities (F 90 %, ':' 6 %, ',' 3 %, '#' 1 %).
     gzip compresses it ~4.8x (the constant-quality files of write_fastq: ~6x), which is what real FASTQ does.
-    Fixed-length reads only (vectorised)."""
+    Reads of any lengths."""
     import gzip
     n = len(offsets) - 1
-    L = int(offsets[1] - offsets[0]) if n else 0
-    assert n == 0 or (np.diff(offsets) == L).all(), "write_fastq_realistic: fixed-length reads only"
     rng = np.random.default_rng(seed)
-    qual = np.frombuffer(b"F:,#", dtype=np.uint8)[rng.choice(4, size=n * L, p=[0.90, 0.06, 0.03, 0.01])].reshape(n, L)
-    seq = np.asarray(arena, dtype=np.uint8).reshape(n, L)
+    offsets = np.asarray(offsets, dtype=np.int64)
+    total = int(offsets[-1] - offsets[0]) if n else 0
+    qual = np.frombuffer(b"F:,#", dtype=np.uint8)[rng.choice(4, size=total, p=[0.90, 0.06, 0.03, 0.01])].tobytes()
+    seq = np.asarray(arena, dtype=np.uint8).tobytes()
+    base = int(offsets[0]) if n else 0
     op = gzip.open if str(path).endswith("gz") else open
     with op(path, "wb") as fh:
         step = 100000
         for s in range(0, n, step):
             parts = []
             for i in range(s, min(n, s + step)):
+                a, b = int(offsets[i]), int(offsets[i + 1])
                 parts.append(b"@A00123:45:HXXXXXXX:1:%d:%d:%d %d:N:0:ACGTACGT\n" % (1101 + i // 400000, 1000 + i % 30000, 1000 + i // 7, mate))
-                parts.append(seq[i].tobytes())
+                parts.append(seq[a:b])
                 parts.append(b"\n+\n")
-                parts.append(qual[i].tobytes())
+                parts.append(qual[a - base:b - base])
                 parts.append(b"\n")
             fh.write(b"".join(parts))
 

@@ -585,3 +585,110 @@ def test_cli_bgzf_fasta_is_sharded_across_ranks(tmp_path):
         rows = re.findall(r"Rank (\d) parses (\d+) bytes of (\d+) \(decompressed; BGZF members\)", r.stdout + r.stderr)
         assert len(rows) == world and sum(int(x[1]) for x in rows) == os.path.getsize(str(tmp_path / "p.fasta"))
     assert p.num_read > 0
+
+
+def _torchrun(world, args, env_extra=None, timeout=900):
+    import socket
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, RD_DIST_BACKEND="gloo", RD_LOCAL_DEVICE="0", PYTHONPATH=root, **(env_extra or {}))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "-m", "ribodetector_amd.detect"] + list(args)
+    r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=timeout)
+    return r, port
+
+
+def _seqlike_fastq(path, n, seed, mate, lengths=(60, 150)):
+    """FASTQ with Illumina-like headers and binned qualities as ONE gzip member (zlib level 6: what bcl2fastq / most pipelines write)"""
+    from ribodetector_amd import synth
+    arena, off, _ = synth.reads_numpy(n, lengths, seed=seed, rrna_frac=0.3)
+    plain = path[:-3]
+    synth.write_fastq_realistic(plain, arena, off, mate=mate, seed=seed)
+    with open(plain, "rb") as fi, open(path, "wb") as fo:
+        fo.write(gzip.compress(fi.read(), 6))
+    return plain
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_cli_single_stream_gz_is_shared_by_the_ranks(tmp_path, world):
+    """round 6: ONE single-stream .gz per mate, W ranks: every rank decodes its own compressed range on its GPU (gz_shard), frames,
+    classifies and writes its part - no shared-memory decode, no label gather. Same files as one process; every rank reports its own
+    range; the ranges add up to the files."""
+    import re
+    from ribodetector_amd import detect
+    n = 80000
+    i1, i2 = str(tmp_path / "r_1.fq.gz"), str(tmp_path / "r_2.fq.gz")
+    _seqlike_fastq(i1, n, 71, 1)
+    _seqlike_fastq(i2, n, 72, 2, lengths=(40, 120))           # (shorter mates: the two files' compressed positions drift apart)
+    one = [str(tmp_path / x) for x in ("a1.fq", "a2.fq.gz", "ar1.fq.gz", "ar2.fq")]
+    p = detect.main(["-l", "120", "-i", i1, i2, "-o", *one[:2], "-r", *one[2:], "-e", "both", "--chunk_size", "1", "-m", "3"])
+    assert p.num_read == n and all(v["path"] == "device" for v in p.ingest.values())
+    two = [str(tmp_path / x) for x in ("b1.fq", "b2.fq.gz", "br1.fq.gz", "br2.fq")]
+    r, port = _torchrun(world, ["-l", "120", "-i", i1, i2, "-o", *two[:2], "-r", *two[2:], "-e", "both", "--chunk_size", "1", "-m", "3"],
+                        {"RD_GZ_SHARD_MIN": "65536"})
+    text = r.stdout + r.stderr
+    assert r.returncode == 0, text[-3000:]
+    for a, b in zip(one, two):
+        assert _read(a) == _read(b) and len(_read(a)) > 0
+    assert _read(one[0] + ".unclassified.gz") == _read(two[0] + ".unclassified.gz")
+    assert not [f for f in os.listdir(tmp_path) if ".part" in f or ".joining" in f]
+    assert not [f for f in os.listdir("/dev/shm") if f.startswith("rd_%d_" % port)]
+    assert "one rank decodes" not in text
+    rows = re.findall(r"Rank (\d) parses (\d+), (\d+) bytes of (\d+), (\d+) \(compressed; ranges of one DEFLATE stream\)", text)
+    assert len(rows) == world
+    assert sum(int(x[1]) for x in rows) == os.path.getsize(i1) and sum(int(x[2]) for x in rows) == os.path.getsize(i2)
+    assert len(set(re.findall(r"Rank (\d) decoded \d+, \d+ compressed bytes into", text))) == world      # every rank decoded for itself
+
+
+def test_cli_single_stream_gz_single_end_fasta_and_refusals(tmp_path):
+    """single-end FASTQ and FASTA .gz under 3 ranks through the ranges; a lane-merged file (two members) is refused by every rank and read
+    by the one-decode path with the same result; a cut file ends the job with zlib's message"""
+    from ribodetector_amd import detect, synth
+    n = 60000
+    i1 = str(tmp_path / "s.fq.gz")
+    plain = _seqlike_fastq(i1, n, 81, 1)
+    one = [str(tmp_path / "a.fq.gz"), str(tmp_path / "ar.fq")]
+    p = detect.main(["-l", "100", "-i", i1, "-o", one[0], "-r", one[1], "--chunk_size", "1", "-m", "3"])
+    two = [str(tmp_path / "b.fq.gz"), str(tmp_path / "br.fq")]
+    r, _ = _torchrun(3, ["-l", "100", "-i", i1, "-o", two[0], "-r", two[1], "--chunk_size", "1", "-m", "3"], {"RD_GZ_SHARD_MIN": "65536"})
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert "ranges of one DEFLATE stream" in r.stdout + r.stderr
+    assert [_read(x) for x in one] == [_read(x) for x in two] and p.num_read == n
+    # FASTA, multi-line
+    a, o, _ = synth.reads_numpy(30000, (40, 260), seed=61, rrna_frac=0.3)
+    b = a.tobytes()
+    fa = str(tmp_path / "p.fasta.gz")
+    with gzip.open(fa, "wb", compresslevel=6) as fh:
+        for i in range(30000):
+            s = b[o[i]:o[i + 1]]
+            fh.write(b">seq%d some text\n" % i + b"".join(s[k:k + 70] + b"\n" for k in range(0, len(s), 70)))
+    one = [str(tmp_path / "fa.non.fa"), str(tmp_path / "fa.rr.fa.gz")]
+    detect.main(["-l", "100", "-i", fa, "-o", one[0], "-r", one[1], "--chunk_size", "1", "-m", "3"])
+    two = [str(tmp_path / "fb.non.fa"), str(tmp_path / "fb.rr.fa.gz")]
+    r, _ = _torchrun(3, ["-l", "100", "-i", fa, "-o", two[0], "-r", two[1], "--chunk_size", "1", "-m", "3"], {"RD_GZ_SHARD_MIN": "65536"})
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert "ranges of one DEFLATE stream" in r.stdout + r.stderr
+    assert [_read(x) for x in one] == [_read(x) for x in two] and len(_read(one[0])) > 0
+    # two lanes merged with cat: refused, read by the one-decode path
+    text = open(plain, "rb").read()
+    cutat = text.rfind(b"\n@", 0, len(text) // 2) + 1
+    lanes = str(tmp_path / "lanes.fq.gz")
+    open(lanes, "wb").write(gzip.compress(text[:cutat], 6) + gzip.compress(text[cutat:], 6))
+    three = [str(tmp_path / "c.fq.gz"), str(tmp_path / "cr.fq")]
+    r, port = _torchrun(3, ["-l", "100", "-i", lanes, "-o", three[0], "-r", three[1], "--chunk_size", "1", "-m", "3"], {"RD_GZ_SHARD_MIN": "65536"})
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert "one rank decodes" in r.stdout + r.stderr and "ranges of one DEFLATE stream" not in r.stdout + r.stderr
+    one = [str(tmp_path / "a.fq.gz"), str(tmp_path / "ar.fq")]
+    assert [_read(x) for x in one] == [_read(x) for x in three]
+    # a cut stream
+    blob = open(i1, "rb").read()
+    cut = str(tmp_path / "cut.fq.gz")
+    open(cut, "wb").write(blob[: len(blob) * 2 // 3])
+    r, port = _torchrun(2, ["-l", "100", "-i", cut, "-o", str(tmp_path / "o.fq"), "--chunk_size", "1", "-m", "3"], {"RD_GZ_SHARD_MIN": "65536"}, timeout=300)
+    assert r.returncode != 0 and "ended before the end-of-stream marker" in r.stdout + r.stderr
+    assert not os.path.exists(str(tmp_path / "o.fq")) and not [f for f in os.listdir("/dev/shm") if f.startswith("rd_%d_" % port)]
