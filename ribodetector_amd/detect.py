@@ -863,7 +863,13 @@ def main(argv=None, log_level=None):
         if fc is not None and seq_pred.num_read > fc[1] and t2 > fc[0]:
             steady = len(seq_pred.input) * (seq_pred.num_read - fc[1]) / (t2 - fc[0])
         seq_pred.timing = {"load_model_s": t1 - t0, "detect_s": t2 - t1, "prefix_k": seq_pred.model.prefix_k,
-                           "reads_per_s_after_first_chunk": steady, "ingest": getattr(seq_pred, "ingest", None)}
+                           "reads_per_s_after_first_chunk": steady, "ingest": getattr(seq_pred, "ingest", None),
+                           "gz_ranges_s": getattr(seq_pred, "gz_shard_s", None), "pinned_cpus": getattr(seq_pred, "pinned_cpus", None)}
+        if os.environ.get("RD_TIMING_OUT"):          # (tools/host_scaling.py, tools/scale_sweep.sh: what a torchrun child measured, per rank)
+            import json
+            with open("%s.rank%d" % (os.environ["RD_TIMING_OUT"], seq_pred.rank), "w") as fh:
+                json.dump(dict(seq_pred.timing, rank=seq_pred.rank, world=seq_pred.world, num_read=seq_pred.num_read,
+                               thread_cpu_s=seq_pred.thread_cpu_s, process_cpu_s=time.process_time()), fh, default=str)
     except BaseException:
         seq_pred.cleanup()                       # a failed run leaves no slot, '<out>.partN' or '<out>.joining' files behind
         if seq_pred.multi:
