@@ -86,6 +86,53 @@ def cpu_baseline(arena_np, n_reads, target_s=12.0):
                       % (n, cores, os.cpu_count() or 0, dt)}
 
 
+class GpuSampler:
+    """Shader clock and package power of one GPU while the timed region runs, from the amdgpu hwmon files of its PCI function (freq1_input
+    in Hz, power1_average / power1_input in microwatts; a read costs microseconds, no tool is started): what tells a 34 M box from a 36 M
+    box - the recurrence kernel is bound by the package power cap, so its rate follows the clock the firmware grants."""
+
+    def __init__(self, torch, dev, period=0.05):
+        import glob
+        import threading
+        self.files, self.samples, self.period = {}, {"sclk_mhz": [], "power_w": []}, period
+        try:
+            p = torch.cuda.get_device_properties(dev)
+            base = "/sys/bus/pci/devices/%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+            for hw in sorted(glob.glob(base + "/hwmon/hwmon*")):
+                for key, names in (("sclk_mhz", ("freq1_input",)), ("power_w", ("power1_average", "power1_input"))):
+                    for nm in names:
+                        if key not in self.files and os.path.exists(os.path.join(hw, nm)):
+                            self.files[key] = os.path.join(hw, nm)
+        except Exception:      # noqa: BLE001 - (no such files: the record says null)
+            pass
+        self._stop = threading.Event()
+        self._th = threading.Thread(target=self._run, daemon=True) if self.files else None
+
+    def _run(self):
+        while not self._stop.is_set():
+            for key, path in self.files.items():
+                try:
+                    with open(path) as fh:
+                        self.samples[key].append(float(fh.read().strip()) / 1e6)      # Hz -> MHz, microwatts -> W
+                except (OSError, ValueError):
+                    pass
+            self._stop.wait(self.period)
+
+    def start(self):
+        if self._th:
+            self._th.start()
+        return self
+
+    def stop(self):
+        self._stop.set()
+        if self._th:
+            self._th.join()
+        out = {}
+        for key, v in self.samples.items():
+            out[key] = {"avg": round(sum(v) / len(v), 1), "min": round(min(v), 1), "max": round(max(v), 1), "samples": len(v)} if v else None
+        return out
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -288,6 +335,10 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     dev = torch.device("cuda", int(os.environ.get("RD_LOCAL_DEVICE", local)))   # override: several ranks on one GPU (tests only)
     torch.cuda.set_device(dev)
+    pinned = None
+    if world > 1:                                          # a rank's threads on its share of the CPUs next to its GPU (RD_PIN=0: off)
+        pinned, how = rdist.pin_rank_cpus(dev.index, local, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
+        pinned = {"cpus": pinned, "how": how}
     multi = rdist.active()                                 # several ranks - or ONE rank under RD_FORCE_DIST=1 (a one-rank RCCL
     backend = dist.get_backend() if multi else None        # communicator: the collectives of the N>1 run, executed on a 1-GPU box)
 
@@ -509,10 +560,12 @@ def main():
     model.profile_enable(True)
     sync()
     th0 = thread_cpu()
+    sampler = GpuSampler(torch, dev).start()
     t0, c0 = time.perf_counter(), time.process_time()
     timed_path(args.steps)
     sync()
     dt, cpu_s = time.perf_counter() - t0, time.process_time() - c0      # cpu_s: user + system time of ALL threads of this rank
+    gpu_state = sampler.stop()
     th1 = thread_cpu()
     by_thread = sorted(((th1[t][1] - th0.get(t, (None, 0.0))[1], th1[t][0]) for t in th1), reverse=True)
     by_thread = [{"thread": nm, "cpu_s": round(c, 3)} for c, nm in by_thread if c >= 0.01][:6]
@@ -524,10 +577,14 @@ def main():
     if multi:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
-    cpu_ranks = [cpu_s]
+    cpu_ranks, gpu_states = [cpu_s], [gpu_state]
     if multi:
-        cpu_ranks = [None] * world
-        dist.all_gather_object(cpu_ranks, cpu_s)
+        both = [None] * world
+        dist.all_gather_object(both, (cpu_s, gpu_state, pinned))
+        cpu_ranks, gpu_states = [b[0] for b in both], [b[1] for b in both]
+        if rank_info:
+            for i, b in zip(rank_info, both):
+                i["gpu_state_in_timed_region"], i["cpus"] = b[1], b[2]
     total_pairs = P * args.steps * world
     c = counts.cpu().tolist()
     assert c[0] + c[1] + c[2] == total_pairs, (c, total_pairs)
@@ -615,6 +672,9 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": (achieved / peak) if achieved else None, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": kname, "launches": launches, "avg_launch_ms": avg_ms,
+                         "effective_clock_ghz": round(gpu_state["sclk_mhz"]["avg"] / 1e3, 3) if gpu_state.get("sclk_mhz") else None,
+                         "package_power_w": gpu_state["power_w"]["avg"] if gpu_state.get("power_w") else None,
+                         "gpu_state_in_timed_region": gpu_states if world > 1 else gpu_state,
                          "what": "achieved = algorithmic FLOPs of the steps the kernel EXECUTES (steps x 131072 + 1024 per read, SURVEY 8d) / "
                                  "avg_launch_ms; the steps a prefix-state table row stands for are looked up, not computed, and are not "
                                  "counted here (frac_counting_table_steps counts them: reads/s x SURVEY 8d FLOPs per read / peak)",

@@ -182,7 +182,8 @@ __device__ __forceinline__ int64_t fq_line_start(const int32_t *__restrict__ lin
 
 __global__ __launch_bounds__(FQ_THREADS) void rd_fq_check_kernel(const uint8_t *__restrict__ text, const int32_t *__restrict__ line_end,
                                                                 FqSummary *__restrict__ sum, int final) {
-    if (sum->status != RD_FQ_OK) return;
+    // (TRUNCATED is this kernel's own verdict, written by workgroup 0 while others may still be starting: it must not stop them)
+    if (sum->status != RD_FQ_OK && sum->status != RD_FQ_TRUNCATED) return;
     const int64_t n = sum->n_records, begin = sum->begin, L = sum->n_lines;
     const int64_t stride = (int64_t)gridDim.x * FQ_THREADS;
     bool dirty = false;
@@ -219,7 +220,8 @@ __global__ __launch_bounds__(FQ_THREADS) void rd_fq_check_kernel(const uint8_t *
 
 // (after rd_fq_check_kernel: a bad header is a status of its own once every workgroup has voted)
 __global__ void rd_fq_verdict_kernel(FqSummary *__restrict__ sum) {
-    if (sum->status == RD_FQ_OK && sum->bad_record != ~0ull && !sum->dirty) sum->status = RD_FQ_HEADER;
+    // (a bad header in front of a truncated tail is the first damage of the stream: it is what the host reader meets first, too)
+    if ((sum->status == RD_FQ_OK || sum->status == RD_FQ_TRUNCATED) && sum->bad_record != ~0ull && !sum->dirty) sum->status = RD_FQ_HEADER;
 }
 
 __global__ __launch_bounds__(FQ_THREADS) void rd_fq_gather_kernel(const uint8_t *__restrict__ text, const int32_t *__restrict__ line_end,

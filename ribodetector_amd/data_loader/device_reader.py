@@ -36,7 +36,7 @@ LINE_DIV = 4                   # the line table of a batch holds window / LINE_D
 EVERY = 4096                   # one record-offset sample per EVERY records travels to the host with the summary: bounds a chunk's bytes
 FQ_ERRORS = {1: "FASTQ record does not start with '@'",
              2: "truncated FASTQ record at end of file (number of lines is not a multiple of 4)",
-             3: "a record longer than %d bytes: set RD_DEVICE_PARSE=0 (the host parser has no record-size limit)" % PAD,
+             3: "a record longer than a batch buffer may be (2 GiB)",
              4: "the batch before this one could not be framed", 5: "more lines than the line table holds"}
 
 
@@ -63,7 +63,8 @@ def device_ingest_kind(path, fmt=None):
 
 
 def device_parse_wanted(path, fmt=None):
-    """FASTQ input, a GPU, and RD_DEVICE_PARSE != 0: plain files, BGZF files, and (RD_DEVICE_INFLATE=stream) single-stream .gz files"""
+    """does the text of this input stay on the device? A GPU and RD_DEVICE_PARSE != 0: plain FASTQ / FASTA files, BGZF files, and
+    single-stream .gz files (the default since round 5; RD_DEVICE_INFLATE=members keeps those with the host's decoders)"""
     return device_ingest_kind(path, fmt) is not None
 
 
@@ -85,6 +86,23 @@ class DeviceChunk:
         self.n, self.dev, self.ready, self.total = n, (text, seq_off, seq_len, rec_start), ready, total
         self.seq_len = seq_len
         self.buf = self.rec_start = self.seq_off = None
+
+    @staticmethod
+    def from_host(c, device, stream):
+        """a chunk of the host reader (fastx_parser.Chunk with its pinned tensors) shipped to the device: what a stream the device
+        decoder gave back (get_seq_chunks_device) is delivered as, so that a run sees ONE kind of chunk"""
+        tbuf, toff, tlen, trs = c.tensors
+        nb = int(tbuf.numel())
+        with torch.cuda.device(device), torch.cuda.stream(stream):
+            text = torch.empty(((nb + 255) // 256) * 256 + 256, dtype=torch.uint8, device=device)
+            text[:nb].copy_(tbuf, non_blocking=True)
+            so, sl, rs = (t.to(device, non_blocking=True) for t in (toff, tlen, trs))
+            total = torch.tensor([nb], dtype=torch.int64).pin_memory()
+            ready = torch.cuda.Event()
+            ready.record(stream)
+        dc = DeviceChunk(len(c.seq_len), text, rs, so, sl, ready, total)
+        dc.shm = c                   # (the pinned source stays alive until the chunk is dropped)
+        return dc
 
     def to_host(self):
         """(text bytes, rec_start, seq_off, seq_len) as numpy arrays - tests and small tools only (this is the copy the path avoids)"""
@@ -118,7 +136,10 @@ class FastqIndexer:
         self.lib = N.lib()
         self.prev = None               # producer side: (text, summary) of the batch queued last - what the next one chains to
         self.last_good = None          # consumer side: the same of the batch FINISHED last (differs after a repair)
-        self.stats = {"batches": 0, "stripped": 0, "reframed": 0, "index_wait_s": 0.0}
+        self.last_carry = 0            # ... and the bytes behind its last complete record: what the next batch's pad must hold
+        self.full_tables = False       # a batch overflowed its line table: the batches queued from now on get full-size tables
+        self._lock = threading.Lock()  # (producer and consumer both touch `prev` after a repair)
+        self.stats = {"batches": 0, "stripped": 0, "reframed": 0, "regrown": 0, "index_wait_s": 0.0}
 
     def _sp(self):
         return C.c_void_p(self.stream.cuda_stream)
@@ -128,14 +149,19 @@ class FastqIndexer:
         with torch.cuda.stream(self.stream):
             return torch.empty(((PAD + int(new_bytes) + 64 + 127) // 64) * 64, dtype=torch.uint8, device=self.device)
 
-    def index(self, text, start, end, final=False, chain=True, prev=None, full_table=False):
+    def index(self, text, start, end, final=False, chain=True, prev=None, full_table=False, pad=None):
         """frame text[start:end] (offsets in the batch buffer; start >= PAD unless the batch stands alone) behind the carry of the
-        batch indexed before (chain) or of an explicit `prev` = (text, summary). Asynchronous: returns the batch, to be finish()-ed."""
+        batch indexed before (chain) or of an explicit `prev` = (text, summary). pad: the room in front of `start` when it is not PAD (a
+        batch framed again behind a record longer than PAD). Asynchronous: returns the batch, to be finish()-ed."""
         b = _Batch()
         if prev is None and chain:
-            prev = self.prev      # (text, summary) as they were queued: a strip replaces the batch's own fields, not these
+            with self._lock:
+                prev = self.prev      # (text, summary) as they were queued: a strip replaces the batch's own fields, not these
+        full_table = full_table or (chain and self.full_tables)
         with torch.cuda.device(self.device), torch.cuda.stream(self.stream):
-            window = (end - start) + (PAD if prev is not None else 0)
+            window = (end - start) + ((PAD if pad is None else pad) if prev is not None else 0)
+            if window >= 0x7fffffff - 4096:
+                raise ValueError(FQ_ERRORS[3])
             b.text = text
             b.line_end = torch.empty((window + 2) if full_table else (window // LINE_DIV + 4096), dtype=torch.int32, device=self.device)
             # what travels to the host: the 64-byte summary and the record-offset samples, in ONE buffer, fetched by a kernel
@@ -156,9 +182,46 @@ class FastqIndexer:
         b.final, b.orig, b.slot, b.gz_slot, b.n = final, None, None, None, None
         b.args, b.chain = (start, end, final), (text, b.summary)
         if chain:
-            self.prev = (text, b.summary)
+            with self._lock:
+                self.prev = b.chain
         self.stats["batches"] += 1
         return b
+
+    _REFRAMED = ("text", "line_end", "summary", "host", "samples", "samples_host", "begin", "end", "consumed", "n", "n_lines", "status", "dirty", "bad_record", "chain")
+
+    def _reframe(self, b):
+        """a batch that could not be framed as it was queued - more lines than its table holds (5: lines of < LINE_DIV bytes on average),
+        chained to a batch that was repaired (4), or behind a record longer than the pad (3: a FASTA contig, an ultra-long read; the
+        reference's parser joins lines without bound, fastx_parser.py:39-55) - is framed again on the consumer's side behind the batch
+        FINISHED last: full-size tables, and a buffer whose pad holds that batch's carry, whatever its size. The producer's chain is
+        moved to the repaired batch if it still ends in this one; the batches queued in between come through here too."""
+        self.stats["reframed"] += 1
+        start, end, final = b.args
+        old_chain = b.chain
+        text, pad = b.text, None
+        if self.last_good is not None and self.last_carry > PAD:
+            self.stats["regrown"] += 1
+            pad = ((self.last_carry + (1 << 16) + 63) // 64) * 64
+            if pad + (end - start) >= 0x7fffffff - 4096:
+                raise ValueError(FQ_ERRORS[3])
+            import logging
+            logging.getLogger("predict").info("A record of more than %d bytes: the batch behind it is framed again with room for %d" % (PAD, pad))
+            with torch.cuda.device(self.device), torch.cuda.stream(self.stream):
+                text = torch.empty(((pad + (end - start) + 64 + 127) // 64) * 64, dtype=torch.uint8, device=self.device)
+                text[pad:pad + (end - start)].copy_(b.text[start:end])
+            start, end = pad, pad + (end - start)
+        if b.status == 5:
+            self.full_tables = True
+        nb = self.index(text, start, end, final=final, chain=False, prev=self.last_good, full_table=True, pad=pad)
+        self.stats["batches"] -= 1
+        self.wait(nb)
+        self._read(nb)
+        for k in self._REFRAMED:
+            setattr(b, k, getattr(nb, k))
+        b.args = nb.args
+        with self._lock:
+            if self.prev is old_chain:
+                self.prev = b.chain
 
     def wait(self, b):
         t0 = time.perf_counter()
@@ -177,22 +240,12 @@ class FastqIndexer:
         left to the caller (the records before the damage are delivered first)."""
         self.wait(b)
         self._read(b)
-        if b.status in (4, 5) and b.chain is not None:
-            # more lines than the table holds (lines of < LINE_DIV bytes on average), or chained to such a batch: framed again, with a
-            # full-size table, behind the batch finished last - the producer keeps chaining new batches to the stale summaries, and
-            # every one of them comes through here (rare: no FASTQ of reads has such lines)
-            self.stats["reframed"] += 1
-            start, end, final = b.args
-            nb = self.index(b.text, start, end, final=final, chain=False, prev=self.last_good, full_table=True)
-            self.stats["batches"] -= 1
-            self.wait(nb)
-            self._read(nb)
-            for k in ("line_end", "summary", "host", "samples", "samples_host", "begin", "end", "consumed", "n", "n_lines", "status", "dirty",
-                      "bad_record", "chain"):
-                setattr(b, k, getattr(nb, k))
+        if b.status in (3, 4, 5) and b.chain is not None:
+            self._reframe(b)
         if b.chain is not None:
             self.last_good = b.chain
-        if b.dirty and b.status == 0:
+            self.last_carry = (b.end - b.consumed) if b.status == 0 else 0
+        if b.dirty and b.status in (0, 2):       # (a truncated tail does not excuse the records in front of it from rstrip())
             self._strip(b)
         if b.status == 0 and b.bad_record != -1 and b.bad_record < b.n:
             b.status = 1
@@ -255,12 +308,18 @@ class FastaIndexer(FastqIndexer):
     without a sequence; the end of the FILE drops such a record, like the reference)."""
     keep_empty_tail = False
 
-    def index(self, text, start, end, final=False, chain=True, prev=None, full_table=False):
+    _REFRAMED = FastqIndexer._REFRAMED + ("norm", "rec_tab", "hdr_tab", "norm_end")
+
+    def index(self, text, start, end, final=False, chain=True, prev=None, full_table=False, pad=None):
         b = _Batch()
         if prev is None and chain:
-            prev = self.prev
+            with self._lock:
+                prev = self.prev
+        full_table = full_table or (chain and self.full_tables)
         with torch.cuda.device(self.device), torch.cuda.stream(self.stream):
-            window = (end - start) + (PAD if prev is not None else 0)
+            window = (end - start) + ((PAD if pad is None else pad) if prev is not None else 0)
+            if window >= 0x7fffffff - 4096:
+                raise ValueError(FQ_ERRORS[3])
             cap_lines = (window + 2) if full_table else (window // LINE_DIV_FA + 4096)
             cap_rec = cap_lines + 2
             norm_cap = ((window + cap_lines + 66 + 255) // 256) * 256
@@ -286,7 +345,8 @@ class FastaIndexer(FastqIndexer):
         b.final, b.orig, b.slot, b.gz_slot, b.n = final, None, None, None, None
         b.args, b.chain = (start, end, final), (text, b.summary)
         if chain:
-            self.prev = (text, b.summary)
+            with self._lock:
+                self.prev = b.chain
         self.stats["batches"] += 1
         return b
 
@@ -298,18 +358,11 @@ class FastaIndexer(FastqIndexer):
     def finish(self, b):
         self.wait(b)
         self._read(b)
-        if b.status in (4, 5) and b.chain is not None:       # (as FastqIndexer.finish: the tables were too small, or the batch chains to one)
-            self.stats["reframed"] += 1
-            start, end, final = b.args
-            nb = self.index(b.text, start, end, final=final, chain=False, prev=self.last_good, full_table=True)
-            self.stats["batches"] -= 1
-            self.wait(nb)
-            self._read(nb)
-            for k in ("line_end", "summary", "host", "samples", "samples_host", "begin", "end", "consumed", "n", "n_lines", "status", "dirty",
-                      "bad_record", "chain", "norm", "rec_tab", "hdr_tab", "norm_end"):
-                setattr(b, k, getattr(nb, k))
+        if b.status in (3, 4, 5) and b.chain is not None:    # (as FastqIndexer.finish: tables or pad too small, or the batch chains to such a one)
+            self._reframe(b)
         if b.chain is not None:
             self.last_good = b.chain
+            self.last_carry = (b.end - b.consumed) if b.status == 0 else 0
         return b
 
     def gather(self, pieces):
@@ -513,33 +566,58 @@ class DeviceFeeder:
                 batch = min(2 * batch, self.PLAIN_BATCH)
 
     def _run_stream(self):
-        """ONE gzip member decoded on the device (gz.DeviceStreamGunzip): batches of compressed bytes, two in flight; a batch's text
-        length is known only when its 64-byte state has arrived, so its records are framed one batch behind the submission. What
-        follows the member in the file (further members; zero padding) goes to zlib on the host, in order."""
+        """The gzip members of a file that are single DEFLATE streams, decoded on the device one after the other (gz.DeviceStreamGunzip,
+        fresh state per member: `cat L001.fq.gz L002.fq.gz` is what lane-merged data looks like): batches of compressed bytes, two in
+        flight; a batch's text length is known only when its 64-byte state has arrived, so its records are framed one batch behind the
+        submission. A file whose FIRST batch the decoder gives back goes to the host reader as a whole (_StreamFallback reaches
+        get_seq_chunks_device: nothing has been delivered yet); a later member it cannot take, to zlib on this thread."""
         tm = self.stage_s
-        dsg = gz.DeviceStreamGunzip(self.device, self.stream)
-        span = dsg.BATCH + dsg.SLACK + 8192
+        span = gz.DeviceStreamGunzip.BATCH + gz.DeviceStreamGunzip.SLACK + 8192
+        if os.environ.get("RD_GZS_BATCH"):
+            span = int(os.environ["RD_GZS_BATCH"]) + gz.DeviceStreamGunzip.SLACK + 8192
         pinned = [torch.empty(span, dtype=torch.uint8, pin_memory=True) for _ in range(self.SLOTS + 1)]
         views = [t.numpy() for t in pinned]
-        free = list(range(len(pinned)))
         fd = os.open(self.path, os.O_RDONLY)
         try:
-            try:
-                self._stream_batches(fd, dsg, pinned, views, free, tm)
-            except _StreamFallback as e:
-                tm["fallback"] = str(e)
-                self.stream.synchronize()
-                with open(self.path, "rb", buffering=0) as fh:
-                    self._host_tail(fh, b"")
+            size, base = os.fstat(fd).st_size, 0
+            tm["members"] = 0
+            while not self._stop:
+                dsg = gz.DeviceStreamGunzip(self.device, self.stream)
+                free = list(range(len(pinned)))
+                try:
+                    end = self._stream_batches(fd, dsg, pinned, views, free, tm, base)
+                except _StreamFallback as e:
+                    if base == 0:
+                        raise
+                    tm["fallback"] = "member at byte %d: %s" % (base, e)
+                    self.stream.synchronize()
+                    with open(self.path, "rb", buffering=0) as fh:
+                        fh.seek(base)
+                        self._host_tail(fh, b"")
+                    return
+                tm["members"] += 1
+                if end is None or end >= size:
+                    return
+                # zero padding behind a member is skipped (Python's gzip module does); what follows must be another member
+                while end < size:
+                    rest = os.pread(fd, 1 << 16, end)
+                    k = len(rest) - len(rest.lstrip(b"\0"))
+                    end += k
+                    if k < len(rest):
+                        break
+                if end >= size:
+                    return
+                base = end
         finally:
             os.close(fd)
 
-    def _stream_batches(self, fd, dsg, pinned, views, free, tm):
+    def _stream_batches(self, fd, dsg, pinned, views, free, tm, base=0):
+        """one member that starts at file offset `base`; returns the offset behind its trailer (None: stopped)"""
         size = os.fstat(fd).st_size
-        hl = gz.gzip_header_len(os.pread(fd, 1 << 16, 0))
+        hl = gz.gzip_header_len(os.pread(fd, 1 << 16, base))
         if hl is None:
             raise ValueError("Compressed file ended before the end-of-stream marker was reached")
-        pos, first, batch = 0, hl * 8, min(self.FIRST, dsg.BATCH)
+        pos, first, batch = base, hl * 8, min(self.FIRST if base == 0 else dsg.BATCH, dsg.BATCH)
         flight = deque()                                  # (ticket, text, pinned slot, file offset of the batch)
         member_end = None
         good = {}                                         # what the last good batch left: where the stream goes on, window, CRC, length
@@ -554,8 +632,8 @@ class DeviceFeeder:
             if member_end is not None:
                 return True                               # (a batch submitted behind the member's last one: nothing of it is used)
             if r["status"]:
-                if at == 0:
-                    # the member's FIRST batch: nothing has been delivered yet, so the whole file can still go to zlib on the host -
+                if at == base:
+                    # the member's FIRST batch: of the file's first member nothing has been delivered yet, so the whole file can still go to the host reader -
                     # what is not text (no block start passes the search: one wave would have to decode everything), what
                     # compresses 100:1, and damaged files, whose error messages are then zlib's
                     raise _StreamFallback(gz.GZS_ERRORS.get(r["status"], "error %d" % r["status"]))
@@ -616,17 +694,12 @@ class DeviceFeeder:
                 break
         while flight:
             if not finish_one():
-                return
+                return None
         if member_end is None:
             if not self._stop:
                 raise ValueError("Compressed file ended before the end-of-stream marker was reached")
-            return
-        if member_end < size:            # further members, or padding: the host's zlib, behind the batches in flight
-            with open(self.path, "rb", buffering=0) as fh:
-                fh.seek(member_end)
-                rest = fh.read(1 << 16)
-                if rest.strip(b"\0"):
-                    self._host_tail(fh, rest)
+            return None
+        return member_end
 
     def _resume_on_host(self, fd, size, start_bit, win_dev, win_valid, crc, total_len):
         """the rest of a gzip member from absolute bit `start_bit` of the file, by zlib: the compressed bytes are shifted to a byte
@@ -839,6 +912,24 @@ def get_seq_chunks_device(seq_file, chunk_size=1048576, byte_range=None, first_c
                 except ValueError as e:
                     err, eof = e, True
                     break
+                except _StreamFallback as e:
+                    # the device decoder gave the file back before it delivered anything (not text, 100:1 text, fixed-Huffman or stored
+                    # blocks at its start, damage): the host reader - parallel decoders, zlib's messages - reads it, and its chunks are
+                    # shipped to the device so that the run still sees one kind of chunk
+                    import logging
+                    logging.getLogger("predict").info("%s: %s - read by the host decoders" % (os.path.basename(str(seq_file)), e))
+                    feeder.close()
+                    if stats is not None:
+                        stats.update({"path": "host", "fallback": str(e)})
+                    stats = None
+                    st = gz.acquire_stream(device)
+                    try:
+                        for c in fx.get_seq_chunks(seq_file, chunk_size=chunk_size, first_chunk=first_chunk, schedule=schedule, device=device):
+                            yield DeviceChunk.from_host(c, device, st)
+                    finally:
+                        st.synchronize()
+                        gz.release_stream(st)
+                    return
                 if b is None:
                     eof = True
                     break

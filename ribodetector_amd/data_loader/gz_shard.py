@@ -182,6 +182,20 @@ class _Phase1:
         return m
 
 
+def _in_threads(fn, items):
+    """fn(item) for every item, side by side when there are several (the work of one input file next to the other's)"""
+    import threading
+    if len(items) <= 1:
+        for it in items:
+            fn(it)
+        return
+    th = [threading.Thread(target=fn, args=(it,), name="rd-gzr") for it in items]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+
+
 def _verdict_x1(metas, world, sizes):
     """None, or why the ranks' ranges do not add up to one decodable member - the same answer on every rank"""
     for f in range(len(sizes)):
@@ -228,6 +242,13 @@ def prepare(paths, rank, world, device, fasta, all_gather, shift_to_prev, log=No
         if not o:
             return None, w
     streams = [gz.acquire_stream(device, priority=-1) for _ in paths]
+    tph = {}                    # seconds per phase of this call (stats of every ResidentRange)
+    tmark = [time.perf_counter()]
+
+    def lap(name):
+        now = time.perf_counter()
+        tph[name] = round(tph.get(name, 0.0) + now - tmark[0], 4)
+        tmark[0] = now
 
     def give_up(why):
         for st in streams:
@@ -245,13 +266,23 @@ def prepare(paths, rank, world, device, fasta, all_gather, shift_to_prev, log=No
             if hl is None:
                 raise ValueError("Compressed file ended before the end-of-stream marker was reached")
             first = hl * 8
-        p1 = _Phase1(path, b[rank], b[rank + 1], sizes[f], first, device, streams[f])
+        ph.append(_Phase1(path, b[rank], b[rank + 1], sizes[f], first, device, streams[f]))
+
+    def run_p1(p1):
         try:
+            torch.cuda.set_device(device)
             p1.run()
         except ValueError as e:                     # (a short read: the file changed or is damaged - the host path reports it)
             p1.meta["status"], p1.meta["why"] = -3, str(e)
-        ph.append(p1)
+        except BaseException as e:                  # noqa: BLE001 - raised on the caller's thread below
+            p1.meta["status"], p1.meta["why"], p1.error = -4, repr(e), e
+    _in_threads(run_p1, ph)                         # (the mates' ranges side by side: file reads and kernels of one hide the other's waits)
+    for p1 in ph:
+        if getattr(p1, "error", None) is not None:
+            raise p1.error
+    lap("p1_decode")
     metas = all_gather([p.meta for p in ph])                         # X1: [rank][file]
+    lap("x1")
     why = _verdict_x1(metas, world, sizes)
     if why is not None:
         return give_up(why)
@@ -309,7 +340,9 @@ def prepare(paths, rank, world, device, fasta, all_gather, shift_to_prev, log=No
         heads_mine.append({"crc": crc, "len": int(h.view(np.uint64)[0]), "status": status, "cut": cut, "head": head, "trailer": trailer,
                            "trailing": sizes[f] - ((metas[world - 1][f]["end_abs"] + 7) // 8 + 8) if rank == world - 1 else 0})
         out.append((ix, texts))
+    lap("p2_resolve")
     x2 = all_gather(heads_mine)                                      # X2: [rank][file]
+    lap("x2")
     for f in range(len(paths)):
         crc, total = 0, 0
         for r in range(world):
@@ -366,9 +399,11 @@ def prepare(paths, rank, world, device, fasta, all_gather, shift_to_prev, log=No
             n_rec += b.n
         counts.append(n_rec)
         ranges.append([ix, batches, 0, st])
+    lap("p3_frame")
     skips = [0] * len(paths)
     if len(paths) > 1:
         x3 = all_gather(counts)                                      # X3: [rank][file]
+        lap("x3")
         before = [[sum(x3[q][f] for q in range(r)) for f in range(len(paths))] for r in range(world + 1)]
         if len(set(before[world])) != 1:
             raise ValueError("paired-end files have different numbers of records")
@@ -410,12 +445,13 @@ def prepare(paths, rank, world, device, fasta, all_gather, shift_to_prev, log=No
                     raise RuntimeError("gz ranges: rank %d sent %d records, %d expected (status %d)" % (rank + 1, b.n, K[rank + 1] - before[rank + 1][f], b.status))
                 batches.append(b)
             ranges[f][2] = skips[f]
+        lap("x4_mates")
     t_all = time.perf_counter() - t_start
     res = []
     for f in range(len(paths)):
         ix, batches, skip, st = ranges[f]
         m = metas[rank][f]
         stats = {"path": "device", "mode": "gz-range", "comp_bytes": m["hi"] - m["lo"], "text_bytes": m["n_text"], "decode_s": round(m["t_decode"], 4),
-                 "prepare_s": round(t_all, 4), "skip_records": skip, "batches": len(batches)}
+                 "prepare_s": round(t_all, 4), "skip_records": skip, "batches": len(batches), "phases_s": dict(tph)}
         res.append(ResidentRange(ix, batches, skip, m["hi"] - m["lo"], st, stats))
     return res, None

@@ -80,6 +80,7 @@ class Predictor:
         self.sharded_parse = False               # several ranks, plain input: every rank parses its own byte range
         self._shared = None                      # gzip input, several ranks of one node: one decode per node (decided once per run)
         self._chunk_reads = None
+        self._use_device = None                  # does the text of the inputs stay on the device? decided once per run
         self._install_cleanup()
 
     # ---- cleanup ------------------------------------------------------------------------------------
@@ -189,6 +190,11 @@ class Predictor:
         else:
             self.device = torch.device('cuda', torch.cuda.current_device())
         self.has_cuda = True
+        if self.multi and self.world > 1:        # (round 6) a rank's threads stay on its share of the CPUs next to its GPU; RD_PIN=0: off
+            lw = int(os.environ.get("LOCAL_WORLD_SIZE", self.world))
+            self.pinned_cpus, how = rdist.pin_rank_cpus(self.device.index, self.local_rank, lw)
+            if self.pinned_cpus is not None:
+                self.logger.info('Rank {} runs on CPUs {} ({})'.format(self.rank, ",".join(str(c) for c in self.pinned_cpus), how))
         model.load_state_dict(self.config.load_state_dict(self.state_key))
         self.logger.info('Model using {} for read length {}{}{}{} loaded'.format(
             self.device, colors.BOLD, colors.OKCYAN, self.len, colors.ENDC))
@@ -377,7 +383,9 @@ class Predictor:
     def _device_parse(self, path):
         """does this input's text stay on the device? FASTQ, plain or BGZF, when every record a rank reads is a record it classifies
         (one rank, or the sharded parse) - under the label gather the chunk's lengths are needed on the host for the shard bounds"""
-        return (not self.multi or self.sharded_parse) and dr.device_parse_wanted(path)
+        if self._use_device is None:      # ONE decision for the run: the mates' chunks must be of one kind (submit_chunk looks at the first)
+            self._use_device = (not self.multi or self.sharded_parse) and all(dr.device_parse_wanted(p) for p in self.input)
+        return self._use_device
 
     def _shared_decode(self):
         """several ranks of ONE node on gzip input: rank 0 inflates and parses the stream once into shared memory (fx.ShmArena)
@@ -459,7 +467,7 @@ class Predictor:
         """Classify the input in chunks and write the outputs (reference detect.py:326-523)."""
         if chunk_reads is None:
             chunk_reads = self.batch_size * self.chunk_size
-        self._chunk_reads, self._shared = chunk_reads, None
+        self._chunk_reads, self._shared, self._use_device = chunk_reads, None, None
         # plain inputs under several ranks: every rank parses, classifies and writes its own byte range (no label exchange)
         plain = not any(fx.file_info(p)[1] for p in self.input)
         # ... and BGZF FASTQ inputs likewise: their members are independent, so every rank inflates (on its own GPU), parses, classifies

@@ -181,3 +181,68 @@ def shift_to_prev(buf, group=None):
         for w in dist.batch_isend_irecv(ops):
             w.wait()
     return recv
+
+
+def _cpulist(text):
+    out = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        out.update(range(int(a), int(b or a) + 1))
+    return out
+
+
+def gpu_numa_node(device_index):
+    """NUMA node of a visible GPU (its PCI function's sysfs entry), or None when the platform does not say (-1: one node, a VM)"""
+    try:
+        p = torch.cuda.get_device_properties(device_index)
+        bdf = "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+        with open("/sys/bus/pci/devices/%s/numa_node" % bdf) as fh:
+            n = int(fh.read().strip())
+        return n if n >= 0 else None
+    except Exception:      # noqa: BLE001 - (no such attribute / file: nothing to go by)
+        return None
+
+
+def pin_rank_cpus(device_index, local_rank, local_world, mode=None):
+    """Keep a rank's host threads near its GPU and out of the other ranks' way: the usable CPUs (sched_getaffinity) of the GPU's NUMA
+    node - all usable CPUs when the platform names no node - are dealt out in equal contiguous shares to the ranks whose GPUs sit on
+    that node, and every thread of this process (the runtime's helper threads exist already; the readers, writers and feeders come
+    later and inherit) is bound to this rank's share. RD_PIN=node binds to the whole node instead, RD_PIN=0 leaves the scheduler alone.
+    Nothing in the reference to match (its DataParallel wrap is dead code, detect.py:95-96). Returns (sorted CPU list, what was done)."""
+    mode = (mode or os.environ.get("RD_PIN", "share")).lower()
+    if mode in ("0", "off", "no") or local_world <= 1 or not hasattr(os, "sched_setaffinity"):
+        return None, "off"
+    usable = set(os.sched_getaffinity(0))
+    node = gpu_numa_node(device_index)
+    cpus, peers = usable, list(range(local_world))
+    if node is not None:
+        try:
+            with open("/sys/devices/system/node/node%d/cpulist" % node) as fh:
+                on_node = _cpulist(fh.read()) & usable
+            if on_node:
+                cpus = on_node
+                nodes = [gpu_numa_node(i) if i < torch.cuda.device_count() else node for i in range(local_world)]
+                same = [i for i in range(local_world) if nodes[i] == node]
+                if local_rank in same:
+                    peers = same
+        except OSError:
+            pass
+    cpus = sorted(cpus)
+    what = "node %s" % node if node is not None else "all usable CPUs"
+    if mode != "node":
+        k, m = peers.index(local_rank) if local_rank in peers else 0, max(1, len(peers))
+        share = cpus[k * len(cpus) // m:(k + 1) * len(cpus) // m]
+        if share:
+            cpus, what = share, "share %d of %d of %s" % (k + 1, m, what)
+    try:
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                os.sched_setaffinity(int(tid), cpus)
+            except OSError:
+                pass
+        os.sched_setaffinity(0, cpus)
+    except OSError as e:
+        return None, "failed: %s" % e
+    return cpus, what

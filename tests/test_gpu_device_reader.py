@@ -404,13 +404,47 @@ def test_fasta_single_stream_gz_and_a_record_longer_than_the_pad(tmp_path, small
     small_batches(1000, 1000)
     pad = dr.PAD
     try:
+        # (round 6) a record longer than the pad - here 4 KiB, batches of 1,000 bytes, so the carry grows over a dozen batches - is
+        # framed again with a pad that holds it: the reference's parser joins lines without bound (fastx_parser.py:39-55)
         dr.PAD = 4096
         q = str(tmp_path / "long.fasta")
-        open(q, "wb").write(b">a\nACGT\n>long\n" + b"ACGT" * 3000 + b"\n>b\nGG\n")
-        with pytest.raises(ValueError, match="RD_DEVICE_PARSE=0"):
-            _dev_chunks(q, 1000)
+        open(q, "wb").write(b">a\nACGT\n>long\n" + b"ACGT" * 3000 + b"\n>b\nGG\n" + b">long2 wrapped\n" + (b"acgtn" * 12 + b"\n") * 200 + b">c\nT\n")
+        st = {}
+        dev = _dev_chunks(q, 1000, stats=st)
+        _same(_host_chunks(q, 1000), dev)
+        assert st["indexer"]["regrown"] >= 2
+        fq = str(tmp_path / "long.fq")
+        rec = lambda k, n: b"@r%d\n%s\n+\n%s\n" % (k, b"ACGT" * n, b"IIII" * n)      # noqa: E731
+        open(fq, "wb").write(rec(0, 10) + rec(1, 2500) + rec(2, 5) + rec(3, 4000) + rec(4, 7))
+        st = {}
+        dev = _dev_chunks(fq, 3, stats=st)
+        _same(_host_chunks(fq, 3), dev)
+        assert st["indexer"]["regrown"] >= 2
     finally:
         dr.PAD = pad
+
+
+def test_records_longer_than_the_real_pad(tmp_path):
+    """a FASTA file with a 40 MiB record (a contig) and a FASTQ file with a 20 MiB read, batches and pad at their product sizes: the
+    default reader frames them - same chunks as the host reader - where round 5 ended the run with 'set RD_DEVICE_PARSE=0'"""
+    rng = np.random.default_rng(5)
+    big = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 40 << 20)].tobytes()
+    fa = str(tmp_path / "contigs.fasta")
+    with open(fa, "wb") as fh:
+        fh.write(b">small1\nACGTACGT\n>contig_40MiB\n" + b"\n".join(big[o:o + 60] for o in range(0, len(big), 60)) + b"\n>small2\nGGCC\n")
+    st = {}
+    dev = _dev_chunks(fa, 1000, stats=st)
+    host = _host_chunks(fa, 1000)
+    _same(host, dev)
+    assert st["indexer"]["regrown"] >= 1 and len(dev[0][3]) == 3 and int(dev[0][3][1]) == 40 << 20
+    fq = str(tmp_path / "ultralong.fq")
+    n = 20 << 20
+    with open(fq, "wb") as fh:
+        fh.write(b"@a\nACGT\n+\nIIII\n" * 1000 + b"@ultra\n" + big[:n] + b"\n+\n" + b"F" * n + b"\n" + b"@z\nGG\n+\nII\n" * 1000)
+    st = {}
+    dev = _dev_chunks(fq, 1500, stats=st)
+    _same(_host_chunks(fq, 1500), dev)
+    assert sum(len(d[3]) for d in dev) == 2001
 
 
 def test_fasta_share_keeps_its_last_record_without_a_sequence(tmp_path):

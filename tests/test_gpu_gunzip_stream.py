@@ -159,6 +159,8 @@ def test_reader_on_single_stream_gz_equals_the_host_reader(tmp_path, fastq, monk
             st = {}
             assert _reader_text(p, stats=st) == want, (name, first)
             assert "fallback" not in st["feeder"], (name, st)
+            if name == "members_and_padding":          # (round 6: every member on the device, not only the first)
+                assert st["feeder"]["members"] == 3, st["feeder"]
         monkeypatch.undo()
         monkeypatch.setenv("RD_DEVICE_INFLATE", "stream")
     # chunk for chunk what the host reader delivers
