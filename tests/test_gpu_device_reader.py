@@ -224,7 +224,8 @@ def test_malformed_streams_are_reported_like_the_host_reader_reports_them(tmp_pa
     open(p, "wb").write(bytes(raw))
     with pytest.raises(ValueError, match="gzip member|not a gzip member|member size"):
         _dev_chunks(p, 1000)
-    # a record longer than the carry pad is refused with the way out named
+    # a record longer than the carry pad (round 5: refused, "set RD_DEVICE_PARSE=0") is framed with a pad grown to hold it - and a
+    # TRUNCATED record behind such a one is still reported
     small_batches(1 << 20, 1 << 20)
     monkey_pad = dr.PAD
     try:
@@ -233,8 +234,11 @@ def test_malformed_streams_are_reported_like_the_host_reader_reports_them(tmp_pa
         p = str(tmp_path / "long.fastq")
         open(p, "wb").write(good + big + good)
         small_batches(1000, 1000)
-        with pytest.raises(ValueError, match="RD_DEVICE_PARSE=0"):
-            _dev_chunks(p, 1000)
+        _same(_host_chunks(p, 1000), _dev_chunks(p, 1000))
+        open(p, "wb").write(good + big + good[:-40])
+        eh, ed = [], []
+        _same(_host_chunks(p, 7, errors=eh), _dev_chunks(p, 7, errors=ed), records_only=True)
+        assert eh and ed and "truncated" in ed[0]
     finally:
         dr.PAD = monkey_pad
 

@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--reads", type=int, default=4000000)
     ap.add_argument("--legs", default="", help="comma-separated CLI legs (default: all)")
     ap.add_argument("--no-bench", action="store_true")
+    ap.add_argument("--gz-repeat", type=int, default=1, help="the single-stream .gz inputs hold the plain files' text this many times")
     a = ap.parse_args()
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     from e2e_bench import usable_cores
@@ -106,8 +107,7 @@ def main():
             arena, off, _ = synth.reads_numpy(a.reads, 100, seed=seed)
             p = os.path.join(d, "r_%d.fq" % mate)
             synth.write_fastq_realistic(p, arena, off, mate, seed=seed)
-            with open(p, "rb") as fi, gzip.open(p + ".gz", "wb", compresslevel=6) as fo:
-                shutil.copyfileobj(fi, fo, 1 << 24)
+            synth.pgzip_file(p, p + ".gz", level=6, repeat=a.gz_repeat)      # ONE gzip member (deflated in parallel, pigz-style)
             files.append(p)
         # the same files as BGZF (framed by the device writer): under several ranks every rank inflates the members of its own share
         import numpy as np
@@ -128,6 +128,7 @@ def main():
         del dgz
         torch.cuda.empty_cache()
         out["cli_reads_per_file"] = a.reads
+        out["gz_reads_per_file"] = a.reads * a.gz_repeat
         out["cli"] = {}
         bg = [os.path.join(d, "bgzf", os.path.basename(f) + ".gz") for f in files]
         legs = (("pe_plain", files), ("pe_gz", [f + ".gz" for f in files]), ("pe_gz_to_gz", [f + ".gz" for f in files]), ("pe_bgzf", bg), ("pe_bgzf_to_gz", bg),
