@@ -124,43 +124,106 @@ def reads_torch(n, length, seed, device, rrna_frac=0.10, sub_rate=0.05, n_rate=0
     return arena, offsets, lens
 
 
-def fastq_image_torch(arena, offsets, lens, mate=1, block=1 << 21):
+SEQLIKE_HEADER = b"@A00123:45:HXXXXXXX:1:tttt:xxxxx:yyyyy m:N:0:ACGTACGT"      # (t / x / y / m: digits filled in per record)
+
+
+def fastq_record_bytes(lens, style="const"):
+    """bytes of record i in the image fastq_image_torch builds: header line + 2 len + 4"""
+    return (18 if style == "const" else len(SEQLIKE_HEADER) + 5) + 2 * lens
+
+
+def fastq_image_torch(arena, offsets, lens, mate=1, block=1 << 21, style="const", seed=0):
     """4-line FASTQ text of the reads as one uint8 tensor on the reads' device - 10^7-read files for the full-size tests are built
-    in HBM in a fraction of a second instead of a Python loop. Record i: '@s' + 9-digit index + '/' + mate + LF, bases, LF '+' LF,
-    'I' * len, LF (18 + 2 len bytes). offsets: int64[n+1] (or [n]); lens: int32[n]."""
+    in HBM in a fraction of a second instead of a Python loop. style "const" (SURVEY 8d): record i = '@s' + 9-digit index + '/' + mate + LF,
+    bases, LF '+' LF, 'I' * len, LF (18 + 2 len bytes). style "seqlike": what a sequencer writes - an Illumina header (SEQLIKE_HEADER: tile,
+    x, y from the index; fixed width so that the image stays one vectorised scatter) and NovaSeq-like binned qualities (F 90 %, ':' 6 %,
+    ',' 3 %, '#' 1 %, as write_fastq_realistic) - the text a .gz benchmark should compress. offsets: int64[n+1] (or [n]); lens: int32[n]."""
     import torch
     dev = arena.device
     n = int(lens.numel())
     L = lens.to(torch.int64)
-    rec = 18 + 2 * L
+    seqlike = style == "seqlike"
+    H = (len(SEQLIKE_HEADER) + 1) if seqlike else 14          # header line with its LF
+    rec = H + 4 + 2 * L
     start = torch.zeros(n + 1, dtype=torch.int64, device=dev)
     torch.cumsum(rec, 0, out=start[1:])
     out = torch.full((int(start[-1].item()),), ord("I"), dtype=torch.uint8, device=dev)
     p10 = torch.tensor([10 ** k for k in range(8, -1, -1)], dtype=torch.int64, device=dev)
+    gen = None
+    if seqlike:
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(1000 + 10 * seed + mate)
+        base_hdr = torch.tensor(list(SEQLIKE_HEADER + b"\n"), dtype=torch.uint8, device=dev)
+        tpos, xpos, ypos, mpos = SEQLIKE_HEADER.index(b"tttt"), SEQLIKE_HEADER.index(b"xxxxx"), SEQLIKE_HEADER.index(b"yyyyy"), SEQLIKE_HEADER.index(b" m:") + 1
+        qchars = torch.tensor(list(b"F:,#"), dtype=torch.uint8, device=dev)
     for s in range(0, n, block):
         e = min(n, s + block)
         idx = torch.arange(s, e, dtype=torch.int64, device=dev)
         st, ln, of = start[s:e], L[s:e], offsets[s:e].to(torch.int64)
-        hdr = torch.empty((e - s, 14), dtype=torch.uint8, device=dev)
-        hdr[:, 0] = ord("@")
-        hdr[:, 1] = ord("s")
-        hdr[:, 2:11] = ((idx[:, None] // p10[None, :]) % 10 + 48).to(torch.uint8)
-        hdr[:, 11] = ord("/")
-        hdr[:, 12] = 48 + int(mate)
-        hdr[:, 13] = 10
-        out[(st[:, None] + torch.arange(14, device=dev)[None, :]).reshape(-1)] = hdr.reshape(-1)
+        if seqlike:
+            hdr = base_hdr[None, :].repeat(e - s, 1)
+            hdr[:, tpos:tpos + 4] = (((1101 + idx // 400000)[:, None] // p10[None, 5:]) % 10 + 48).to(torch.uint8)
+            hdr[:, xpos:xpos + 5] = (((10000 + idx % 20000)[:, None] // p10[None, 4:]) % 10 + 48).to(torch.uint8)
+            hdr[:, ypos:ypos + 5] = (((10000 + (idx // 7) % 90000)[:, None] // p10[None, 4:]) % 10 + 48).to(torch.uint8)
+            hdr[:, mpos] = 48 + int(mate)
+        else:
+            hdr = torch.empty((e - s, 14), dtype=torch.uint8, device=dev)
+            hdr[:, 0] = ord("@")
+            hdr[:, 1] = ord("s")
+            hdr[:, 2:11] = ((idx[:, None] // p10[None, :]) % 10 + 48).to(torch.uint8)
+            hdr[:, 11] = ord("/")
+            hdr[:, 12] = 48 + int(mate)
+            hdr[:, 13] = 10
+        out[(st[:, None] + torch.arange(H, device=dev)[None, :]).reshape(-1)] = hdr.reshape(-1)
         tot = int(ln.sum().item())
         if tot:
             rid = torch.repeat_interleave(torch.arange(e - s, device=dev), ln, output_size=tot)
             cum = torch.cumsum(ln, 0) - ln
             k = torch.arange(tot, dtype=torch.int64, device=dev) - cum[rid]
-            out[st[rid] + 14 + k] = arena[of[rid] + k]
-        sep = st + 14 + ln
+            out[st[rid] + H + k] = arena[of[rid] + k]
+            if seqlike:
+                u = torch.rand(tot, device=dev, generator=gen)
+                q = (u >= 0.90).to(torch.int64) + (u >= 0.96).to(torch.int64) + (u >= 0.99).to(torch.int64)
+                out[st[rid] + H + ln[rid] + 3 + k] = qchars[q]
+        sep = st + H + ln
         out[sep] = 10
         out[sep + 1] = ord("+")
         out[sep + 2] = 10
         out[st + rec[s:e] - 1] = 10
     return out
+
+
+def bgzip_file(src, dst, level=6, threads=None, block=65280):
+    """`src` as BGZF the way bgzip / htslib write it - one zlib-deflated member per 65,280 input bytes, 'BC' subfield, the empty
+    end-of-file member - by several threads. (This build's own device writer frames BGZF too, but with its own encoder; a benchmark of
+    what a user's bgzip-made file costs must not read that.)"""
+    import os
+    import struct
+    import zlib
+    from concurrent.futures import ThreadPoolExecutor
+    threads = threads or max(1, len(os.sched_getaffinity(0)))
+
+    def members(data):
+        out = []
+        for i in range(0, len(data), block):
+            piece = data[i:i + block]
+            co = zlib.compressobj(level, zlib.DEFLATED, -15)
+            d = co.compress(piece) + co.flush()
+            out.append(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(d) + 25) + d
+                       + struct.pack("<II", zlib.crc32(piece) & 0xffffffff, len(piece)))
+        return b"".join(out)
+    with open(src, "rb") as fi, open(dst, "wb") as fo, ThreadPoolExecutor(threads) as ex:
+        window = []
+        while True:
+            data = fi.read(block * 128)
+            if not data:
+                break
+            window.append(ex.submit(members, data))
+            if len(window) >= 2 * threads:
+                fo.write(window.pop(0).result())
+        for w in window:
+            fo.write(w.result())
+        fo.write(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
 
 
 def pgzip_file(src, dst, level=6, threads=None, chunk=8 << 20, repeat=1):

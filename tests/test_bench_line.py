@@ -21,8 +21,9 @@ def _full(n_ranks=1):
     for k, v in full["e2e_cli"].items():            # the round-4 record's legs under this round's names, + the three new ones
         if isinstance(v, dict) and "reads_per_s" in v:
             legs["plain_to_plain" if k == "large" else k] = dict(v, reads_per_s_after_first_chunk=1.07 * v["reads_per_s"])
-    for extra in ("bgzf_to_plain", "bgzf_to_gz_host_parse", "plain_to_plain_host_parse"):
-        legs[extra] = dict(legs["plain_to_gz"])
+    for extra in ("bgzf_to_plain", "bgzf_to_gz_host_parse", "plain_to_plain_host_parse", "seqlike_plain_to_gz", "seqlike_bgzf_to_gz", "seqlike_gz_to_gz"):
+        legs[extra] = dict(legs["plain_to_gz"])          # (round 6: the three legs on sequencer-like files; the *_host_parse legs left the line)
+    full["roofline"].update(effective_clock_ghz=1.873, package_power_w=1288.4)
     full["e2e_cli"] = legs
     full["cpu_baseline"]["sample_short"] = "first 229376 reads of rank 0's R1 stream; C port (AVX + OpenMP) of the padded 100-step BiLSTM, batch 1024/thread, 16 threads, 12.3 s"
     full["n_gpus"] = n_ranks
@@ -46,6 +47,7 @@ def test_compact_line_fits_the_drivers_tail():
         assert {"value", "unit", "cores", "kind", "sample"} <= set(j["cpu_baseline"])
         assert abs(j["roofline"]["frac"] - j["roofline"]["achieved"] / j["roofline"]["peak"]) < 1e-4
         assert j["e2e_bgzf_to_gz"]["rps"] > 0 and j["e2e_plain_to_plain"]["host_cores_busy"] > 0 and "ranks" not in j["config"]
+        assert j["e2e_seqlike_gz_to_gz"]["rps"] > 0 and "e2e_bgzf_to_gz_host_parse" not in j and j["roofline"]["effective_clock_ghz"] == 1.873
         assert "parity_sample" in j and j["alt_fp32_frac"] > 0.5
 
 

@@ -96,16 +96,20 @@ class E2E:
       in_kind: "plain" | "gz" (ONE gzip member per file - what sequencers write) | "bgzf" (65,280-byte members - bgzip, this build's writer)
     The CLI logs at WARNING here (its per-chunk INFO lines would be most of stderr)."""
 
-    def __init__(self, torch, synth, arenas, offsets, lens, L, ensure):
-        self.torch, self.synth = torch, synth
+    def __init__(self, torch, synth, arenas, offsets, lens, L, ensure, style="const"):
+        """style "const": SURVEY 8d's files (header @s<idx>/<mate>, quality 'I' * len; BGZF framed by this build's device writer, the single
+        stream by libdeflate / zlib level 1 - the files of rounds 3-5). style "seqlike": what a user has - Illumina headers, binned
+        qualities (synth.fastq_image_torch), BGZF made by zlib level 6 per 65,280-byte block (what bgzip writes), the single stream by
+        zlib level 6 (synth.pgzip_file)."""
+        self.torch, self.synth, self.style = torch, synth, style
         self.L, self.ensure, self.n = L, ensure, int(lens.numel())
         self.lens, self.dev = lens, arenas[0].device
         self.dir = tempfile.mkdtemp(prefix="rd_e2e_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
         self.files = {"plain": []}
-        self.how = {"plain": None}
+        self.how = {"plain": None if style == "const" else "Illumina headers, binned qualities"}
         for m, a in enumerate(arenas):
             p = os.path.join(self.dir, "r_%d.fq" % (m + 1))
-            synth.fastq_image_torch(a, offsets, lens, mate=m + 1).cpu().numpy().tofile(p)
+            synth.fastq_image_torch(a, offsets, lens, mate=m + 1, style=style, seed=m).cpu().numpy().tofile(p)
             self.files["plain"].append(p)
         self.plain_bytes = sum(os.path.getsize(p) for p in self.files["plain"])
         self._ncall = 0
@@ -116,7 +120,7 @@ class E2E:
     def save(self):
         """what a child process needs to run legs on these files (E2E.from_dir)"""
         with open(os.path.join(self.dir, "e2e_meta.json"), "w") as fh:
-            json.dump({"L": self.L, "ensure": self.ensure, "n": self.n, "files": self.files, "how": self.how, "plain_bytes": self.plain_bytes}, fh)
+            json.dump({"L": self.L, "ensure": self.ensure, "n": self.n, "files": self.files, "how": self.how, "plain_bytes": self.plain_bytes, "style": self.style}, fh)
 
     @classmethod
     def from_dir(cls, d):
@@ -124,6 +128,7 @@ class E2E:
         e = cls.__new__(cls)
         e.dir, e.L, e.ensure, e.n, e.files, e.how, e.plain_bytes = d, m["L"], m["ensure"], m["n"], m["files"], m["how"], m["plain_bytes"]
         e.torch = e.synth = e.lens = e.dev = None
+        e.style = m.get("style", "const")
         return e
 
     def leg_in_child(self, in_kind="plain", out_gz=False, timed_calls=3, threads=None, env=None):
@@ -152,6 +157,15 @@ class E2E:
             return self.files[kind]
         torch = self.torch
         plain = self.files["plain"]
+        if self.style == "seqlike" and kind in ("bgzf", "gz"):     # made by zlib level 6, as a user's bgzip / gzip would
+            from ribodetector_amd import synth as sy
+            outs = [p[:-3] + (".bgzf.fq.gz" if kind == "bgzf" else ".one.fq.gz") for p in plain]
+            for p, q in zip(plain, outs):
+                (sy.bgzip_file if kind == "bgzf" else sy.pgzip_file)(p, q, level=6)
+            self.files[kind] = outs
+            self.how[kind] = ("BGZF members of 65,280 bytes, zlib level 6 (what bgzip writes)" if kind == "bgzf" else
+                              "one gzip member per file, zlib level 6 (deflated in 8 MiB pieces primed with the 32 KiB before them, as pigz does)")
+            return outs
         if kind == "bgzf":          # framed by the device writer, outside every timed region
             import numpy as np
             from ribodetector_amd.gz import DeviceGzip, eof_block
@@ -395,8 +409,25 @@ def bench_legs(a):
                 "gz_to_gz_host_inflate_all_cores": ("gz", True, usable_cores(), {"RD_DEVICE_INFLATE": "members"})}
         want = [k for k in (a.legs.split(",") if a.legs else legs) if k]
         for k in want:                  # every leg in a process of its own (the input files are built once, here)
+            if k not in legs:
+                continue
             kind, out_gz, threads, env = legs[k]
             rec[k] = e.leg_in_child(kind, out_gz, threads=threads, env=dict(env, **xenv))
+    # the same records as a user's files would hold them (round 6): Illumina headers, binned qualities, zlib-6 BGZF / single stream
+    slegs = {"seqlike_plain_to_gz": ("plain", True), "seqlike_bgzf_to_gz": ("bgzf", True), "seqlike_gz_to_gz": ("gz", True)}
+    swant = [k for k in (a.legs.split(",") if a.legs else slegs) if k in slegs]
+    if swant and not a.no_seqlike:
+        r1 = [synth.reads_torch(P, RL, seed=2000 + i, device=dev) for i in range(nslices)]
+        r2 = [synth.reads_torch(P, RL, seed=7000 + i, device=dev) for i in range(nslices)] if paired else None
+        arenas = [cat(r1, rep)] + ([cat(r2, rep)] if paired else [])
+        with E2E(torch, synth, arenas, offs_l, lens.repeat(rep * nslices), a.max_len, a.ensure, style="seqlike") as e:
+            del arenas, r1, r2
+            for kind in {slegs[k][0] for k in swant} - {"plain"}:
+                e.inputs(kind)
+            e.lens = None
+            torch.cuda.empty_cache()
+            for k in swant:
+                rec[k] = e.leg_in_child(slegs[k][0], slegs[k][1], env=dict(xenv))
     print(json.dumps(rec))
 
 
@@ -412,6 +443,7 @@ def main():
     ap.add_argument("--var-len", action="store_true")
     ap.add_argument("--ensure", default="rrna")
     ap.add_argument("--legs", default=None, help="with --bench-legs: only these legs (comma-separated names)")
+    ap.add_argument("--no-seqlike", action="store_true", help="with --bench-legs: skip the second file set (sequencer-like text, zlib-6 inputs)")
     ap.add_argument("--one-leg", default=None, metavar="DIR", help=argparse.SUPPRESS)      # child of E2E.leg_in_child
     ap.add_argument("--in-kind", default="plain", help=argparse.SUPPRESS)
     ap.add_argument("--out-gz", action="store_true", help=argparse.SUPPRESS)

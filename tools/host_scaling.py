@@ -56,7 +56,7 @@ def run_cli(world, inputs, outdir, tag, threads, shared_decode="1", gz_out=False
     outs = [os.path.join(outdir, "%s_w%d_%d.fq%s" % (tag, world, i, ".gz" if gz_out else "")) for i in range(len(inputs))]
     base = ["-l", "100", "-i", *inputs, "-o", *outs, "-t", str(threads)] + (["-e", "rrna"] if len(inputs) == 2 else [])
     tfile = os.path.join(outdir, "timing_%s_w%d" % (tag, world))
-    env = dict(os.environ, RD_PREFIX_K="12", RD_SHARED_DECODE=shared_decode, RD_TIMING_OUT=tfile, **(extra_env or {}))
+    env = dict(os.environ, RD_PREFIX_K=os.environ.get("RD_PREFIX_K", "12"), RD_SHARED_DECODE=shared_decode, RD_TIMING_OUT=tfile, **(extra_env or {}))
     if world == 1:
         cmd = [sys.executable, "-m", "ribodetector_amd.detect"] + base
     else:
@@ -67,7 +67,12 @@ def run_cli(world, inputs, outdir, tag, threads, shared_decode="1", gz_out=False
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1800)
     dt, cpu = time.perf_counter() - t0, child_cpu() - c0
     if r.returncode != 0:
-        return {"error": (r.stdout + r.stderr)[-1500:]}
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "hs_err_%s_w%d.log" % (tag, world)), "a") as fh:
+            fh.write((r.stdout + r.stderr)[-60000:])
+        import re
+        tb = re.findall(r"(?:Error|error|Exception)[^\n]*", r.stdout + r.stderr)
+        return {"error": (r.stdout + r.stderr)[-600:], "error_lines": tb[:12], "env": extra_env or {}}
     import gzip
     import hashlib
     sha = [hashlib.sha1((gzip.open if gz_out else open)(o, "rb").read()).hexdigest() for o in outs]      # (of the text)
