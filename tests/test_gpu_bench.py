@@ -154,7 +154,8 @@ def test_scale_sweep_script_on_one_gpu(tmp_path):
     rank 0 against each rank's own recomputation) and lists its ranks' devices; the JSON carries efficiency against N = 1 and the
     agreement of the N = 1 rank-group run with the plain line."""
     out = tmp_path / "sweep.json"
-    env = dict(os.environ, RD_DIST_BACKEND="gloo", RD_LOCAL_DEVICE="0", RD_PREFIX_K="8")
+    env = dict(os.environ, RD_DIST_BACKEND="gloo", RD_LOCAL_DEVICE="0", RD_PREFIX_K="8", RD_SWEEP_SHARE_GPU="1", RD_SWEEP_CLI_RECORDS="262144",
+               RD_SWEEP_CLI_NS="1 8")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
     r = subprocess.run(["bash", os.path.join(ROOT, "tools", "scale_sweep.sh"), str(out), "--pairs-per-step", "16384", "--steps", "2", "--warmup", "1"],
@@ -168,6 +169,14 @@ def test_scale_sweep_script_on_one_gpu(tmp_path):
         assert all(rk["device"] == "cuda:0" and rk["first_gather_s"] >= 0 for rk in p["ranks"])
         assert p["efficiency_vs_n1"] is not None
     assert j["plain_line_reads_per_s"] > 1e5 and "n1_group_over_plain" in j
+    # round 6: the CLI's flows ride along at the same N (here N = 1 and 8): BGZF -> gz, plain -> plain, single-stream gz -> gz, every one of them
+    # sharded (at N = 8 the .gz is decoded range by range on the ranks' GPU), outputs equal to the N = 1 run's
+    for n in (1, 8):
+        fl = pts[n]["cli"]
+        assert set(fl) == {"bgzf_to_gz", "plain_to_plain", "gz_to_gz"}, fl
+        assert all(v["cli_reads_per_s"] > 1e4 and v["outputs_equal_n1"] and v["cores_busy"] > 0 for v in fl.values()), fl
+    assert pts[8]["cli"]["gz_to_gz"]["ingest_modes"] == ["gz-range"] and pts[1]["cli"]["gz_to_gz"]["ingest_modes"] == ["device"]
+    assert all(c is None or c.get("how") for c in pts[8]["cpus"])
 
 
 def test_gather_self_check_catches_a_wrong_gather():

@@ -52,7 +52,8 @@ def run_bench(world, pairs):
             "host_cores_busy": c["host_cores_busy"], "host_cores_usable": c["host_cores_usable"], "dist_backend": c["dist_backend"]}
 
 
-def run_cli(world, inputs, outdir, tag, threads, shared_decode="1", gz_out=False, extra_env=None):
+def run_cli(world, inputs, outdir, tag, threads, shared_decode="1", gz_out=False, extra_env=None, share_gpu=True):
+    """share_gpu: the ranks share GPU 0 and exchange over gloo (a 1-GPU box); False: one GPU per rank over RCCL (tools/scale_cli.py)"""
     outs = [os.path.join(outdir, "%s_w%d_%d.fq%s" % (tag, world, i, ".gz" if gz_out else "")) for i in range(len(inputs))]
     base = ["-l", "100", "-i", *inputs, "-o", *outs, "-t", str(threads)] + (["-e", "rrna"] if len(inputs) == 2 else [])
     tfile = os.path.join(outdir, "timing_%s_w%d" % (tag, world))
@@ -60,7 +61,8 @@ def run_cli(world, inputs, outdir, tag, threads, shared_decode="1", gz_out=False
     if world == 1:
         cmd = [sys.executable, "-m", "ribodetector_amd.detect"] + base
     else:
-        env.update(RD_DIST_BACKEND="gloo", RD_LOCAL_DEVICE="0")
+        if share_gpu:
+            env.update(RD_DIST_BACKEND="gloo", RD_LOCAL_DEVICE="0")
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
                "--master-port", str(free_port()), "-m", "ribodetector_amd.detect"] + base
     c0, t0 = child_cpu(), time.perf_counter()
@@ -87,7 +89,7 @@ def run_cli(world, inputs, outdir, tag, threads, shared_decode="1", gz_out=False
     nread = max((t["num_read"] for t in tj), default=0) * len(inputs)
     return {"ranks": world, "threads_flag": threads, "wall_s_whole_process": dt, "cpu_s_all_ranks": cpu, "cores_busy": cpu / dt, "output_sha1": sha,
             "detect_s_max_over_ranks": det, "reads_per_s_detect": nread / det if det else None,
-            "gz_ranges_s": [t.get("gz_ranges_s") for t in tj], "ingest_modes": sorted({str(v.get("mode", v.get("path"))) for t in tj for v in (t.get("ingest") or {}).values()}),
+            "gz_ranges_s": [t.get("gz_ranges_s") for t in tj], "ingest_modes": sorted({str((v.get("feeder") or {}).get("mode") or v.get("path")) for t in tj for v in (t.get("ingest") or {}).values()}),
             "env": extra_env or {}}
 
 

@@ -29,6 +29,16 @@ for N in $NS; do
     env -u RD_FORCE_DIST python bench.py --gpus $N $FLAGS --full-out $TMP/n$N.json > /dev/null 2> $TMP/n$N.err; echo "N=$N rc=$?" >> $TMP/rc
   fi
 done
+# the CLI's flows at the same N (round 6): sequencer-like files in tmpfs, built once; BGZF -> gz, plain -> plain, single-stream gz -> gz
+# under torch.distributed.run, one GPU per rank (RD_SWEEP_CLI=0: skip; RD_SWEEP_SHARE_GPU=1: all ranks on GPU 0 over gloo, for a 1-GPU box)
+if [ "${RD_SWEEP_CLI:-1}" != 0 ]; then
+  CLID=$(mktemp -d -p /dev/shm rd_sweep_XXXX 2>/dev/null || mktemp -d)
+  python tools/scale_cli.py --make $CLID --records ${RD_SWEEP_CLI_RECORDS:-8388608} > $TMP/cli_make.json 2> $TMP/cli_make.err
+  for N in ${RD_SWEEP_CLI_NS:-$NS}; do
+    python tools/scale_cli.py --run $CLID --gpus $N ${RD_SWEEP_SHARE_GPU:+--share-gpu} > $TMP/cli$N.json 2> $TMP/cli$N.err
+  done
+  rm -rf $CLID
+fi
 python - "$TMP" "$OUT" $NS <<'PY'
 import json, os, sys
 tmp, out, ns = sys.argv[1], sys.argv[2], [int(x) for x in sys.argv[3:]]
@@ -43,6 +53,7 @@ if plain and plain2:
 rec = {"plain_line_reads_per_s": plain and plain["value"], "plain_runs": plain and plain.get("values"), "points": [],
        "rc": open(os.path.join(tmp, "rc")).read().split("\n")[:-1]}
 base = None
+cli_ref = {}
 for n in ns:
     j = load("n%d.json" % n)
     if j is None:
@@ -55,7 +66,15 @@ for n in ns:
           "rccl_ranks": j["config"]["rccl_ranks"], "host_cores_busy": j["config"]["host_cores_busy"],
           "gather_self_check": j["config"].get("gather_self_check"),
           "ranks": [{k: r[k] for k in ("rank", "device", "device_uuid", "first_gather_s")} for r in (j["config"].get("ranks") or [])],
-          "efficiency_vs_n1": (j["value"] / (n * base)) if base else None}
+          "efficiency_vs_n1": (j["value"] / (n * base)) if base else None,
+          "gpu_state": j["roofline"].get("gpu_state_in_timed_region"), "cpus": [r.get("cpus") for r in (j["config"].get("ranks") or [])]}
+    cli = load("cli%d.json" % n)
+    if cli:          # the CLI's flows at this N: reads/s of detect() over the ranks, host cores busy, outputs against the N = 1 run's
+        pt["cli"] = cli["flows"]
+        for name, fl in cli["flows"].items():
+            if "output_sha1" in fl:
+                cli_ref.setdefault(name, fl["output_sha1"])
+                fl["outputs_equal_n1"] = fl.pop("output_sha1") == cli_ref[name]
     rec["points"].append(pt)
 if plain and base:
     rec["n1_group_over_plain"] = base / plain["value"]
