@@ -270,6 +270,18 @@ class GzipStream {
     }
     void refill_input() {
         if (in_eof_) return;
+        // Whole bytes waiting in the bit buffer go back into the byte buffer first: what is moved to the front below starts at ip_, and
+        // align_byte() - a stored block, i.e. every sync flush of a pigz-made stream - hands unread bytes back by moving ip_ DOWN. (Round
+        // 6: a block header within the last KiB of an input buffer, followed by a stored block, moved ip_ below zero: "Compressed file
+        // ended ..." in the middle of a good file, about once per GB of pigz output.)
+        {
+            const unsigned back = bitcnt_ >> 3;
+            if (back && back <= ip_) {
+                ip_ -= back;
+                bitcnt_ &= 7;
+                bitbuf_ &= (1ull << bitcnt_) - 1;
+            }
+        }
         if (ip_ > 0) {
             memmove(ib_.data(), ib_.data() + ip_, iend_ - ip_);
             iend_ -= ip_;
@@ -568,8 +580,12 @@ class GzipStream {
                     return -1;
                 }
                 ip_ = p;
+                bitbuf_ = bb;          // (refill_input hands the bit buffer's whole bytes back: it must see the live one)
+                bitcnt_ = bc;
                 refill_input();
                 p = ip_;
+                bb = bitbuf_;
+                bc = bitcnt_;
                 safe = isafe();
                 if (p > safe && !in_eof_) {   // cannot happen with IN_CAP >> 24
                     err = "input buffer too small";

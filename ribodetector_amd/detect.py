@@ -877,7 +877,8 @@ def main(argv=None, log_level=None):
             import json
             with open("%s.rank%d" % (os.environ["RD_TIMING_OUT"], seq_pred.rank), "w") as fh:
                 json.dump(dict(seq_pred.timing, rank=seq_pred.rank, world=seq_pred.world, num_read=seq_pred.num_read,
-                               thread_cpu_s=seq_pred.thread_cpu_s, process_cpu_s=time.process_time()), fh, default=str)
+                               thread_cpu_s=seq_pred.thread_cpu_s, process_cpu_s=time.process_time(), main_thread_s=getattr(seq_pred, "_stage_s", None),
+                               phases_s=getattr(seq_pred, "phases_s", None)), fh, default=str)
     except BaseException:
         seq_pred.cleanup()                       # a failed run leaves no slot, '<out>.partN' or '<out>.joining' files behind
         if seq_pred.multi:

@@ -384,3 +384,19 @@ def test_parallel_decoder_on_flushed_streams_like_pigz(tmp_path):
             assert rc == 0 and got == data, (mode, step, err, st)
             if step > 3000:
                 assert st["used"] >= 4 and st["fell_back"] == 0, st
+
+
+def test_sequential_decoder_on_pigz_streams_larger_than_its_input_buffer(tmp_path):
+    """round 6: a pigz-made member (sync flush = an empty stored block every piece) of many input buffers. A block header inside the
+    last KiB of a buffer made the decoder refill with whole bytes still in its bit buffer; the stored block behind it then handed
+    'unread bytes' back that had left the buffer: "Compressed file ended ..." in the middle of a good file - about once per GB of
+    pigz output, in the decoder every fallback ends in."""
+    arena, off, _ = synth.reads_numpy(200000, 100, seed=9)
+    src = tmp_path / "t.fq"
+    synth.write_fastq_realistic(str(src), arena, off, 1, seed=9)
+    data = src.read_bytes()
+    for chunk in (300000, 131072, 70001):
+        p = tmp_path / ("pigz_%d.fq.gz" % chunk)
+        synth.pgzip_file(str(src), str(p), level=6, chunk=chunk)
+        rc, got, err = gunzip(p, len(data) + 16)
+        assert rc == 0 and got == data, (chunk, err, len(got))

@@ -89,7 +89,8 @@ def run_cli(world, inputs, outdir, tag, threads, shared_decode="1", gz_out=False
     nread = max((t["num_read"] for t in tj), default=0) * len(inputs)
     return {"ranks": world, "threads_flag": threads, "wall_s_whole_process": dt, "cpu_s_all_ranks": cpu, "cores_busy": cpu / dt, "output_sha1": sha,
             "detect_s_max_over_ranks": det, "reads_per_s_detect": nread / det if det else None,
-            "gz_ranges_s": [t.get("gz_ranges_s") for t in tj], "ingest_modes": sorted({str((v.get("feeder") or {}).get("mode") or v.get("path")) for t in tj for v in (t.get("ingest") or {}).values()}),
+            "gz_ranges_s": [t.get("gz_ranges_s") for t in tj], "detect_s_by_rank": [round(t["detect_s"], 3) for t in tj],
+            "slowest_rank": max(tj, key=lambda t: t["detect_s"], default=None), "ingest_modes": sorted({str((v.get("feeder") or {}).get("mode") or v.get("path")) for t in tj for v in (t.get("ingest") or {}).values()}),
             "env": extra_env or {}}
 
 
