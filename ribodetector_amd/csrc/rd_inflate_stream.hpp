@@ -548,175 +548,49 @@ __global__ __launch_bounds__(64) void rd_gzs_scan_kernel(const GzsSec *__restric
     }
 }
 
-// one workgroup, the sections in order: windows[slot + 1] = the 32 KiB of text behind section `slot` (windows[0] = the carried one).
-// Thread t owns window bytes [32 t, 32 t + 32): the 32 symbols they come from (the section's last 32 Ki symbols) are fetched one
-// section AHEAD (they do not depend on the window), resolved through the window in LDS, written back 32 bytes at a time.
-__global__ __launch_bounds__(1024) void rd_gzs_window_kernel(const uint16_t *__restrict__ syms, int cap, const GzsSec *__restrict__ sec, const int32_t *__restrict__ plist,
-                                                             const int32_t *__restrict__ wslot, int nsec, GzsState *__restrict__ st, const uint8_t *__restrict__ win_in,
-                                                             uint8_t *__restrict__ windows, uint8_t *__restrict__ win_out) {
-    __shared__ __attribute__((aligned(16))) uint8_t W[2][GZS_WIN];
-    __shared__ int s_bad;
-    const int tid = threadIdx.x;
-    if (st->status != GZS_OK) return;
-    for (int i = tid; i < GZS_WIN; i += 1024) {
-        const uint8_t b = win_in ? win_in[i] : 0;
-        W[0][i] = b;
-        windows[i] = b;
-    }
-    if (tid == 0) s_bad = 0;
-    int cur = 0;
-    uint32_t valid = st->win_valid;                 // bytes at the END of the window that are text
-    const int nslots = wslot[nsec];
-    u32x4 pre[4];                                   // the 32 symbols of this thread for the section about to be processed
-    auto fetch = [&](int slot) {
-        if (slot >= nslots) return;
+// ---- the window chain, on SYMBOLS and in parallel (round 6) -----------------------------------------------------------------------------
+// The 32 KiB behind a section are a function of the 32 KiB in front of it: entry i is a byte the section produced, or "entry j of the
+// window before" (a marker that survived). Such maps compose - a marker into the previous window is replaced by that window's entry,
+// itself a byte or a marker - so the chain need not run in order on one workgroup (round 5: 1,256 sections x 1.6 us, 4.9 ms per batch)
+// and need not know the text in front of the batch at all:
+//   rd_gzs_symwin_kernel   one workgroup per GROUP of GZS_GROUP consecutive sections, all groups at once: the group's sections in order,
+//                          starting from the identity map; windows16[slot] = the window in front of section `slot` RELATIVE to the window
+//                          in front of its group, gmaps[g] = the window behind group g likewise;
+//   rd_gzs_chain_kernel    one workgroup, the groups in order (a gather of 32 Ki entries each): gwin[g] = the window in front of group g,
+//                          from the window in front of the batch - bytes (a stream decoded from its first byte: rd_gz_stream_inflate) or
+//                          itself a map (a RANGE of the stream whose predecessor is still being decoded: rd_gz_range_decode);
+//   rd_gzs_resolve_kernel  all sections in parallel: a marker goes through windows16[slot], what is still a marker through gwin[group].
+// A marker that survives all of it points in front of the member's first byte (streaming: GZS_WINDOW) or into the window in front of
+// the range (range mode: it stays in the 16-bit text until the ranks have exchanged their maps).
+constexpr int GZS_GROUP = 32;
+
+// thread t of the workgroup owns window entries [32 t, 32 t + 32); W = the current window in LDS (64 KiB); `pre` = the thread's 32 symbols
+// of the section about to be processed, fetched one section ahead (they do not depend on the window)
+struct GzsWinStep {
+    const uint16_t *syms;
+    int cap;
+    const GzsSec *sec;
+    const int32_t *plist;
+    int tid;
+    u32x4 pre[4];
+    __device__ __forceinline__ void fetch(int slot, int end) {
+        if (slot >= end) return;
         const int k = plist[slot];
         const int n = (int)sec[k].n_syms;
         if (n < GZS_WIN) return;                    // (short section: the slow path reads its symbols itself)
         const uint8_t *src = reinterpret_cast<const uint8_t *>(syms + (size_t)k * (size_t)cap + (size_t)(n - GZS_WIN) + (size_t)tid * 32);
 #pragma unroll
         for (int q = 0; q < 4; ++q) __builtin_memcpy(&pre[q], src + 16 * q, 16);
-    };
-    fetch(0);
-    __syncthreads();
-    bool bad = false;
-    for (int slot = 0; slot < nslots; ++slot) {
+    }
+    // the window behind section `slot` into out[16] (two entries per dword); reads W; the caller barriers, stores, barriers
+    __device__ __forceinline__ void step(int slot, int end, const uint16_t *W, uint32_t (&out)[16]) {
         const int k = plist[slot];
         const int n = (int)sec[k].n_syms;
-        const uint8_t *Wp = W[cur];
-        uint8_t *Wn = W[cur ^ 1];
-        uint8_t *gdst = windows + (size_t)(slot + 1) * GZS_WIN;
         if (n >= GZS_WIN) {
             u32x4 now[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) now[q] = pre[q];
-            fetch(slot + 1);                        // the next section's symbols travel while this one is resolved
-            uint32_t out[8];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const uint32_t two = now[q][j];
-                    uint32_t packed = 0;
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const uint32_t sy = (two >> (16 * h)) & 0xffffu;
-                        uint32_t b = sy;
-                        if (sy & GZS_MARK) {
-                            const uint32_t w = sy & 0x7fffu;
-                            bad = bad || w < (uint32_t)GZS_WIN - valid;
-                            b = Wp[w];
-                        }
-                        packed |= (b & 0xffu) << (8 * h);
-                    }
-                    const int pos = q * 8 + j * 2;          // byte index within the thread's 32
-                    out[pos >> 2] = (pos & 2) ? (out[pos >> 2] | (packed << 16)) : packed;
-                }
-            }
-            u32x4 o0 = {out[0], out[1], out[2], out[3]}, o1 = {out[4], out[5], out[6], out[7]};
-            *reinterpret_cast<u32x4 *>(Wn + tid * 32) = o0;
-            *reinterpret_cast<u32x4 *>(Wn + tid * 32 + 16) = o1;
-            *reinterpret_cast<u32x4 *>(gdst + tid * 32) = o0;
-            *reinterpret_cast<u32x4 *>(gdst + tid * 32 + 16) = o1;
-        } else {
-            const uint16_t *sy = syms + (size_t)k * (size_t)cap;
-            for (int i = tid; i < GZS_WIN; i += 1024) {
-                uint8_t b;
-                if (i >= GZS_WIN - n) {
-                    const uint32_t s = sy[i - (GZS_WIN - n)];
-                    if (s & GZS_MARK) {
-                        const uint32_t w = s & 0x7fffu;
-                        bad = bad || w < (uint32_t)GZS_WIN - valid;
-                        b = Wp[w];
-                    } else {
-                        b = (uint8_t)s;
-                    }
-                } else {
-                    b = Wp[i + n];
-                }
-                Wn[i] = b;
-                gdst[i] = b;
-            }
-            fetch(slot + 1);
-        }
-        __syncthreads();
-        valid = valid + (uint32_t)n > (uint32_t)GZS_WIN ? (uint32_t)GZS_WIN : valid + (uint32_t)n;
-        cur ^= 1;
-    }
-    if (bad) s_bad = 1;
-    __syncthreads();
-    for (int i = tid; i < GZS_WIN; i += 1024) win_out[i] = W[cur][i];
-    if (tid == 0) {
-        st->win_valid = valid;
-        if (s_bad) st->status = GZS_WINDOW;          // (markers of the LAST 32 KiB only; the member's CRC covers the rest)
-    }
-}
-
-constexpr int GZS_RTILE = 8192;     // symbols per workgroup of the resolve pass
-__global__ __launch_bounds__(256) void rd_gzs_resolve_kernel(const uint16_t *__restrict__ syms, int cap, const GzsSec *__restrict__ sec, const uint32_t *__restrict__ found,
-                                                            const int64_t *__restrict__ off, const int32_t *__restrict__ wslot, int tiles_per_sec,
-                                                            const uint8_t *__restrict__ windows, GzsState *__restrict__ st, uint8_t *__restrict__ text) {
-    const int k = blockIdx.x / tiles_per_sec, t = blockIdx.x % tiles_per_sec;
-    if (st->status != GZS_OK && st->status != GZS_WINDOW) return;
-    if (found[k] == GZS_NONE || wslot[k + 1] == wslot[k]) return;       // a section that is not part of the text
-    const int n = (int)sec[k].n_syms;
-    const int i0 = t * GZS_RTILE;
-    if (i0 >= n) return;
-    const uint16_t *sy = syms + (size_t)k * (size_t)cap;
-    const uint8_t *W = windows + (size_t)wslot[k] * GZS_WIN;
-    uint8_t *dst = text + off[k];
-    const int i1 = i0 + GZS_RTILE < n ? i0 + GZS_RTILE : n;
-    for (int i = i0 + (int)threadIdx.x; i < i1; i += 256) {
-        const uint32_t s = sy[i];
-        dst[i] = (s & GZS_MARK) ? W[s & 0x7fffu] : (uint8_t)s;
-    }
-}
-
-// ---- a RANGE of the stream decoded before the text in front of it is known (round 6: one .gz shared by the ranks of a node) -----------------
-// Rank r of W decodes the compressed bytes [r S / W, (r + 1) S / W) of ONE DEFLATE stream on its own GPU while rank r - 1 is still decoding
-// its share: the 32 KiB of text in front of the range are not known yet. Everything above works without them up to the window chain;
-// here the chain is run on SYMBOLS - a window entry is a byte or a marker "byte i of the window the RANGE started with" (markers compose:
-// a marker into the previous section's window is replaced by that window's entry, itself a byte or a marker) - and the batch's text is
-// written as 16-bit symbols of the same kind (sym_text). The last window of the range, in that form, is the range's MAP: the window
-// behind it as a function of the window in front of it, 64 KiB. The ranks exchange their maps, apply them in rank order (W - 1 gathers of
-// 32 Ki entries) and every rank then turns its symbols into bytes (rd_gzs_symtext_kernel): no rank ever waits for another one's decode.
-
-// one workgroup, the sections in order (the kernel above on 16-bit entries): windows16[slot + 1] = the 32 Ki symbols behind section `slot`,
-// windows16[0] = map_in (what the batch before left; null: the identity - the batch opens the range). Thread t owns entries [32 t, 32 t + 32);
-// ONE LDS window of 64 KiB: the new entries wait in registers for the barrier behind the reads of the old ones.
-__global__ __launch_bounds__(1024) void rd_gzs_symwin_kernel(const uint16_t *__restrict__ syms, int cap, const GzsSec *__restrict__ sec, const int32_t *__restrict__ plist,
-                                                             const int32_t *__restrict__ wslot, int nsec, const GzsState *__restrict__ st, const uint16_t *__restrict__ map_in,
-                                                             uint16_t *__restrict__ windows16, uint16_t *__restrict__ map_out) {
-    __shared__ __attribute__((aligned(16))) uint16_t W[GZS_WIN];
-    const int tid = threadIdx.x;
-    if (st->status != GZS_OK) return;
-    for (int i = tid; i < GZS_WIN; i += 1024) {
-        const uint16_t b = map_in ? map_in[i] : (uint16_t)(GZS_MARK | (uint32_t)i);
-        W[i] = b;
-        windows16[i] = b;
-    }
-    const int nslots = wslot[nsec];
-    u32x4 pre[4];                                   // the 32 symbols of this thread for the section about to be processed
-    auto fetch = [&](int slot) {
-        if (slot >= nslots) return;
-        const int k = plist[slot];
-        const int n = (int)sec[k].n_syms;
-        if (n < GZS_WIN) return;
-        const uint8_t *src = reinterpret_cast<const uint8_t *>(syms + (size_t)k * (size_t)cap + (size_t)(n - GZS_WIN) + (size_t)tid * 32);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) __builtin_memcpy(&pre[q], src + 16 * q, 16);
-    };
-    fetch(0);
-    __syncthreads();
-    for (int slot = 0; slot < nslots; ++slot) {
-        const int k = plist[slot];
-        const int n = (int)sec[k].n_syms;
-        uint32_t out[16];                           // this thread's 32 new entries, two per dword
-        if (n >= GZS_WIN) {
-            u32x4 now[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) now[q] = pre[q];
-            fetch(slot + 1);
+            fetch(slot + 1, end);                   // the next section's symbols travel while this one is resolved
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
 #pragma unroll
@@ -742,10 +616,41 @@ __global__ __launch_bounds__(1024) void rd_gzs_symwin_kernel(const uint16_t *__r
                 }
                 out[j >> 1] = (j & 1) ? (out[j >> 1] | (b << 16)) : b;
             }
-            fetch(slot + 1);
+            fetch(slot + 1, end);
         }
+    }
+};
+
+__global__ __launch_bounds__(1024) void rd_gzs_symwin_kernel(const uint16_t *__restrict__ syms, int cap, const GzsSec *__restrict__ sec, const int32_t *__restrict__ plist,
+                                                             const int32_t *__restrict__ wslot, int nsec, const GzsState *__restrict__ st,
+                                                             uint16_t *__restrict__ windows16, uint16_t *__restrict__ gmaps) {
+    __shared__ __attribute__((aligned(16))) uint16_t W[GZS_WIN];
+    const int tid = threadIdx.x;
+    if (st->status != GZS_OK) return;
+    const int nslots = wslot[nsec];
+    const int s0 = (int)blockIdx.x * GZS_GROUP;
+    if (s0 >= nslots) return;
+    const int s1 = s0 + GZS_GROUP < nslots ? s0 + GZS_GROUP : nslots;
+    {   // the identity: entry i = "entry i of the window in front of the group"
+        uint32_t id[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) id[j] = (GZS_MARK | (uint32_t)(tid * 32 + 2 * j)) | ((GZS_MARK | (uint32_t)(tid * 32 + 2 * j + 1)) << 16);
+        uint16_t *g0 = windows16 + (size_t)s0 * GZS_WIN + tid * 32;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const u32x4 o = {id[4 * q], id[4 * q + 1], id[4 * q + 2], id[4 * q + 3]};
+            *reinterpret_cast<u32x4 *>(W + tid * 32 + 8 * q) = o;
+            *reinterpret_cast<u32x4 *>(g0 + 8 * q) = o;
+        }
+    }
+    GzsWinStep ws{syms, cap, sec, plist, tid, {}};
+    ws.fetch(s0, s1);
+    __syncthreads();
+    for (int slot = s0; slot < s1; ++slot) {
+        uint32_t out[16];
+        ws.step(slot, s1, W, out);
         __syncthreads();                            // every read of the old window is over
-        uint16_t *gdst = windows16 + (size_t)(slot + 1) * GZS_WIN + tid * 32;
+        uint16_t *gdst = (slot + 1 < s1 ? windows16 + (size_t)(slot + 1) * GZS_WIN : gmaps + (size_t)blockIdx.x * GZS_WIN) + tid * 32;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const u32x4 o = {out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]};
@@ -754,26 +659,117 @@ __global__ __launch_bounds__(1024) void rd_gzs_symwin_kernel(const uint16_t *__r
         }
         __syncthreads();
     }
-    for (int i = tid; i < GZS_WIN; i += 1024) map_out[i] = W[i];
 }
 
-// all sections in parallel: symbols -> symbols whose markers point into the RANGE's first window, at their offsets in the batch's text
-__global__ __launch_bounds__(256) void rd_gzs_resolve16_kernel(const uint16_t *__restrict__ syms, int cap, const GzsSec *__restrict__ sec, const uint32_t *__restrict__ found,
-                                                              const int64_t *__restrict__ off, const int32_t *__restrict__ wslot, int tiles_per_sec,
-                                                              const uint16_t *__restrict__ windows16, const GzsState *__restrict__ st, uint16_t *__restrict__ sym_text) {
-    const int k = blockIdx.x / tiles_per_sec, t = blockIdx.x % tiles_per_sec;
+// one workgroup: gwin[0] = the window in front of the batch - win8 (bytes, of which the LAST st->win_valid are text: the entries in front of
+// them stay markers and any use of them is a distance too far back), or map_in (16-bit entries: range mode), or the identity (a range's first
+// batch) -, gwin[g + 1] = gmaps[g] applied to gwin[g]. The last one goes to map_out (16-bit) and / or win_out (bytes).
+__global__ __launch_bounds__(1024) void rd_gzs_chain_kernel(const uint16_t *__restrict__ gmaps, const int32_t *__restrict__ wslot, int nsec, GzsState *__restrict__ st,
+                                                            const uint8_t *__restrict__ win8, const uint16_t *__restrict__ map_in, int streaming,
+                                                            uint16_t *__restrict__ gwin, uint16_t *__restrict__ map_out, uint8_t *__restrict__ win_out) {
+    __shared__ __attribute__((aligned(16))) uint16_t W[GZS_WIN];
+    __shared__ int s_bad;
+    const int tid = threadIdx.x;
     if (st->status != GZS_OK) return;
-    if (found[k] == GZS_NONE || wslot[k + 1] == wslot[k]) return;
+    const uint32_t valid = streaming ? (st->win_valid > (uint32_t)GZS_WIN ? (uint32_t)GZS_WIN : st->win_valid) : 0u;
+    for (int i = tid; i < GZS_WIN; i += 1024) {
+        uint16_t b = (uint16_t)(GZS_MARK | (uint32_t)i);
+        if (map_in) b = map_in[i];
+        else if (win8 && (uint32_t)i >= (uint32_t)GZS_WIN - valid) b = win8[i];
+        W[i] = b;
+        gwin[i] = b;
+    }
+    if (tid == 0) s_bad = 0;
+    const int nslots = wslot[nsec];
+    const int ngroups = (nslots + GZS_GROUP - 1) / GZS_GROUP;
+    u32x4 pre[4];
+    auto fetch = [&](int g) {
+        if (g >= ngroups) return;
+        const uint8_t *src = reinterpret_cast<const uint8_t *>(gmaps + (size_t)g * GZS_WIN + (size_t)tid * 32);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) __builtin_memcpy(&pre[q], src + 16 * q, 16);
+    };
+    fetch(0);
+    __syncthreads();
+    for (int g = 0; g < ngroups; ++g) {
+        u32x4 now[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) now[q] = pre[q];
+        fetch(g + 1);
+        uint32_t out[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t two = now[q][j];
+                uint32_t lo = two & 0xffffu, hi = two >> 16;
+                if (lo & GZS_MARK) lo = W[lo & 0x7fffu];
+                if (hi & GZS_MARK) hi = W[hi & 0x7fffu];
+                out[q * 4 + j] = lo | (hi << 16);
+            }
+        }
+        __syncthreads();
+        uint16_t *gdst = gwin + (size_t)(g + 1) * GZS_WIN + tid * 32;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const u32x4 o = {out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]};
+            *reinterpret_cast<u32x4 *>(W + tid * 32 + 8 * q) = o;
+            *reinterpret_cast<u32x4 *>(gdst + 8 * q) = o;
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < GZS_WIN; i += 1024) {
+        const uint16_t b = W[i];
+        if (map_out) map_out[i] = b;
+        if (win_out) win_out[i] = (uint8_t)b;
+    }
+    if (streaming) {
+        // how much of the last window is text: what was valid before + what the batch produced. A marker inside that part points in
+        // front of the member's first byte (the markers of the LAST 32 KiB only; the member's CRC covers the rest)
+        __shared__ uint32_t s_nv;
+        if (tid == 0) {
+            const uint64_t v = (uint64_t)valid + (uint64_t)st->n_text;
+            s_nv = v > (uint64_t)GZS_WIN ? (uint32_t)GZS_WIN : (uint32_t)v;
+        }
+        __syncthreads();
+        const uint32_t nv = s_nv;
+        bool bad = false;
+        for (int i = tid; i < GZS_WIN; i += 1024) bad = bad || ((W[i] & GZS_MARK) && (uint32_t)i >= (uint32_t)GZS_WIN - nv);
+        if (bad) s_bad = 1;
+        __syncthreads();
+        if (tid == 0) {
+            st->win_valid = nv;
+            if (s_bad) st->status = GZS_WINDOW;
+        }
+    }
+}
+
+constexpr int GZS_RTILE = 8192;     // symbols per workgroup of the resolve pass
+// all sections in parallel: symbols -> bytes (OUT16 = false; a marker that survives - in front of the member - becomes 0 and is the CRC's
+// to report) or -> 16-bit symbols whose markers point into the window in front of the RANGE (OUT16 = true), at their offsets in the text
+template <bool OUT16>
+__global__ __launch_bounds__(256) void rd_gzs_resolve_kernel(const uint16_t *__restrict__ syms, int cap, const GzsSec *__restrict__ sec, const uint32_t *__restrict__ found,
+                                                            const int64_t *__restrict__ off, const int32_t *__restrict__ wslot, int tiles_per_sec,
+                                                            const uint16_t *__restrict__ windows16, const uint16_t *__restrict__ gwin, const GzsState *__restrict__ st,
+                                                            uint8_t *__restrict__ text, uint16_t *__restrict__ sym_text) {
+    const int k = blockIdx.x / tiles_per_sec, t = blockIdx.x % tiles_per_sec;
+    if (st->status != GZS_OK && st->status != GZS_WINDOW) return;
+    if (found[k] == GZS_NONE || wslot[k + 1] == wslot[k]) return;       // a section that is not part of the text
     const int n = (int)sec[k].n_syms;
     const int i0 = t * GZS_RTILE;
     if (i0 >= n) return;
     const uint16_t *sy = syms + (size_t)k * (size_t)cap;
-    const uint16_t *W = windows16 + (size_t)wslot[k] * GZS_WIN;
-    uint16_t *dst = sym_text + off[k];
+    const int slot = wslot[k];
+    const uint16_t *W1 = windows16 + (size_t)slot * GZS_WIN, *W0 = gwin + (size_t)(slot / GZS_GROUP) * GZS_WIN;
     const int i1 = i0 + GZS_RTILE < n ? i0 + GZS_RTILE : n;
     for (int i = i0 + (int)threadIdx.x; i < i1; i += 256) {
-        const uint32_t s = sy[i];
-        dst[i] = (s & GZS_MARK) ? W[s & 0x7fffu] : (uint16_t)s;
+        uint32_t s = sy[i];
+        if (s & GZS_MARK) {
+            s = W1[s & 0x7fffu];
+            if (s & GZS_MARK) s = W0[s & 0x7fffu];
+        }
+        if (OUT16) sym_text[off[k] + i] = (uint16_t)s;
+        else text[off[k] + i] = (uint8_t)s;
     }
 }
 
@@ -893,15 +889,16 @@ __global__ __launch_bounds__(64) void rd_gzs_fold_kernel(const uint32_t *__restr
 }
 
 struct GzsPlan {
-    int nsec, tiles_per_sec, ctiles;
-    size_t found_bytes, sec_bytes, off_bytes, wslot_bytes, plist_bytes, crc_bytes, windows_bytes, syms_bytes, total;
+    int nsec, tiles_per_sec, ctiles, ngroups;
+    size_t found_bytes, sec_bytes, off_bytes, wslot_bytes, plist_bytes, crc_bytes, windows_bytes, gmaps_bytes, gwin_bytes, syms_bytes, total;
 };
-GzsPlan gzs_plan(int64_t data_bytes, int32_t section_bytes, int32_t cap_syms, int64_t text_cap, bool sym = false) {
+GzsPlan gzs_plan(int64_t data_bytes, int32_t section_bytes, int32_t cap_syms, int64_t text_cap) {
     GzsPlan p;
     p.nsec = (int)((data_bytes + section_bytes - 1) / section_bytes);
     if (p.nsec < 1) p.nsec = 1;
     p.tiles_per_sec = (cap_syms + GZS_RTILE - 1) / GZS_RTILE;
     p.ctiles = (int)((text_cap + GZS_CTILE - 1) / GZS_CTILE) + 1;
+    p.ngroups = (p.nsec + GZS_GROUP - 1) / GZS_GROUP;
     auto al = [](size_t x) { return (x + 255) / 256 * 256; };
     p.found_bytes = al((size_t)(p.nsec + 1) * 4);
     p.sec_bytes = al((size_t)p.nsec * sizeof(GzsSec));
@@ -909,9 +906,11 @@ GzsPlan gzs_plan(int64_t data_bytes, int32_t section_bytes, int32_t cap_syms, in
     p.wslot_bytes = al((size_t)(p.nsec + 1) * 4);
     p.plist_bytes = al((size_t)(p.nsec + 1) * 4);
     p.crc_bytes = al((size_t)p.ctiles * 4);
-    p.windows_bytes = al((size_t)(p.nsec + 1) * GZS_WIN * (sym ? 2 : 1));      // (range mode: 16-bit entries)
+    p.windows_bytes = al((size_t)(p.nsec + 1) * GZS_WIN * 2);      // (16-bit entries: a window relative to its group's)
+    p.gmaps_bytes = al((size_t)p.ngroups * GZS_WIN * 2);
+    p.gwin_bytes = al((size_t)(p.ngroups + 1) * GZS_WIN * 2);
     p.syms_bytes = al((size_t)p.nsec * (size_t)cap_syms * 2);
-    p.total = p.found_bytes + p.sec_bytes + p.off_bytes + p.wslot_bytes + p.plist_bytes + p.crc_bytes + p.windows_bytes + p.syms_bytes;
+    p.total = p.found_bytes + p.sec_bytes + p.off_bytes + p.wslot_bytes + p.plist_bytes + p.crc_bytes + p.windows_bytes + p.gmaps_bytes + p.gwin_bytes + p.syms_bytes;
     return p;
 }
 

@@ -672,7 +672,9 @@ int rd_gz_stream_inflate(const uint8_t *comp, int64_t comp_bytes, int64_t data_b
     int32_t *wslot = (int32_t *)w; w += p.wslot_bytes;
     int32_t *plist = (int32_t *)w; w += p.plist_bytes;
     uint32_t *tcrc = (uint32_t *)w; w += p.crc_bytes;
-    uint8_t *windows = (uint8_t *)w; w += p.windows_bytes;
+    uint16_t *windows16 = (uint16_t *)w; w += p.windows_bytes;
+    uint16_t *gmaps = (uint16_t *)w; w += p.gmaps_bytes;
+    uint16_t *gwin = (uint16_t *)w; w += p.gwin_bytes;
     uint16_t *syms = (uint16_t *)w;
     hipStream_t st = (hipStream_t)stream;
     const uint32_t end_bits = (uint32_t)(valid_bytes * 8), sec_bits = (uint32_t)section_bytes * 8u;
@@ -682,10 +684,12 @@ int rd_gz_stream_inflate(const uint8_t *comp, int64_t comp_bytes, int64_t data_b
                        p.nsec, first_start_bit, C, carry_delta_bits, found);
     hipLaunchKernelGGL(rd_gzs_decode_kernel, dim3((unsigned)((p.nsec + GZI_WAVES - 1) / GZI_WAVES)), dim3(64 * GZI_WAVES), 0, st, comp, comp_bytes, end_bits, p.nsec, found,
                        syms, (int)cap_syms, sec);
-    hipLaunchKernelGGL(rd_gzs_scan_kernel, dim3(1), dim3(1), 0, st, sec, found, p.nsec, (int)at_eof, text_cap, off, wslot, plist, S, C, 0);
-    hipLaunchKernelGGL(rd_gzs_window_kernel, dim3(1), dim3(1024), 0, st, syms, (int)cap_syms, sec, plist, wslot, p.nsec, S, win_in, windows, win_out);
-    hipLaunchKernelGGL(rd_gzs_resolve_kernel, dim3((unsigned)(p.nsec * p.tiles_per_sec)), dim3(256), 0, st, syms, (int)cap_syms, sec, found, off, wslot, p.tiles_per_sec,
-                       windows, S, text);
+    hipLaunchKernelGGL(rd_gzs_scan_kernel, dim3(1), dim3(64), 0, st, sec, found, p.nsec, (int)at_eof, text_cap, off, wslot, plist, S, C, 0);
+    // the window chain on symbols: the groups of sections side by side, then the groups in order (rd_inflate_stream.hpp)
+    hipLaunchKernelGGL(rd_gzs_symwin_kernel, dim3((unsigned)p.ngroups), dim3(1024), 0, st, syms, (int)cap_syms, sec, plist, wslot, p.nsec, S, windows16, gmaps);
+    hipLaunchKernelGGL(rd_gzs_chain_kernel, dim3(1), dim3(1024), 0, st, gmaps, wslot, p.nsec, S, win_in, (const uint16_t *)nullptr, 1, gwin, (uint16_t *)nullptr, win_out);
+    hipLaunchKernelGGL(rd_gzs_resolve_kernel<false>, dim3((unsigned)(p.nsec * p.tiles_per_sec)), dim3(256), 0, st, syms, (int)cap_syms, sec, found, off, wslot,
+                       p.tiles_per_sec, windows16, gwin, S, text, (uint16_t *)nullptr);
     hipLaunchKernelGGL(rd_gzs_crc_kernel, dim3((unsigned)((p.ctiles + 3) / 4)), dim3(256), 0, st, text, S, tcrc);
     hipLaunchKernelGGL(rd_gzs_fold_kernel, dim3(1), dim3(64), 0, st, tcrc, S);
     RD_HIP(hipGetLastError());
@@ -695,7 +699,7 @@ int rd_gz_stream_inflate(const uint8_t *comp, int64_t comp_bytes, int64_t data_b
 // ---- a range of one DEFLATE stream: symbols first, bytes once the window in front of the range is known (rd_inflate_stream.hpp) -----------
 size_t rd_gz_range_workspace_bytes(int64_t data_bytes, int32_t section_bytes, int32_t cap_syms, int64_t text_cap) {
     if (data_bytes < 0 || section_bytes < 1024 || cap_syms < 1024 || text_cap < 0) return 0;
-    return gzs_plan(data_bytes, section_bytes, cap_syms, text_cap, true).total;
+    return gzs_plan(data_bytes, section_bytes, cap_syms, text_cap).total;
 }
 
 int rd_gz_range_decode(const uint8_t *comp, int64_t comp_bytes, int64_t data_bytes, int64_t valid_bytes, int32_t section_bytes, int32_t cap_syms,
@@ -708,7 +712,7 @@ int rd_gz_range_decode(const uint8_t *comp, int64_t comp_bytes, int64_t data_byt
         cap_syms < 1024 || text_cap < 0)
         RD_FAIL(RD_E_INVALID, "rd_gz_range_decode: bad sizes (a batch holds < 256 MiB of compressed bytes)");
     if ((carry == nullptr) != (map_in == nullptr)) RD_FAIL(RD_E_INVALID, "rd_gz_range_decode: carry and map_in go together (both null: the range's first batch)");
-    const GzsPlan p = gzs_plan(data_bytes, section_bytes, cap_syms, text_cap, true);
+    const GzsPlan p = gzs_plan(data_bytes, section_bytes, cap_syms, text_cap);
     if (workspace_bytes < p.total) RD_FAIL(RD_E_WORKSPACE, "rd_gz_range_decode: workspace too small: %zu < %zu", workspace_bytes, p.total);
     char *w = (char *)workspace;
     uint32_t *found = (uint32_t *)w; w += p.found_bytes;
@@ -718,6 +722,8 @@ int rd_gz_range_decode(const uint8_t *comp, int64_t comp_bytes, int64_t data_byt
     int32_t *plist = (int32_t *)w; w += p.plist_bytes;
     w += p.crc_bytes;
     uint16_t *windows16 = (uint16_t *)w; w += p.windows_bytes;
+    uint16_t *gmaps = (uint16_t *)w; w += p.gmaps_bytes;
+    uint16_t *gwin = (uint16_t *)w; w += p.gwin_bytes;
     uint16_t *syms = (uint16_t *)w;
     hipStream_t st = (hipStream_t)stream;
     const uint32_t end_bits = (uint32_t)(valid_bytes * 8), sec_bits = (uint32_t)section_bytes * 8u;
@@ -728,10 +734,11 @@ int rd_gz_range_decode(const uint8_t *comp, int64_t comp_bytes, int64_t data_byt
                        p.nsec, first_start_bit, C, carry_delta_bits, found);
     hipLaunchKernelGGL(rd_gzs_decode_kernel, dim3((unsigned)((p.nsec + GZI_WAVES - 1) / GZI_WAVES)), dim3(64 * GZI_WAVES), 0, st, comp, comp_bytes, end_bits, p.nsec, found,
                        syms, (int)cap_syms, sec);
-    hipLaunchKernelGGL(rd_gzs_scan_kernel, dim3(1), dim3(1), 0, st, sec, found, p.nsec, (int)at_eof, text_cap, off, wslot, plist, S, C, search0);
-    hipLaunchKernelGGL(rd_gzs_symwin_kernel, dim3(1), dim3(1024), 0, st, syms, (int)cap_syms, sec, plist, wslot, p.nsec, S, map_in, windows16, map_out);
-    hipLaunchKernelGGL(rd_gzs_resolve16_kernel, dim3((unsigned)(p.nsec * p.tiles_per_sec)), dim3(256), 0, st, syms, (int)cap_syms, sec, found, off, wslot, p.tiles_per_sec,
-                       windows16, S, sym_text);
+    hipLaunchKernelGGL(rd_gzs_scan_kernel, dim3(1), dim3(64), 0, st, sec, found, p.nsec, (int)at_eof, text_cap, off, wslot, plist, S, C, search0);
+    hipLaunchKernelGGL(rd_gzs_symwin_kernel, dim3((unsigned)p.ngroups), dim3(1024), 0, st, syms, (int)cap_syms, sec, plist, wslot, p.nsec, S, windows16, gmaps);
+    hipLaunchKernelGGL(rd_gzs_chain_kernel, dim3(1), dim3(1024), 0, st, gmaps, wslot, p.nsec, S, (const uint8_t *)nullptr, map_in, 0, gwin, map_out, (uint8_t *)nullptr);
+    hipLaunchKernelGGL(rd_gzs_resolve_kernel<true>, dim3((unsigned)(p.nsec * p.tiles_per_sec)), dim3(256), 0, st, syms, (int)cap_syms, sec, found, off, wslot,
+                       p.tiles_per_sec, windows16, gwin, S, (uint8_t *)nullptr, sym_text);
     RD_HIP(hipGetLastError());
     return RD_OK;
 }
