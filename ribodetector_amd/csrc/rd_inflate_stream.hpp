@@ -26,6 +26,12 @@ constexpr uint32_t GZS_NONE = 0xffffffffu;
 constexpr uint32_t GZS_SEARCH = 0xfffffffeu;     // first_start_bit of a RANGE that begins inside the stream: section 0 looks for its start like the others
 constexpr int GZS_WIN = 32768;
 constexpr uint32_t GZS_MARK = 0x8000u;
+#ifndef RD_GZS_WAVES
+#define RD_GZS_WAVES 4
+#endif
+constexpr int GZS_WAVES = RD_GZS_WAVES;     // sections per workgroup of the search / decode kernels (one per wave). More of them per workgroup = the
+                                            // same waves on fewer compute units: a CU that holds a section's wave holds no recurrence workgroup
+struct __attribute__((aligned(16))) GzsSmem { GziWave w[GZS_WAVES]; };
 enum { GZS_OK = 0, GZS_DECODE = 1, GZS_MISMATCH = 2, GZS_OVERFLOW = 3, GZS_NOSTOP = 4, GZS_WINDOW = 5, GZS_TEXTCAP = 6, GZS_NOSTART = 7 };
 
 struct GzsSec {            // what the decode of one section left
@@ -358,20 +364,20 @@ __device__ __forceinline__ int gzs_blocks(GziWave &S, int lane, const uint8_t *_
 }
 
 // found[k] = the first block start in section k's bits (k = 0: given - the member's first block, or what the batch before found)
-__global__ __launch_bounds__(64 * GZI_WAVES) __attribute__((amdgpu_waves_per_eu(6, 8))) void rd_gzs_search_kernel(
+__global__ __launch_bounds__(64 * GZS_WAVES) __attribute__((amdgpu_waves_per_eu(6, 8))) void rd_gzs_search_kernel(
     const uint8_t *__restrict__ comp, int64_t limit, uint32_t end_bits, uint32_t sec_bits, int nsec, uint32_t first_start, const GzsState *__restrict__ carry,
     int64_t carry_delta_bits, uint32_t *__restrict__ found) {
-    __shared__ GziSmem SM;
+    __shared__ GzsSmem SM;
     __shared__ uint8_t KT[512];       // three code-length-code lengths (3 bits each) -> the sum of their 2^(7 - length), 0 for length 0
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     GziWave &S = SM.w[wave];
-    for (int e = threadIdx.x; e < 512; e += 64 * GZI_WAVES) {
+    for (int e = threadIdx.x; e < 512; e += 64 * GZS_WAVES) {
         uint32_t t = 0;
         for (int j = 0; j < 3; ++j) { const uint32_t l = ((uint32_t)e >> (3 * j)) & 7u; t += l ? (128u >> l) : 0u; }
         KT[e] = (uint8_t)t;
     }
     __syncthreads();
-    for (int k = blockIdx.x * GZI_WAVES + wave; k <= nsec; k += gridDim.x * GZI_WAVES) {
+    for (int k = blockIdx.x * GZS_WAVES + wave; k <= nsec; k += gridDim.x * GZS_WAVES) {
         if (k == 0 && !(carry == nullptr && first_start == GZS_SEARCH)) {
             uint32_t st = first_start;
             if (carry) {
@@ -452,13 +458,13 @@ __global__ __launch_bounds__(64 * GZI_WAVES) __attribute__((amdgpu_waves_per_eu(
 
 // (8 waves per SIMD = 64 VGPRs: the same time alone - a wave is a latency chain -, and beside the recurrence kernel the sections' workgroups
 // pack eight to a CU instead of seven: a CU that holds one of them holds no recurrence workgroup)
-__global__ __launch_bounds__(64 * GZI_WAVES) __attribute__((amdgpu_waves_per_eu(8, 8))) void rd_gzs_decode_kernel(
+__global__ __launch_bounds__(64 * GZS_WAVES) __attribute__((amdgpu_waves_per_eu(8, 8))) void rd_gzs_decode_kernel(
     const uint8_t *__restrict__ comp, int64_t limit, uint32_t end_bits, int nsec, const uint32_t *__restrict__ found, uint16_t *__restrict__ syms, int cap,
     GzsSec *__restrict__ sec) {
-    __shared__ GziSmem SM;
+    __shared__ GzsSmem SM;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     GziWave &S = SM.w[wave];
-    for (int k = blockIdx.x * GZI_WAVES + wave; k < nsec; k += gridDim.x * GZI_WAVES) {
+    for (int k = blockIdx.x * GZS_WAVES + wave; k < nsec; k += gridDim.x * GZS_WAVES) {
         const uint32_t st = (uint32_t)__builtin_amdgcn_readfirstlane((int)found[k]);      // (wave-uniform: bit positions live in SGPRs)
         GzsSec r{0u, 0u, (uint32_t)GZS_OK, 0u};
         if (st != GZS_NONE) {

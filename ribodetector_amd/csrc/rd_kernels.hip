@@ -680,9 +680,9 @@ int rd_gz_stream_inflate(const uint8_t *comp, int64_t comp_bytes, int64_t data_b
     const uint32_t end_bits = (uint32_t)(valid_bytes * 8), sec_bits = (uint32_t)section_bytes * 8u;
     GzsState *S = (GzsState *)state;
     const GzsState *C = (const GzsState *)carry;
-    hipLaunchKernelGGL(rd_gzs_search_kernel, dim3((unsigned)((p.nsec + 1 + GZI_WAVES - 1) / GZI_WAVES)), dim3(64 * GZI_WAVES), 0, st, comp, comp_bytes, end_bits, sec_bits,
+    hipLaunchKernelGGL(rd_gzs_search_kernel, dim3((unsigned)((p.nsec + 1 + GZS_WAVES - 1) / GZS_WAVES)), dim3(64 * GZS_WAVES), 0, st, comp, comp_bytes, end_bits, sec_bits,
                        p.nsec, first_start_bit, C, carry_delta_bits, found);
-    hipLaunchKernelGGL(rd_gzs_decode_kernel, dim3((unsigned)((p.nsec + GZI_WAVES - 1) / GZI_WAVES)), dim3(64 * GZI_WAVES), 0, st, comp, comp_bytes, end_bits, p.nsec, found,
+    hipLaunchKernelGGL(rd_gzs_decode_kernel, dim3((unsigned)((p.nsec + GZS_WAVES - 1) / GZS_WAVES)), dim3(64 * GZS_WAVES), 0, st, comp, comp_bytes, end_bits, p.nsec, found,
                        syms, (int)cap_syms, sec);
     hipLaunchKernelGGL(rd_gzs_scan_kernel, dim3(1), dim3(64), 0, st, sec, found, p.nsec, (int)at_eof, text_cap, off, wslot, plist, S, C, 0);
     // the window chain on symbols: the groups of sections side by side, then the groups in order (rd_inflate_stream.hpp)
@@ -730,9 +730,9 @@ int rd_gz_range_decode(const uint8_t *comp, int64_t comp_bytes, int64_t data_byt
     GzsState *S = (GzsState *)state;
     const GzsState *C = (const GzsState *)carry;
     const int search0 = (C == nullptr && first_start_bit == GZS_SEARCH) ? 1 : 0;
-    hipLaunchKernelGGL(rd_gzs_search_kernel, dim3((unsigned)((p.nsec + 1 + GZI_WAVES - 1) / GZI_WAVES)), dim3(64 * GZI_WAVES), 0, st, comp, comp_bytes, end_bits, sec_bits,
+    hipLaunchKernelGGL(rd_gzs_search_kernel, dim3((unsigned)((p.nsec + 1 + GZS_WAVES - 1) / GZS_WAVES)), dim3(64 * GZS_WAVES), 0, st, comp, comp_bytes, end_bits, sec_bits,
                        p.nsec, first_start_bit, C, carry_delta_bits, found);
-    hipLaunchKernelGGL(rd_gzs_decode_kernel, dim3((unsigned)((p.nsec + GZI_WAVES - 1) / GZI_WAVES)), dim3(64 * GZI_WAVES), 0, st, comp, comp_bytes, end_bits, p.nsec, found,
+    hipLaunchKernelGGL(rd_gzs_decode_kernel, dim3((unsigned)((p.nsec + GZS_WAVES - 1) / GZS_WAVES)), dim3(64 * GZS_WAVES), 0, st, comp, comp_bytes, end_bits, p.nsec, found,
                        syms, (int)cap_syms, sec);
     hipLaunchKernelGGL(rd_gzs_scan_kernel, dim3(1), dim3(64), 0, st, sec, found, p.nsec, (int)at_eof, text_cap, off, wslot, plist, S, C, search0);
     hipLaunchKernelGGL(rd_gzs_symwin_kernel, dim3((unsigned)p.ngroups), dim3(1024), 0, st, syms, (int)cap_syms, sec, plist, wslot, p.nsec, S, windows16, gmaps);

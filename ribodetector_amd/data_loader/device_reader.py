@@ -45,18 +45,18 @@ def device_ingest_kind(path, fmt=None):
     "stream" (any other gzip file - one DEFLATE stream, what sequencers write: the two-pass decoder of csrc/rd_inflate_stream.hpp;
     RD_DEVICE_INFLATE=members keeps such files with the host's decoders) | None (FASTA, no GPU, RD_DEVICE_PARSE=0,
     RD_DEVICE_INFLATE=0 for .gz)"""
-    if os.environ.get("RD_DEVICE_PARSE", "1") == "0" or not torch.cuda.is_available():
-        return None
     from . import fastx_parser as fx
+    if fx.ingest_env("RD_DEVICE_PARSE", "1") == "0" or not torch.cuda.is_available():
+        return None
     fmt = fmt or fx.get_seq_format(path)
     if not fmt.startswith("fq"):
         # FASTA (round 5: rd_fasta_index re-writes and indexes the batch on the device); RD_DEVICE_FASTA=0 keeps the host parser
-        if os.environ.get("RD_DEVICE_FASTA", "1") == "0":
+        if fx.ingest_env("RD_DEVICE_FASTA", "1") == "0":
             return None
     if fmt.endswith("gz"):
         if fx.device_inflate_wanted(path):
             return "bgzf"
-        if os.environ.get("RD_DEVICE_INFLATE", "auto") not in ("0", "members") and fx.file_info(path)[1] and gz.is_member_indexed(path) is None:
+        if fx.ingest_env("RD_DEVICE_INFLATE", "auto") not in ("0", "members") and fx.file_info(path)[1] and gz.is_member_indexed(path) is None:
             return "stream"
         return None
     return None if fx.file_info(path)[1] else "plain"      # (a gzip file under a plain name goes to the host reader, which sniffs the magic)

@@ -311,12 +311,31 @@ class ShmArena:
         return Chunk(buf[:nb].numpy(), rs[:n + 1].numpy(), so[:n].numpy(), sl[:n].numpy(), True, None, (buf[:nb], so[:n], sl[:n], rs[:n + 1]))
 
 
+def ingest_env(name, default):
+    """one of the three older ingest switches - RD_DEVICE_PARSE, RD_DEVICE_FASTA, RD_DEVICE_INFLATE - as set, or as RD_INGEST implies:
+        RD_INGEST=device   (default) text stays on the GPU: plain, BGZF and single-stream .gz, FASTQ and FASTA
+        RD_INGEST=members  records framed on the GPU, BGZF members inflated there, a single-stream .gz by the host's decoders (round 4)
+        RD_INGEST=host     the host reader for everything (parallel decoders, pinned chunks, H2D per chunk: rounds 1-3)
+    The old names keep working and win where both are set."""
+    v = os.environ.get(name)
+    if v is not None:
+        return v
+    mode = os.environ.get("RD_INGEST", "device").lower()
+    if mode == "host":
+        return {"RD_DEVICE_PARSE": "0", "RD_DEVICE_FASTA": "0", "RD_DEVICE_INFLATE": "0"}.get(name, default)
+    if mode == "members":
+        return {"RD_DEVICE_INFLATE": "members"}.get(name, default)
+    if mode != "device":
+        raise RuntimeError("RD_INGEST must be device, members or host; got %r" % mode)
+    return default
+
+
 def device_inflate_wanted(path):
     """a GPU, and a .gz that starts with BGZF blocks (bgzip / htslib output, and every .gz the CLI writes with its device deflate):
     its members are inflated on the device. RD_DEVICE_INFLATE=0 keeps the host's decoders; =1 also takes files of this build's host
     writer (4 MiB members: a wave per member is a long time per member - the host's parallel member decoder suits them better)."""
     import os
-    mode = os.environ.get("RD_DEVICE_INFLATE", "auto")
+    mode = ingest_env("RD_DEVICE_INFLATE", "auto")
     if mode == "0":
         return False
     import torch

@@ -758,3 +758,22 @@ def test_device_ingest_choice_for_fasta(tmp_path, monkeypatch):
     monkeypatch.delenv("RD_DEVICE_FASTA")
     monkeypatch.setenv("RD_DEVICE_PARSE", "0")
     assert dr.device_ingest_kind(a) is None
+
+
+def test_rd_ingest_folds_the_three_older_switches(monkeypatch):
+    """RD_INGEST=device | members | host stands for RD_DEVICE_PARSE / RD_DEVICE_FASTA / RD_DEVICE_INFLATE; the old names still win"""
+    import pytest
+    from ribodetector_amd.data_loader import fastx_parser as fx
+    for k in ("RD_INGEST", "RD_DEVICE_PARSE", "RD_DEVICE_FASTA", "RD_DEVICE_INFLATE"):
+        monkeypatch.delenv(k, raising=False)
+    assert [fx.ingest_env(k, d) for k, d in (("RD_DEVICE_PARSE", "1"), ("RD_DEVICE_FASTA", "1"), ("RD_DEVICE_INFLATE", "auto"))] == ["1", "1", "auto"]
+    monkeypatch.setenv("RD_INGEST", "host")
+    assert [fx.ingest_env(k, d) for k, d in (("RD_DEVICE_PARSE", "1"), ("RD_DEVICE_FASTA", "1"), ("RD_DEVICE_INFLATE", "auto"))] == ["0", "0", "0"]
+    monkeypatch.setenv("RD_DEVICE_INFLATE", "members")
+    assert fx.ingest_env("RD_DEVICE_INFLATE", "auto") == "members" and fx.ingest_env("RD_DEVICE_PARSE", "1") == "0"
+    monkeypatch.delenv("RD_DEVICE_INFLATE")
+    monkeypatch.setenv("RD_INGEST", "members")
+    assert [fx.ingest_env(k, d) for k, d in (("RD_DEVICE_PARSE", "1"), ("RD_DEVICE_INFLATE", "auto"))] == ["1", "members"]
+    monkeypatch.setenv("RD_INGEST", "sometimes")
+    with pytest.raises(RuntimeError, match="RD_INGEST"):
+        fx.ingest_env("RD_DEVICE_PARSE", "1")
