@@ -101,13 +101,15 @@ def find_record_cut(head, prev_byte, fasta):
 
 
 class _Phase1:
-    """P1 of one file on one rank"""
+    """P1 of one file on one rank: the compressed bytes [lo, hi) as 16-bit symbols. A gzip member that ENDS inside the range (a lane-merged
+    file: `cat L001.fq.gz L002.fq.gz`) closes a SEGMENT - its trailer is kept for the CRC check - and the next member is decoded from its
+    own first block with a fresh decoder: nothing in front of a member's first byte can be referenced, so that segment needs no window."""
 
     def __init__(self, path, lo, hi, size, first_bit, device, stream):
         self.path, self.lo, self.hi, self.size, self.first_bit, self.device, self.stream = path, lo, hi, size, first_bit, device, stream
-        self.syms = []             # [(int16 tensor, n)]
-        self.meta = {"status": 0, "why": None, "n_text": 0, "first_abs": None, "next_abs": None, "final": 0, "end_abs": None, "map": None,
-                     "lo": lo, "hi": hi, "t_decode": 0.0}
+        self.segs = []             # [{"syms": [(int16 tensor, n)], "n_text", "final", "trailer"}]
+        self.meta = {"status": 0, "why": None, "n_text": 0, "first_abs": None, "next_abs": None, "ended": False, "fresh_after": False, "map": None,
+                     "segs": [], "lo": lo, "hi": hi, "t_decode": 0.0}
 
     def run(self):
         t0 = time.perf_counter()
@@ -115,7 +117,8 @@ class _Phase1:
         if self.hi <= self.lo:                           # (an empty share: nothing starts here, the range before decodes through)
             m["status"], m["why"] = -1, "a rank's share of the file is empty"
             return m
-        dg = gz.DeviceRangeGunzip(self.device, self.stream)
+        D = gz.DeviceRangeGunzip
+        dg = D(self.device, self.stream)
         span = dg.BATCH + dg.SLACK + 8192
         want = min(span, self.hi - self.lo + dg.SLACK + 8192)
         pinned = [torch.empty(want, dtype=torch.uint8, pin_memory=True) for _ in range(3)]
@@ -123,18 +126,16 @@ class _Phase1:
         free = [0, 1, 2]
         flight = []
         fd = os.open(self.path, os.O_RDONLY)
-        pos, first = self.lo, self.first_bit
-        last = None
+        pos, first, next_data = self.lo, self.first_bit, None
+        seg = {"syms": [], "n_text": 0, "final": False, "trailer": None}
+        member_end = None          # file offset behind the trailer of the member that just ended (the batches in flight behind it are dropped)
 
         def finish_one():
-            nonlocal last
+            nonlocal member_end
             tk, slot, at = flight.pop(0)
             r = dg.finish(tk)
             free.append(slot)
-            if m["status"]:
-                return
-            if last is not None and last["final"]:
-                m["status"], m["why"] = -2, "a second gzip member (or padding) behind the first inside a rank's share"
+            if m["status"] or member_end is not None:
                 return
             if r["status"]:
                 m["status"], m["why"] = r["status"], "%s in the batch at byte %d" % (gz.GZS_ERRORS.get(r["status"], "error %d" % r["status"]), at)
@@ -143,22 +144,65 @@ class _Phase1:
             if m["first_abs"] is None:
                 m["first_abs"] = at * 8 + r["first_start"] if r["first_start"] != 0xffffffff else None
             with torch.cuda.stream(self.stream):
-                self.syms.append((tk["sym"][:n].clone(), n))
+                seg["syms"].append((tk["sym"][:n].clone(), n))
             tk["sym"] = None
+            seg["n_text"] += n
             m["n_text"] += n
-            m["final"] = r["final"]
-            m["end_abs"] = at * 8 + r["end_bit"] if r["final"] else None
-            m["next_abs"] = None if r["final"] else at * 8 + r["next_start"]
-            last = r
+            if r["final"]:
+                end = at + (r["end_bit"] + 7) // 8
+                tr = os.pread(fd, 8, end)
+                if len(tr) < 8:
+                    m["status"], m["why"] = -3, "Compressed file ended before the end-of-stream marker was reached"
+                    return
+                seg["final"], seg["trailer"] = True, tr
+                member_end = end + 8
+                m["next_abs"] = None
+            else:
+                m["next_abs"] = at * 8 + r["next_start"]
         try:
-            while pos < self.hi and not m["status"]:
-                data = min(dg.BATCH, self.hi - pos)
+            while not m["status"]:
+                if member_end is not None:               # a member ended: what follows it?
+                    while flight:
+                        finish_one()
+                    self.segs.append(seg)
+                    e = member_end
+                    while e < self.size:                 # zero padding between members is skipped (Python's gzip module does)
+                        rest = os.pread(fd, 1 << 16, e)
+                        k = len(rest) - len(rest.lstrip(b"\0"))
+                        e += k
+                        if k < len(rest):
+                            break
+                    seg = None
+                    if e >= self.size:
+                        m["ended"] = True
+                        break
+                    hl = gz.gzip_header_len(os.pread(fd, 1 << 16, e))      # (ValueError: not a gzip member - the host path reports it)
+                    if hl is None:
+                        raise ValueError("Compressed file ended before the end-of-stream marker was reached")
+                    m["fresh_after"] = True
+                    if e >= self.hi:                     # the next member starts in the next rank's share: exactly there, or the ranks disagree
+                        m["next_abs"] = (e + hl) * 8
+                        break
+                    dg = D(self.device, self.stream)     # the next member: a fresh decoder, from its first block
+                    seg = {"syms": [], "n_text": 0, "final": False, "trailer": None}
+                    pos, first, member_end = e, hl * 8, None
+                    m["fresh_after"] = False
+                    rem = (self.hi - pos) % dg.SECTION   # (a first batch that brings the section grid back in line with the share's end)
+                    next_data = rem if rem else None
+                    continue
+                if pos >= self.hi:
+                    if flight:
+                        finish_one()
+                        continue
+                    break
+                data = next_data or min(dg.BATCH, self.hi - pos)
+                next_data = None
                 valid = min(data + dg.SLACK, self.size - pos)
                 at_eof = pos + valid >= self.size
-                while len(flight) >= 2:
+                while len(flight) >= 2 and member_end is None and not m["status"]:
                     finish_one()
-                if m["status"]:
-                    break
+                if m["status"] or member_end is not None:
+                    continue
                 slot = free.pop()
                 have = 0
                 while have < valid:
@@ -172,11 +216,14 @@ class _Phase1:
                 first = 0xffffffff
             while flight:
                 finish_one()
+            if seg is not None:
+                self.segs.append(seg)
         finally:
             os.close(fd)
         if not m["status"]:
             self.stream.synchronize()
-            m["map"] = dg.map.cpu().numpy().view(np.uint16).copy()
+            m["map"] = dg.map.cpu().numpy().view(np.uint16).copy() if dg.map is not None else (np.arange(WIN, dtype=np.uint16) | 0x8000)
+            m["segs"] = [{"n_text": sg["n_text"], "final": sg["final"], "trailer": sg["trailer"]} for sg in self.segs]
         m["t_decode"] = time.perf_counter() - t0
         self.dg = dg
         return m
@@ -197,7 +244,7 @@ def _in_threads(fn, items):
 
 
 def _verdict_x1(metas, world, sizes):
-    """None, or why the ranks' ranges do not add up to one decodable member - the same answer on every rank"""
+    """None, or why the ranks' ranges do not add up to the file's members - the same answer on every rank"""
     for f in range(len(sizes)):
         for r in range(world):
             m = metas[r][f]
@@ -206,13 +253,28 @@ def _verdict_x1(metas, world, sizes):
             if m["first_abs"] is None:
                 return "rank %d found no block start" % r
             if r + 1 < world:
-                if m["final"]:
-                    return "the gzip member ends inside the share of rank %d (several members: a lane-merged file)" % r
+                if m["ended"]:
+                    return "only padding behind the share of rank %d" % r
                 if m["next_abs"] != metas[r + 1][f]["first_abs"]:
                     return "the share of rank %d does not start where rank %d says the stream goes on" % (r + 1, r)
-            elif not m["final"]:
+            elif not m["ended"]:
                 return "Compressed file ended before the end-of-stream marker was reached"
     return None
+
+
+def start_window(metas, f, rank):
+    """(window uint8[32768], valid) in front of rank `rank`'s share of file f: the maps of the ranks before applied in order; a rank whose
+    share holds the end of a member hands on only what it decoded behind it (nothing in front of a member's first byte is text of it)"""
+    window, valid = np.zeros(WIN, dtype=np.uint8), 0
+    for r in range(rank):
+        m = metas[r][f]
+        if m["fresh_after"]:
+            window, valid = np.zeros(WIN, dtype=np.uint8), 0
+        elif len(m["segs"]) > 1:
+            window, valid = gz.apply_map(m["map"], np.zeros(WIN, dtype=np.uint8)), min(WIN, m["segs"][-1]["n_text"])
+        else:
+            window, valid = gz.apply_map(m["map"], window), min(WIN, valid + m["n_text"])
+    return window, valid
 
 
 def fits(paths, world, device):
@@ -289,28 +351,30 @@ def prepare(paths, rank, world, device, fasta, all_gather, shift_to_prev, log=No
     # ---- P2: the window in front of this rank's range; symbols -> bytes; first record boundary ----------------------------------------------
     out, heads_mine = [], []
     for f, path in enumerate(paths):
-        window, valid = np.zeros(WIN, dtype=np.uint8), 0
-        for r in range(rank):
-            window = gz.apply_map(metas[r][f]["map"], window)
-            valid = min(WIN, valid + metas[r][f]["n_text"])
+        window, valid = start_window(metas, f, rank)
         p1, st = ph[f], streams[f]
         ix = (dr.FastaIndexer if fasta[f] else dr.FastqIndexer)(device, st)
-        with torch.cuda.stream(st):
-            win_dev = torch.from_numpy(window).to(device) if valid else None
-            rstate = torch.zeros(8, dtype=torch.int64, device=device)
-        texts = []
-        for sym, n in p1.syms:
-            text = ix.alloc_text(n)
-            if n:
-                p1.dg.resolve(sym, n, win_dev, valid, text[dr.PAD:], rstate)
-            texts.append((text, n))
-        p1.syms = None
+        texts, seg_states = [], []
+        for si, sg in enumerate(p1.segs):           # a segment behind a member's end starts a member: no window in front of it
+            with torch.cuda.stream(st):
+                win_dev = torch.from_numpy(window).to(device) if (si == 0 and valid) else None
+                rstate = torch.zeros(8, dtype=torch.int64, device=device)
+            for sym, n in sg["syms"]:
+                text = ix.alloc_text(n)
+                if n:
+                    p1.dg.resolve(sym, n, win_dev, valid if si == 0 else 0, text[dr.PAD:], rstate)
+                texts.append((text, n))
+            sg["syms"] = None
+            seg_states.append(rstate)
         st.synchronize()
-        h = rstate.cpu().numpy()
-        crc, status = int(h.view(np.uint32)[4]), int(h.view(np.uint32)[5])
+        seg_res, status = [], 0
+        for rstate in seg_states:
+            h = rstate.cpu().numpy()
+            seg_res.append({"crc": int(h.view(np.uint32)[4]), "len": int(h.view(np.uint64)[0])})
+            status = status or int(h.view(np.uint32)[5])
         cut, head = 0, b""
         if rank > 0 and not status:
-            prev = int(window[-1]) if valid else None
+            prev = int(window[-1]) if valid else None      # (None: a member starts with the share - and so does a line)
             probe, cut = HEAD_PROBE, None
             flat_n = sum(n for _, n in texts)
             while cut is None:
@@ -330,43 +394,35 @@ def prepare(paths, rank, world, device, fasta, all_gather, shift_to_prev, log=No
                     break
                 probe *= 4
             head = head[:cut] if cut is not None and cut >= 0 else b""
-        trailer = None
-        if rank == world - 1:
-            m = metas[rank][f]
-            end = (m["end_abs"] + 7) // 8
-            with open(path, "rb") as fh:
-                fh.seek(end)
-                trailer = fh.read(8)
-        heads_mine.append({"crc": crc, "len": int(h.view(np.uint64)[0]), "status": status, "cut": cut, "head": head, "trailer": trailer,
-                           "trailing": sizes[f] - ((metas[world - 1][f]["end_abs"] + 7) // 8 + 8) if rank == world - 1 else 0})
+        heads_mine.append({"segs": seg_res, "status": status, "cut": cut, "head": head})
         out.append((ix, texts))
     lap("p2_resolve")
     x2 = all_gather(heads_mine)                                      # X2: [rank][file]
     lap("x2")
-    for f in range(len(paths)):
+    for f in range(len(paths)):                     # every member's CRC-32 and ISIZE: the ranks' pieces combined in order
         crc, total = 0, 0
         for r in range(world):
             e = x2[r][f]
             if e["status"]:
                 return give_up("invalid distance too far back (rank %d)" % r)
             if e["cut"] is None or e["cut"] < 0:
-                return give_up("a record longer than %d bytes at the start of the share of rank %d" % (dr.PAD, r))
-            if e["len"] != metas[r][f]["n_text"]:
-                return give_up("rank %d resolved %d of %d bytes" % (r, e["len"], metas[r][f]["n_text"]))
-            crc = gz.crc32_combine(crc, e["crc"], e["len"])
-            total += e["len"]
-        tr = x2[world - 1][f]["trailer"]
-        if tr is None or len(tr) < 8:
+                return give_up("no record starts in the first %d bytes of the share of rank %d" % (dr.PAD, r))
+            if len(e["segs"]) != len(metas[r][f]["segs"]):
+                return give_up("rank %d resolved %d of %d segments" % (r, len(e["segs"]), len(metas[r][f]["segs"])))
+            for got, sg in zip(e["segs"], metas[r][f]["segs"]):
+                if got["len"] != sg["n_text"]:
+                    return give_up("rank %d resolved %d of %d bytes" % (r, got["len"], sg["n_text"]))
+                crc = gz.crc32_combine(crc, got["crc"], got["len"])
+                total += got["len"]
+                if sg["final"]:
+                    tr = sg["trailer"]
+                    if int.from_bytes(tr[:4], "little") != crc:
+                        return give_up("CRC check failed")
+                    if int.from_bytes(tr[4:], "little") != (total & 0xffffffff):
+                        return give_up("Incorrect length of data produced")
+                    crc, total = 0, 0
+        if total:
             return give_up("Compressed file ended before the end-of-stream marker was reached")
-        if int.from_bytes(tr[:4], "little") != crc:
-            return give_up("CRC check failed")
-        if int.from_bytes(tr[4:], "little") != (total & 0xffffffff):
-            return give_up("Incorrect length of data produced")
-        if x2[world - 1][f]["trailing"] > 0:
-            with open(paths[f], "rb") as fh:
-                fh.seek(sizes[f] - x2[world - 1][f]["trailing"])
-                if fh.read(1 << 16).strip(b"\0"):
-                    return give_up("a second gzip member behind the first (a lane-merged file)")
     # ---- P3: framing; the head of the next rank closes this rank's last record ----------------------------------------------------------------
     ranges, counts = [], []
     for f, path in enumerate(paths):

@@ -7,6 +7,9 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# RD_TEST_FULL=1: the fuzz / soak-like GPU tests at their full sizes (500 + 300 fuzzed files, the 2^20-read oracle tail): what the builder runs on
+# its own lease; the default sizes keep the driver's GPU suite under seven minutes
+FULL = os.environ.get("RD_TEST_FULL") == "1"
 
 
 def pytest_configure(config):

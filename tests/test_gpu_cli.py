@@ -674,7 +674,7 @@ def test_cli_single_stream_gz_single_end_fasta_and_refusals(tmp_path):
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     assert "ranges of one DEFLATE stream" in r.stdout + r.stderr
     assert [_read(x) for x in one] == [_read(x) for x in two] and len(_read(one[0])) > 0
-    # two lanes merged with cat: refused, read by the one-decode path
+    # two lanes merged with cat: the member that ends inside a rank's share closes a segment there, the ranges go on
     text = open(plain, "rb").read()
     cutat = text.rfind(b"\n@", 0, len(text) // 2) + 1
     lanes = str(tmp_path / "lanes.fq.gz")
@@ -682,9 +682,17 @@ def test_cli_single_stream_gz_single_end_fasta_and_refusals(tmp_path):
     three = [str(tmp_path / "c.fq.gz"), str(tmp_path / "cr.fq")]
     r, port = _torchrun(3, ["-l", "100", "-i", lanes, "-o", three[0], "-r", three[1], "--chunk_size", "1", "-m", "3"], {"RD_GZ_SHARD_MIN": "65536"})
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
-    assert "one rank decodes" in r.stdout + r.stderr and "ranges of one DEFLATE stream" not in r.stdout + r.stderr
+    assert "ranges of one DEFLATE stream" in r.stdout + r.stderr
     one = [str(tmp_path / "a.fq.gz"), str(tmp_path / "ar.fq")]
     assert [_read(x) for x in one] == [_read(x) for x in three]
+    # stored blocks (gzip level 0): the block-start search does not take them - refused by every rank, read by the one-decode path
+    lvl0 = str(tmp_path / "stored.fq.gz")
+    open(lvl0, "wb").write(gzip.compress(text, 0))
+    four = [str(tmp_path / "d.fq.gz"), str(tmp_path / "dr.fq")]
+    r, port = _torchrun(3, ["-l", "100", "-i", lvl0, "-o", four[0], "-r", four[1], "--chunk_size", "1", "-m", "3"], {"RD_GZ_SHARD_MIN": "65536"})
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert "one rank decodes" in r.stdout + r.stderr and "ranges of one DEFLATE stream" not in r.stdout + r.stderr
+    assert [_read(x) for x in one] == [_read(x) for x in four]
     # a cut stream
     blob = open(i1, "rb").read()
     cut = str(tmp_path / "cut.fq.gz")

@@ -149,11 +149,13 @@ def _fuzz_text(rng, nrec):
 
 
 def test_fuzz_plain_and_bgzf_against_the_host_reader(tmp_path, small_batches):
-    """500 files: the chunks of the device reader == the chunks of the host reader, plain and BGZF, with small random batch sizes and
-    chunk sizes (the records of a chunk come from up to dozens of batches; the carry is exercised at every offset)"""
+    """200 files (RD_TEST_FULL=1: 500): the chunks of the device reader == the chunks of the host reader, plain and BGZF, with small random
+    batch sizes and chunk sizes (the records of a chunk come from up to dozens of batches; the carry is exercised at every offset)"""
+    from conftest import FULL
     rng = np.random.default_rng(11)
     n_files = n_err = 0
-    for it in range(250):
+    iters = 250 if FULL else 100
+    for it in range(iters):
         nrec = int(rng.choice([0, 1, 2, 3, 5, 17, 100, 400, 1500]))
         text = _fuzz_text(rng, nrec)
         first = int(rng.choice([1, 3, 50, 700, 5000, 1 << 20]))
@@ -172,7 +174,7 @@ def test_fuzz_plain_and_bgzf_against_the_host_reader(tmp_path, small_batches):
             assert de == he, (q, de, he)
             _same(host, dev)
             n_files += 1
-    assert n_files == 500 and n_err < 25
+    assert n_files == 2 * iters and n_err < 25
 
 
 def test_large_file_many_batches(tmp_path):
@@ -342,11 +344,13 @@ def test_fasta_reference_parser_text(golden, tmp_path, small_batches):
 
 
 def test_fasta_fuzz_plain_and_bgzf_against_the_host_reader(tmp_path, small_batches):
-    """300 files: the device's FASTA chunks == the host reader's (normalised text, rec_start, seq_off, seq_len), plain and BGZF, small
-    random batch and chunk sizes: the carry (the raw text from the last header line on) is exercised at every offset"""
+    """120 files (RD_TEST_FULL=1: 300): the device's FASTA chunks == the host reader's (normalised text, rec_start, seq_off, seq_len), plain
+    and BGZF, small random batch and chunk sizes: the carry (the raw text from the last header line on) is exercised at every offset"""
+    from conftest import FULL
     rng = np.random.default_rng(12)
     n_files = 0
-    for it in range(150):
+    iters = 150 if FULL else 60
+    for it in range(iters):
         nrec = int(rng.choice([0, 1, 2, 3, 5, 17, 100, 400]))
         text = _fuzz_fasta(rng, nrec)
         first = int(rng.choice([1, 3, 50, 700, 5000, 1 << 20]))
@@ -360,7 +364,7 @@ def test_fasta_fuzz_plain_and_bgzf_against_the_host_reader(tmp_path, small_batch
         for q in (p, pz):
             _same(host, _dev_chunks(q, chunk, fc))
             n_files += 1
-    assert n_files == 300
+    assert n_files == 2 * iters
 
 
 def test_fasta_large_file_and_what_stays_with_the_host(tmp_path):
