@@ -103,7 +103,10 @@ def find_record_cut(head, prev_byte, fasta):
 class _Phase1:
     """P1 of one file on one rank: the compressed bytes [lo, hi) as 16-bit symbols. A gzip member that ENDS inside the range (a lane-merged
     file: `cat L001.fq.gz L002.fq.gz`) closes a SEGMENT - its trailer is kept for the CRC check - and the next member is decoded from its
-    own first block with a fresh decoder: nothing in front of a member's first byte can be referenced, so that segment needs no window."""
+    own first block with a fresh decoder: nothing in front of a member's first byte can be referenced, so that segment needs no window.
+    A member that ends within a block of the share's END hands over to the next rank only if that rank's search found exactly the next
+    member's first block (an empty or fixed-Huffman member there is not found: the ranks see the disagreement and the one-decode path reads
+    the file - about one lane-merged file in 10^4)."""
 
     def __init__(self, path, lo, hi, size, first_bit, device, stream):
         self.path, self.lo, self.hi, self.size, self.first_bit, self.device, self.stream = path, lo, hi, size, first_bit, device, stream
