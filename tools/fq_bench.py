@@ -124,6 +124,36 @@ def main():
         assert r["status"] == 0 and r["final"] and r["n_text"] == tb and r["crc"] == (zlib.crc32(raw) & 0xffffffff), r
         put("rd_gz_stream_inflate (zlib level 6, one batch of %d sections)" % r["n_sections"], ms, tb, "text produced")
         out["stream"] = {"compressed_bytes": len(blob), "sections": r["n_sections"], "section_bytes": dsg.SECTION}
+        # round 6: the second half of the same stream as a RANGE - decoded without the text in front of it (rd_gz_range_decode: symbols and the
+        # range's map), then symbols -> bytes with the window the first half leaves (rd_gz_range_resolve); the text must be zlib's
+        half = (len(blob) // 2) // dsg.SECTION * dsg.SECTION
+        drg = gz.DeviceRangeGunzip(dev, st)
+        drg.BATCH = dsg.BATCH
+        src2 = torch.from_numpy(np.frombuffer(blob[half:], dtype=np.uint8).copy()).pin_memory()
+        tk = [None]
+
+        def do_range():
+            drg.carry = drg.map = None
+            tk[0] = drg.submit(src2, len(blob) - half, len(blob) - half, gz.GZS_SEARCH, True)
+        ms = timed(do_range, reps=5)
+        r2 = drg.finish(tk[0])
+        assert r2["status"] == 0 and r2["final"], r2
+        n2 = r2["n_text"]
+        first = drg.submit(torch.from_numpy(np.frombuffer(blob[:half + dsg.SLACK], dtype=np.uint8).copy()).pin_memory(), min(len(blob), half + dsg.SLACK), half, hl * 8, False)
+        r1 = drg.finish(first)          # (the first half, for its map: the window in front of the second)
+        assert r1["status"] == 0 and half * 8 + r2["first_start"] == r1["next_start"] and r1["n_text"] + n2 == tb, (r1, r2)
+        win = gz.apply_map(drg.map.cpu().numpy(), np.zeros(32768, dtype=np.uint8))
+        put("rd_gz_range_decode (the stream's second half, window unknown: %d sections)" % r2["n_sections"], ms, n2, "text produced, as 16-bit symbols")
+        win_dev = torch.from_numpy(win).to(dev)
+        rstate = torch.zeros(8, dtype=torch.int64, device=dev)
+        out8 = torch.empty(n2 + 64, dtype=torch.uint8, device=dev)
+
+        def do_resolve():
+            rstate.zero_()
+            drg.resolve(tk[0]["sym"], n2, win_dev, 32768, out8, rstate)
+        ms = timed(do_resolve, reps=5)
+        assert out8[:n2].cpu().numpy().tobytes() == raw[tb - n2:], "range text differs from zlib's"
+        put("rd_gz_range_resolve (symbols -> bytes + CRC-32)", ms, 3 * n2, "2 B symbol read + 1 B written per text byte")
     s = json.dumps(out)
     if a.out:
         open(a.out, "w").write(json.dumps(out, indent=1))
