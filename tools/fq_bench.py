@@ -139,6 +139,7 @@ def main():
         r2 = drg.finish(tk[0])
         assert r2["status"] == 0 and r2["final"], r2
         n2 = r2["n_text"]
+        drg.carry = drg.map = None
         first = drg.submit(torch.from_numpy(np.frombuffer(blob[:half + dsg.SLACK], dtype=np.uint8).copy()).pin_memory(), min(len(blob), half + dsg.SLACK), half, hl * 8, False)
         r1 = drg.finish(first)          # (the first half, for its map: the window in front of the second)
         assert r1["status"] == 0 and half * 8 + r2["first_start"] == r1["next_start"] and r1["n_text"] + n2 == tb, (r1, r2)
