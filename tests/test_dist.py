@@ -208,3 +208,56 @@ def test_shared_memory_chunks_reach_the_other_ranks(tmp_path):
     assert all(g[0] == h.hexdigest() and int(g[1]) == n == 20000 for g in got), got
     assert int(got[0][2]) >= 20                                                  # many chunks, ramped sizes
     assert not [f for f in os.listdir("/dev/shm") if f.startswith("rd_test_%d_" % port)]
+
+
+def _shift_worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from ribodetector_amd import dist as rdist
+    rdist.init_from_env(backend="gloo")
+    # rank r sends r * 1000 + 7 bytes of value r to rank r - 1 (rank 2 sends nothing: None); rank 0's own buffer goes nowhere
+    buf = None if rank == 2 else torch.full((rank * 1000 + 7,), rank, dtype=torch.uint8)
+    got = rdist.shift_to_prev(buf)
+    np.save(os.path.join(tmp, "got%d.npy" % rank), np.zeros(0, np.uint8) if got is None else got.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shift_to_prev_three_ranks(tmp_path):
+    """dist.shift_to_prev (round 6: the mate records in front of a rank's common cut travel to the rank before, data_loader/gz_shard.py):
+    rank r receives exactly what rank r + 1 sent, the last rank and the neighbour of a rank that sent nothing receive nothing"""
+    port = _free_port()
+    mp.spawn(_shift_worker, args=(4, port, str(tmp_path)), nprocs=4, join=True)
+    got = [np.load(str(tmp_path / ("got%d.npy" % r))) for r in range(4)]
+    assert got[0].size == 1007 and (got[0] == 1).all()
+    assert got[1].size == 0                       # rank 2 sent nothing
+    assert got[2].size == 3007 and (got[2] == 3).all()
+    assert got[3].size == 0
+
+
+def test_pin_rank_cpus_deals_equal_shares():
+    """dist.pin_rank_cpus without a GPU (no NUMA node to go by): the usable CPUs in equal contiguous shares, the process bound to its own;
+    RD_PIN=0 and a single rank leave the affinity alone"""
+    from ribodetector_amd import dist as rdist
+    if not hasattr(os, "sched_setaffinity"):
+        pytest.skip("no sched_setaffinity")
+    before = sorted(os.sched_getaffinity(0))
+    try:
+        assert rdist.pin_rank_cpus(0, 0, 1) == (None, "off")
+        assert rdist.pin_rank_cpus(0, 1, 4, mode="0") == (None, "off")
+        assert sorted(os.sched_getaffinity(0)) == before
+        if len(before) >= 4:
+            cpus, how = rdist.pin_rank_cpus(0, 1, 4)
+            k = len(before)
+            assert cpus == before[k // 4:2 * k // 4] and "share 2 of 4" in how and sorted(os.sched_getaffinity(0)) == cpus
+            os.sched_setaffinity(0, before)
+            cpus, how = rdist.pin_rank_cpus(0, 3, 4, mode="node")
+            assert cpus == before and "share" not in how
+    finally:
+        os.sched_setaffinity(0, before)
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                os.sched_setaffinity(int(tid), before)
+            except OSError:
+                pass
+    assert rdist._cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}
