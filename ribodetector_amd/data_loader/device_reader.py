@@ -470,6 +470,7 @@ class DeviceFeeder:
         return False
 
     def _run(self):
+        self._t0 = time.perf_counter()
         try:
             torch.cuda.set_device(self.device)          # the current device is per thread (and defaults to 0)
             self.stream = gz.acquire_stream(self.device, priority=-1)
@@ -657,6 +658,7 @@ class DeviceFeeder:
                 member_end = end + 8
             good.update(abs_next=at * 8 + r["next_start"], win=tk["keep"][2], win_valid=r["win_valid"], crc=r["crc"], total_len=r["total_len"])
             b = self.ix.index(text, PAD, PAD + r["n_text"])
+            tm.setdefault("first_batch_framed_at_s", round(time.perf_counter() - self._t0, 4))      # (since the feeder thread started)
             tm["batches"] += 1
             tm["bytes"] += r["n_text"]
             return self._put(b)
@@ -684,6 +686,7 @@ class DeviceFeeder:
             t2 = time.perf_counter()
             text = self.ix.alloc_text(dsg.text_cap(data))
             tk = dsg.submit(pinned[slot], valid, data, first, at_eof, text[PAD:])
+            tm.setdefault("first_batch_submitted_at_s", round(time.perf_counter() - self._t0, 4))
             flight.append((tk, text, slot, pos))
             tm["read"] += t2 - t1
             tm["submit"] += time.perf_counter() - t2

@@ -124,9 +124,9 @@ class _Phase1:
         dg = D(self.device, self.stream)
         span = dg.BATCH + dg.SLACK + 8192
         want = min(span, self.hi - self.lo + dg.SLACK + 8192)
-        pinned = [torch.empty(want, dtype=torch.uint8, pin_memory=True) for _ in range(3)]
+        pinned = [torch.empty(want, dtype=torch.uint8, pin_memory=True) for _ in range(2)]     # (one batch in flight while the next is read)
         views = [t.numpy() for t in pinned]
-        free = [0, 1, 2]
+        free = [0, 1]
         flight = []
         fd = os.open(self.path, os.O_RDONLY)
         pos, first, next_data = self.lo, self.first_bit, None
@@ -203,6 +203,8 @@ class _Phase1:
                 valid = min(data + dg.SLACK, self.size - pos)
                 at_eof = pos + valid >= self.size
                 while len(flight) >= 2 and member_end is None and not m["status"]:
+                    finish_one()
+                while not free and flight:               # (a batch's pinned bytes are free once its state has arrived)
                     finish_one()
                 if m["status"] or member_end is not None:
                     continue
