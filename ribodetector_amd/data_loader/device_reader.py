@@ -394,6 +394,7 @@ class DeviceFeeder:
 
     BATCH = 48 << 20          # compressed bytes per BGZF batch (~200 MB of text)
     FIRST = 6 << 20           # the first batch (the first chunk is small too); doubling up to BATCH
+    STREAM_FIRST = None       # ... of a single-stream .gz when it is to differ from FIRST (a section's decode is a latency chain: a batch of any size takes >= 12 ms)
     MAX_MEMBERS = 4096        # members per batch: at most 256 MiB of text whatever the members claim
     PLAIN_BATCH = 96 << 20    # bytes of a plain file per batch
     PLAIN_FIRST = 12 << 20
@@ -618,7 +619,7 @@ class DeviceFeeder:
         hl = gz.gzip_header_len(os.pread(fd, 1 << 16, base))
         if hl is None:
             raise ValueError("Compressed file ended before the end-of-stream marker was reached")
-        pos, first, batch = base, hl * 8, min(self.FIRST if base == 0 else dsg.BATCH, dsg.BATCH)
+        pos, first, batch = base, hl * 8, min(int(os.environ.get("RD_GZS_FIRST", self.STREAM_FIRST or self.FIRST)) if base == 0 else dsg.BATCH, dsg.BATCH)
         flight = deque()                                  # (ticket, text, pinned slot, file offset of the batch)
         member_end = None
         good = {}                                         # what the last good batch left: where the stream goes on, window, CRC, length
