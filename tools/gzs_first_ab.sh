@@ -6,8 +6,8 @@ cd $R
 mkdir -p gpurun_out/ab
 OUT=gpurun_out/ab/gzs_first.txt
 : > $OUT
-for rep in 1 2; do
-for first in 6291456 16777216 33554432 67108864; do
+for rep in 1; do
+for first in 6291456 25165824 67108864; do
   for mode in "" "--single-end"; do
     python tools/e2e_bench.py --bench-legs --legs gz_to_gz,seqlike_gz_to_gz --env RD_GZS_FIRST=$first $mode 2>/dev/null | python -c "
 import sys,json
