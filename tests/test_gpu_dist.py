@@ -90,7 +90,13 @@ def test_cli_modes_over_one_rank_rccl(tmp_path, ext):
     inp = str(tmp_path / ("in" + ext))
     synth.write_fastq(inp, a, o, 1)
     outs = {}
-    for name, env in (("forced", _env()), ("plain", {k: v for k, v in _env().items() if k != "RD_FORCE_DIST"})):
+    # (round 6: the single-stream .gz goes through the range decoder - gz_shard's all_gather_object / shift over the one-rank RCCL group - when the
+    # file is large enough to share; 64 KiB per rank is for this test; "gather" keeps the older label-gather mode covered)
+    runs = [("forced", _env(RD_GZ_SHARD_MIN="65536")), ("plain", {k: v for k, v in _env().items() if k != "RD_FORCE_DIST"})]
+    if ext.endswith("gz"):
+        runs.append(("gather", _env(RD_GZ_SHARD="0")))
+    logs = {}
+    for name, env in runs:
         out, rr = str(tmp_path / (name + ".non.fq")), str(tmp_path / (name + ".rrna.fq.gz"))   # (.gz: deflated on the device, and under the
                                                                                                 # label gather sent to rank 0 over RCCL)
         r = subprocess.run([sys.executable, "-m", "ribodetector_amd.detect", "-l", "100", "-i", inp, "-o", out, "-r", rr, "--chunk_size", "1", "-m", "3"],
@@ -98,5 +104,9 @@ def test_cli_modes_over_one_rank_rccl(tmp_path, ext):
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
         import gzip
         outs[name] = (open(out, "rb").read(), gzip.open(rr, "rb").read())
+        logs[name] = r.stdout + r.stderr
     assert outs["forced"] == outs["plain"] and len(outs["plain"][0]) > 0 and len(outs["plain"][1]) > 0
-    assert sorted(os.listdir(tmp_path)) == sorted(["in" + ext, "forced.non.fq", "forced.rrna.fq.gz", "plain.non.fq", "plain.rrna.fq.gz"])
+    assert all(o == outs["plain"] for o in outs.values())
+    if ext.endswith("gz"):
+        assert "ranges of one DEFLATE stream" in logs["forced"] and "ranges of one DEFLATE stream" not in logs["gather"]
+    assert sorted(os.listdir(tmp_path)) == sorted(["in" + ext] + [n + x for n in outs for x in (".non.fq", ".rrna.fq.gz")])
