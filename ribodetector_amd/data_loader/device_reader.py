@@ -394,7 +394,9 @@ class DeviceFeeder:
 
     BATCH = 48 << 20          # compressed bytes per BGZF batch (~200 MB of text)
     FIRST = 6 << 20           # the first batch (the first chunk is small too); doubling up to BATCH
-    STREAM_FIRST = None       # ... of a single-stream .gz when it is to differ from FIRST (a section's decode is a latency chain: a batch of any size takes >= 12 ms)
+    FIRST_DEFAULT = 6 << 20   # (a test that patches FIRST also sets the stream reader's first batch)
+    STREAM_FIRST = None       # ... of a single-stream .gz when it is to differ from FIRST (tests); the product: a whole batch at once - a section's decode is
+                              # a latency chain, a batch of any size takes >= 12 ms (profiles/r06_gzs_first_ab.txt: 6 -> 64 MiB +1-2 % paired, +2-5 % single-end)
     MAX_MEMBERS = 4096        # members per batch: at most 256 MiB of text whatever the members claim
     PLAIN_BATCH = 96 << 20    # bytes of a plain file per batch
     PLAIN_FIRST = 12 << 20
@@ -619,7 +621,7 @@ class DeviceFeeder:
         hl = gz.gzip_header_len(os.pread(fd, 1 << 16, base))
         if hl is None:
             raise ValueError("Compressed file ended before the end-of-stream marker was reached")
-        pos, first, batch = base, hl * 8, min(int(os.environ.get("RD_GZS_FIRST", self.STREAM_FIRST or self.FIRST)) if base == 0 else dsg.BATCH, dsg.BATCH)
+        pos, first, batch = base, hl * 8, min(int(os.environ.get("RD_GZS_FIRST", self.STREAM_FIRST or (self.FIRST if self.FIRST != DeviceFeeder.FIRST_DEFAULT else dsg.BATCH))) if base == 0 else dsg.BATCH, dsg.BATCH)
         flight = deque()                                  # (ticket, text, pinned slot, file offset of the batch)
         member_end = None
         good = {}                                         # what the last good batch left: where the stream goes on, window, CRC, length
@@ -660,6 +662,8 @@ class DeviceFeeder:
             good.update(abs_next=at * 8 + r["next_start"], win=tk["keep"][2], win_valid=r["win_valid"], crc=r["crc"], total_len=r["total_len"])
             b = self.ix.index(text, PAD, PAD + r["n_text"])
             tm.setdefault("first_batch_framed_at_s", round(time.perf_counter() - self._t0, 4))      # (since the feeder thread started)
+            if len(tm.setdefault("batches_framed_at_s", [])) < 8:
+                tm["batches_framed_at_s"].append((round(time.perf_counter() - self._t0, 4), int(r["n_text"])))
             tm["batches"] += 1
             tm["bytes"] += r["n_text"]
             return self._put(b)

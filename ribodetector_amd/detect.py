@@ -468,6 +468,7 @@ class Predictor:
         if chunk_reads is None:
             chunk_reads = self.batch_size * self.chunk_size
         self._chunk_reads, self._shared, self._use_device = chunk_reads, None, None
+        self._timeline, self._t_run = [], time.perf_counter()
         # plain inputs under several ranks: every rank parses, classifies and writes its own byte range (no label exchange)
         plain = not any(fx.file_info(p)[1] for p in self.input)
         # ... and BGZF FASTQ inputs likewise: their members are independent, so every rank inflates (on its own GPU), parses, classifies
@@ -668,7 +669,11 @@ class Predictor:
             prev = None
             for chunks in stream:
                 t0 = time.perf_counter()
+                if len(self._timeline) < 24:          # (the first chunks' way through the pipeline, seconds since the run started: tools/first_chunk_probe.py)
+                    self._timeline.append(("chunk_of_%d_read" % len(chunks[0].seq_len), round(t0 - self._t_run, 4)))
                 tk = self.submit_chunk(chunks)
+                if len(self._timeline) < 24:
+                    self._timeline.append(("submitted", round(time.perf_counter() - self._t_run, 4)))
                 self._stage_s["classify"] += time.perf_counter() - t0
                 if prev is not None:
                     yield prev
@@ -679,6 +684,8 @@ class Predictor:
             for chunks, tk in in_flight(self._chunk_stream(chunk_reads)):
                 t0 = time.perf_counter()
                 labels = self.collect_chunk(tk)
+                if len(self._timeline) < 24:
+                    self._timeline.append(("labels", round(time.perf_counter() - self._t_run, 4)))
                 self._stage_s["classify"] += time.perf_counter() - t0
                 num_read += len(chunks[0].seq_len)
                 if self._first_chunk is None:
@@ -872,7 +879,8 @@ def main(argv=None, log_level=None):
             steady = len(seq_pred.input) * (seq_pred.num_read - fc[1]) / (t2 - fc[0])
         seq_pred.timing = {"load_model_s": t1 - t0, "detect_s": t2 - t1, "prefix_k": seq_pred.model.prefix_k,
                            "reads_per_s_after_first_chunk": steady, "ingest": getattr(seq_pred, "ingest", None),
-                           "gz_ranges_s": getattr(seq_pred, "gz_shard_s", None), "pinned_cpus": getattr(seq_pred, "pinned_cpus", None)}
+                           "gz_ranges_s": getattr(seq_pred, "gz_shard_s", None), "pinned_cpus": getattr(seq_pred, "pinned_cpus", None),
+                           "first_chunks_timeline": getattr(seq_pred, "_timeline", None)}
         if os.environ.get("RD_TIMING_OUT"):          # (tools/host_scaling.py, tools/scale_sweep.sh: what a torchrun child measured, per rank)
             import json
             with open("%s.rank%d" % (os.environ["RD_TIMING_OUT"], seq_pred.rank), "w") as fh:

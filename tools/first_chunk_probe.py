@@ -17,6 +17,6 @@ for rep in range(3):
     pr = detect.main(["-l", "100", "-i", *files, "-o", d + "/o1.fq.gz", d + "/o2.fq.gz", "-e", "rrna"], log_level="WARNING")
     dt = time.perf_counter() - t0
     fc = pr._first_chunk
-    print(json.dumps({"wall": round(dt, 3), "timing": {k: v for k, v in pr.timing.items() if k != "ingest"}, "first_chunk_labels_at_s_after_detect_start": None,
-                      "feeders": {k: {x: v["feeder"].get(x) for x in ("first_batch_submitted_at_s", "first_batch_framed_at_s", "read", "wait_slot", "submit", "batches")} for k, v in pr.ingest.items()}}))
+    print(json.dumps({"wall": round(dt, 3), "timing": {k: v for k, v in pr.timing.items() if k != "ingest"}, "start": time.strftime("%H:%M:%S"), "first_chunk_labels_at_s_after_detect_start": None,
+                      "feeders": {k: {x: v["feeder"].get(x) for x in ("first_batch_submitted_at_s", "batches_framed_at_s", "read", "wait_slot", "submit", "batches")} for k, v in pr.ingest.items()}}))
 import shutil; shutil.rmtree(d)
