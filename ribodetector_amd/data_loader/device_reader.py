@@ -439,10 +439,12 @@ class DeviceFeeder:
         """stop, join, and give the stream back once it has drained"""
         self.stop()
         self.join()
-        st, self.stream = getattr(self, "stream", None), None
-        if st is not None:
-            st.synchronize()
-            gz.release_stream(st, priority=-1)
+        for name in ("stream", "dstream"):
+            st = getattr(self, name, None)
+            setattr(self, name, None)
+            if st is not None:
+                st.synchronize()
+                gz.release_stream(st, priority=-1)
 
     # ---- consumer side --------------------------------------------------------------------------------
     def next_batch(self):
@@ -585,8 +587,13 @@ class DeviceFeeder:
         try:
             size, base = os.fstat(fd).st_size, 0
             tm["members"] = 0
+            # the decoder's kernels on a stream of their own: a batch's decode is one long latency chain (>= 12 ms), and the framing of the batch
+            # BEFORE it and the gathers of the consumer's chunks - microseconds of work - were queued behind it on the feeder's one stream:
+            # the first chunk of a file left the reader when its LAST batch had been decoded (tools/first_chunk_probe.py, round 6)
+            if getattr(self, "dstream", None) is None:
+                self.dstream = gz.acquire_stream(self.device, priority=-1)
             while not self._stop:
-                dsg = gz.DeviceStreamGunzip(self.device, self.stream)
+                dsg = gz.DeviceStreamGunzip(self.device, self.dstream)
                 free = list(range(len(pinned)))
                 try:
                     end = self._stream_batches(fd, dsg, pinned, views, free, tm, base)
@@ -594,6 +601,7 @@ class DeviceFeeder:
                     if base == 0:
                         raise
                     tm["fallback"] = "member at byte %d: %s" % (base, e)
+                    self.dstream.synchronize()
                     self.stream.synchronize()
                     with open(self.path, "rb", buffering=0) as fh:
                         fh.seek(base)
@@ -690,6 +698,10 @@ class DeviceFeeder:
                 have += k
             t2 = time.perf_counter()
             text = self.ix.alloc_text(dsg.text_cap(data))
+            if dsg.stream is not self.ix.stream:          # (the buffer comes from the indexer's stream's pool: whatever last used it there is over first)
+                ev = torch.cuda.Event()
+                ev.record(self.ix.stream)
+                dsg.stream.wait_event(ev)
             tk = dsg.submit(pinned[slot], valid, data, first, at_eof, text[PAD:])
             tm.setdefault("first_batch_submitted_at_s", round(time.perf_counter() - self._t0, 4))
             flight.append((tk, text, slot, pos))
