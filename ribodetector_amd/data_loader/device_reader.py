@@ -476,6 +476,7 @@ class DeviceFeeder:
 
     def _run(self):
         self._t0 = time.perf_counter()
+        self.stage_s["thread_started_at"] = self._t0            # (perf_counter: against Predictor._t_run, tools/first_chunk_probe.py)
         try:
             torch.cuda.set_device(self.device)          # the current device is per thread (and defaults to 0)
             self.stream = gz.acquire_stream(self.device, priority=-1)

@@ -880,7 +880,7 @@ def main(argv=None, log_level=None):
         seq_pred.timing = {"load_model_s": t1 - t0, "detect_s": t2 - t1, "prefix_k": seq_pred.model.prefix_k,
                            "reads_per_s_after_first_chunk": steady, "ingest": getattr(seq_pred, "ingest", None),
                            "gz_ranges_s": getattr(seq_pred, "gz_shard_s", None), "pinned_cpus": getattr(seq_pred, "pinned_cpus", None),
-                           "first_chunks_timeline": getattr(seq_pred, "_timeline", None)}
+                           "first_chunks_timeline": getattr(seq_pred, "_timeline", None), "run_started_at": getattr(seq_pred, "_t_run", None)}
         if os.environ.get("RD_TIMING_OUT"):          # (tools/host_scaling.py, tools/scale_sweep.sh: what a torchrun child measured, per rank)
             import json
             with open("%s.rank%d" % (os.environ["RD_TIMING_OUT"], seq_pred.rank), "w") as fh:

@@ -18,5 +18,5 @@ for rep in range(3):
     dt = time.perf_counter() - t0
     fc = pr._first_chunk
     print(json.dumps({"wall": round(dt, 3), "timing": {k: v for k, v in pr.timing.items() if k != "ingest"}, "start": time.strftime("%H:%M:%S"), "first_chunk_labels_at_s_after_detect_start": None,
-                      "feeders": {k: {x: v["feeder"].get(x) for x in ("first_batch_submitted_at_s", "batches_framed_at_s", "read", "wait_slot", "submit", "batches")} for k, v in pr.ingest.items()}}))
+                      "feeders": {k: {x: (v["feeder"].get(x) if x != "thread_started_at" else round(v["feeder"].get(x, 0) - pr.timing["run_started_at"], 4)) for x in ("thread_started_at", "first_batch_submitted_at_s", "batches_framed_at_s", "read", "wait_slot", "submit", "batches")} for k, v in pr.ingest.items()}}))
 import shutil; shutil.rmtree(d)
