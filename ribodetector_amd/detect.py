@@ -357,6 +357,7 @@ class Predictor:
 
         def work():
             try:
+                self._timeline.append(("reader_thread_%s" % os.path.basename(str(path)), round(time.perf_counter() - self._t_run, 4)))
                 # FASTQ whose text can stay on the device (plain files, BGZF): H2D of the file's bytes, members inflated and records
                 # framed there - no parser thread at all (data_loader/device_reader.py; RD_DEVICE_PARSE=0 keeps the host parser)
                 if arena is None and self._device_parse(path):
@@ -556,6 +557,7 @@ class Predictor:
                 for fh in handles:
                     fh.set_eof_marker(False)
         num_read = num_nonrrna = num_rrna = num_unknown = 0
+        self._timeline.append(("outputs_open", round(time.perf_counter() - self._t_run, 4)))
         self._stage_s = {"wait_reader": 0.0, "classify": 0.0, "wait_writer": 0.0}   # main-thread seconds per pipeline stage
         self.thread_cpu_s = {}                                                      # CPU seconds of the pipeline's Python threads, by role
         main_cpu0 = time.thread_time()
@@ -669,10 +671,10 @@ class Predictor:
             prev = None
             for chunks in stream:
                 t0 = time.perf_counter()
-                if len(self._timeline) < 24:          # (the first chunks' way through the pipeline, seconds since the run started: tools/first_chunk_probe.py)
+                if len(self._timeline) < 30:          # (the first chunks' way through the pipeline, seconds since the run started: tools/first_chunk_probe.py)
                     self._timeline.append(("chunk_of_%d_read" % len(chunks[0].seq_len), round(t0 - self._t_run, 4)))
                 tk = self.submit_chunk(chunks)
-                if len(self._timeline) < 24:
+                if len(self._timeline) < 30:
                     self._timeline.append(("submitted", round(time.perf_counter() - self._t_run, 4)))
                 self._stage_s["classify"] += time.perf_counter() - t0
                 if prev is not None:
@@ -680,11 +682,12 @@ class Predictor:
                 prev = (chunks, tk)
             if prev is not None:
                 yield prev
+        self._timeline.append(("writers_started", round(time.perf_counter() - self._t_run, 4)))
         try:
             for chunks, tk in in_flight(self._chunk_stream(chunk_reads)):
                 t0 = time.perf_counter()
                 labels = self.collect_chunk(tk)
-                if len(self._timeline) < 24:
+                if len(self._timeline) < 30:
                     self._timeline.append(("labels", round(time.perf_counter() - self._t_run, 4)))
                 self._stage_s["classify"] += time.perf_counter() - t0
                 num_read += len(chunks[0].seq_len)

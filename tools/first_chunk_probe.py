@@ -12,9 +12,10 @@ for mate in (1, 2):
     synth.pgzip_file(p, p + ".gz", 6)
     files.append(p + ".gz")
     del a, o, l
-for rep in range(3):
+plain = [f[:-3] for f in files]
+for rep in range(4):
     t0 = time.perf_counter()
-    pr = detect.main(["-l", "100", "-i", *files, "-o", d + "/o1.fq.gz", d + "/o2.fq.gz", "-e", "rrna"], log_level="WARNING")
+    pr = detect.main(["-l", "100", "-i", *(files if rep < 3 else plain), "-o", d + "/o1.fq.gz", d + "/o2.fq.gz", "-e", "rrna"], log_level="WARNING")
     dt = time.perf_counter() - t0
     fc = pr._first_chunk
     print(json.dumps({"wall": round(dt, 3), "timing": {k: v for k, v in pr.timing.items() if k != "ingest"}, "start": time.strftime("%H:%M:%S"), "first_chunk_labels_at_s_after_detect_start": None,
