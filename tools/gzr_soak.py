@@ -113,6 +113,18 @@ def main():
             why = res[0][1]
             key = why.split(" (rank")[0].split(" in the batch")[0][:70]
             rec["refusal_reasons"][key] = rec["refusal_reasons"].get(key, 0) + 1
+            if "per rank" not in key and "is empty" not in key and "slot holds" not in key and len(rec.setdefault("other_refusals", [])) < 40:
+                import zlib as _z
+                ends, q = [], 0          # where the members end (file offsets), by zlib
+                while q < len(blob) and blob[q:].strip(b"\0"):
+                    dd = _z.decompressobj(31)
+                    dd.decompress(blob[q:])
+                    q = len(blob) - len(dd.unused_data)
+                    ends.append(q)
+                    while q < len(blob) and blob[q] == 0:
+                        q += 1
+                rec["other_refusals"].append({"why": why, "world": world, "size": len(blob), "member_ends": ends, "cuts": gs.range_bounds(len(blob), world),
+                                              "batch": gz.DeviceStreamGunzip.BATCH})
             if len({x[1] for x in res}) != 1:
                 rec["disagreements"] += 1
             continue
