@@ -444,7 +444,7 @@ class DeviceFeeder:
             setattr(self, name, None)
             if st is not None:
                 st.synchronize()
-                gz.release_stream(st, priority=-1)
+                gz.release_stream(st, priority=getattr(self, "_dprio", -1) if name == "dstream" else -1)
 
     # ---- consumer side --------------------------------------------------------------------------------
     def next_batch(self):
@@ -592,7 +592,8 @@ class DeviceFeeder:
             # BEFORE it and the gathers of the consumer's chunks - microseconds of work - were queued behind it on the feeder's one stream:
             # the first chunk of a file left the reader when its LAST batch had been decoded (tools/first_chunk_probe.py, round 6)
             if getattr(self, "dstream", None) is None:
-                self.dstream = gz.acquire_stream(self.device, priority=-1)
+                self._dprio = int(os.environ.get("RD_GZS_PRIORITY", "-1"))      # (A/B: 0 = the decoder at the recurrence's priority, framing above it)
+                self.dstream = gz.acquire_stream(self.device, priority=self._dprio)
             while not self._stop:
                 dsg = gz.DeviceStreamGunzip(self.device, self.dstream)
                 free = list(range(len(pinned)))
