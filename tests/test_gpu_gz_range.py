@@ -272,6 +272,18 @@ def test_a_refusal_is_every_ranks_refusal(tmp_path, monkeypatch):
     G = Ranks(3)
     res = G.run(lambda r: gs.prepare([p], r, 3, DEV, [False], G.all_gather(r), G.shift(r)))
     assert all(rr is None for rr, _ in res) and len({why for _, why in res}) == 1
+    # one flipped bit in the middle of a good member: a decode error, a share that no longer starts where the one before ends, or - when
+    # the damaged bits still decode - a CRC-32 that does not match: whichever it is, the same refusal on every rank (the one-decode path
+    # then reports the damage with zlib's words)
+    blob = bytearray(gzip.compress(text, 6))
+    for at in (len(blob) // 2, len(blob) // 3 + 7, len(blob) * 4 // 5):
+        bad = bytearray(blob)
+        bad[at] ^= 0x10
+        q = str(tmp_path / "flipped.fq.gz")
+        open(q, "wb").write(bytes(bad))
+        G = Ranks(3)
+        res = G.run(lambda r: gs.prepare([q], r, 3, DEV, [False], G.all_gather(r), G.shift(r)))
+        assert all(rr is None for rr, _ in res) and len({why for _, why in res}) == 1, res
     tiny = str(tmp_path / "tiny.fq.gz")
     open(tiny, "wb").write(gzip.compress(text[:100000], 6))
     G = Ranks(2)
