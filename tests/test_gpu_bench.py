@@ -214,24 +214,44 @@ def test_two_gpu_rccl_when_available():
     _, j = _line(r.stdout, fp)
     assert j["n_gpus"] == 2 and j["config"]["dist_backend"] == "nccl" and j["config"]["gather_self_check"] == "passed"
     assert len({rk["device_uuid"] for rk in j["config"]["ranks"]}) == 2
-    # the CLI across the two devices: gz input (one decode per node through shared memory, label gather over RCCL) and plain input
-    # (sharded parse, device gzip of every rank's part) against the one-process run
+    # the CLI across the two devices against the one-process run: single-stream gz input through the range decoder (round 6: every rank
+    # decodes its own range on ITS GPU, maps all-gathered over RCCL), the same with RD_GZ_SHARD=0 (one decode per node through shared memory,
+    # label gather over RCCL), plain input (sharded parse, device gzip of every rank's part), and paired gz mates whose compressed
+    # positions drift (the records in front of the common cut travel to the rank before: dist.shift_to_prev over RCCL point-to-point)
+    import gzip
     import tempfile
     sys.path.insert(0, ROOT)
     from ribodetector_amd import synth
+
+    def run(pre, args, extra):
+        r = subprocess.run(pre + args, cwd=ROOT, env=dict(env, **extra), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        return r.stdout + r.stderr
+    one = [sys.executable, "-m", "ribodetector_amd.detect"]
+    two = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29731",
+           "-m", "ribodetector_amd.detect"]
     with tempfile.TemporaryDirectory() as d:
         a, o, _ = synth.reads_numpy(200000, (40, 140), seed=5, rrna_frac=0.3)
-        for ext in (".fq.gz", ".fq"):
+        a2, o2, _ = synth.reads_numpy(200000, (60, 100), seed=6, rrna_frac=0.3)
+        for ext, extra, ranges in ((".fq.gz", {}, True), (".fq.gz", {"RD_GZ_SHARD": "0"}, False), (".fq", {}, False)):
             inp = os.path.join(d, "in" + ext)
             synth.write_fastq(inp, a, o, 1)
             got = {}
-            for tag, pre in (("one", [sys.executable, "-m", "ribodetector_amd.detect"]),
-                             ("two", [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                                      "127.0.0.1", "--master-port", "29731", "-m", "ribodetector_amd.detect"])):
+            for tag, pre in (("one", one), ("two", two)):
                 out, rr = os.path.join(d, tag + ".non.fq.gz"), os.path.join(d, tag + ".rrna.fq")
-                r = subprocess.run(pre + ["-l", "100", "-i", inp, "-o", out, "-r", rr, "--chunk_size", "4", "-m", "3"], cwd=ROOT, env=env,
-                                   capture_output=True, text=True, timeout=900)
-                assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-                import gzip
+                log = run(pre, ["-l", "100", "-i", inp, "-o", out, "-r", rr, "--chunk_size", "4", "-m", "3"], extra)
                 got[tag] = (gzip.open(out, "rb").read(), open(rr, "rb").read())
+                if tag == "two":
+                    assert ("ranges of one DEFLATE stream" in log) == ranges, log[-1500:]
             assert got["one"] == got["two"] and len(got["one"][0]) > 0 and len(got["one"][1]) > 0
+        i1, i2 = os.path.join(d, "m_1.fq.gz"), os.path.join(d, "m_2.fq.gz")
+        synth.write_fastq(i1, a, o, 1)
+        synth.write_fastq(i2, a2, o2, 2, prefix="the_second_mate_has_longer_headers")
+        got = {}
+        for tag, pre in (("one", one), ("two", two)):
+            outs = [os.path.join(d, "%s.%s" % (tag, x)) for x in ("n1.fq", "n2.fq.gz", "r1.fq.gz", "r2.fq")]
+            log = run(pre, ["-l", "100", "-i", i1, i2, "-o", *outs[:2], "-r", *outs[2:], "-e", "rrna", "--chunk_size", "4", "-m", "3"], {})
+            got[tag] = [(gzip.open(x, "rb") if x.endswith("gz") else open(x, "rb")).read() for x in outs]
+            if tag == "two":
+                assert "ranges of one DEFLATE stream" in log and len(set(__import__("re").findall(r"Rank (\d) decoded", log))) == 2
+        assert got["one"] == got["two"] and all(len(x) > 0 for x in got["one"])
