@@ -214,6 +214,10 @@ def test_two_gpu_rccl_when_available():
     _, j = _line(r.stdout, fp)
     assert j["n_gpus"] == 2 and j["config"]["dist_backend"] == "nccl" and j["config"]["gather_self_check"] == "passed"
     assert len({rk["device_uuid"] for rk in j["config"]["ranks"]}) == 2
+    _cli_two_rank_cases(env)
+
+
+def _cli_two_rank_cases(env):
     # the CLI across the two devices against the one-process run: single-stream gz input through the range decoder (round 6: every rank
     # decodes its own range on ITS GPU, maps all-gathered over RCCL), the same with RD_GZ_SHARD=0 (one decode per node through shared memory,
     # label gather over RCCL), plain input (sharded parse, device gzip of every rank's part), and paired gz mates whose compressed
@@ -255,3 +259,14 @@ def test_two_gpu_rccl_when_available():
             if tag == "two":
                 assert "ranges of one DEFLATE stream" in log and len(set(__import__("re").findall(r"Rank (\d) decoded", log))) == 2
         assert got["one"] == got["two"] and all(len(x) > 0 for x in got["one"])
+
+
+
+def test_two_rank_cli_cases_on_one_gpu():
+    """the CLI cases of test_two_gpu_rccl_when_available with both ranks on this box's one GPU over gloo (RD_TEST_FULL=1 only: the flows
+    themselves are covered by tests/test_gpu_cli.py; this keeps the two-GPU test's own code from rotting on 1-GPU boxes)"""
+    from conftest import FULL
+    if not FULL:
+        pytest.skip("RD_TEST_FULL=1")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    _cli_two_rank_cases(dict(env, RD_DIST_BACKEND="gloo", RD_LOCAL_DEVICE="0"))
