@@ -12,9 +12,11 @@
 //   rd_gzs_decode_kernel   section k is decoded from its start to the start the next section found, with an UNKNOWN window: the
 //                          output is 16-bit symbols, a byte or a marker "byte i of the 32 KiB before this section"; a section that
 //                          does not end exactly where the next one starts poisons the batch (nothing speculative is accepted);
-//   rd_gzs_scan_kernel     symbols per section -> text offsets; the member's end (BFINAL) closes the list;
-//   rd_gzs_window_kernel   in order, one workgroup: the last 32 KiB of every section resolved against the window before it;
-//   rd_gzs_resolve_kernel  all sections in parallel: symbols -> bytes at their offsets in the batch's text;
+//   rd_gzs_scan_kernel     one wave: symbols per section -> text offsets; the member's end (BFINAL) closes the list;
+//   rd_gzs_symwin_kernel   the window chain on SYMBOLS (round 6): one workgroup per group of 32 sections, all groups at once, each from the
+//   rd_gzs_chain_kernel    identity map; then one workgroup applies the group maps in order to the window in front of the batch;
+//   rd_gzs_resolve_kernel  all sections in parallel: symbols -> bytes at their offsets in the batch's text (range mode: -> 16-bit symbols
+//                          whose markers point into the window in front of the RANGE; rd_gzs_symtext_kernel makes bytes of them later);
 //   rd_gzs_crc_kernel / rd_gzs_fold_kernel   CRC-32 per 64 KiB of text, folded into the stream's running CRC (x^(8 n) mod P).
 // The stream's state (window, CRC, length, where the next batch starts) lives in HBM and is carried from batch to batch on the stream.
 #pragma once
