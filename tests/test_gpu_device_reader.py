@@ -453,6 +453,22 @@ def test_records_longer_than_the_real_pad(tmp_path):
     dev = _dev_chunks(fq, 1500, stats=st)
     _same(_host_chunks(fq, 1500), dev)
     assert sum(len(d[3]) for d in dev) == 2001
+    # ... and through the CLI: the default (device) reader writes what the host reader writes, no switch needed
+    from ribodetector_amd import detect
+    for inp, ext in ((fa, "fa"), (fq, "fq")):
+        outs = {}
+        for mode in ("device", "host"):
+            os.environ["RD_INGEST"] = mode
+            try:
+                o, r = str(tmp_path / ("%s.non.%s" % (mode, ext))), str(tmp_path / ("%s.rrna.%s.gz" % (mode, ext)))
+                p = detect.main(["-l", "100", "-i", inp, "-o", o, "-r", r, "--chunk_size", "1", "-m", "3"], log_level="WARNING")
+                import gzip
+                outs[mode] = (open(o, "rb").read(), gzip.open(r, "rb").read(), p.num_read)
+                assert (mode == "device") == bool(p.ingest and all(v["path"] == "device" for v in p.ingest.values()))
+            finally:
+                del os.environ["RD_INGEST"]
+        assert outs["device"] == outs["host"] and outs["device"][2] == (3 if ext == "fa" else 2001)
+        assert len(outs["device"][0]) + len(outs["device"][1]) > (40 << 20 if ext == "fa" else 40 << 20)
 
 
 def test_fasta_share_keeps_its_last_record_without_a_sequence(tmp_path):
