@@ -333,7 +333,7 @@ RD_API int rd_select_pack(const uint8_t *text, int64_t text_bytes, const int64_t
  *   data_bytes + section_bytes unless the file ends; the next batch's buffer starts `data_bytes` further: carry_delta_bits =
  *   8 * data_bytes). first_start_bit: where the member's first block starts (first batch: behind the gzip header; else ignored and taken
  *   from `carry` = the state the batch before left [dev]). win_in / win_out [dev] 32 KiB: the text behind the batch before / this one.
- *   text [dev] receives state->n_text bytes (<= text_cap). state [dev] rd_gzs_state: status RD_GZS_* (MISMATCH: a section did not
+ *   text [dev, 8-byte aligned] receives state->n_text bytes (<= text_cap). state [dev] rd_gzs_state: status RD_GZS_* (MISMATCH: a section did not
  *   end where the next one starts - nothing speculative is ever accepted; OVERFLOW: a section made more than cap_syms symbols; ...),
  *   final: the member ended in this batch at bit `end_bit` of comp (its trailer - CRC-32, ISIZE - follows at the next byte boundary: the
  *   caller compares them with state->crc and total_len). Asynchronous on `stream`. */

@@ -770,15 +770,44 @@ __global__ __launch_bounds__(256) void rd_gzs_resolve_kernel(const uint16_t *__r
     const int slot = wslot[k];
     const uint16_t *W1 = windows16 + (size_t)slot * GZS_WIN, *W0 = gwin + (size_t)(slot / GZS_GROUP) * GZS_WIN;
     const int i1 = i0 + GZS_RTILE < n ? i0 + GZS_RTILE : n;
-    for (int i = i0 + (int)threadIdx.x; i < i1; i += 256) {
-        uint32_t s = sy[i];
+    const int64_t o = off[k];
+    auto res = [&](uint32_t s) -> uint32_t {
         if (s & GZS_MARK) {
             s = W1[s & 0x7fffu];
             if (s & GZS_MARK) s = W0[s & 0x7fffu];
         }
-        if (OUT16) sym_text[off[k] + i] = (uint16_t)s;
-        else text[off[k] + i] = (uint8_t)s;
+        return s;
+    };
+    auto one = [&](int i) {
+        const uint32_t s = res(sy[i]);
+        if (OUT16) sym_text[o + i] = (uint16_t)s;
+        else text[o + i] = (uint8_t)s;
+    };
+    // eight symbols per thread and step: one 16-byte load (the slot is aligned, the tile's first symbol need not be), one 8-byte store (16 bytes
+    // in range mode) at an aligned place of the text; the few symbols in front of the first aligned place and behind the last whole eight go one by one
+    const int tid = (int)threadIdx.x;
+    int lead = (int)((8 - ((o + i0) & 7)) & 7);
+    if (lead > i1 - i0) lead = i1 - i0;
+    if (tid < lead) one(i0 + tid);
+    const int v0 = i0 + lead, nvec = (i1 - v0) >> 3;
+    for (int g = tid; g < nvec; g += 256) {
+        const int i = v0 + 8 * g;
+        u32x4 v;
+        __builtin_memcpy(&v, sy + i, 16);
+        uint32_t r[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = res((v[j >> 1] >> (16 * (j & 1))) & 0xffffu);
+        if (OUT16) {
+            const u32x4 w = {r[0] | (r[1] << 16), r[2] | (r[3] << 16), r[4] | (r[5] << 16), r[6] | (r[7] << 16)};
+            *reinterpret_cast<u32x4 *>(sym_text + o + i) = w;
+        } else {
+            const uint2 w = make_uint2((r[0] & 0xffu) | ((r[1] & 0xffu) << 8) | ((r[2] & 0xffu) << 16) | (r[3] << 24),
+                                       (r[4] & 0xffu) | ((r[5] & 0xffu) << 8) | ((r[6] & 0xffu) << 16) | (r[7] << 24));
+            *reinterpret_cast<uint2 *>(text + o + i) = w;
+        }
     }
+    const int t0 = v0 + 8 * nvec;
+    if (tid < i1 - t0) one(t0 + tid);
 }
 
 // the range's symbols -> bytes, once the window in front of the range is known (`valid` = how many of its LAST bytes are text of the member:

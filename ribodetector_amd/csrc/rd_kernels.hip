@@ -659,7 +659,8 @@ int rd_gz_stream_inflate(const uint8_t *comp, int64_t comp_bytes, int64_t data_b
                          uint32_t first_start_bit, const rd_gzs_state *carry, int64_t carry_delta_bits, int32_t at_eof, const uint8_t *win_in,
                          uint8_t *win_out, uint8_t *text, int64_t text_cap, rd_gzs_state *state, void *workspace, size_t workspace_bytes, void *stream) {
     if (!comp || !win_out || !text || !state || !workspace) RD_FAIL(RD_E_INVALID, "rd_gz_stream_inflate: null pointer");
-    if (((uintptr_t)comp & 3) || ((uintptr_t)workspace & 255)) RD_FAIL(RD_E_INVALID, "rd_gz_stream_inflate: comp must be 4-byte aligned, workspace 256-byte aligned");
+    if (((uintptr_t)comp & 3) || ((uintptr_t)workspace & 255) || ((uintptr_t)text & 7))
+        RD_FAIL(RD_E_INVALID, "rd_gz_stream_inflate: comp must be 4-byte aligned, text 8-byte aligned, workspace 256-byte aligned");
     if (data_bytes <= 0 || valid_bytes < data_bytes || comp_bytes < valid_bytes || valid_bytes >= (1LL << 28) || section_bytes < 1024 || (section_bytes & 3) ||
         cap_syms < 1024 || text_cap < 0)
         RD_FAIL(RD_E_INVALID, "rd_gz_stream_inflate: bad sizes (a batch holds < 256 MiB of compressed bytes)");
