@@ -700,3 +700,25 @@ def test_cli_single_stream_gz_single_end_fasta_and_refusals(tmp_path):
     r, port = _torchrun(2, ["-l", "100", "-i", cut, "-o", str(tmp_path / "o.fq"), "--chunk_size", "1", "-m", "3"], {"RD_GZ_SHARD_MIN": "65536"}, timeout=300)
     assert r.returncode != 0 and "ended before the end-of-stream marker" in r.stdout + r.stderr
     assert not [f for f in os.listdir("/dev/shm") if f.startswith("rd_%d_" % port)]
+
+
+def test_cli_mates_of_different_ingest_kinds(tmp_path):
+    """advisor, round 5: whether the text stays on the device is decided ONCE per run - a pair whose first mate the device reader takes (a
+    plain file) and whose second it does not (a gzip file under a plain name: the host reader sniffs the magic) used to crash on the first
+    chunk; both go through the host reader now, and the outputs are those of two plain files"""
+    from ribodetector_amd import detect, synth
+    n = 30000
+    a1, o1, _ = synth.reads_numpy(n, (40, 140), seed=91, rrna_frac=0.3)
+    a2, o2, _ = synth.reads_numpy(n, (40, 140), seed=92, rrna_frac=0.3)
+    p1, p2 = str(tmp_path / "r_1.fq"), str(tmp_path / "r_2.fq")
+    synth.write_fastq(p1, a1, o1, 1)
+    synth.write_fastq(p2, a2, o2, 2)
+    want = [str(tmp_path / x) for x in ("a1.fq", "a2.fq.gz")]
+    pa = detect.main(["-l", "100", "-i", p1, p2, "-o", *want, "-e", "rrna", "--chunk_size", "1", "-m", "3"], log_level="WARNING")
+    assert all(v["path"] == "device" for v in pa.ingest.values())
+    disguised = str(tmp_path / "z_2.fq")                     # gzip bytes, plain name
+    open(disguised, "wb").write(gzip.compress(open(p2, "rb").read(), 4))
+    got = [str(tmp_path / x) for x in ("b1.fq", "b2.fq.gz")]
+    pb = detect.main(["-l", "100", "-i", p1, disguised, "-o", *got, "-e", "rrna", "--chunk_size", "1", "-m", "3"], log_level="WARNING")
+    assert not pb.ingest and pb.num_read == pa.num_read == n
+    assert [_read(x) for x in want] == [_read(x) for x in got]
